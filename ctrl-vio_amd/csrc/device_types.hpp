@@ -1,0 +1,93 @@
+// device_types.hpp -- POD descriptors shared by host packer and kernels (HBM layout of a batch of windows).
+//
+// A batch is the concatenation of independent windows.  Every per-window array lives at an offset
+// recorded in WinMeta; kernels are launched over (element, window) grids and exit early for windows
+// whose LM loop has terminated (Lm::status != 0) -- the LM control flow never returns to the host.
+#pragma once
+#include <stdint.h>
+
+namespace ctv {
+
+struct WinMeta {
+  int32_t K, F, L, M, NB, V, P, N;
+  int32_t pn, pnb;
+  int32_t knot0, bias0, lm0;   // offsets into state arrays (knots, bias states, landmarks)
+  int32_t imu0, grp0, ngrp;    // IMU samples (sorted by group) / groups
+  int32_t vis0, bc0;           // visual blocks / bias-chain links
+  int32_t u0, p0;              // offsets into per-unknown (sum N) and per-pose-unknown (sum P) arrays
+  int32_t ldw, Lpad;           // W is [Lpad][ldw] (landmark-major, zero padded; ldw % 32 == 0, Lpad % 2 == 0)
+  int32_t pv0, pblk0;          // prior vectors (sum pn) / prior blocks
+  int32_t fix_ld, lock_bg, lock_ba, fixed_upto;
+  int64_t H0;                  // offset of the P*P block in Hpp / S (doubles)
+  int64_t W0;                  // offset of W (elements)
+  int64_t pH0;                 // offset of the prior's J0^T J0 (pn*pn doubles)
+  int64_t dt_ns;
+  double inv_dt;               // 1e9 / dt_ns  (reference spline_segment.h:58)
+  double q_CI[4], p_CI[3], gravity[3], imu_w[6], img_w, cauchy_a, ld_lo, ld_hi;
+};
+
+// A run of IMU samples sharing the same 4 active knots (segment s) and the same bias state.
+struct ImuGroup { int32_t win, s, bias, start, count; };
+
+// Per-window Levenberg-Marquardt state (Ceres 1.14 TrustRegionMinimizer variables).
+struct Lm {
+  double cost, cand_cost, initial_cost;
+  double mu, nu;               // trust-region radius, decrease factor
+  double model_change;
+  double step2, xnorm2, cand_xnorm2;
+  unsigned long long gmax_bits; // max-norm of x - Plus(x, -g) as the bit pattern of a non-negative double
+  int32_t iter, invalid, status; // status 0 = running, else 1 + termination code
+  int32_t need_lin, scaled, last_ok, step_valid, chol_fail, accept;
+  int32_t nsucc, nunsucc, pad;
+};
+
+struct LmParams {
+  double ftol, gtol, ptol, max_radius, min_radius, min_rel_dec, min_diag, max_diag;
+  int32_t max_invalid, max_iters;
+};
+
+// Device pointers of one batch.  T = scalar of the linearisation kernels (float product / double debug).
+template <class T> struct Dev {
+  int32_t nwin, Ktot, Ftot, Ltot, Mtot, Gtot, Vtot, NBtot, Utot, maxN, maxP, maxPn;
+  const WinMeta *wins;
+  // state, fp64 master copies: current and candidate
+  double *quat, *pos, *bias, *rho, *ld;
+  double *cquat, *cpos, *cbias, *crho, *cld;
+  const int32_t *knot_win, *bias_win, *lm_win;
+  // IMU factors (sorted by group)
+  const ImuGroup *groups;
+  const int32_t *imu_grp;
+  const T *imu_u;        // [Mtot] normalised time in the segment
+  const T *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
+  T *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
+  // visual factors
+  const int32_t *v_win, *v_lm;
+  const int64_t *v_ti, *v_tj;   // relative to the window's t0
+  const int32_t *v_rowi, *v_rowj;
+  const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
+  T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
+  T *rv;                 // [2][Vtot]
+  int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
+  // bias chain
+  const int32_t *bc_win, *bc_i, *bc_j;
+  const double *bc_w;    // [NBtot][6]
+  // prior (J0^T J0, J0^T r0, r0^T r0 precomputed on the host in fp64)
+  const double *pH, *pb0, *pc0;
+  const int32_t *pcol;   // [sum pn] unknown index of each prior dimension
+  const int32_t *p_kind, *p_index, *p_off;
+  const double *p_x0;
+  // normal equations
+  double *Hpp;           // [sum P*P] lower triangle used
+  T *W;                  // Hpl^T, landmark-major
+  double *Hll, *g;       // [Ltot], [Utot]
+  double *S, *rhs;       // Schur complement (lower) and its right-hand side [sum P]
+  double *dd, *dinv;     // LM damping per unknown [Utot]; 1/(Hll + dd) [Ltot]
+  double *cscale;        // Jacobi scaling [Utot]
+  double *delta;         // step [Utot]
+  const uint8_t *active; // [Utot] unknown is in the reduced program
+  Lm *lm;
+  int32_t *n_active;
+  LmParams prm;
+};
+
+}  // namespace ctv

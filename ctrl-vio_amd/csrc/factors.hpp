@@ -1,0 +1,309 @@
+// factors.hpp -- per-residual-block device evaluation (residual + analytic Jacobian), templated on
+// the scalar.  Knots are addressed by global index: the 4 active control points of an evaluation at
+// time t are knots s..s+3 with s = (t - t0)/dt, so the reference's SplineMeta / parameter-pointer
+// bookkeeping (src/spline/spline_segment.h:131-191, trajectory_estimator.cpp:114-141) disappears.
+//
+//   imu_eval     SplitSpineView::Evaluate (split_spline_view.h:67-214) fused with
+//                IMUFactor::Evaluate (trajectory_value_factor.h:141-248)
+//   visual_eval  ImageFeatureDelayFactor::Evaluate (image_feature_factor.h:63-269) with
+//                So3SplineView::EvaluateRp/EvaluateRTp/VelocityBody (so3_spline_view.h:136-276,356-411),
+//                RdSplineView::evaluate (rd_spline_view.h:63-94) and ceres::CauchyLoss + Corrector
+//                (restated in the reference at marginalization_factor.cpp:39-67)
+#pragma once
+#include "so3.hpp"
+
+namespace ctv {
+
+template <class T> struct Knots4 {
+  Q4<T> q[4];
+  V3<T> p[4];  // positions relative to a per-block origin (residuals are translation invariant)
+};
+
+// Quantities of a 4-knot group that do not depend on the evaluation time u.
+template <class T> struct SegConst {
+  V3<T> d[3];      // d_i = log(R_i^-1 R_{i+1})
+  M3<T> JrI[3];    // Jr^-1(d_i)
+};
+template <class T> CTV_DI void seg_const(const Knots4<T> &k, SegConst<T> &sc, bool want_jac) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    sc.d[i] = so3_log(qmul(qconj(k.q[i]), k.q[i + 1]));
+    if (want_jac) sc.JrI[i] = so3_Jr_inv(sc.d[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IMU block.  Local column order of J (6 x 30): rot k0..k3 (12) | pos k0..k3 (12) | bg (3) | ba (3).
+// Sink::put(row, col, value) receives the non-zero Jacobian entries; r[6] is returned whitened.
+template <class T, class Sink>
+CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T> gravity, const T bias[6],
+                     const T gyro[3], const T acc[3], const T w[6], T r[6], bool want_jac, Sink &sink) {
+  T lamA[4], lamR[4], lamW[4];
+  basis<T, false, 2>(u, idt * idt, lamA);
+  basis<T, true, 0>(u, T(1), lamR);
+  basis<T, true, 1>(u, idt, lamW);
+
+  V3<T> accel = mk<T>(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accel = accel + lamA[i] * k.p[i];
+
+  Q4<T> Ainv[3], accq = qmk<T>(0, 0, 0, 1);
+  M3<T> Apost[4], JrK[3];
+  Apost[3] = m3_id<T>();
+#pragma unroll
+  for (int i = 2; i >= 0; --i) {
+    const V3<T> nkd = (-lamR[i + 1]) * sc.d[i];
+    Ainv[i] = so3_exp(nkd);
+    accq = qmul(accq, Ainv[i]);
+    if (want_jac) { Apost[i] = q2R(accq); JrK[i] = so3_Jr(nkd); }
+  }
+  V3<T> om[4];
+  om[0] = mk<T>(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) om[i + 1] = qrot(Ainv[i], om[i]) + lamW[i + 1] * sc.d[i];
+
+  const Q4<T> Rinv_q = qmul(accq, qconj(k.q[0]));
+  const V3<T> ag = accel + gravity;
+  const V3<T> a_pred = qrot(Rinv_q, ag);
+  r[0] = w[0] * (om[3].x - (gyro[0] - bias[0]));
+  r[1] = w[1] * (om[3].y - (gyro[1] - bias[1]));
+  r[2] = w[2] * (om[3].z - (gyro[2] - bias[2]));
+  r[3] = w[3] * (a_pred.x - (acc[0] - bias[3]));
+  r[4] = w[4] * (a_pred.y - (acc[1] - bias[4]));
+  r[5] = w[5] * (a_pred.z - (acc[2] - bias[5]));
+  if (!want_jac) return;
+
+  // gyro rows: d(omega)/d(d_j), split_spline_view.h:157-181
+  M3<T> Jw[4], Ja[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { Jw[i] = m3_zero<T>(); Ja[i] = m3_zero<T>(); }
+  {
+    M3<T> dod = scale(Apost[1], lamW[1]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i > 0) dod = add(scale(mul(mul_hat(Apost[i], om[i]), JrK[i]), lamR[i + 1]), scale(Apost[i + 1], lamW[i + 1]));
+      Jw[i] = sub(Jw[i], mulT(dod, sc.JrI[i]));
+      Jw[i + 1] = add(Jw[i + 1], mul(dod, sc.JrI[i]));
+    }
+  }
+  // accel rows, split_spline_view.h:183-211 (three R_accum entries: the reference's 2-entry array is a bug)
+  const M3<T> Rinv = q2R(Rinv_q);
+  {
+    const M3<T> lhs = mul_hat(Rinv, ag);
+    M3<T> Racc = q2R(k.q[0]);
+    Ja[0] = add(Ja[0], mul(lhs, Racc));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i > 0) Racc = mulT(Racc, q2R(Ainv[i - 1]));
+      const M3<T> dad = scale(mul(mul(lhs, Racc), JrK[i]), lamR[i + 1]);
+      Ja[i] = sub(Ja[i], mulT(dad, sc.JrI[i]));
+      Ja[i + 1] = add(Ja[i + 1], mul(dad, sc.JrI[i]));
+    }
+  }
+  // trajectory_value_factor.h:198-245
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        sink.put(a, 3 * kk + b, w[a] * Jw[kk].m[3 * a + b]);
+        sink.put(3 + a, 3 * kk + b, w[3 + a] * Ja[kk].m[3 * a + b]);
+        sink.put(3 + a, 12 + 3 * kk + b, w[3 + a] * lamA[kk] * Rinv.m[3 * a + b]);
+      }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { sink.put(a, 24 + a, w[a]); sink.put(3 + a, 27 + a, w[3 + a]); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SO(3) spline views on 4 knots.
+// EvaluateRp (so3_spline_view.h:136-198): returns R(t); J[k] = per-knot 3x3 "partial" Jacobians.
+template <class T> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SegConst<T> &sc, T u, M3<T> J[4], bool want_jac) {
+  T c[4];
+  basis<T, true, 0>(u, T(1), c);
+  Q4<T> accq = qmk<T>(0, 0, 0, 1);
+  M3<T> Apost[4], JrK[3];
+  Apost[3] = m3_id<T>();
+#pragma unroll
+  for (int i = 2; i >= 0; --i) {
+    const V3<T> kd = c[i + 1] * sc.d[i];
+    accq = qmul(accq, so3_exp(neg(kd)));
+    if (want_jac) { JrK[i] = so3_Jr(kd); Apost[i] = q2R(accq); }
+  }
+  const Q4<T> res = qmul(q[0], qconj(accq));
+  if (want_jac) {
+    J[0] = Apost[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const M3<T> Jh = scale(mul(Apost[i + 1], JrK[i]), c[i + 1]);
+      J[i] = sub(J[i], mulT(Jh, sc.JrI[i]));
+      J[i + 1] = mul(Jh, sc.JrI[i]);
+    }
+  }
+  return res;
+}
+// EvaluateRTp (so3_spline_view.h:208-276): returns R(t)^T.
+template <class T> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SegConst<T> &sc, T u, M3<T> J[4], bool want_jac) {
+  T c[4];
+  basis<T, true, 0>(u, T(1), c);
+  Q4<T> S[4];
+  M3<T> JrK[3];
+  S[0] = q[0];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const V3<T> kd = c[i + 1] * sc.d[i];
+    S[i + 1] = qmul(S[i], so3_exp(kd));
+    if (want_jac) JrK[i] = so3_Jr(neg(kd));
+  }
+  if (want_jac) {
+    J[0] = q2R(S[0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const M3<T> Jh = scale(mul(q2R(S[i]), JrK[i]), c[i + 1]);
+      J[i] = sub(J[i], mulT(Jh, sc.JrI[i]));
+      J[i + 1] = mul(Jh, sc.JrI[i]);
+    }
+  }
+  return qconj(S[3]);
+}
+// VelocityBody value (so3_spline_view.h:356-411)
+template <class T> CTV_DI V3<T> eval_omega(const SegConst<T> &sc, T u, T idt) {
+  T c[4], dc[4];
+  basis<T, true, 0>(u, T(1), c);
+  basis<T, true, 1>(u, idt, dc);
+  V3<T> rv = dc[1] * sc.d[0];
+#pragma unroll
+  for (int i = 1; i < 3; ++i) rv = qrot(so3_exp((-c[i + 1]) * sc.d[i]), rv) + dc[i + 1] * sc.d[i];
+  return rv;
+}
+// R(t) only (So3Spline::evaluate, so3_spline.h:240-289)
+template <class T> CTV_DI Q4<T> eval_R(const Q4<T> q[4], const SegConst<T> &sc, T u) {
+  T c[4];
+  basis<T, true, 0>(u, T(1), c);
+  Q4<T> res = q[0];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) res = qmul(res, so3_exp(c[i + 1] * sc.d[i]));
+  return res;
+}
+
+template <class T> struct Calib {
+  Q4<T> q_CI;
+  V3<T> p_CI;
+  T img_w, cauchy_a;
+};
+
+// Visual block.  Local column order of J (2 x 50): rot_i (12) | pos_i (12) | rot_j (12) | pos_j (12) | rho | ld.
+// Outputs are already robust-corrected (r~ = sqrt(rho') r, J~ = sqrt(rho')(J - alpha/s r r^T J)); returns
+// the block's cost contribution rho(s)/2.  Emit::put(col, j0, j1) receives column `col` of J~ (both rows).
+template <class T, class Emit>
+CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt, const Calib<T> &cal, T pix, T piy, T pjx,
+                     T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac, Emit &emit) {
+  SegConst<T> sci, scj;
+  seg_const(ki, sci, want_jac);
+  seg_const(kj, scj, want_jac);
+  const T inv_d = T(1) / d_inv;
+  const V3<T> x_ci = mk<T>(pix * inv_d, piy * inv_d, inv_d);
+  const V3<T> p_Ii = qrot(cal.q_CI, x_ci) + cal.p_CI;
+
+  M3<T> JR0[4], JR1[4];
+  const Q4<T> S_IitoG = eval_Rp(ki.q, sci, ui, JR0, want_jac);
+  const Q4<T> S_GtoIj = eval_RTp(kj.q, scj, uj, JR1, want_jac);
+  T cp0[4], cp1[4];
+  basis<T, false, 0>(ui, T(1), cp0);
+  basis<T, false, 0>(uj, T(1), cp1);
+  V3<T> p_IiinG = mk<T>(0, 0, 0), p_IjinG = mk<T>(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { p_IiinG = p_IiinG + cp0[i] * ki.p[i]; p_IjinG = p_IjinG + cp1[i] * kj.p[i]; }
+
+  const V3<T> p_G = qrot(S_IitoG, p_Ii) + p_IiinG;
+  const Q4<T> S_ItoC = qconj(cal.q_CI);
+  const Q4<T> S_GtoCj = qmul(S_ItoC, S_GtoIj);
+  const V3<T> dpg = p_G - p_IjinG;
+  const V3<T> x_j = qrot(S_GtoCj, dpg) - qrot(S_ItoC, cal.p_CI);
+  const T dji = T(1) / x_j.z;
+  const T sw = cal.img_w;
+  const T r0 = sw * (x_j.x * dji - pjx), r1 = sw * (x_j.y * dji - pjy);
+
+  // robust loss (Cauchy): rho(s) = b log(1 + s/b), rho' = 1/(1+s/b), rho'' = -rho'^2/b
+  const T s = r0 * r0 + r1 * r1;
+  T cost, sq = T(1), rs = T(1), alpha_sq = T(0);
+  if (cal.cauchy_a > T(0)) {
+    const T b = cal.cauchy_a * cal.cauchy_a, c = T(1) / b;
+    const T inv = T(1) / (T(1) + s * c);
+    cost = T(0.5) * b * t_log1p(s * c);
+    const T rho1 = inv, rho2 = -c * inv * inv;
+    sq = t_sqrt(rho1);
+    if (s == T(0) || rho2 <= T(0)) { rs = sq; alpha_sq = T(0); }
+    else { const T D = T(1) + T(2) * s * rho2 / rho1; const T al = T(1) - t_sqrt(D); rs = sq / (T(1) - al); alpha_sq = al / s; }
+  } else {
+    cost = T(0.5) * s;
+  }
+  r[0] = rs * r0;
+  r[1] = rs * r1;
+  if (!want_jac) return cost;
+
+  // corrector applied column by column
+  auto out = [&](int col, T j0, T j1) {
+    const T rj = r0 * j0 + r1 * j1;
+    emit.put(col, sq * (j0 - alpha_sq * r0 * rj), sq * (j1 - alpha_sq * r1 * rj));
+  };
+  // J_v (image_feature_factor.h:184-186)
+  const T Jv[6] = {dji, T(0), -dji * dji * x_j.x, T(0), dji, -dji * dji * x_j.y};
+  const M3<T> RGCj = q2R(S_GtoCj), RIiG = q2R(S_IitoG);
+  const M3<T> RGCjRi = mul(RGCj, RIiG);
+  {
+    const M3<T> t0 = mul_hat(RGCjRi, p_Ii), t1 = mul_hat(RGCj, dpg);
+    T lhsR0[6], lhsP0[6], lhsR1[6];  // :192-197 (lhsP1 = -lhsP0)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        T s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          s0 += Jv[3 * a + kx] * t0.m[3 * kx + b]; s1 += Jv[3 * a + kx] * RGCj.m[3 * kx + b]; s2 += Jv[3 * a + kx] * t1.m[3 * kx + b];
+        }
+        lhsR0[3 * a + b] = -s0; lhsP0[3 * a + b] = s1; lhsR1[3 * a + b] = s2;
+      }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        T a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          a0 += lhsR0[c] * JR0[kk].m[3 * c + b]; a1 += lhsR0[3 + c] * JR0[kk].m[3 * c + b];
+          b0 += lhsR1[c] * JR1[kk].m[3 * c + b]; b1 += lhsR1[3 + c] * JR1[kk].m[3 * c + b];
+        }
+        out(3 * kk + b, sw * a0, sw * a1);
+        out(24 + 3 * kk + b, sw * b0, sw * b1);
+        out(12 + 3 * kk + b, sw * cp0[kk] * lhsP0[b], sw * cp0[kk] * lhsP0[3 + b]);
+        out(36 + 3 * kk + b, -sw * cp1[kk] * lhsP0[b], -sw * cp1[kk] * lhsP0[3 + b]);
+      }
+  }
+  // inverse depth (image_feature_factor.h:239-248)
+  {
+    const V3<T> y = mul(RGCjRi, qrot(cal.q_CI, x_ci));
+    const T f = -inv_d * sw;
+    out(48, f * (Jv[0] * y.x + Jv[2] * y.z), f * (Jv[4] * y.y + Jv[5] * y.z));
+  }
+  // line delay (image_feature_factor.h:251-264)
+  {
+    T dcp0[4], dcp1[4];
+    basis<T, false, 1>(ui, idt, dcp0);
+    basis<T, false, 1>(uj, idt, dcp1);
+    V3<T> v_i = mk<T>(0, 0, 0), v_j = mk<T>(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v_i = v_i + dcp0[i] * ki.p[i]; v_j = v_j + dcp1[i] * kj.p[i]; }
+    const V3<T> Om_i = eval_omega(sci, ui, idt), Om_j = eval_omega(scj, uj, idt);
+    const M3<T> RGIj = q2R(S_GtoIj);
+    const V3<T> a1 = qrot(S_GtoIj, rowi * v_i - rowj * v_j);
+    const V3<T> a2 = (-rowj) * cross(Om_j, mul(RGIj, dpg));
+    const V3<T> a3 = rowi * mul(RGIj, mul(RIiG, cross(Om_i, p_Ii)));
+    const V3<T> Jx = qrot(S_ItoC, a1 + a2 + a3);
+    out(49, sw * (Jv[0] * Jx.x + Jv[2] * Jx.z), sw * (Jv[4] * Jx.y + Jv[5] * Jx.z));
+  }
+  return cost;
+}
+
+}  // namespace ctv

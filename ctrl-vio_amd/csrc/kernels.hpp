@@ -1,0 +1,943 @@
+// kernels.hpp -- gfx950 kernels of the sliding-window solve.  One launch covers a whole batch of windows.
+//
+//   linearise : k_imu_linearize (LDS-staged J, per-group A^T A tiles), k_vis_linearize (J materialised, SoA)
+//   assemble  : k_zero_normal, k_assemble_imu, k_assemble_vis, k_assemble_misc (bias chain + prior), k_post_linearize
+//   solve     : k_damping, k_schur_mfma / k_schur_generic, k_rhs, k_cholesky_solve, k_backsub
+//   update    : k_update, k_imu_cost, k_vis_cost, k_misc_cost
+//   control   : k_lm_init, k_begin_iter, k_lm_control, k_accept   (Ceres 1.14 trust-region semantics)
+//   query     : k_spline_eval
+#pragma once
+#include "device_types.hpp"
+#include "factors.hpp"
+
+namespace ctv {
+
+__device__ __forceinline__ bool lin_needed(const Lm &lm) { return lm.status == 0 && lm.need_lin != 0; }
+
+// local column -> unknown index maps
+__device__ __forceinline__ int imu_col(int c, int s, int K, int bias) {
+  if (c < 12) return 6 * (s + c / 3) + c % 3;
+  if (c < 24) return 6 * (s + (c - 12) / 3) + 3 + (c - 12) % 3;
+  return 6 * K + 6 * bias + (c - 24);
+}
+__device__ __forceinline__ int vis_col(int c, int si, int sj, int P) {
+  if (c < 12) return 6 * (si + c / 3) + c % 3;
+  if (c < 24) return 6 * (si + (c - 12) / 3) + 3 + (c - 12) % 3;
+  if (c < 36) return 6 * (sj + (c - 24) / 3) + (c - 24) % 3;
+  if (c < 48) return 6 * (sj + (c - 36) / 3) + 3 + (c - 36) % 3;
+  if (c == 48) return -1;  // inverse depth: landmark block
+  return P - 1;            // line delay
+}
+
+template <class T> __device__ __forceinline__ void load_knots(const double *quat, const double *pos, int k0, const double *origin,
+                                                            Knots4<T> &k) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double *q = quat + 4 * (k0 + i), *p = pos + 3 * (k0 + i);
+    k.q[i] = qmk<T>((T)q[0], (T)q[1], (T)q[2], (T)q[3]);
+    k.p[i] = mk<T>((T)(p[0] - origin[0]), (T)(p[1] - origin[1]), (T)(p[2] - origin[2]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ control
+template <class T> __global__ void k_lm_init(Dev<T> d, double mu, int keep_scale) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.nwin) return;
+  Lm &lm = d.lm[w];
+  lm.cost = lm.cand_cost = lm.initial_cost = 0;
+  lm.mu = mu; lm.nu = 2.0; lm.model_change = 0;
+  lm.step2 = lm.xnorm2 = lm.cand_xnorm2 = 0;
+  lm.gmax_bits = 0ull;
+  lm.iter = 0; lm.invalid = 0; lm.status = 0;
+  lm.need_lin = 1; lm.scaled = keep_scale ? lm.scaled : 0; lm.last_ok = 1; lm.step_valid = 0; lm.chol_fail = 0; lm.accept = 0;
+  lm.nsucc = lm.nunsucc = 0;
+}
+template <class T> __global__ void k_set_initial_cost(Dev<T> d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.nwin) return;
+  Lm &lm = d.lm[w];
+  lm.cost = lm.initial_cost = lm.cand_cost;
+  lm.cand_cost = 0;
+}
+template <class T> __global__ void k_force_lin(Dev<T> d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < d.nwin) { d.lm[w].need_lin = 1; d.lm[w].status = 0; }
+}
+
+// FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration.
+template <class T> __global__ void k_begin_iter(Dev<T> d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.nwin) return;
+  Lm &lm = d.lm[w];
+  if (lm.status) return;
+  if (lm.need_lin) { lm.scaled = 1; lm.need_lin = 0; }
+  if (lm.iter >= d.prm.max_iters) { lm.status = 1 + 0; return; }
+  if (lm.last_ok && __longlong_as_double((long long)lm.gmax_bits) <= d.prm.gtol) { lm.status = 1 + 1; return; }
+  if (lm.mu <= d.prm.min_radius) { lm.status = 1 + 4; return; }
+  lm.iter += 1;
+  lm.cand_cost = 0; lm.step2 = 0; lm.cand_xnorm2 = 0;
+  lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0;
+  atomicAdd(d.n_active, 1);
+}
+
+// ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful / LM radius update.
+template <class T> __global__ void k_lm_control(Dev<T> d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.nwin) return;
+  Lm &lm = d.lm[w];
+  if (lm.status || !lm.step_valid) return;
+  const double step_norm = sqrt(lm.step2), x_norm = sqrt(lm.xnorm2);
+  if (step_norm <= d.prm.ptol * (x_norm + d.prm.ptol)) { lm.status = 1 + 2; return; }
+  const double cost_change = lm.cost - lm.cand_cost;
+  if (fabs(cost_change) <= d.prm.ftol * lm.cost) { lm.status = 1 + 3; return; }
+  const double rel = cost_change / lm.model_change;
+  if (rel > d.prm.min_rel_dec && isfinite(lm.cand_cost)) {
+    lm.accept = 1;
+    lm.cost = lm.cand_cost;
+    lm.xnorm2 = lm.cand_xnorm2;
+    const double t = 2.0 * rel - 1.0;
+    double f = 1.0 - t * t * t;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    lm.mu = fmin(lm.mu / f, d.prm.max_radius);
+    lm.nu = 2.0; lm.last_ok = 1; lm.nsucc += 1; lm.need_lin = 1;
+  } else {
+    lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ zero
+template <class T> __global__ void k_zero_normal(Dev<T> d) {
+  const int w = blockIdx.y;
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  const long long nH = (long long)m.P * m.P, nW = (long long)m.Lpad * m.ldw;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nW; i += stride) d.W[m.W0 + i] = T(0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.N; i += stride) d.g[m.u0 + i] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.L; i += stride) d.Hll[m.lm0 + i] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) d.lm[w].gmax_bits = 0ull;
+}
+
+// ------------------------------------------------------------------------------------------------ IMU
+template <class T, int N> struct alignas(N * sizeof(T)) VecN { T v[N]; };
+
+template <class T> struct ImuLdsSink {
+  T *base;  // &A[0*KS + 6*lane]
+  int ks;
+  __device__ __forceinline__ void put(int row, int col, T v) { base[col * ks + row] = v; }
+};
+template <class T> struct NullSink {
+  __device__ __forceinline__ void put(int, int, T) {}
+};
+
+// One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane
+// evaluates one sample, writes its 6 Jacobian rows + residual as columns of A^T into LDS ([32][KS],
+// column-major in k so that the reduction reads 4 consecutive k per ds_read), then the wave forms the
+// group's 31x31 block A^T A = [J^T J, J^T r; r^T J, r^T r] with a 4x4 register tile per lane
+// (rows {ti+8a}, cols {tj+8b}: conflict-free LDS reads) and stores it -- no atomics, deterministic.
+template <class T, int CHUNK> __global__ __launch_bounds__(64) void k_imu_linearize(Dev<T> d) {
+  constexpr int KCH = 6 * CHUNK, KS = KCH + 4;
+  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
+  T *A = reinterpret_cast<T *>(smraw);
+  const ImuGroup grp = d.groups[blockIdx.x];
+  const int w = grp.win;
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  const int lane = threadIdx.x;
+  Knots4<T> k;
+  load_knots<T>(d.quat, d.pos, m.knot0 + grp.s, d.pos + 3 * (m.knot0 + grp.s), k);
+  SegConst<T> sc;
+  seg_const(k, sc, true);
+  T bias[6], wgt[6];
+  const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { bias[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
+  const V3<T> grav = mk<T>((T)m.gravity[0], (T)m.gravity[1], (T)m.gravity[2]);
+  const T idt = (T)m.inv_dt;
+  const int ti = lane >> 3, tj = lane & 7;
+  T acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
+
+  for (int c0 = 0; c0 < grp.count; c0 += CHUNK) {
+    const int nval = min(CHUNK, grp.count - c0);
+    const int kmax = (6 * nval + 3) & ~3;
+    for (int e = lane; e < 32 * kmax; e += 64) A[(e / kmax) * KS + (e % kmax)] = T(0);
+    __syncthreads();
+    if (lane < nval) {
+      const int idx = m.imu0 + grp.start + c0 + lane;
+      T gy[3], ac[3], r[6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
+      ImuLdsSink<T> sink{A + 6 * lane, KS};
+      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, r, true, sink);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) A[30 * KS + 6 * lane + i] = r[i];
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < kmax; k0 += 4) {
+      VecN<T, 4> av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        av[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (ti + 8 * a) * KS + k0);
+        bv[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (tj + 8 * a) * KS + k0);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
+    }
+    __syncthreads();
+  }
+  T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
+}
+
+// Scatter the group tiles into Hpp (lower triangle, fp64) and g.
+template <class T> __global__ void k_assemble_imu(Dev<T> d) {
+  const ImuGroup grp = d.groups[blockIdx.x];
+  const int w = grp.win;
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  const T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
+  for (int e = threadIdx.x; e < 31 * 30; e += blockDim.x) {
+    const int b = e / 30, a = e % 30;  // a < 30 : unknown row; b <= 30
+    const double v = (double)tile[a * 32 + b];
+    const int ga = imu_col(a, grp.s, m.K, grp.bias);
+    if (b == 30) { atomicAdd(&d.g[m.u0 + ga], v); continue; }
+    const int gb = imu_col(b, grp.s, m.K, grp.bias);
+    if (ga >= gb) atomicAdd(&d.Hpp[m.H0 + (long long)ga * m.P + gb], v);
+  }
+}
+
+// Residual-only pass: one lane per IMU sample, cost accumulated in fp64.
+template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, int force) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0;
+  int w = -1;
+  if (idx < d.Mtot) {
+    const ImuGroup grp = d.groups[d.imu_grp[idx]];
+    w = grp.win;
+    if (d.lm[w].status == 0 && (d.lm[w].step_valid || force)) {
+      const WinMeta &m = d.wins[w];
+      Knots4<T> k;
+      load_knots<T>(quat, pos, m.knot0 + grp.s, pos + 3 * (m.knot0 + grp.s), k);
+      SegConst<T> sc;
+      seg_const(k, sc, false);
+      T b[6], wgt[6], gy[3], ac[3], r[6];
+      const double *bp = bias + 6 * (m.bias0 + grp.bias);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { b[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
+      NullSink<T> ns;
+      imu_eval<T>(k, sc, d.imu_u[idx], (T)m.inv_dt, mk<T>((T)m.gravity[0], (T)m.gravity[1], (T)m.gravity[2]), b, gy, ac, wgt, r, false, ns);
+      T s = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) s += r[i] * r[i];
+      c = 0.5 * (double)s;
+    } else {
+      w = -1;
+    }
+  }
+  // wave reduction when the whole wave belongs to one window, else per-lane atomics
+  const int w0 = __shfl(w, 0);
+  if (__all(w == w0)) {
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && w0 >= 0) atomicAdd(&d.lm[w0].cand_cost, c);
+  } else if (w >= 0) {
+    atomicAdd(&d.lm[w].cand_cost, c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ visual
+template <class T> struct VisGlobalSink {
+  T *J;        // &Jv[v]
+  size_t stride;
+  __device__ __forceinline__ void put(int col, T j0, T j1) { J[(size_t)(2 * col) * stride] = j0; J[(size_t)(2 * col + 1) * stride] = j1; }
+};
+template <class T> struct VisNullSink {
+  __device__ __forceinline__ void put(int, T, T) {}
+};
+
+// time -> (first active knot, u) in integer ns (reference spline_segment.h:83-85); the line delay is
+// truncated to integer ns exactly as image_feature_factor.h:72.
+__device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int row, double ld, int &s, double &u) {
+  const long long ld_ns = (long long)(ld * 1e9);
+  const long long tau = t_rel + (long long)row * ld_ns;
+  s = (int)(tau / m.dt_ns);
+  u = (double)(tau % m.dt_ns) / (double)m.dt_ns;
+}
+
+// One lane per visual block.  LIN: evaluate r~, J~ (robust-corrected) and materialise them (SoA, coalesced);
+// otherwise residual only.  Cost contributions are reduced per wave and added in fp64.
+template <class T, bool LIN>
+__global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, int force) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0;
+  int w = -1;
+  if (v < d.Vtot) {
+    w = d.v_win[v];
+    const Lm &lm = d.lm[w];
+    const bool run = LIN ? lin_needed(lm) : (lm.status == 0 && (lm.step_valid || force));
+    if (run) {
+      const WinMeta &m = d.wins[w];
+      int si, sj;
+      double ui, uj;
+      const double ld = ldp[w];
+      const int rowi = d.v_rowi[v], rowj = d.v_rowj[v];
+      vis_times(m, d.v_ti[v], rowi, ld, si, ui);
+      vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
+      si = max(0, min(si, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
+      sj = max(0, min(sj, m.K - 4));
+      const double *origin = pos + 3 * (m.knot0 + si);
+      Knots4<T> ki, kj;
+      load_knots<T>(quat, pos, m.knot0 + si, origin, ki);
+      load_knots<T>(quat, pos, m.knot0 + sj, origin, kj);
+      Calib<T> cal;
+      cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
+      cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
+      cal.img_w = (T)m.img_w;
+      cal.cauchy_a = (T)m.cauchy_a;
+      const size_t V = (size_t)d.Vtot;
+      const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
+      T r[2];
+      if (LIN) {
+        VisGlobalSink<T> sink{d.Jv + v, V};
+        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v], d.v_obs[3 * V + v],
+                                   (T)rowi, (T)rowj, d_inv, r, true, sink);
+        d.rv[v] = r[0]; d.rv[V + v] = r[1];
+        d.vs[v] = si; d.vs[V + v] = sj;
+      } else {
+        VisNullSink<T> sink;
+        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v], d.v_obs[3 * V + v],
+                                   (T)rowi, (T)rowj, d_inv, r, false, sink);
+      }
+    } else {
+      w = -1;
+    }
+  }
+  if (!LIN) {
+    const int w0 = __shfl(w, 0);
+    if (__all(w == w0)) {
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+      if ((threadIdx.x & 63) == 0 && w0 >= 0) atomicAdd(&d.lm[w0].cand_cost, c);
+    } else if (w >= 0) {
+      atomicAdd(&d.lm[w].cand_cost, c);
+    }
+  }
+}
+
+// One wave per visual block: J~^T J~ and J~^T r~ scattered by global unknown index (the two ends may share
+// knots -- all ordered pairs are added, so shared knots sum correctly; reference image_feature_factor.h:165-180,215,233).
+template <class T> __global__ __launch_bounds__(64) void k_assemble_vis(Dev<T> d) {
+  const int v = blockIdx.x;
+  const int w = d.v_win[v];
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  __shared__ T J[100];
+  __shared__ int gc[50];
+  __shared__ T r[2];
+  const int lane = threadIdx.x;
+  const size_t V = (size_t)d.Vtot;
+  const int si = d.vs[v], sj = d.vs[V + v];
+  const int l = d.v_lm[v];
+  for (int e = lane; e < 100; e += 64) J[e] = d.Jv[(size_t)e * V + v];  // J[2*col + row]
+  if (lane < 50) gc[lane] = vis_col(lane, si, sj, m.P);
+  if (lane < 2) r[lane] = d.rv[(size_t)lane * V + v];
+  __syncthreads();
+  for (int e = lane; e < 2500; e += 64) {
+    const int a = e / 50, b = e % 50;
+    if (b == 48 && a != 48) continue;
+    const T h = J[2 * a] * J[2 * b] + J[2 * a + 1] * J[2 * b + 1];
+    if (a == 48) {
+      if (b == 48) atomicAdd(&d.Hll[m.lm0 + l], (double)h);
+      else atomicAdd(&d.W[m.W0 + (long long)l * m.ldw + gc[b]], h);
+    } else {
+      const int ga = gc[a], gb = gc[b];
+      if (ga >= gb) atomicAdd(&d.Hpp[m.H0 + (long long)ga * m.P + gb], (double)h);
+    }
+  }
+  if (lane < 50) {
+    const double gv = (double)(J[2 * lane] * r[0] + J[2 * lane + 1] * r[1]);
+    const int ga = (lane == 48) ? (m.P + l) : gc[lane];
+    atomicAdd(&d.g[m.u0 + ga], gv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bias chain + prior
+__device__ __forceinline__ const double *prior_block_ptr(const WinMeta &m, int kind, int idx, const double *quat, const double *pos,
+                                                         const double *bias, const double *ldp, int w) {
+  switch (kind) {
+    case 0: return quat + 4 * (m.knot0 + idx);
+    case 1: return pos + 3 * (m.knot0 + idx);
+    case 2: return bias + 6 * (m.bias0 + idx);
+    case 3: return bias + 6 * (m.bias0 + idx) + 3;
+    default: return ldp + w;
+  }
+}
+
+// BiasFactor (trajectory_value_factor.h:45-99) and MarginalizationFactor (marginalization_factor.cpp:326-373), fp64.
+// With the prior written r = r0 + J0 dx:  J^T r = J0^T r0 + (J0^T J0) dx,  |r|^2 = r0^T r0 + 2 b0.dx + dx^T (J0^T J0) dx.
+// LIN: add to Hpp / g.  Otherwise: cost only (into lm.cand_cost).
+template <class T, bool LIN>
+__global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, const double *pos, const double *bias, const double *ldp, int force) {
+  const int w = blockIdx.x;
+  const Lm &lm = d.lm[w];
+  if (LIN ? !lin_needed(lm) : !(lm.status == 0 && (lm.step_valid || force))) return;
+  const WinMeta &m = d.wins[w];
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  double *dx = smd;                 // [pn]
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double cost = 0.0;
+  for (int e = tid; e < m.NB * 6; e += 256) {
+    const int b = e / 6, k = e % 6;
+    const int bi = d.bc_i[m.bc0 + b], bj = d.bc_j[m.bc0 + b];
+    const double wv = d.bc_w[(size_t)(m.bc0 + b) * 6 + k];
+    const double r = wv * (bias[6 * (m.bias0 + bj) + k] - bias[6 * (m.bias0 + bi) + k]);
+    cost += 0.5 * r * r;
+    if (LIN) {
+      const int ii = 6 * m.K + 6 * bi + k, jj = 6 * m.K + 6 * bj + k;
+      atomicAdd(&d.g[m.u0 + ii], -wv * r);
+      atomicAdd(&d.g[m.u0 + jj], wv * r);
+      atomicAdd(&d.Hpp[m.H0 + (long long)ii * m.P + ii], wv * wv);
+      atomicAdd(&d.Hpp[m.H0 + (long long)jj * m.P + jj], wv * wv);
+      const int hi = max(ii, jj), lo = min(ii, jj);
+      atomicAdd(&d.Hpp[m.H0 + (long long)hi * m.P + lo], -wv * wv);
+    }
+  }
+  const int n = m.pn;
+  if (n > 0) {
+    for (int b = tid; b < m.pnb; b += 256) {
+      const int kind = d.p_kind[m.pblk0 + b], idx = d.p_index[m.pblk0 + b], off = d.p_off[m.pblk0 + b];
+      const double *x = prior_block_ptr(m, kind, idx, quat, pos, bias, ldp, w);
+      const double *x0 = d.p_x0 + 4 * (size_t)(m.pblk0 + b);
+      if (kind == 0) {  // dx = 2 vec(q0^-1 q), sign-fixed (marginalization_factor.cpp:344-350)
+        const Q4<double> dq = qmul_raw(qmk<double>(-x0[0], -x0[1], -x0[2], x0[3]), qmk<double>(x[0], x[1], x[2], x[3]));
+        const double sg = (dq.w >= 0) ? 2.0 : -2.0;
+        dx[off] = sg * dq.x; dx[off + 1] = sg * dq.y; dx[off + 2] = sg * dq.z;
+      } else {
+        const int sz = (kind == 4) ? 1 : 3;
+        for (int k = 0; k < sz; ++k) dx[off + k] = x[k] - x0[k];
+      }
+    }
+    __syncthreads();
+    const double *pH = d.pH + m.pH0, *b0 = d.pb0 + m.pv0;
+    const int *pcol = d.pcol + m.pv0;
+    for (int i = tid; i < n; i += 256) {
+      double hd = 0.0;
+      for (int j = 0; j < n; ++j) hd += pH[(size_t)i * n + j] * dx[j];
+      cost += dx[i] * (b0[i] + 0.5 * hd);
+      if (LIN && pcol[i] >= 0) atomicAdd(&d.g[m.u0 + pcol[i]], b0[i] + hd);
+    }
+    if (tid == 0) cost += 0.5 * d.pc0[w];
+    if (LIN) {
+      for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        const int ci = pcol[i], cj = pcol[j];
+        if (ci >= 0 && cj >= 0 && ci >= cj) atomicAdd(&d.Hpp[m.H0 + (long long)ci * m.P + cj], pH[e]);
+      }
+    }
+  }
+  if (!LIN) {
+    red[tid] = cost;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    if (tid == 0) atomicAdd(&d.lm[w].cand_cost, red[0]);
+  }
+}
+
+// Jacobi scaling (computed once, at iteration 0: Ceres jacobi_scaling), gradient max-norm of
+// x - Plus(x, -g) (Ceres gradient_max_norm) and |x|^2 of the reduced program.
+template <class T> __global__ void k_post_linearize(Dev<T> d) {
+  const int w = blockIdx.y;
+  Lm &lm = d.lm[w];
+  if (!lin_needed(lm)) return;
+  const WinMeta &m = d.wins[w];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m.N) return;
+  const bool act = d.active[m.u0 + j] != 0;
+  if (!lm.scaled) {
+    const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.P + j] : d.Hll[m.lm0 + j - m.P];
+    d.cscale[m.u0 + j] = act ? 1.0 / (1.0 + sqrt(fmax(h, 0.0))) : 1.0;
+  }
+  if (!act) return;
+  const double *g = d.g + m.u0;
+  double gm = 0.0, x2 = 0.0;
+  const int K6 = 6 * m.K;
+  if (j < K6) {
+    const int k = j / 6, c = j % 6;
+    if (c == 0) {  // rotation block: ambient difference q - q*exp(-g)
+      const double *q = d.quat + 4 * (m.knot0 + k);
+      const Q4<double> q0 = qmk<double>(q[0], q[1], q[2], q[3]);
+      const Q4<double> q1 = qmul(q0, so3_exp(mk<double>(-g[j], -g[j + 1], -g[j + 2])));
+      gm = fmax(fmax(fabs(q0.x - q1.x), fabs(q0.y - q1.y)), fmax(fabs(q0.z - q1.z), fabs(q0.w - q1.w)));
+      x2 = q0.x * q0.x + q0.y * q0.y + q0.z * q0.z + q0.w * q0.w;
+    } else if (c >= 3) {
+      gm = fabs(g[j]);
+      const double p = d.pos[3 * (m.knot0 + k) + c - 3];
+      x2 = p * p;
+    }
+  } else if (j < m.P - 1) {
+    gm = fabs(g[j]);
+    const double b = d.bias[6 * m.bias0 + (j - K6)];
+    x2 = b * b;
+  } else if (j == m.P - 1) {
+    const double ld = d.ld[w];
+    double nl = ld - g[j];
+    if (!m.fix_ld) nl = fmin(fmax(nl, m.ld_lo), m.ld_hi);
+    gm = fabs(ld - nl);
+    x2 = ld * ld;
+  } else {
+    gm = fabs(g[j]);
+    const double r = d.rho[m.lm0 + j - m.P];
+    x2 = r * r;
+  }
+  if (gm > 0.0) atomicMax(&lm.gmax_bits, (unsigned long long)__double_as_longlong(gm));
+  if (lm.iter == 0 && x2 > 0.0) atomicAdd(&lm.xnorm2, x2);
+}
+
+// ------------------------------------------------------------------------------------------------ Schur + solve
+// LM diagonal D^2 = clamp(diag(J^T J), min, max) / mu on the Jacobi-scaled system (Ceres
+// LevenbergMarquardtStrategy::ComputeStep), expressed for the unscaled system: dd_j = clamp(c_j^2 H_jj)/(mu c_j^2).
+template <class T> __global__ void k_damping(Dev<T> d) {
+  const int w = blockIdx.y;
+  const Lm &lm = d.lm[w];
+  if (lm.status) return;
+  const WinMeta &m = d.wins[w];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m.N) return;
+  const bool act = d.active[m.u0 + j] != 0;
+  const double c = d.cscale[m.u0 + j];
+  const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.P + j] : d.Hll[m.lm0 + j - m.P];
+  double s = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
+  const double dd = act ? s / (lm.mu * c * c) : 0.0;
+  d.dd[m.u0 + j] = dd;
+  if (j >= m.P) d.dinv[m.lm0 + j - m.P] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
+}
+
+__device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> (bi >= bj), row-major over the lower triangle
+  bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  bj = t - bi * (bi + 1) / 2;
+}
+
+// S = Hpp + D^2 - W^T diag(dinv) W (lower triangle) on the matrix cores: one wave per 32x32 tile,
+// v_mfma_f32_32x32x2_f32 over the landmark dimension (2 landmarks per instruction), operands read
+// straight from the landmark-major W (32 consecutive floats per half-wave: coalesced).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
+  const int w = blockIdx.y;
+  if (d.lm[w].status) return;
+  const WinMeta &m = d.wins[w];
+  const int nt = (m.P + 31) / 32;
+  if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;
+  int bi, bj;
+  tile_decode(blockIdx.x, bi, bj);
+  const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+  const int i = 32 * bi + l31, j = 32 * bj + l31;
+  const float ai = (i < m.P && d.active[m.u0 + i]) ? 1.0f : 0.0f;
+  const float aj = (j < m.P && d.active[m.u0 + j]) ? 1.0f : 0.0f;
+  const float *Wp = d.W + m.W0;
+  const double *dinv = d.dinv + m.lm0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int l0 = 0; l0 < m.Lpad; l0 += 2) {
+    const int l = l0 + half;
+    const float di = (l < m.L) ? (float)dinv[l] : 0.0f;
+    const float a = Wp[(long long)l * m.ldw + i] * ai;
+    const float b = Wp[(long long)l * m.ldw + j] * aj * di;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  double *S = d.S + m.H0;
+  const double *H = d.Hpp + m.H0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int ii = 32 * bi + row, jj = 32 * bj + l31;
+    if (ii < m.P && jj <= ii) {
+      const bool on = d.active[m.u0 + ii] && d.active[m.u0 + jj];
+      double val;
+      if (on) val = H[(long long)ii * m.P + jj] - (double)acc[r] + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
+      else val = (ii == jj) ? 1.0 : 0.0;
+      S[(long long)ii * m.P + jj] = val;
+    }
+  }
+}
+
+// Same contraction on the vector ALU, any scalar type (fp64 debugging path / use_mfma = 0).
+template <class T> __global__ void k_schur_generic(Dev<T> d) {
+  const int w = blockIdx.y;
+  if (d.lm[w].status) return;
+  const WinMeta &m = d.wins[w];
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)m.P * m.P) return;
+  const int ii = (int)(e / m.P), jj = (int)(e % m.P);
+  if (jj > ii) return;
+  const bool on = d.active[m.u0 + ii] && d.active[m.u0 + jj];
+  double val;
+  if (on) {
+    const T *Wp = d.W + m.W0;
+    double acc = 0.0;
+    for (int l = 0; l < m.L; ++l) acc += (double)Wp[(long long)l * m.ldw + ii] * (double)Wp[(long long)l * m.ldw + jj] * d.dinv[m.lm0 + l];
+    val = d.Hpp[m.H0 + (long long)ii * m.P + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
+  } else {
+    val = (ii == jj) ? 1.0 : 0.0;
+  }
+  d.S[m.H0 + (long long)ii * m.P + jj] = val;
+}
+
+// rhs_p = -g_p + W^T diag(dinv) g_l
+template <class T> __global__ void k_rhs(Dev<T> d) {
+  const int w = blockIdx.y;
+  if (d.lm[w].status) return;
+  const WinMeta &m = d.wins[w];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.P) return;
+  double v = 0.0;
+  if (d.active[m.u0 + i]) {
+    const T *Wp = d.W + m.W0;
+    v = -d.g[m.u0 + i];
+    for (int l = 0; l < m.L; ++l) v += (double)Wp[(long long)l * m.ldw + i] * d.dinv[m.lm0 + l] * d.g[m.u0 + m.P + l];
+  }
+  d.rhs[m.p0 + i] = v;
+}
+
+// Dense fp64 Cholesky + two triangular solves of the P x P reduced system, one workgroup per window.
+// Right-looking, 32-column panels: the diagonal block is factored in LDS, the panel below it is solved
+// one row per lane against the LDS block and kept in LDS for the trailing update.  Result in delta[0..P).
+template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T> d) {
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) double smc[];
+  double *D = smc;             // [32][33]
+  double *yb = smc + 32 * 33;  // [32]
+  int &s_fail = *reinterpret_cast<int *>(yb + 32);  // kept in the dynamic region: a static __shared__ would shift its base off 8 B
+  double *Lp = yb + 34;        // [rows][33]
+  double *S = d.S + m.H0;
+  double *x = d.delta + m.u0;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  for (int jb = 0; jb < P; jb += 32) {
+    const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0;
+    for (int e = tid; e < nb * nb; e += 256) {
+      const int i = e / nb, j = e % nb;
+      D[i * 33 + j] = (j <= i) ? S[(long long)(jb + i) * P + jb + j] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+      if (tid == 0) {
+        double dj = D[j * 33 + j];
+        if (!(dj > 0.0) || !isfinite(dj)) { s_fail = 1; dj = 1.0; }
+        D[j * 33 + j] = sqrt(dj);
+      }
+      __syncthreads();
+      const double djj = D[j * 33 + j];
+      if (tid > j && tid < nb) D[tid * 33 + j] /= djj;
+      __syncthreads();
+      const int n2 = nb - j - 1;
+      for (int e = tid; e < n2 * n2; e += 256) {
+        const int ii = e / n2, cc = e % n2;
+        if (cc <= ii) D[(j + 1 + ii) * 33 + j + 1 + cc] -= D[(j + 1 + ii) * 33 + j] * D[(j + 1 + cc) * 33 + j];
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += 256) {
+      const int i = e / nb, j = e % nb;
+      if (j <= i) S[(long long)(jb + i) * P + jb + j] = D[i * 33 + j];
+    }
+    for (int r = tid; r < nt; r += 256) {  // panel rows: L21 = A21 L11^-T
+      double a[32];
+      double *Srow = S + (long long)(r0 + r) * P + jb;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) a[j] = (j < nb) ? Srow[j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (j < nb) {
+          double s = a[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) s -= a[k] * D[j * 33 + k];
+          a[j] = s / D[j * 33 + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (j < nb) Srow[j] = a[j];
+        Lp[r * 33 + j] = (j < nb) ? a[j] : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < nt; r += 256) {  // trailing update A22 -= L21 L21^T (lower)
+      double a[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) a[j] = Lp[r * 33 + j];
+      double *Srow = S + (long long)(r0 + r) * P + r0;
+      for (int c = 0; c <= r; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += a[k] * Lp[c * 33 + k];
+        Srow[c] -= s;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- forward substitution L y = rhs
+  for (int i = tid; i < P; i += 256) x[i] = d.rhs[m.p0 + i];
+  __syncthreads();
+  for (int jb = 0; jb < P; jb += 32) {
+    const int nb = min(32, P - jb), r0 = jb + nb;
+    if (tid < 64) {  // wave 0: 32x32 triangular solve with cross-lane broadcasts
+      const int lane = tid;
+      double row[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) row[k] = (lane < nb && k <= lane && k < nb) ? S[(long long)(jb + lane) * P + jb + k] : 0.0;
+      double bi = (lane < nb) ? x[jb + lane] : 0.0;
+      double dii = 1.0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) if (k == lane) dii = row[k];
+      if (lane >= nb) dii = 1.0;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const double yj = __shfl(bi, j) / __shfl(dii, j);
+        if (lane > j) bi -= row[j] * yj;
+        if (lane == j) bi = yj;
+      }
+      if (lane < nb) { x[jb + lane] = bi; yb[lane] = bi; }
+    }
+    __syncthreads();
+    for (int i = r0 + tid; i < P; i += 256) {
+      const double *Srow = S + (long long)i * P + jb;
+      double s = 0.0;
+      for (int k = 0; k < nb; ++k) s += Srow[k] * yb[k];
+      x[i] -= s;
+    }
+    __syncthreads();
+  }
+  // ---- backward substitution L^T x = y
+  const int nblk = (P + 31) / 32;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int jb = 32 * b, nb = min(32, P - jb);
+    if (tid < 64) {
+      const int lane = tid;
+      double col[32];  // column `lane` of the diagonal block: L[jb+i][jb+lane], i >= lane
+#pragma unroll
+      for (int i = 0; i < 32; ++i) col[i] = (lane < nb && i >= lane && i < nb) ? S[(long long)(jb + i) * P + jb + lane] : 0.0;
+      double bj = (lane < nb) ? x[jb + lane] : 0.0;
+      double djj = 1.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) if (i == lane) djj = col[i];
+      if (lane >= nb) djj = 1.0;
+#pragma unroll
+      for (int i = 31; i >= 0; --i) {
+        const double xi = __shfl(bj, i) / __shfl(djj, i);
+        if (lane < i) bj -= col[i] * xi;
+        if (lane == i) bj = xi;
+      }
+      if (lane < nb) { x[jb + lane] = bj; yb[lane] = bj; }
+    }
+    __syncthreads();
+    for (int j = tid; j < jb; j += 256) {
+      double s = 0.0;
+      for (int ii = 0; ii < nb; ++ii) s += S[(long long)(jb + ii) * P + j] * yb[ii];
+      x[j] -= s;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) lm.chol_fail = s_fail;
+}
+
+// delta_l = dinv_l (-g_l - W_l . delta_p);  model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres'
+// -(J y)^T (r + J y / 2) when (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
+template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status) return;
+  const WinMeta &m = d.wins[w];
+  __shared__ double red[256];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  double *x = d.delta + m.u0;
+  const double *g = d.g + m.u0, *dd = d.dd + m.u0;
+  const T *Wp = d.W + m.W0;
+  for (int l = tid; l < m.L; l += 256) {
+    double s = -g[m.P + l];
+    const T *Wr = Wp + (long long)l * m.ldw;
+    for (int i = 0; i < m.P; ++i) s -= (double)Wr[i] * x[i];
+    x[m.P + l] = d.active[m.u0 + m.P + l] ? s * d.dinv[m.lm0 + l] : 0.0;
+  }
+  __syncthreads();
+  double mc = 0.0;
+  for (int j = tid; j < m.N; j += 256) {
+    const double dj = x[j];
+    if (!isfinite(dj)) bad = 1;
+    if (d.active[m.u0 + j]) mc += 0.5 * dj * (dd[j] * dj - g[j]);
+  }
+  red[tid] = mc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  if (tid == 0) {
+    lm.model_change = red[0];
+    const bool valid = !lm.chol_fail && !bad && (red[0] > 0.0);
+    if (valid) { lm.step_valid = 1; lm.invalid = 0; }
+    else {
+      lm.step_valid = 0;
+      if (++lm.invalid >= d.prm.max_invalid) lm.status = 1 + 5;
+      else { lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ update
+// candidate = Plus(x, delta): q <- q*exp(d) (ceres_local_param.h:137-145), additive elsewhere, line delay
+// projected on its box (trajectory_estimator.cpp:316-317).  ACCEPT: copy candidate -> current where accepted.
+template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double step2 = 0.0, x2 = 0.0;
+  int w = -1;
+  if (t < d.Ktot) {
+    w = d.knot_win[t];
+    const Lm &lm = d.lm[w];
+    if (ACCEPT) {
+      if (lm.accept) {
+        for (int c = 0; c < 4; ++c) d.quat[4 * t + c] = d.cquat[4 * t + c];
+        for (int c = 0; c < 3; ++c) d.pos[3 * t + c] = d.cpos[3 * t + c];
+      }
+      return;
+    }
+    if (lm.status || !lm.step_valid) return;
+    const WinMeta &m = d.wins[w];
+    const int k = t - m.knot0;
+    const double *dl = d.delta + m.u0 + 6 * k;
+    const bool ar = d.active[m.u0 + 6 * k] != 0, ap = d.active[m.u0 + 6 * k + 3] != 0;
+    const Q4<double> q0 = qmk<double>(d.quat[4 * t], d.quat[4 * t + 1], d.quat[4 * t + 2], d.quat[4 * t + 3]);
+    Q4<double> q1 = q0;
+    if (ar) q1 = qmul(q0, so3_exp(mk<double>(dl[0], dl[1], dl[2])));
+    d.cquat[4 * t] = q1.x; d.cquat[4 * t + 1] = q1.y; d.cquat[4 * t + 2] = q1.z; d.cquat[4 * t + 3] = q1.w;
+    if (ar) {
+      step2 += (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) + (q1.z - q0.z) * (q1.z - q0.z) + (q1.w - q0.w) * (q1.w - q0.w);
+      x2 += q1.x * q1.x + q1.y * q1.y + q1.z * q1.z + q1.w * q1.w;
+    }
+    for (int c = 0; c < 3; ++c) {
+      const double p0 = d.pos[3 * t + c], p1 = ap ? p0 + dl[3 + c] : p0;
+      d.cpos[3 * t + c] = p1;
+      if (ap) { step2 += (p1 - p0) * (p1 - p0); x2 += p1 * p1; }
+    }
+  } else if (t < d.Ktot + d.Ftot) {
+    const int f = t - d.Ktot;
+    w = d.bias_win[f];
+    const Lm &lm = d.lm[w];
+    if (ACCEPT) {
+      if (lm.accept) for (int c = 0; c < 6; ++c) d.bias[6 * f + c] = d.cbias[6 * f + c];
+      return;
+    }
+    if (lm.status || !lm.step_valid) return;
+    const WinMeta &m = d.wins[w];
+    const int u = 6 * m.K + 6 * (f - m.bias0);
+    for (int c = 0; c < 6; ++c) {
+      const bool a = d.active[m.u0 + u + c] != 0;
+      const double b0 = d.bias[6 * f + c], b1 = a ? b0 + d.delta[m.u0 + u + c] : b0;
+      d.cbias[6 * f + c] = b1;
+      if (a) { step2 += (b1 - b0) * (b1 - b0); x2 += b1 * b1; }
+    }
+  } else if (t < d.Ktot + d.Ftot + d.Ltot) {
+    const int l = t - d.Ktot - d.Ftot;
+    w = d.lm_win[l];
+    const Lm &lm = d.lm[w];
+    if (ACCEPT) {
+      if (lm.accept) d.rho[l] = d.crho[l];
+      return;
+    }
+    if (lm.status || !lm.step_valid) return;
+    const WinMeta &m = d.wins[w];
+    const int u = m.P + (l - m.lm0);
+    const bool a = d.active[m.u0 + u] != 0;
+    const double r0 = d.rho[l], r1 = a ? r0 + d.delta[m.u0 + u] : r0;
+    d.crho[l] = r1;
+    if (a) { step2 += (r1 - r0) * (r1 - r0); x2 += r1 * r1; }
+  } else if (t < d.Ktot + d.Ftot + d.Ltot + d.nwin) {
+    w = t - d.Ktot - d.Ftot - d.Ltot;
+    const Lm &lm = d.lm[w];
+    if (ACCEPT) {
+      if (lm.accept) d.ld[w] = d.cld[w];
+      return;
+    }
+    if (lm.status || !lm.step_valid) return;
+    const WinMeta &m = d.wins[w];
+    const bool a = d.active[m.u0 + m.P - 1] != 0;
+    const double l0 = d.ld[w];
+    double l1 = a ? l0 + d.delta[m.u0 + m.P - 1] : l0;
+    if (a && !m.fix_ld) l1 = fmin(fmax(l1, m.ld_lo), m.ld_hi);
+    d.cld[w] = l1;
+    if (a) { step2 += (l1 - l0) * (l1 - l0); x2 += l1 * l1; }
+  } else {
+    return;
+  }
+  if (!ACCEPT && w >= 0) {
+    atomicAdd(&d.lm[w].step2, step2);
+    atomicAdd(&d.lm[w].cand_xnorm2, x2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ trajectory query
+// Se3Spline::poseNs / transVelWorld / rotVelBody / transAccelWorld (se3_spline.h:361-399), fp64, one lane per query.
+template <class T>
+__global__ void k_spline_eval(Dev<T> d, int w, int n, const long long *t_rel, double *pose7, double *vel3, double *omega3, double *acc3,
+                              int *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const WinMeta &m = d.wins[w];
+  const long long st = t_rel[i];
+  const int s = (int)(st / m.dt_ns);
+  if (st < 0 || s < 0 || s + 3 >= m.K) { atomicExch(err, 1); return; }
+  const double u = (double)(st % m.dt_ns) / (double)m.dt_ns;
+  const double zero3[3] = {0, 0, 0};
+  Knots4<double> k;
+  load_knots<double>(d.quat, d.pos, m.knot0 + s, zero3, k);
+  SegConst<double> sc;
+  seg_const(k, sc, false);
+  const double idt = m.inv_dt;
+  if (pose7) {
+    const Q4<double> q = eval_R(k.q, sc, u);
+    double c[4];
+    basis<double, false, 0>(u, 1.0, c);
+    V3<double> p = mk<double>(0, 0, 0);
+    for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
+    double *o = pose7 + 7 * (size_t)i;
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+  }
+  if (vel3) {
+    double c[4];
+    basis<double, false, 1>(u, idt, c);
+    V3<double> p = mk<double>(0, 0, 0);
+    for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
+    vel3[3 * (size_t)i] = p.x; vel3[3 * (size_t)i + 1] = p.y; vel3[3 * (size_t)i + 2] = p.z;
+  }
+  if (acc3) {
+    double c[4];
+    basis<double, false, 2>(u, idt * idt, c);
+    V3<double> p = mk<double>(0, 0, 0);
+    for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
+    acc3[3 * (size_t)i] = p.x; acc3[3 * (size_t)i + 1] = p.y; acc3[3 * (size_t)i + 2] = p.z;
+  }
+  if (omega3) {
+    const V3<double> o = eval_omega(sc, u, idt);
+    omega3[3 * (size_t)i] = o.x; omega3[3 * (size_t)i + 1] = o.y; omega3[3 * (size_t)i + 2] = o.z;
+  }
+}
+
+}  // namespace ctv

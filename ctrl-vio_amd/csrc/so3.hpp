@@ -1,0 +1,244 @@
+// so3.hpp -- device-side SO(3) / small fixed-size algebra for gfx950, templated on the scalar.
+//
+// Conventions follow the reference (quaternion storage x,y,z,w; right perturbation R*exp(d)):
+//   exp/log          src/sophus_lib/so3.hpp:534-569 / 220-262
+//   Jr / Jr^-1       src/utils/sophus_utils.hpp:166-199 / 210-242
+//   q*q renormalise  src/sophus_lib/so3.hpp:338-355
+// T = double reproduces the reference's branches and thresholds (eps 1e-10).  T = float keeps the
+// same functions but evaluates the cancellation-prone coefficients ((1-cos)/t^2, (t-sin)/t^3,
+// 1/t^2-(1+cos)/(2 t sin)) by half-angle identities / Taylor series below |t| < 1, because the
+// reference's closed forms lose all fp32 digits at the ~1e-2 rad knot-to-knot rotations seen here.
+#pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CTV_DI __host__ __device__ __forceinline__
+#else  // plain g++ build of the same math, used ONLY by tests/host_math_check.cpp (not a product path)
+#include <cmath>
+#define CTV_DI inline
+#endif
+
+namespace ctv {
+
+template <class T> struct V3 { T x, y, z; };
+template <class T> struct Q4 { T x, y, z, w; };
+template <class T> struct M3 { T m[9]; };  // row-major
+
+template <class T> CTV_DI V3<T> mk(T x, T y, T z) { V3<T> v; v.x = x; v.y = y; v.z = z; return v; }
+template <class T> CTV_DI V3<T> operator+(V3<T> a, V3<T> b) { return mk<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> CTV_DI V3<T> operator-(V3<T> a, V3<T> b) { return mk<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> CTV_DI V3<T> operator*(T s, V3<T> a) { return mk<T>(s * a.x, s * a.y, s * a.z); }
+template <class T> CTV_DI V3<T> neg(V3<T> a) { return mk<T>(-a.x, -a.y, -a.z); }
+template <class T> CTV_DI T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> CTV_DI V3<T> cross(V3<T> a, V3<T> b) {
+  return mk<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+template <class T> CTV_DI M3<T> m3_id() { M3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = T(0); r.m[0] = r.m[4] = r.m[8] = T(1); return r; }
+template <class T> CTV_DI M3<T> m3_zero() { M3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = T(0); return r; }
+template <class T> CTV_DI M3<T> mul(const M3<T> &A, const M3<T> &B) {
+  M3<T> C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+  return C;
+}
+template <class T> CTV_DI M3<T> mulT(const M3<T> &A, const M3<T> &B) {  // A * B^T
+  M3<T> C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[3 * j] + A.m[3 * i + 1] * B.m[3 * j + 1] + A.m[3 * i + 2] * B.m[3 * j + 2];
+  return C;
+}
+template <class T> CTV_DI V3<T> mul(const M3<T> &A, V3<T> v) {
+  return mk<T>(A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z,
+               A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z);
+}
+template <class T> CTV_DI M3<T> scale(const M3<T> &A, T s) { M3<T> C; for (int i = 0; i < 9; ++i) C.m[i] = s * A.m[i]; return C; }
+template <class T> CTV_DI M3<T> add(const M3<T> &A, const M3<T> &B) { M3<T> C; for (int i = 0; i < 9; ++i) C.m[i] = A.m[i] + B.m[i]; return C; }
+template <class T> CTV_DI M3<T> sub(const M3<T> &A, const M3<T> &B) { M3<T> C; for (int i = 0; i < 9; ++i) C.m[i] = A.m[i] - B.m[i]; return C; }
+// hat: src/sophus_lib/so3.hpp:618-627
+template <class T> CTV_DI M3<T> hat(V3<T> w) {
+  M3<T> H;
+  H.m[0] = 0; H.m[1] = -w.z; H.m[2] = w.y; H.m[3] = w.z; H.m[4] = 0; H.m[5] = -w.x; H.m[6] = -w.y; H.m[7] = w.x; H.m[8] = 0;
+  return H;
+}
+// A * hat(w)
+template <class T> CTV_DI M3<T> mul_hat(const M3<T> &A, V3<T> w) {
+  M3<T> C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const T a0 = A.m[3 * i], a1 = A.m[3 * i + 1], a2 = A.m[3 * i + 2];
+    C.m[3 * i] = a1 * w.z - a2 * w.y;
+    C.m[3 * i + 1] = a2 * w.x - a0 * w.z;
+    C.m[3 * i + 2] = a0 * w.y - a1 * w.x;
+  }
+  return C;
+}
+
+template <class T> CTV_DI Q4<T> qmk(T x, T y, T z, T w) { Q4<T> q; q.x = x; q.y = y; q.z = z; q.w = w; return q; }
+template <class T> CTV_DI Q4<T> qconj(Q4<T> a) { return qmk<T>(-a.x, -a.y, -a.z, a.w); }
+template <class T> CTV_DI Q4<T> qmul_raw(Q4<T> a, Q4<T> b) {
+  return qmk<T>(a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+                a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
+}
+template <class T> CTV_DI Q4<T> qmul(Q4<T> a, Q4<T> b) {
+  Q4<T> o = qmul_raw(a, b);
+  const T n2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+  const T s = T(2) / (T(1) + n2);
+  o.x *= s; o.y *= s; o.z *= s; o.w *= s;
+  return o;
+}
+template <class T> CTV_DI V3<T> qrot(Q4<T> q, V3<T> v) {
+  const V3<T> qv = mk<T>(q.x, q.y, q.z);
+  V3<T> uv = cross(qv, v);
+  uv = T(2) * uv;
+  return v + q.w * uv + cross(qv, uv);
+}
+template <class T> CTV_DI M3<T> q2R(Q4<T> q) {
+  const T tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const T twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const T tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  M3<T> R;
+  R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz; R.m[2] = txz + twy;
+  R.m[3] = txy + twz; R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+  R.m[6] = txz - twy; R.m[7] = tyz + twx; R.m[8] = 1 - (txx + tyy);
+  return R;
+}
+
+// ---- transcendental wrappers
+CTV_DI float t_sin(float x) { return sinf(x); }
+CTV_DI double t_sin(double x) { return sin(x); }
+CTV_DI float t_cos(float x) { return cosf(x); }
+CTV_DI double t_cos(double x) { return cos(x); }
+CTV_DI float t_atan(float x) { return atanf(x); }
+CTV_DI double t_atan(double x) { return atan(x); }
+CTV_DI float t_sqrt(float x) { return sqrtf(x); }
+CTV_DI double t_sqrt(double x) { return sqrt(x); }
+CTV_DI float t_log1p(float x) { return log1pf(x); }
+CTV_DI double t_log1p(double x) { return log1p(x); }
+CTV_DI float t_abs(float x) { return fabsf(x); }
+CTV_DI double t_abs(double x) { return fabs(x); }
+
+// ---- exp: so3.hpp:534-569 (series branch below eps; fp32 switches to the series earlier)
+CTV_DI Q4<double> so3_exp(V3<double> w) {
+  const double th2 = dot(w, w), th = sqrt(th2);
+  double im, re;
+  if (th < 1e-10) {
+    const double th4 = th2 * th2;
+    im = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+    re = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+  } else {
+    im = sin(0.5 * th) / th;
+    re = cos(0.5 * th);
+  }
+  return qmk<double>(im * w.x, im * w.y, im * w.z, re);
+}
+CTV_DI Q4<float> so3_exp(V3<float> w) {
+  const float th2 = dot(w, w);
+  float im, re;
+  if (th2 < 1e-4f) {
+    const float th4 = th2 * th2;
+    im = 0.5f - (1.0f / 48.0f) * th2 + (1.0f / 3840.0f) * th4;
+    re = 1.0f - (1.0f / 8.0f) * th2 + (1.0f / 384.0f) * th4;
+  } else {
+    const float th = sqrtf(th2);
+    im = sinf(0.5f * th) / th;
+    re = cosf(0.5f * th);
+  }
+  return qmk<float>(im * w.x, im * w.y, im * w.z, re);
+}
+
+// ---- log: so3.hpp:220-262 (atan form)
+CTV_DI V3<double> so3_log(Q4<double> q) {
+  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z, n = sqrt(n2), w = q.w;
+  double f;
+  if (n < 1e-10) f = 2.0 / w - 2.0 * n2 / (w * w * w);
+  else if (fabs(w) < 1e-10) f = (w > 0 ? 3.14159265358979323846 : -3.14159265358979323846) / n;
+  else f = 2.0 * atan(n / w) / n;
+  return mk<double>(f * q.x, f * q.y, f * q.z);
+}
+CTV_DI V3<float> so3_log(Q4<float> q) {
+  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
+  float f;
+  if (n2 < 1e-6f * w * w) {              // atan(x)/x = 1 - x^2/3 + x^4/5, x = n/w
+    const float x2 = n2 / (w * w);
+    f = (2.0f / w) * (1.0f - x2 * (1.0f / 3.0f) + x2 * x2 * 0.2f);
+  } else if (fabsf(w) < 1e-5f) {
+    f = (w > 0 ? 3.14159265f : -3.14159265f) / sqrtf(n2);
+  } else {
+    const float n = sqrtf(n2);
+    f = 2.0f * atanf(n / w) / n;
+  }
+  return mk<float>(f * q.x, f * q.y, f * q.z);
+}
+
+// ---- Jr: I - a*hat + b*hat^2,  a = (1-cos t)/t^2, b = (t - sin t)/t^3   (sophus_utils.hpp:166-199)
+CTV_DI void jr_coeffs(double n2, double &a, double &b) {
+  if (n2 > 1e-10) { const double n = sqrt(n2); a = (1 - cos(n)) / n2; b = (n - sin(n)) / (n2 * n); }
+  else { a = 0.5; b = 1.0 / 6.0; }
+}
+CTV_DI void jr_coeffs(float n2, float &a, float &b) {
+  if (n2 < 1.0f) {
+    // a = 1/2 - t^2/24 + t^4/720 - t^6/40320 + t^8/3628800 ; b = 1/6 - t^2/120 + t^4/5040 - t^6/362880 + t^8/39916800
+    a = 0.5f + n2 * (-1.0f / 24.0f + n2 * (1.0f / 720.0f + n2 * (-1.0f / 40320.0f + n2 * (1.0f / 3628800.0f))));
+    b = 1.0f / 6.0f + n2 * (-1.0f / 120.0f + n2 * (1.0f / 5040.0f + n2 * (-1.0f / 362880.0f + n2 * (1.0f / 39916800.0f))));
+  } else {
+    const float n = sqrtf(n2), sh = sinf(0.5f * n);
+    a = 2.0f * sh * sh / n2;
+    b = (n - sinf(n)) / (n2 * n);
+  }
+}
+template <class T> CTV_DI M3<T> so3_Jr(V3<T> phi) {
+  T a, b;
+  jr_coeffs(dot(phi, phi), a, b);
+  const M3<T> H = hat(phi), H2 = mul(H, H);
+  M3<T> J = m3_id<T>();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J.m[i] += -a * H.m[i] + b * H2.m[i];
+  return J;
+}
+// ---- Jr^-1: I + hat/2 + c*hat^2, c = 1/t^2 - (1+cos t)/(2 t sin t)   (sophus_utils.hpp:210-242)
+CTV_DI double jrinv_coeff(double n2) {
+  if (n2 > 1e-10) { const double n = sqrt(n2); return 1.0 / n2 - (1 + cos(n)) / (2 * n * sin(n)); }
+  return 1.0 / 12.0;
+}
+CTV_DI float jrinv_coeff(float n2) {
+  if (n2 < 1.0f)  // 1/12 + t^2/720 + t^4/30240 + t^6/1209600 + t^8/47900160
+    return 1.0f / 12.0f + n2 * (1.0f / 720.0f + n2 * (1.0f / 30240.0f + n2 * (1.0f / 1209600.0f + n2 * (1.0f / 47900160.0f))));
+  const float n = sqrtf(n2);
+  return 1.0f / n2 - (1 + cosf(n)) / (2 * n * sinf(n));
+}
+template <class T> CTV_DI M3<T> so3_Jr_inv(V3<T> phi) {
+  const T c = jrinv_coeff(dot(phi, phi));
+  const M3<T> H = hat(phi), H2 = mul(H, H);
+  M3<T> J = m3_id<T>();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J.m[i] += T(0.5) * H.m[i] + c * H2.m[i];
+  return J;
+}
+
+// ---- uniform cubic B-spline basis (reference src/spline/spline_common.h:76-153; evaluated as in
+//      so3_spline_view.h:438-459, rd_spline_view.h:124-145).  c[i] = idt^D * sum_j M[i][j] * b_D(u)[j].
+template <class T, bool CUMULATIVE, int D> CTV_DI void basis(T u, T idt_pow, T c[4]) {
+  // monomial derivative vector p[j] = base(D,j) * u^(j-D)
+  T p[4] = {T(0), T(0), T(0), T(0)};
+  if (D == 0) { p[0] = 1; p[1] = u; p[2] = u * u; p[3] = u * u * u; }
+  else if (D == 1) { p[1] = 1; p[2] = 2 * u; p[3] = 3 * u * u; }
+  else { p[2] = 2; p[3] = 6 * u; }
+  const T s = idt_pow * T(1.0 / 6.0);
+  if (CUMULATIVE) {
+    c[0] = s * (6 * p[0]);
+    c[1] = s * (5 * p[0] + 3 * p[1] - 3 * p[2] + p[3]);
+    c[2] = s * (p[0] + 3 * p[1] + 3 * p[2] - 2 * p[3]);
+    c[3] = s * (p[3]);
+  } else {
+    c[0] = s * (p[0] - 3 * p[1] + 3 * p[2] - p[3]);
+    c[1] = s * (4 * p[0] - 6 * p[2] + 3 * p[3]);
+    c[2] = s * (p[0] + 3 * p[1] + 3 * p[2] - 3 * p[3]);
+    c[3] = s * (p[3]);
+  }
+}
+
+}  // namespace ctv

@@ -1,0 +1,143 @@
+"""Python host side above the C ABI: a batch of sliding windows solved on one MI355X.
+
+Mirrors the call pattern of the reference's TrajectoryManager::UpdateTrajectory
+(src/estimator/trajectory_manager.cpp:350-463): build an estimator, add the window's factors,
+Solve(max_iterations), copy the state back -- except that many independent windows are solved per call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .window import Window
+
+
+class Solver:
+    """One handle = one HIP stream + the HBM buffers of a batch of windows."""
+
+    def __init__(self, device: int = 0, precision: str = "fp32", use_mfma: bool = True, check_every: int = 4, **tolerances):
+        self._lib = capi.load_library()
+        if self._lib.ctvio_device_count() <= 0:
+            raise capi.CtvioError("no HIP device: ctrl-vio_amd has no CPU fallback")
+        opt = capi.Options()
+        self._lib.ctvio_default_options(C.byref(opt))
+        opt.device = device
+        opt.precision = capi.FP64 if precision in ("fp64", capi.FP64) else capi.FP32
+        opt.use_mfma = int(bool(use_mfma))
+        opt.check_every = int(check_every)
+        for k, v in tolerances.items():
+            if not hasattr(opt, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(opt, k, v)
+        self._h = C.c_void_p()
+        capi.check(self._lib.ctvio_create(C.byref(opt), C.byref(self._h)))
+        self.windows: list[Window] = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ctvio_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- batch construction
+    def clear(self):
+        capi.check(self._lib.ctvio_clear(self._h))
+        self.windows = []
+
+    def add_window(self, w: Window) -> int:
+        keep = []
+        cw = capi.to_cwindow(w, keep)
+        wid = C.c_int32(-1)
+        capi.check(self._lib.ctvio_add_window(self._h, C.byref(cw), C.byref(wid)))
+        self.windows.append(w)
+        return wid.value
+
+    def upload(self):
+        capi.check(self._lib.ctvio_upload(self._h))
+
+    def set_windows(self, windows):
+        self.clear()
+        for w in windows:
+            self.add_window(w)
+        self.upload()
+
+    @property
+    def n(self) -> int:
+        return int(self._lib.ctvio_num_windows(self._h))
+
+    # ---- solve
+    def solve(self, max_iterations: int = 15, writeback: bool = True):
+        """Solve every window of the batch; returns list of summary dicts.  With writeback the
+        Window objects passed to add_window are updated in place (Ceres updates double* in place)."""
+        n = self.n
+        sm = (capi.Summary * n)()
+        capi.check(self._lib.ctvio_solve(self._h, int(max_iterations), C.cast(sm, C.c_void_p)))
+        if writeback:
+            for i, w in enumerate(self.windows):
+                self.get_state(i, into=w)
+        return [s.as_dict() for s in sm]
+
+    def solve_raw(self, max_iterations: int = 15):
+        """Solve without any host-side copy besides the summaries (used by bench.py)."""
+        capi.check(self._lib.ctvio_solve(self._h, int(max_iterations), None))
+
+    def get_state(self, wid: int, into: Window | None = None) -> Window:
+        w = into if into is not None else self.windows[wid].copy()
+        ld = C.c_double()
+        capi.check(self._lib.ctvio_get_state(self._h, wid, capi._p(w.quat), capi._p(w.pos), capi._p(w.bias), capi._p(w.rho),
+                                             C.cast(C.byref(ld), C.c_void_p)))
+        w.ld = float(ld.value)
+        return w
+
+    def set_state(self, wid: int, w: Window):
+        w.normalize()
+        capi.check(self._lib.ctvio_set_state(self._h, wid, capi._p(w.quat), capi._p(w.pos), capi._p(w.bias), capi._p(w.rho), float(w.ld)))
+
+    # ---- diagnostics
+    def linearize(self, wid: int):
+        w = self.windows[wid]
+        P, L, N = w.P, w.L, w.N
+        H = np.zeros((P, P)); W = np.zeros((P, max(L, 1))); Hll = np.zeros(max(L, 1)); g = np.zeros(N); cost = C.c_double()
+        capi.check(self._lib.ctvio_linearize(self._h, wid, capi._p(H), capi._p(W), capi._p(Hll), capi._p(g),
+                                             C.cast(C.byref(cost), C.c_void_p)))
+        return H, W[:, :L], Hll[:L], g, float(cost.value)
+
+    def cost(self, wid: int) -> float:
+        c = C.c_double()
+        capi.check(self._lib.ctvio_cost(self._h, wid, C.cast(C.byref(c), C.c_void_p)))
+        return float(c.value)
+
+    def lm_step(self, wid: int, mu: float = 1e4):
+        w = self.windows[wid]
+        d = np.zeros(w.N); mc = C.c_double()
+        capi.check(self._lib.ctvio_lm_step(self._h, wid, float(mu), capi._p(d), C.cast(C.byref(mc), C.c_void_p)))
+        return d, float(mc.value)
+
+    def spline_eval(self, wid: int, t_ns):
+        t = np.ascontiguousarray(t_ns, np.int64)
+        n = t.shape[0]
+        pose = np.zeros((n, 7)); vel = np.zeros((n, 3)); om = np.zeros((n, 3)); acc = np.zeros((n, 3))
+        capi.check(self._lib.ctvio_spline_eval(self._h, wid, n, capi._p(t), capi._p(pose), capi._p(vel), capi._p(om), capi._p(acc)))
+        return pose, vel, om, acc
+
+    def last_timing(self):
+        ms = np.zeros(8)
+        capi.check(self._lib.ctvio_last_timing(self._h, capi._p(ms)))
+        return ms
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.ctvio_stream(self._h) or 0)

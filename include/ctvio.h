@@ -1,0 +1,158 @@
+/*
+ * ctvio.h -- C ABI of libctvio.so: the MI355X (gfx950) sliding-window continuous-time VIO solve.
+ *
+ * Drop-in boundary for the Ceres build-and-solve behind the reference's
+ * `ctrlvio::TrajectoryEstimator` (reference src/estimator/trajectory_estimator.h:61-206).  The reference
+ * has no FFI; its seam is that C++ class, driven by TrajectoryManager::UpdateTrajectory
+ * (src/estimator/trajectory_manager.cpp:317-483).  Every entry point below cites the reference
+ * interface it replaces.  include/ctvio_estimator.hpp is the header-only C++ adaptor with the
+ * reference's method names that a maintainer compiles src/estimator against.
+ *
+ * Conventions: plain C, caller-owned buffers, fp64 at the ABI regardless of device precision,
+ * int status codes (no exceptions, like the reference: trajectory_estimator.cpp has no error paths),
+ * one solver handle per host thread / HIP stream.  Parameters are addressed by INDEX (knot k,
+ * bias state f, landmark l), not by pointer identity as in Ceres.
+ *
+ * Unknown ordering of every dense quantity:
+ *   knot k : rot 6k..6k+2, pos 6k+3..6k+5 ; bias f : bg 6K+6f.., ba 6K+6f+3.. ; line delay 6K+6F ;
+ *   P = 6K+6F+1 ; inverse depth l : P+l ; N = P+L.
+ */
+#ifndef CTVIO_H_
+#define CTVIO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ctvio_solver ctvio_solver;
+
+enum ctvio_status {
+  CTVIO_OK = 0,
+  CTVIO_ERR_INVALID = 1,    /* bad argument / inconsistent sizes / time outside the spline */
+  CTVIO_ERR_NO_DEVICE = 2,  /* no HIP device: the product path has NO CPU fallback */
+  CTVIO_ERR_HIP = 3,        /* a HIP runtime call failed (ctvio_last_error has the text) */
+  CTVIO_ERR_STATE = 4       /* call order violated (e.g. solve before upload) */
+};
+
+enum ctvio_precision { CTVIO_FP32 = 0 /* product */, CTVIO_FP64 = 1 /* debugging the kernels against the oracle */ };
+
+/* Kinds of parameter blocks kept by a marginalisation prior (reference
+ * marginalization_factor.h:115-129 keep_block_*; sizes 4->local 3, 3, 3, 3, 1). */
+enum { CTVIO_PK_ROT = 0, CTVIO_PK_POS = 1, CTVIO_PK_BG = 2, CTVIO_PK_BA = 3, CTVIO_PK_LD = 4 };
+
+/* Replaces TrajectoryEstimatorOptions (trajectory_estimator_options.h:34-68) + the ceres::Solver::Options
+ * set in TrajectoryEstimator::Solve (trajectory_estimator.cpp:371-398).  Zero-initialise then call
+ * ctvio_default_options.                                                                        */
+typedef struct ctvio_options {
+  int32_t device;               /* HIP device ordinal */
+  int32_t precision;            /* ctvio_precision of the residual/Jacobian kernels */
+  int32_t use_mfma;             /* Schur SYRK on v_mfma_f32_32x32x2_f32 (FP32 only) */
+  int32_t check_every;          /* host polls "all windows terminated" every n LM iterations */
+  double function_tolerance;    /* 1e-6  Ceres defaults, see SURVEY.md Appendix A */
+  double gradient_tolerance;    /* 1e-10 */
+  double parameter_tolerance;   /* 1e-8 */
+  double initial_radius;        /* 1e4 */
+  double max_radius, min_radius;/* 1e16, 1e-32 */
+  double min_relative_decrease; /* 1e-3 */
+  double min_lm_diagonal, max_lm_diagonal; /* 1e-6, 1e32 */
+  int32_t max_consecutive_invalid_steps;   /* 5 */
+  int32_t reserved;
+} ctvio_options;
+
+/* One sliding window = what TrajectoryManager::UpdateTrajectory feeds a fresh TrajectoryEstimator
+ * (trajectory_manager.cpp:331-451).  All pointers are read during ctvio_add_window only.          */
+typedef struct ctvio_window {
+  int32_t K, F, L, M, NB, V;    /* knots, bias states (frames), landmarks, IMU, bias-chain, visual blocks */
+  int32_t pn, pnb;              /* prior residual dim / kept blocks (0: no prior) */
+  int64_t t0_ns, dt_ns;         /* Se3Spline(time_interval_ns, start_time_ns), se3_spline.h:108-111 */
+  const double *quat;           /* K*4 (x,y,z,w): getKnotSO3(i).data(), se3_spline.h:271 */
+  const double *pos;            /* K*3: getKnotPos(i).data(), se3_spline.h:283 */
+  const double *bias;           /* F*6 (bg, ba): para_bg_vec / para_ba_vec, trajectory_manager.cpp:332-342 */
+  const double *rho;            /* L: para_Feature[l][0], trajectory_manager.h:96 */
+  double ld, ld_lo, ld_hi;      /* trajectory_->line_delay, ld_lower, ld_upper (trajectory.h:55-62,99-103) */
+  int32_t fix_ld;               /* trajectory_->fix_ld (trajectory_estimator.cpp:312-318) */
+  int32_t lock_bg, lock_ba;     /* options.lock_wb / lock_ab (trajectory_estimator.cpp:236-245) */
+  int32_t fixed_upto;           /* SetFixedIndex(idx) / lock_traj (trajectory_estimator.cpp:134-138); -1 none */
+  double q_CI[4], p_CI[3];      /* ImageFeatureDelayFactor::S_CtoI / p_CinI (image_feature_factor.h:273-274) */
+  double gravity[3];            /* AddIMUMeasurementAnalytic gravity argument */
+  double imu_w[6];              /* info_vec (opt_weight.h:124-126) */
+  double img_w;                 /* ImageFeatureDelayFactor::sqrt_info = img_w*I2 (trajectory_manager.cpp:57) */
+  double cauchy_a;              /* ceres::CauchyLoss(a) (trajectory_estimator.cpp:321-322); <= 0 : none */
+  /* AddIMUMeasurementAnalytic (trajectory_estimator.h:102-106) x M */
+  const int64_t *imu_t; const double *imu_gyro, *imu_acc; const int32_t *imu_bias;
+  /* AddBiasFactor (trajectory_estimator.h:109-112) x NB : r = w .* (b_j - b_i), dt = 1 */
+  const int32_t *bc_i, *bc_j; const double *bc_w;
+  /* AddImageFeatureDelayAnalytic (trajectory_estimator.h:128-131) x V */
+  const int32_t *v_lm; const int64_t *v_ti, *v_tj; const int32_t *v_rowi, *v_rowj;
+  const double *v_pi, *v_pj;    /* V*2 (x, y), z = 1 */
+  /* AddMarginalizationFactor (trajectory_estimator.h:146-148): r = r0 + J0*dx over the kept blocks */
+  const double *pJ0;            /* pn*pn COLUMN-major (Eigen default of linearized_jacobians) */
+  const double *pr0;            /* pn */
+  const int32_t *p_kind, *p_index, *p_off; /* pnb: block kind, knot/frame index, column offset (keep_block_idx - m) */
+  const double *p_x0;           /* pnb*4: keep_block_data (quaternion x,y,z,w or 3-vector / scalar, zero padded) */
+} ctvio_window;
+
+/* Replaces ceres::Solver::Summary (callers only print BriefReport(): trajectory_manager.cpp:314,455). */
+typedef struct ctvio_summary {
+  int32_t iterations;           /* Ceres-style iteration counter at exit */
+  int32_t num_successful, num_unsuccessful;
+  int32_t termination;          /* 0 max-iterations 1 gradient 2 parameter 3 function 4 min-radius 5 failure */
+  double initial_cost, final_cost, final_radius;
+} ctvio_summary;
+
+void ctvio_default_options(ctvio_options *opt);
+const char *ctvio_status_string(int32_t status);
+const char *ctvio_last_error(void);
+int32_t ctvio_device_count(void);
+
+/* new TrajectoryEstimator(trajectory, option) / ~TrajectoryEstimator (trajectory_estimator.h:76-84):
+ * one handle owns a HIP stream and the device buffers of a BATCH of independent windows.            */
+int32_t ctvio_create(const ctvio_options *opt, ctvio_solver **out);
+void ctvio_destroy(ctvio_solver *s);
+
+/* Drop all windows of the batch (a fresh estimator per solve in the reference: trajectory_manager.cpp:350). */
+int32_t ctvio_clear(ctvio_solver *s);
+/* The Add*Factor calls of one UpdateTrajectory, recorded as one window; returns the window id in *id. */
+int32_t ctvio_add_window(ctvio_solver *s, const ctvio_window *w, int32_t *id);
+/* Pack (sort IMU samples into (segment,bias) groups, prior J0^T J0, ...) and copy to HBM. */
+int32_t ctvio_upload(ctvio_solver *s);
+int32_t ctvio_num_windows(const ctvio_solver *s);
+
+/* TrajectoryEstimator::Solve(max_iterations) (trajectory_estimator.cpp:367-408) for every window of the
+ * batch, device-resident LM with Ceres 1.14 trust-region semantics.  out: n_windows summaries (may be NULL). */
+int32_t ctvio_solve(ctvio_solver *s, int32_t max_iterations, ctvio_summary *out);
+
+/* Results back to the caller's live state (Ceres updates the double* in place; here explicit). */
+int32_t ctvio_get_state(ctvio_solver *s, int32_t id, double *quat, double *pos, double *bias, double *rho, double *ld);
+/* Overwrite the state of an uploaded window (re-solve the same factors from another initial guess). */
+int32_t ctvio_set_state(ctvio_solver *s, int32_t id, const double *quat, const double *pos, const double *bias,
+                        const double *rho, double ld);
+
+/* ---- diagnostics used by the per-kernel parity tests (ResidualSummary analogue,
+ *      trajectory_estimator.h:37-59,168-171) ---- */
+/* Linearise window id at its current state: Hpp (P*P row-major, symmetric filled), W (P*L row-major,
+ * Hpl block), Hll (L), g (N), cost.  Any pointer may be NULL. */
+int32_t ctvio_linearize(ctvio_solver *s, int32_t id, double *Hpp, double *W, double *Hll, double *g, double *cost);
+/* Cost only (residual kernels). */
+int32_t ctvio_cost(ctvio_solver *s, int32_t id, double *cost);
+/* One LM step for radius mu at the current state (Jacobi scaling from this same point): delta (N),
+ * model cost change; the state is not modified. */
+int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, double *model_cost_change);
+
+/* Batched trajectory query on the device: Se3Spline::poseNs / transVelWorld / rotVelBody / transAccelWorld
+ * (se3_spline.h:361-399).  pose7 = (px,py,pz,qx,qy,qz,qw).  Any output may be NULL. */
+int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3,
+                          double *omega3, double *acc3);
+
+/* Wall-clock of the last ctvio_solve split per phase [ms]: 0 linearise 1 assemble 2 schur 3 cholesky
+ * 4 update+cost 5 control, plus [6] = total and [7] = LM iterations launched.  From HIP events. */
+int32_t ctvio_last_timing(ctvio_solver *s, double *ms8);
+/* The HIP stream every kernel of this solver is launched on (hipStream_t), for external event timing. */
+void *ctvio_stream(ctvio_solver *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTVIO_H_ */

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/ctvio.h declares, and
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+
+def test_header_symbols_exported(cv):
+    cv.capi.build_library()
+    lib = cv.capi.load_library()
+    hdr = open(cv.capi.HDR).read()
+    declared = set(re.findall(r"\b(ctvio_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(cv.capi.SYMBOLS), declared ^ set(cv.capi.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_default_options_and_strings(cv):
+    lib = cv.capi.load_library()
+    o = cv.capi.Options()
+    lib.ctvio_default_options(C.byref(o))
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert o.initial_radius == 1e4 and o.max_consecutive_invalid_steps == 5 and o.precision == cv.capi.FP32
+    assert lib.ctvio_status_string(0) == b"ok"
+    assert b"no CPU fallback" in lib.ctvio_status_string(2)
+
+
+def test_no_gpu_fails_loudly(cv):
+    lib = cv.capi.load_library()
+    if lib.ctvio_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.ctvio_create(None, C.byref(h))
+    assert rc == 2 and not h.value
+    with pytest.raises(cv.capi.CtvioError):
+        cv.Solver()
+
+
+def test_struct_layout_matches_header(cv):
+    """ctvio_window / ctvio_options field order in the ctypes mirror follows the header."""
+    hdr = open(cv.capi.HDR).read()
+    body = hdr[hdr.index("typedef struct ctvio_window {"):hdr.index("} ctvio_window;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct ctvio_window {", "").strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(int32_t|int64_t|double)\s*", "", decl)
+        for part in decl.split(","):
+            part = part.strip().lstrip("*").strip()
+            part = re.sub(r"\[\d+\]", "", part)
+            if part:
+                names.append(part)
+    assert names == [f[0] for f in cv.capi.CWindow._fields_]
