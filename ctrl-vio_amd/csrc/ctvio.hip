@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -83,6 +84,8 @@ static int prior_block_size(int kind) { return kind == CTVIO_PK_LD ? 1 : 3; }
 
 template <class T> class SolverImpl : public SolverBase {
  public:
+  static constexpr int VCH = sizeof(T) == 4 ? 32 : 16;   // visual blocks per work item (k_assemble_vis)
+  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 1) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
   explicit SolverImpl(const ctvio_options &o) : opt_(o) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -94,6 +97,7 @@ template <class T> class SolverImpl : public SolverBase {
     for (auto &e : ev_) HIPCHK(hipEventCreate(&e));
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int clear() override { wins_.clear(); uploaded_ = false; return CTVIO_OK; }
@@ -156,6 +160,8 @@ template <class T> class SolverImpl : public SolverBase {
     std::vector<int32_t> knot_win, bias_win, lm_win, imu_grp, v_win, v_lm, v_rowi, v_rowj, bc_win, bc_i, bc_j, pcol, p_kind, p_index, p_off;
     std::vector<int64_t> v_ti, v_tj;
     std::vector<ImuGroup> groups;
+    std::vector<VisItem> vitems;
+    size_t vis_lds_bytes = vis_stage_bytes();
     std::vector<T> imu_u;
     std::vector<uint8_t> active;
     int64_t H0 = 0, W0 = 0, pH0 = 0;
@@ -210,13 +216,33 @@ template <class T> class SolverImpl : public SolverBase {
         }
       }
       m.ngrp = (int)groups.size() - m.grp0;
-      // visual
-      for (int v = 0; v < w.V; ++v) {
+      // visual: sort by frame pair (then rows) so that consecutive blocks hit the same knot quadruples, cut into items
+      std::vector<int> vord(w.V);
+      std::iota(vord.begin(), vord.end(), 0);
+      std::stable_sort(vord.begin(), vord.end(), [&](int a, int b) {
+        if (h.v_ti[a] != h.v_ti[b]) return h.v_ti[a] < h.v_ti[b];
+        if (h.v_tj[a] != h.v_tj[b]) return h.v_tj[a] < h.v_tj[b];
+        if (h.v_rowi[a] != h.v_rowi[b]) return h.v_rowi[a] < h.v_rowi[b];
+        return h.v_rowj[a] < h.v_rowj[b];
+      });
+      m.vitem0 = (int)vitems.size();
+      for (int i = 0; i < w.V; ++i) {
+        const int v = vord[i];
+        const bool fresh = (i == 0) || h.v_ti[v] != h.v_ti[vord[i - 1]] || h.v_tj[v] != h.v_tj[vord[i - 1]] || vitems.back().count >= VCH;
+        if (fresh) vitems.push_back(VisItem{V0 + i, 0});
+        vitems.back().count++;
         v_win.push_back(wi); v_lm.push_back(h.v_lm[v]);
         v_ti.push_back(h.v_ti[v] - w.t0_ns); v_tj.push_back(h.v_tj[v] - w.t0_ns);
         v_rowi.push_back(h.v_rowi[v]); v_rowj.push_back(h.v_rowj[v]);
-        v_obs[(size_t)0 * Vtot_ + V0 + v] = (T)h.v_pi[2 * v]; v_obs[(size_t)1 * Vtot_ + V0 + v] = (T)h.v_pi[2 * v + 1];
-        v_obs[(size_t)2 * Vtot_ + V0 + v] = (T)h.v_pj[2 * v]; v_obs[(size_t)3 * Vtot_ + V0 + v] = (T)h.v_pj[2 * v + 1];
+        v_obs[(size_t)0 * Vtot_ + V0 + i] = (T)h.v_pi[2 * v]; v_obs[(size_t)1 * Vtot_ + V0 + i] = (T)h.v_pi[2 * v + 1];
+        v_obs[(size_t)2 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v]; v_obs[(size_t)3 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v + 1];
+      }
+      m.nvitem = (int)vitems.size() - m.vitem0;
+      {
+        const size_t K6 = 6 * (size_t)w.K, nH = K6 * (K6 + 1) / 2 + K6 + 1;
+        const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(T) + vis_stage_bytes();
+        m.vis_lds = need <= 160 * 1024 ? 1 : 0;
+        vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : vis_stage_bytes());
       }
       // bias chain
       for (int b = 0; b < w.NB; ++b) { bc_win.push_back(wi); bc_i.push_back(h.bc_i[b]); bc_j.push_back(h.bc_j[b]); }
@@ -288,7 +314,7 @@ template <class T> class SolverImpl : public SolverBase {
       H0 += (int64_t)m.P * m.P; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)n * n;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, n);
     }
-    const size_t chol_lds = (size_t)(32 * 33 + 34 + (size_t)std::max(maxP - 32, 0) * 33) * sizeof(double);
+    const size_t chol_lds = (size_t)(32 * 34 + 32 + 34 + ((size_t)std::max(maxP - 32, 0) + 8) * 32) * sizeof(double);
     if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~640)");
     // ---- device buffers
     Dev<T> &d = dev_;
@@ -313,6 +339,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_Jv_.alloc((size_t)100 * std::max(Vtot_, 1))); HIPCHK(b_rv_.alloc((size_t)2 * std::max(Vtot_, 1))); HIPCHK(b_vs_.alloc((size_t)2 * std::max(Vtot_, 1)));
     d.v_win = b_v_win_.p; d.v_lm = b_v_lm_.p; d.v_ti = b_v_ti_.p; d.v_tj = b_v_tj_.p; d.v_rowi = b_v_rowi_.p; d.v_rowj = b_v_rowj_.p;
     d.v_obs = b_v_obs_.p; d.Jv = b_Jv_.p; d.rv = b_rv_.p; d.vs = b_vs_.p;
+    HIPCHK(b_vitems_.upload(vitems, stream_)); d.vitems = b_vitems_.p;
     HIPCHK(b_bc_win_.upload(bc_win, stream_)); HIPCHK(b_bc_i_.upload(bc_i, stream_)); HIPCHK(b_bc_j_.upload(bc_j, stream_)); HIPCHK(b_bc_w_.upload(bc_w, stream_));
     d.bc_win = b_bc_win_.p; d.bc_i = b_bc_i_.p; d.bc_j = b_bc_j_.p; d.bc_w = b_bc_w_.p;
     HIPCHK(b_pH_.upload(pH, stream_)); HIPCHK(b_pb0_.upload(pb0, stream_)); HIPCHK(b_pc0_.upload(pc0, stream_)); HIPCHK(b_pcol_.upload(pcol, stream_));
@@ -321,7 +348,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_Hpp_.alloc((size_t)H0)); HIPCHK(b_S_.alloc((size_t)H0)); HIPCHK(b_W_.alloc((size_t)W0)); HIPCHK(b_Hll_.alloc((size_t)L0));
     HIPCHK(b_g_.alloc((size_t)U0)); HIPCHK(b_rhs_.alloc((size_t)Pp0)); HIPCHK(b_dd_.alloc((size_t)U0)); HIPCHK(b_dinv_.alloc((size_t)L0));
     HIPCHK(b_cscale_.alloc((size_t)U0)); HIPCHK(b_delta_.alloc((size_t)U0)); HIPCHK(b_active_.upload(active, stream_));
-    HIPCHK(b_lm_.alloc((size_t)nw)); HIPCHK(b_nact_.alloc(1));
+    HIPCHK(b_lm_.alloc((size_t)nw)); HIPCHK(b_nact_.alloc(1)); HIPCHK(b_dbg_.alloc(64));
+    d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? b_dbg_.p : nullptr;
     d.Hpp = b_Hpp_.p; d.S = b_S_.p; d.W = b_W_.p; d.Hll = b_Hll_.p; d.g = b_g_.p; d.rhs = b_rhs_.p; d.dd = b_dd_.p; d.dinv = b_dinv_.p;
     d.cscale = b_cscale_.p; d.delta = b_delta_.p; d.active = b_active_.p; d.lm = b_lm_.p; d.n_active = b_nact_.p;
     HIPCHK(hipMemsetAsync(b_lm_.p, 0, sizeof(Lm) * nw, stream_));
@@ -329,6 +357,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipMemsetAsync(b_cscale_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     chol_lds_ = chol_lds;
+    vis_lds_ = vis_lds_bytes;
     uploaded_ = true;
     return CTVIO_OK;
   }
@@ -357,8 +386,11 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_assemble() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
+    if (d.Vtot) {  // few windows: split each window's items over several workgroups to fill the chip
+      const int parts = std::min(8, std::max(1, 256 / nw));
+      hipLaunchKernelGGL((k_assemble_vis<T, VCH>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
+    }
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d);
-    if (d.Vtot) hipLaunchKernelGGL((k_assemble_vis<T>), dim3(d.Vtot), dim3(64), 0, stream_, d);
     hipLaunchKernelGGL((k_misc<T, true>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, d.quat, d.pos, d.bias, d.ld, 0);
     hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
   }
@@ -367,10 +399,10 @@ template <class T> class SolverImpl : public SolverBase {
     const int nw = d.nwin;
     hipLaunchKernelGGL((k_damping<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
     launch_schur();
-    hipLaunchKernelGGL((k_rhs<T>), dim3(nblk(d.maxP, 256), nw), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL((k_rhs<T>), dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
     mark(3);
     hipLaunchKernelGGL((k_cholesky_solve<T>), dim3(nw), dim3(256), chol_lds_, stream_, d);
-    hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(1024), 0, stream_, d);
   }
   void launch_schur();
   void launch_cost(bool candidate, int force) {
@@ -423,6 +455,13 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipEventElapsedTime(&ms, ev_[8], ev_[9]));
     std::fill(timing_, timing_ + 8, 0.0);
     timing_[6] = ms; timing_[7] = it;
+    if (d.dbg) {
+      long long st[64];
+      HIPCHK(hipMemcpy(st, d.dbg, sizeof st, hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[ctvio] cholesky clock64 deltas:");
+      for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n");
+    }
     if (out)
       for (int w = 0; w < nw; ++w) {
         out[w].iterations = lm[w].iter; out[w].num_successful = lm[w].nsucc; out[w].num_unsuccessful = lm[w].nunsucc;
@@ -572,7 +611,8 @@ template <class T> class SolverImpl : public SolverBase {
   std::vector<WinMeta> meta_;
   Dev<T> dev_;
   int Mtot_ = 0, Vtot_ = 0;
-  size_t chol_lds_ = 0;
+  size_t chol_lds_ = 0, vis_lds_ = 0;
+  DBuf<VisItem> b_vitems_;
   DBuf<WinMeta> b_meta_;
   DBuf<double> b_quat_, b_pos_, b_bias_, b_rho_, b_ld_, b_cquat_, b_cpos_, b_cbias_, b_crho_, b_cld_, b_bc_w_, b_pH_, b_pb0_, b_pc0_, b_p_x0_;
   DBuf<double> b_Hpp_, b_S_, b_Hll_, b_g_, b_rhs_, b_dd_, b_dinv_, b_cscale_, b_delta_;
@@ -583,6 +623,7 @@ template <class T> class SolverImpl : public SolverBase {
   DBuf<T> b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_;
   DBuf<uint8_t> b_active_;
   DBuf<Lm> b_lm_;
+  DBuf<long long> b_dbg_;
 };
 
 template <> void SolverImpl<float>::launch_schur() {

@@ -13,7 +13,9 @@ struct WinMeta {
   int32_t pn, pnb;
   int32_t knot0, bias0, lm0;   // offsets into state arrays (knots, bias states, landmarks)
   int32_t imu0, grp0, ngrp;    // IMU samples (sorted by group) / groups
-  int32_t vis0, bc0;           // visual blocks / bias-chain links
+  int32_t vis0, bc0;           // visual blocks (sorted by frame pair) / bias-chain links
+  int32_t vitem0, nvitem;      // visual work items (<= CH consecutive blocks of one frame pair)
+  int32_t vis_lds, pad0;       // 1: the packed visual Hessian fits in LDS (k_assemble_vis)
   int32_t u0, p0;              // offsets into per-unknown (sum N) and per-pose-unknown (sum P) arrays
   int32_t ldw, Lpad;           // W is [Lpad][ldw] (landmark-major, zero padded; ldw % 32 == 0, Lpad % 2 == 0)
   int32_t pv0, pblk0;          // prior vectors (sum pn) / prior blocks
@@ -25,6 +27,8 @@ struct WinMeta {
   double inv_dt;               // 1e9 / dt_ns  (reference spline_segment.h:58)
   double q_CI[4], p_CI[3], gravity[3], imu_w[6], img_w, cauchy_a, ld_lo, ld_hi;
 };
+
+struct VisItem { int32_t start, count; };  // start = global visual block index
 
 // A run of IMU samples sharing the same 4 active knots (segment s) and the same bias state.
 struct ImuGroup { int32_t win, s, bias, start, count; };
@@ -68,6 +72,7 @@ template <class T> struct Dev {
   T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
   T *rv;                 // [2][Vtot]
   int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
+  const VisItem *vitems;
   // bias chain
   const int32_t *bc_win, *bc_i, *bc_j;
   const double *bc_w;    // [NBtot][6]
@@ -87,6 +92,7 @@ template <class T> struct Dev {
   const uint8_t *active; // [Utot] unknown is in the reduced program
   Lm *lm;
   int32_t *n_active;
+  long long *dbg;        // optional clock64() stamps (profiling aid), may be null
   LmParams prm;
 };
 

@@ -336,40 +336,149 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
   }
 }
 
-// One wave per visual block: J~^T J~ and J~^T r~ scattered by global unknown index (the two ends may share
-// knots -- all ordered pairs are added, so shared knots sum correctly; reference image_feature_factor.h:165-180,215,233).
-template <class T> __global__ __launch_bounds__(64) void k_assemble_vis(Dev<T> d) {
-  const int v = blockIdx.x;
-  const int w = d.v_win[v];
+// Visual assembly: gridDim.y workgroups (8 waves each) per window.  The host sorted the visual blocks by
+// frame pair and cut them into items of <= CH blocks; blocks of an item that evaluate on the same knot
+// quadruples (si, sj) form a run.  A wave stages its item's J~ (100 x n) and r~ in LDS (all loads of a pass
+// in flight together), then forms the run's 50 x 50 product [J~_pose | r~]^T [J~_pose | r~] with a 7 x 7
+// register tile per lane (rows {ti+8a}, cols {tj+8b}; K = 2 * run length) and adds it into an LDS-resident
+// copy of the window's visual Hessian (packed lower triangle over the 6K knot unknowns + the line-delay
+// row): ~1.2k ds_add per RUN instead of ~1.3k global atomics per BLOCK.  The two ends of a block may share
+// knots (reference image_feature_factor.h:165-180,215,233): every ordered column pair whose unknowns satisfy
+// g(a) >= g(b) is added, so shared knots sum correctly.  Landmark terms (W row, Hll, g_rho) stay per block.
+// Windows whose packed Hessian does not fit in LDS (vis_lds = 0) add straight into Hpp.
+template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d) {
+  constexpr int CHP = CH + 1, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;
+  const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
-  __shared__ T J[100];
-  __shared__ int gc[50];
-  __shared__ T r[2];
-  const int lane = threadIdx.x;
-  const size_t V = (size_t)d.Vtot;
-  const int si = d.vs[v], sj = d.vs[V + v];
-  const int l = d.v_lm[v];
-  for (int e = lane; e < 100; e += 64) J[e] = d.Jv[(size_t)e * V + v];  // J[2*col + row]
-  if (lane < 50) gc[lane] = vis_col(lane, si, sj, m.P);
-  if (lane < 2) r[lane] = d.rv[(size_t)lane * V + v];
+  if (m.V == 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
+  T *Hs = reinterpret_cast<T *>(smv);
+  const int K6 = 6 * m.K, tri = K6 * (K6 + 1) / 2;
+  const int nH = m.vis_lds ? tri + K6 + 1 : 0;
+  T *stage = Hs + ((nH + 3) & ~3);                                    // [NW][102][CHP]
+  int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < nH; i += 512) Hs[i] = T(0);
   __syncthreads();
-  for (int e = lane; e < 2500; e += 64) {
-    const int a = e / 50, b = e % 50;
-    if (b == 48 && a != 48) continue;
-    const T h = J[2 * a] * J[2 * b] + J[2 * a + 1] * J[2 * b + 1];
-    if (a == 48) {
-      if (b == 48) atomicAdd(&d.Hll[m.lm0 + l], (double)h);
-      else atomicAdd(&d.W[m.W0 + (long long)l * m.ldw + gc[b]], h);
-    } else {
-      const int ga = gc[a], gb = gc[b];
-      if (ga >= gb) atomicAdd(&d.Hpp[m.H0 + (long long)ga * m.P + gb], (double)h);
-    }
+  T *Js = stage + wave * 102 * CHP;
+  int *ks = keys + wave * 2 * CH;
+  const size_t V = (size_t)d.Vtot;
+  const int per_round = NW * nparts;
+  const int rounds = (m.nvitem + per_round - 1) / per_round;
+  double *Hg = d.Hpp + m.H0;
+  const int ti = lane >> 3, tj = lane & 7;
+  // local column c (0..47 knot columns, 48 line delay, 49 residual) -> first of its two staging rows
+  int rowa[7], rowb[7];
+#pragma unroll
+  for (int a = 0; a < 7; ++a) {
+    const int ca = ti + 8 * a, cb = tj + 8 * a;
+    rowa[a] = ca < 48 ? 2 * ca : (ca == 48 ? 98 : (ca == 49 ? 100 : -1));
+    rowb[a] = cb < 48 ? 2 * cb : (cb == 48 ? 98 : (cb == 49 ? 100 : -1));
   }
-  if (lane < 50) {
-    const double gv = (double)(J[2 * lane] * r[0] + J[2 * lane + 1] * r[1]);
-    const int ga = (lane == 48) ? (m.P + l) : gc[lane];
-    atomicAdd(&d.g[m.u0 + ga], gv);
+  for (int r = 0; r < rounds; ++r) {
+    const int it = (r * nparts + part) * NW + wave;
+    int n = 0, v0 = 0;
+    if (it < m.nvitem) { const VisItem I = d.vitems[m.vitem0 + it]; n = I.count; v0 = I.start; }
+    {
+      const int c = lane % CH, rr = lane / CH;
+      T tmp[NPASS];
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = i * RPP + rr;
+        tmp[i] = T(0);
+        if (row < 102 && c < n) tmp[i] = (row < 100) ? d.Jv[(size_t)row * V + v0 + c] : d.rv[(size_t)(row - 100) * V + v0 + c];
+      }
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int row = i * RPP + rr;
+        if (row < 102) Js[row * CHP + c] = tmp[i];
+      }
+    }
+    if (lane < n) { ks[lane] = d.vs[v0 + lane]; ks[CH + lane] = d.vs[V + v0 + lane]; }
+    __syncthreads();
+    int start = 0;
+    while (start < n) {
+      const int si = ks[start], sj = ks[CH + start];
+      const bool diff = (lane > start && lane < n) && (ks[lane] != si || ks[CH + lane] != sj);
+      const unsigned long long mask = __ballot(diff);
+      const int end = mask ? (__ffsll((long long)mask) - 1) : n;
+      T acc[7][7];
+#pragma unroll
+      for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = 0; b < 7; ++b) acc[a][b] = T(0);
+      for (int v = start; v < end; ++v) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          T av[7], bv[7];
+#pragma unroll
+          for (int a = 0; a < 7; ++a) {
+            av[a] = rowa[a] >= 0 ? Js[(rowa[a] + rr) * CHP + v] : T(0);
+            bv[a] = rowb[a] >= 0 ? Js[(rowb[a] + rr) * CHP + v] : T(0);
+          }
+#pragma unroll
+          for (int a = 0; a < 7; ++a)
+#pragma unroll
+            for (int b = 0; b < 7; ++b) acc[a][b] += av[a] * bv[b];
+        }
+      }
+      int ga[7], gb[7];
+#pragma unroll
+      for (int a = 0; a < 7; ++a) {
+        const int ca = ti + 8 * a, cb = tj + 8 * a;
+        ga[a] = ca < 48 ? vis_col(ca, si, sj, m.P) : (ca == 48 ? m.P - 1 : -1);
+        gb[a] = cb < 48 ? vis_col(cb, si, sj, m.P) : (cb == 48 ? m.P - 1 : (cb == 49 ? -2 : -1));
+      }
+#pragma unroll
+      for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+          if (ga[a] < 0 || gb[b] == -1) continue;
+          if (gb[b] == -2) { atomicAdd(&d.g[m.u0 + ga[a]], (double)acc[a][b]); continue; }  // J~^T r~
+          if (ga[a] < gb[b]) continue;
+          if (m.vis_lds) {
+            const int idx = (ga[a] == m.P - 1) ? tri + (gb[b] == m.P - 1 ? K6 : gb[b]) : ga[a] * (ga[a] + 1) / 2 + gb[b];
+            atomicAdd(&Hs[idx], acc[a][b]);
+          } else {
+            atomicAdd(&Hg[(long long)ga[a] * m.P + gb[b]], (double)acc[a][b]);
+          }
+        }
+      // landmark terms per block: W row (49), Hll, g_rho
+      for (int e = lane; e < (end - start) * 51; e += 64) {
+        const int v = start + e / 51, b = e % 51;
+        const int l = d.v_lm[v0 + v];
+        const T jr0 = Js[96 * CHP + v], jr1 = Js[97 * CHP + v];
+        if (b < 49) {
+          const int cb = b < 48 ? b : 49;
+          const T h = jr0 * Js[(2 * cb) * CHP + v] + jr1 * Js[(2 * cb + 1) * CHP + v];
+          atomicAdd(&d.W[m.W0 + (long long)l * m.ldw + vis_col(cb, si, sj, m.P)], h);
+        } else if (b == 49) {
+          atomicAdd(&d.Hll[m.lm0 + l], (double)(jr0 * jr0 + jr1 * jr1));
+        } else {
+          atomicAdd(&d.g[m.u0 + m.P + l], (double)(jr0 * Js[100 * CHP + v] + jr1 * Js[101 * CHP + v]));
+        }
+      }
+      start = end;
+    }
+    __syncthreads();
+  }
+  if (m.vis_lds) {
+    for (int i = tid; i < nH; i += 512) {
+      const T hv = Hs[i];
+      if (hv == T(0)) continue;
+      int ga, gb;
+      if (i < tri) {
+        ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
+        while ((ga + 1) * (ga + 2) / 2 <= i) ++ga;
+        while (ga * (ga + 1) / 2 > i) --ga;
+        gb = i - ga * (ga + 1) / 2;
+      } else {
+        ga = m.P - 1;
+        gb = (i - tri) < K6 ? (i - tri) : m.P - 1;
+      }
+      atomicAdd(&Hg[(long long)ga * m.P + gb], (double)hv);
+    }
   }
 }
 
@@ -597,25 +706,43 @@ template <class T> __global__ void k_schur_generic(Dev<T> d) {
   d.S[m.H0 + (long long)ii * m.P + jj] = val;
 }
 
-// rhs_p = -g_p + W^T diag(dinv) g_l
-template <class T> __global__ void k_rhs(Dev<T> d) {
+// rhs_p = -g_p + W^T diag(dinv) g_l.  256 threads = 64 unknowns x 4 landmark slices (coalesced over the unknowns).
+template <class T> __global__ __launch_bounds__(256) void k_rhs(Dev<T> d) {
   const int w = blockIdx.y;
   if (d.lm[w].status) return;
   const WinMeta &m = d.wins[w];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.P) return;
+  __shared__ double part[4][64];
+  const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + li;
   double v = 0.0;
-  if (d.active[m.u0 + i]) {
-    const T *Wp = d.W + m.W0;
-    v = -d.g[m.u0 + i];
-    for (int l = 0; l < m.L; ++l) v += (double)Wp[(long long)l * m.ldw + i] * d.dinv[m.lm0 + l] * d.g[m.u0 + m.P + l];
+  if (i < m.P && d.active[m.u0 + i]) {
+    const T *Wp = d.W + m.W0 + i;
+    const double *dinv = d.dinv + m.lm0, *gl = d.g + m.u0 + m.P;
+    for (int l = sl; l < m.L; l += 4) v += (double)Wp[(long long)l * m.ldw] * (dinv[l] * gl[l]);
   }
-  d.rhs[m.p0 + i] = v;
+  part[sl][li] = v;
+  __syncthreads();
+  if (sl == 0 && i < m.P) {
+    const double s = part[0][li] + part[1][li] + part[2][li] + part[3][li];
+    d.rhs[m.p0 + i] = d.active[m.u0 + i] ? s - d.g[m.u0 + i] : 0.0;
+  }
 }
 
-// Dense fp64 Cholesky + two triangular solves of the P x P reduced system, one workgroup per window.
-// Right-looking, 32-column panels: the diagonal block is factored in LDS, the panel below it is solved
-// one row per lane against the LDS block and kept in LDS for the trailing update.  Result in delta[0..P).
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Dense fp64 Cholesky of the P x P reduced system + solve, one workgroup per window, right-looking with
+// 32-column panels:
+//   1. wave 0 holds the 32x32 diagonal block one row per lane in registers and factors it with
+//      v_readlane broadcasts (no LDS, no barriers inside the 32 pivot steps);
+//   2. every lane solves one panel row against the factored block (LDS broadcast reads);
+//   3. trailing update A22 -= L21 L21^T with 4x4 register tiles from the LDS-resident panel.
+// The right-hand side rides along as an extra matrix row (Cholesky of [S b; b^T .]), so y = L^-1 b needs no
+// separate forward substitution; only the block back-substitution L^T x = y remains.  Result in delta[0..P).
 template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
@@ -623,110 +750,130 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
   const WinMeta &m = d.wins[w];
   const int P = m.P, tid = threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) double smc[];
-  double *D = smc;             // [32][33]
-  double *yb = smc + 32 * 33;  // [32]
-  int &s_fail = *reinterpret_cast<int *>(yb + 32);  // kept in the dynamic region: a static __shared__ would shift its base off 8 B
-  double *Lp = yb + 34;        // [rows][33]
+  double *Dt = smc;               // [32][34] factored diagonal block, TRANSPOSED: Dt[k][j] = L[j][k]
+  double *dinvs = smc + 32 * 34;  // [32] 1 / L_jj
+  double *yb = dinvs + 32;        // [32]
+  int &s_fail = *reinterpret_cast<int *>(yb + 32);
+  double *LpT = yb + 34;          // [32][RS] panel (+ rhs row) TRANSPOSED: LpT[k][r], rows padded to a multiple of 4
   double *S = d.S + m.H0;
+  double *y = d.rhs + m.p0;       // augmented row; becomes L^-1 rhs
   double *x = d.delta + m.u0;
   if (tid == 0) s_fail = 0;
   __syncthreads();
+  long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 60) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
   for (int jb = 0; jb < P; jb += 32) {
-    const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0;
-    for (int e = tid; e < nb * nb; e += 256) {
-      const int i = e / nb, j = e % nb;
-      D[i * 33 + j] = (j <= i) ? S[(long long)(jb + i) * P + jb + j] : 0.0;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-      if (tid == 0) {
-        double dj = D[j * 33 + j];
-        if (!(dj > 0.0) || !isfinite(dj)) { s_fail = 1; dj = 1.0; }
-        D[j * 33 + j] = sqrt(dj);
-      }
-      __syncthreads();
-      const double djj = D[j * 33 + j];
-      if (tid > j && tid < nb) D[tid * 33 + j] /= djj;
-      __syncthreads();
-      const int n2 = nb - j - 1;
-      for (int e = tid; e < n2 * n2; e += 256) {
-        const int ii = e / n2, cc = e % n2;
-        if (cc <= ii) D[(j + 1 + ii) * 33 + j + 1 + cc] -= D[(j + 1 + ii) * 33 + j] * D[(j + 1 + cc) * 33 + j];
-      }
-      __syncthreads();
-    }
-    for (int e = tid; e < nb * nb; e += 256) {
-      const int i = e / nb, j = e % nb;
-      if (j <= i) S[(long long)(jb + i) * P + jb + j] = D[i * 33 + j];
-    }
-    for (int r = tid; r < nt; r += 256) {  // panel rows: L21 = A21 L11^-T
+    const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0, ntr = nt + 1;  // ntr: trailing rows incl. the rhs row
+    const int ntr4 = (ntr + 3) & ~3, RS = ntr4;
+    if (tid < 64) {
+      const int lane = tid;
       double a[32];
-      double *Srow = S + (long long)(r0 + r) * P + jb;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) a[j] = (j < nb) ? Srow[j] : 0.0;
+      for (int c = 0; c < 32; ++c) {
+        double v = (c == lane) ? 1.0 : 0.0;
+        if (lane < nb && c < nb) v = (c <= lane) ? S[(long long)(jb + lane) * P + jb + c] : 0.0;
+        a[c] = v;
+      }
+      int bad = 0;
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
-        if (j < nb) {
-          double s = a[j];
+        const double pj = readlane_d(a[j], j);
+        const bool ok = (pj > 0.0) && isfinite(pj);
+        if (!ok) bad = 1;
+        // 1/sqrt(pj): hardware estimate + two Newton steps (short dependent chain instead of sqrt + divide)
+        const double ps = ok ? pj : 1.0;
+        double di = __builtin_amdgcn_rsq(ps);
+        const double hp = 0.5 * ps;
+        di = di * (1.5 - hp * di * di);
+        di = di * (1.5 - hp * di * di);
+        a[j] *= di;  // lane j: sqrt(pj); lanes > j: L[i][j]
+        if (lane == j) dinvs[j] = di;
 #pragma unroll
-          for (int k = 0; k < j; ++k) s -= a[k] * D[j * 33 + k];
-          a[j] = s / D[j * 33 + j];
+        for (int c = j + 1; c < 32; ++c) a[c] -= a[j] * readlane_d(a[j], c);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          Dt[c * 34 + lane] = (c <= lane) ? a[c] : 0.0;
+          if (lane < nb && c <= lane && c < nb) S[(long long)(jb + lane) * P + jb + c] = a[c];
         }
       }
+      if (lane == 0 && bad) s_fail = 1;
+    }
+    __syncthreads();
+    CTV_STAMP();
+    for (int r = tid; r < ntr4; r += 256) {  // panel rows (and the rhs row): L21 = A21 L11^-T, in place in the LDS panel
+      double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + jb : y + jb;
+      const bool live = r < ntr;
+      double *lr = LpT + r;  // element j of this row lives at lr[j * RS]: consecutive lanes -> consecutive addresses
+      {
+        double tmp[32];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        if (j < nb) Srow[j] = a[j];
-        Lp[r * 33 + j] = (j < nb) ? a[j] : 0.0;
+        for (int j = 0; j < 32; ++j) tmp[j] = (live && j < nb) ? Srow[j] : 0.0;  // 32 independent loads in flight
+#pragma unroll
+        for (int j = 0; j < 32; ++j) lr[j * RS] = tmp[j];
+      }
+      for (int k = 0; k < nb; ++k) {  // column sweep: entry k becomes final, then the columns to its right are updated
+        const double lk = lr[k * RS] * dinvs[k];
+        lr[k * RS] = lk;
+        const double *dk = Dt + k * 34;
+#pragma unroll 4
+        for (int j = k + 1; j < nb; ++j) lr[j * RS] -= lk * dk[j];
+      }
+      if (live) {
+        double tmp[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) tmp[j] = lr[j * RS];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (j < nb) Srow[j] = tmp[j];
       }
     }
     __syncthreads();
-    for (int r = tid; r < nt; r += 256) {  // trailing update A22 -= L21 L21^T (lower)
-      double a[32];
+    CTV_STAMP();
+    // trailing update with 4x4 tiles over the lower triangle of the (nt + rhs row) x nt block;
+    // LpT is k-major, so a tile's 4 row values / 4 column values are one contiguous 32-byte LDS read each
+    const int mt = ntr4 / 4, ntile = mt * (mt + 1) / 2;
+    for (int t = tid; t < ntile; t += 256) {
+      int tr = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+      while (tr * (tr + 1) / 2 > t) --tr;
+      const int tc = t - tr * (tr + 1) / 2;
+      double acc[4][4];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) a[j] = Lp[r * 33 + j];
-      double *Srow = S + (long long)(r0 + r) * P + r0;
-      for (int c = 0; c <= r; ++c) {
-        double s = 0.0;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += a[k] * Lp[c * 33 + k];
-        Srow[c] -= s;
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+      const double *pr = LpT + 4 * tr, *pc = LpT + 4 * tc;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) {
+        const VecN<double, 4> rv = *reinterpret_cast<const VecN<double, 4> *>(pr + k * RS);
+        const VecN<double, 4> cv = *reinterpret_cast<const VecN<double, 4> *>(pc + k * RS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += rv.v[i] * cv.v[j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * tr + i;
+        if (r >= ntr) continue;
+        double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + r0 : y + r0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = 4 * tc + j;
+          if (c < nt && (c <= r)) Srow[c] -= acc[i][j];
+        }
       }
     }
     __syncthreads();
+    CTV_STAMP();
   }
-  // ---- forward substitution L y = rhs
-  for (int i = tid; i < P; i += 256) x[i] = d.rhs[m.p0 + i];
+  // ---- block back-substitution L^T x = y
+  for (int i = tid; i < P; i += 256) x[i] = y[i];
   __syncthreads();
-  for (int jb = 0; jb < P; jb += 32) {
-    const int nb = min(32, P - jb), r0 = jb + nb;
-    if (tid < 64) {  // wave 0: 32x32 triangular solve with cross-lane broadcasts
-      const int lane = tid;
-      double row[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) row[k] = (lane < nb && k <= lane && k < nb) ? S[(long long)(jb + lane) * P + jb + k] : 0.0;
-      double bi = (lane < nb) ? x[jb + lane] : 0.0;
-      double dii = 1.0;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) if (k == lane) dii = row[k];
-      if (lane >= nb) dii = 1.0;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const double yj = __shfl(bi, j) / __shfl(dii, j);
-        if (lane > j) bi -= row[j] * yj;
-        if (lane == j) bi = yj;
-      }
-      if (lane < nb) { x[jb + lane] = bi; yb[lane] = bi; }
-    }
-    __syncthreads();
-    for (int i = r0 + tid; i < P; i += 256) {
-      const double *Srow = S + (long long)i * P + jb;
-      double s = 0.0;
-      for (int k = 0; k < nb; ++k) s += Srow[k] * yb[k];
-      x[i] -= s;
-    }
-    __syncthreads();
-  }
-  // ---- backward substitution L^T x = y
   const int nblk = (P + 31) / 32;
   for (int b = nblk - 1; b >= 0; --b) {
     const int jb = 32 * b, nb = min(32, P - jb);
@@ -736,60 +883,79 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
 #pragma unroll
       for (int i = 0; i < 32; ++i) col[i] = (lane < nb && i >= lane && i < nb) ? S[(long long)(jb + i) * P + jb + lane] : 0.0;
       double bj = (lane < nb) ? x[jb + lane] : 0.0;
-      double djj = 1.0;
+      double rdj = 1.0;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) if (i == lane) djj = col[i];
-      if (lane >= nb) djj = 1.0;
+      for (int i = 0; i < 32; ++i) if (i == lane && lane < nb) rdj = 1.0 / col[i];
 #pragma unroll
       for (int i = 31; i >= 0; --i) {
-        const double xi = __shfl(bj, i) / __shfl(djj, i);
+        const double xi = readlane_d(bj, i) * readlane_d(rdj, i);
         if (lane < i) bj -= col[i] * xi;
         if (lane == i) bj = xi;
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (lane < nb) { x[jb + lane] = bj; yb[lane] = bj; }
     }
     __syncthreads();
     for (int j = tid; j < jb; j += 256) {
-      double s = 0.0;
-      for (int ii = 0; ii < nb; ++ii) s += S[(long long)(jb + ii) * P + j] * yb[ii];
-      x[j] -= s;
+      double lv[32];
+#pragma unroll
+      for (int ii = 0; ii < 32; ++ii) lv[ii] = (ii < nb) ? S[(long long)(jb + ii) * P + j] : 0.0;  // all loads in flight at once
+      double sacc = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 32; ++ii) sacc += lv[ii] * ((ii < nb) ? yb[ii] : 0.0);
+      x[j] -= sacc;
     }
     __syncthreads();
   }
+  CTV_STAMP();
   if (tid == 0) lm.chol_fail = s_fail;
+#undef CTV_STAMP
 }
 
-// delta_l = dinv_l (-g_l - W_l . delta_p);  model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres'
-// -(J y)^T (r + J y / 2) when (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
-template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
+// delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
+// model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres' -(J y)^T (r + J y / 2) when
+// (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
+template <class T> __global__ __launch_bounds__(1024) void k_backsub(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
   if (lm.status) return;
   const WinMeta &m = d.wins[w];
-  __shared__ double red[256];
+  __shared__ double red[1024];
   __shared__ int bad;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) bad = 0;
   __syncthreads();
   double *x = d.delta + m.u0;
   const double *g = d.g + m.u0, *dd = d.dd + m.u0;
   const T *Wp = d.W + m.W0;
-  for (int l = tid; l < m.L; l += 256) {
-    double s = -g[m.P + l];
-    const T *Wr = Wp + (long long)l * m.ldw;
-    for (int i = 0; i < m.P; ++i) s -= (double)Wr[i] * x[i];
-    x[m.P + l] = d.active[m.u0 + m.P + l] ? s * d.dinv[m.lm0 + l] : 0.0;
+  const int nwave = blockDim.x >> 6;
+  for (int l0 = 8 * wave; l0 < m.L; l0 += 8 * nwave) {  // 8 rows of W per pass: 8 independent loads per lane in flight
+    double acc8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
+    for (int i = lane; i < m.P; i += 64) {
+      const double xi = x[i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc8[u] += (l0 + u < m.L) ? (double)Wp[(long long)(l0 + u) * m.ldw + i] * xi : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      double sacc = acc8[u];
+      for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off);
+      const int l = l0 + u;
+      if (lane == 0 && l < m.L) x[m.P + l] = d.active[m.u0 + m.P + l] ? (-g[m.P + l] - sacc) * d.dinv[m.lm0 + l] : 0.0;
+    }
   }
   __syncthreads();
   double mc = 0.0;
-  for (int j = tid; j < m.N; j += 256) {
+  for (int j = tid; j < m.N; j += blockDim.x) {
     const double dj = x[j];
     if (!isfinite(dj)) bad = 1;
     if (d.active[m.u0 + j]) mc += 0.5 * dj * (dd[j] * dj - g[j]);
   }
   red[tid] = mc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
   if (tid == 0) {
     lm.model_change = red[0];
     const bool valid = !lm.chol_fail && !bad && (red[0] > 0.0);
