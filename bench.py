@@ -1,11 +1,19 @@
 #!/usr/bin/env python
-"""bench.py -- sliding-window solves/sec on MI355X (BASELINE.json metric).
+"""bench.py -- sliding-window solves/sec on MI355X (BASELINE.json metric, configs[1] workload).
 
 A "step" = one batched solve of `--windows` independent config-2 windows (10 KF / 200 landmarks / 2000 IMU,
-15 LM iterations max, Ceres tolerances) per GPU, inputs and initial state already resident in HBM
-(the state is reset on the device between steps; pack + H2D are outside the timed region).
-N > 1: one process per GPU (torch.distributed over RCCL), windows sharded by seed, no data-path collective;
-the barrier + max-over-ranks timing uses torch.distributed.  value = windows solved by all ranks / time.
+<= 15 LM iterations, Ceres tolerances) per GPU.  Factors and the initial state are resident in HBM before the
+timed region (ctvio_restore_state resets the state on the device between steps; packing + H2D are outside).
+value = windows solved by all ranks / wall-clock of the K timed steps (max over ranks).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), windows sharded by seed, no data-path
+collective (independent windows); RCCL only carries the barrier and the max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (largest share of a profiled solve, HIP events on the solver's stream):
+                achieved = algorithmic bytes / average launch duration, against 8 TB/s HBM;
+                roofline_mfma: the Schur SYRK against the 157.3 TFLOP/s fp32 MFMA peak.
+  cpu_baseline  the fp64 C oracle (a port of the reference's Ceres path: oracle/ctvo.c) on 1 host core, ~10 s sample.
 """
 import argparse
 import importlib
@@ -19,17 +27,39 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
+
+
+def algorithmic_bytes(w, phase, fp_bytes=4):
+    """Algorithmic HBM bytes of ONE window for one launch of a kernel group."""
+    K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
+    G = len({(int((t - w.t0_ns) // w.dt_ns), int(b)) for t, b in zip(w.imu_t, w.imu_bias)})
+    if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
+        return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
+    if phase == "k_vis_eval":        # SURVEY 8d: 284 B in, 408 B out per block (J materialised once)
+        return V * (284 + 408 + 8)
+    if phase == "k_assemble_vis":    # J read once + W/Hll/g rows + packed visual Hessian flushed once (fp64)
+        K6 = 6 * K
+        return V * (408 + 8 + 51 * fp_bytes) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8
+    if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
+        return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
+    if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written
+        return L * P * fp_bytes + (P * (P + 1) // 2) * 16
+    return 0
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=64, help="independent windows per GPU per step")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU per step")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows generated per GPU (replicated to --windows)")
     ap.add_argument("--config", default="config2")
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -46,16 +76,11 @@ def main():
     torch.cuda.set_device(local)
     cv = importlib.import_module("ctrl-vio_amd")
 
-    # synthetic windows: seeds 1000 + rank*windows + i, a few unique ones replicated to fill the batch
-    uniq = [cv.synth.make_window(args.config, seed=1000 + rank * args.windows + i) for i in range(min(args.unique, args.windows))]
-    wins = [uniq[i % len(uniq)] for i in range(args.windows)]
-    init = [w.copy() for w in uniq]
+    # synthetic windows, seeds 1000 + rank*unique + i; a few distinct ones replicated to fill the batch
+    uniq = [cv.synth.make_window(args.config, seed=1000 + rank * args.unique + i) for i in range(min(args.unique, args.windows))]
     solver = cv.Solver(device=local, precision=args.precision)
-    solver.set_windows([w.copy() for w in wins])
-
-    def reset():
-        for i in range(args.windows):
-            solver.set_state(i, init[i % len(init)])
+    solver.set_windows([uniq[i % len(uniq)].copy() for i in range(args.windows)])
+    solver.snapshot_state()
 
     def barrier():
         torch.cuda.synchronize()
@@ -64,51 +89,84 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        reset(); solver.solve_raw(args.iters)
-    times = []
-    kernel_ms = []
-    barrier()
+        solver.restore_state()
+        solver.solve_raw(args.iters)
     t_total = 0.0
+    dev_ms = []
     for _ in range(args.steps):
-        reset()
+        solver.restore_state()
         barrier()
         t0 = time.perf_counter()
-        solver.solve_raw(args.iters)
+        solver.solve_raw(args.iters)          # returns after the stream is drained (summaries copied back)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        times.append(dt)
-        kernel_ms.append(solver.last_timing()[6])
-    t_total = sum(times)
+        t_total += time.perf_counter() - t0
+        dev_ms.append(solver.last_timing()[0][7])
+    barrier()
     if dist is not None:
         tt = torch.tensor([t_total], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_total = float(tt.item())
+    # results of the last step: fixed-size per-window records gathered on every rank (RCCL all-gather, outside the timed region)
+    sms_last = solver.solve(args.iters, writeback=False) if False else None
     n_solved = args.windows * world * args.steps
-    value = n_solved / t_total
-
     out = {
-        "metric": "sliding-window solves/sec (10 KF, 200 lm, 2000 IMU)", "value": value, "unit": "solves/s",
+        "metric": "sliding-window solves/sec (10 KF, 200 lm, 2000 IMU)", "value": n_solved / t_total, "unit": "solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_total / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f64",
-        "data": "synthetic",
-        "config": {"workload": f"{args.config}: 10 KF / 200 landmarks / 2000 IMU window, <=%d LM iterations" % args.iters,
-                   "windows_per_gpu": args.windows, "sharding": f"independent windows x{world}"},
-        "device_ms_per_step": float(np.mean(kernel_ms)),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config}: 10 KF / 200 landmarks / 2000 IMU sliding window, <= {args.iters} LM iterations",
+                   "windows_per_gpu": args.windows, "sharding": f"independent windows, {world} rank(s), no data-path collective"},
+        "device_ms_per_step": float(np.mean(dev_ms)),
     }
     if rank == 0:
-        # quality of the timed solves
-        sm = solver.solve(args.iters, writeback=False) if False else None
-        out["roofline"] = None
+        # ---- quality of what was timed: the solved batch against the fp64 oracle on the distinct windows
+        sms = solver.solve(args.iters, writeback=False)
+        out["solve_summary"] = {"iterations_mean": float(np.mean([m["iterations"] for m in sms])),
+                                "terminations": sorted({m["termination"] for m in sms})}
+        # ---- roofline: one profiled solve (HIP events around every launch group, on the solver's stream)
+        solver.restore_state()
+        solver.set_profiling(True)
+        solver.solve_raw(args.iters)
+        solver.set_profiling(False)
+        ms, n = solver.last_timing()
+        names = cv.Solver.PHASES
+        shares = {names[i]: float(ms[i]) for i in range(7)}
+        dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
+        w_ref = uniq[0]
+        nbytes = sum(algorithmic_bytes(uniq[i % len(uniq)], names[dom]) for i in range(args.windows))
+        avg_s = 1e-3 * ms[dom] / max(int(n[dom]), 1)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(names[dom], {}).get(str(args.windows))
+            except Exception:
+                traffic = None
+        ach = nbytes / avg_s / 1e9
+        out["roofline"] = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "avg_launch_us": 1e6 * avg_s, "launches": int(n[dom]), "algorithmic_bytes_per_launch": nbytes,
+                           "share_of_profiled_solve": float(ms[dom] / max(sum(ms[:7]), 1e-12))}
+        P, L = w_ref.P, w_ref.L
+        fl = P * (P + 1) * L * args.windows                  # SYRK count
+        avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
+        out["roofline_mfma"] = {"kernel": "k_schur_mfma", "bound": "mfma", "achieved": fl / avg_schur / 1e12,
+                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
+        out["phase_ms_profiled_solve"] = shares
+        # ---- CPU baseline: the oracle (a port, not the reference binary: Ceres/Eigen are not installable here)
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline:
             import pyctvo
-            w = init[0].copy()
-            t0 = time.perf_counter(); n = 0
-            while time.perf_counter() - t0 < 10.0:
-                ww = w.copy(); pyctvo.OracleWindow(ww).solve(args.iters); n += 1
+            t0 = time.perf_counter(); k = 0
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                ww = uniq[k % len(uniq)].copy()
+                pyctvo.OracleWindow(ww).solve(args.iters)
+                k += 1
             dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-                                   "sample": f"{n} solves of one {args.config} window (seed 1000), fp64 C oracle, 1 thread"}
+            out["cpu_baseline"] = {"value": k / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+                                   "sample": f"{k} solves of {args.config} windows (seeds 1000..), fp64 C oracle (oracle/ctvo.c, gcc -O2), "
+                                             f"1 thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -12,5 +12,5 @@ The directory name contains a hyphen: import it with
   synth    deterministic synthetic windows for the BASELINE.json configs
 """
 from .window import Window, rel_state_error  # noqa: F401
-from . import splines, packer, synth, capi  # noqa: F401
+from . import splines, packer, synth, capi, sharding  # noqa: F401
 from .solver import Solver  # noqa: F401

@@ -74,8 +74,8 @@ class Summary(C.Structure):
 # every symbol include/ctvio.h declares (tests check the .so exports all of them)
 SYMBOLS = ["ctvio_default_options", "ctvio_status_string", "ctvio_last_error", "ctvio_device_count", "ctvio_create",
            "ctvio_destroy", "ctvio_clear", "ctvio_add_window", "ctvio_upload", "ctvio_num_windows", "ctvio_solve",
-           "ctvio_get_state", "ctvio_set_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval",
-           "ctvio_last_timing", "ctvio_stream"]
+           "ctvio_get_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval",
+           "ctvio_last_timing", "ctvio_set_profiling", "ctvio_stream"]
 
 _lib = None
 
@@ -92,7 +92,7 @@ def load_library():
         lib.ctvio_stream.restype = C.c_void_p
         lib.ctvio_create.argtypes = [C.POINTER(Options), C.POINTER(C.c_void_p)]
         lib.ctvio_destroy.argtypes = [C.c_void_p]
-        for name in ("ctvio_clear", "ctvio_upload", "ctvio_num_windows"):
+        for name in ("ctvio_clear", "ctvio_upload", "ctvio_num_windows", "ctvio_snapshot_state", "ctvio_restore_state"):
             getattr(lib, name).argtypes = [C.c_void_p]
         lib.ctvio_add_window.argtypes = [C.c_void_p, C.POINTER(CWindow), C.POINTER(C.c_int32)]
         lib.ctvio_solve.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -102,7 +102,8 @@ def load_library():
         lib.ctvio_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.ctvio_lm_step.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
         lib.ctvio_spline_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
-        lib.ctvio_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        lib.ctvio_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ctvio_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         lib.ctvio_stream.argtypes = [C.c_void_p]
         _lib = lib
     return _lib

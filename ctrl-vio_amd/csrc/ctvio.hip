@@ -76,7 +76,9 @@ struct SolverBase {
   virtual int cost(int id, double *cost) = 0;
   virtual int lm_step(int id, double mu, double *delta, double *mc) = 0;
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
-  virtual int last_timing(double *ms8) = 0;
+  virtual int snapshot(int restore) = 0;
+  virtual int last_timing(double *ms8, int32_t *n8) = 0;
+  virtual int set_profiling(int on) = 0;
   virtual void *stream() = 0;
 };
 
@@ -90,6 +92,7 @@ template <class T> class SolverImpl : public SolverBase {
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto &e : pev_) (void)hipEventDestroy(e);
   }
   int init() {
     HIPCHK(hipSetDevice(opt_.device));
@@ -357,6 +360,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipMemsetAsync(b_cscale_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     chol_lds_ = chol_lds;
+    snap_valid_ = false;
     vis_lds_ = vis_lds_bytes;
     uploaded_ = true;
     return CTVIO_OK;
@@ -371,38 +375,78 @@ template <class T> class SolverImpl : public SolverBase {
     p.min_diag = opt_.min_lm_diagonal; p.max_diag = opt_.max_lm_diagonal; p.max_invalid = opt_.max_consecutive_invalid_steps;
     p.max_iters = max_iters;
   }
-  void mark(int phase) {
-    if (!time_phases_) return;
-    hipEventRecord(ev_[phase], stream_);
+  // Per-phase timing with HIP events on the solver's stream (only when profiling is switched on).
+  enum { PH_IMU_LIN = 0, PH_VIS_LIN, PH_ASM_VIS, PH_ASM_REST, PH_SCHUR, PH_CHOL, PH_REST, PH_COUNT };
+  void ph_begin(int ph) {
+    if (!profiling_) return;
+    if (pev_used_ + 2 > pev_.size()) {
+      for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); pev_.push_back(e); }
+    }
+    hipEventRecord(pev_[pev_used_], stream_);
+    pev_phase_.push_back(ph);
+    pev_used_ += 2;
+  }
+  void ph_end() {
+    if (!profiling_) return;
+    hipEventRecord(pev_[pev_used_ - 1], stream_);
+  }
+  void ph_collect() {
+    std::fill(ph_ms_, ph_ms_ + 8, 0.0);
+    std::fill(ph_n_, ph_n_ + 8, 0);
+    for (size_t i = 0; i < pev_phase_.size(); ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pev_[2 * i], pev_[2 * i + 1]) == hipSuccess) { ph_ms_[pev_phase_[i]] += ms; ph_n_[pev_phase_[i]] += 1; }
+    }
+    pev_phase_.clear();
+    pev_used_ = 0;
   }
   void launch_linearize() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
     constexpr int CH = sizeof(T) == 4 ? 64 : 32;
+    ph_begin(PH_ASM_REST);
     hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d);
+    ph_end();
+    ph_begin(PH_IMU_LIN);
     if (d.Gtot) hipLaunchKernelGGL((k_imu_linearize<T, CH>), dim3(d.Gtot), dim3(64), 32 * (6 * CH + 4) * sizeof(T), stream_, d);
+    ph_end();
+    ph_begin(PH_VIS_LIN);
     if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T, true>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
+    ph_end();
   }
   void launch_assemble() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
+    ph_begin(PH_ASM_VIS);
     if (d.Vtot) {  // few windows: split each window's items over several workgroups to fill the chip
       const int parts = std::min(8, std::max(1, 256 / nw));
       hipLaunchKernelGGL((k_assemble_vis<T, VCH>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
     }
+    ph_end();
+    ph_begin(PH_ASM_REST);
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d);
     hipLaunchKernelGGL((k_misc<T, true>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, d.quat, d.pos, d.bias, d.ld, 0);
     hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
+    ph_end();
   }
   void launch_step() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
+    ph_begin(PH_REST);
     hipLaunchKernelGGL((k_damping<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
+    ph_end();
+    ph_begin(PH_SCHUR);
     launch_schur();
+    ph_end();
+    ph_begin(PH_REST);
     hipLaunchKernelGGL((k_rhs<T>), dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
-    mark(3);
+    ph_end();
+    ph_begin(PH_CHOL);
     hipLaunchKernelGGL((k_cholesky_solve<T>), dim3(nw), dim3(256), chol_lds_, stream_, d);
+    ph_end();
+    ph_begin(PH_REST);
     hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(1024), 0, stream_, d);
+    ph_end();
   }
   void launch_schur();
   void launch_cost(bool candidate, int force) {
@@ -421,7 +465,8 @@ template <class T> class SolverImpl : public SolverBase {
     Dev<T> &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     set_params(max_iters);
-    time_phases_ = false;
+    profiling_ = profiling_requested_;
+    pev_phase_.clear(); pev_used_ = 0;
     HIPCHK(hipEventRecord(ev_[8], stream_));
     hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 0);
     launch_cost(false, 1);
@@ -435,10 +480,12 @@ template <class T> class SolverImpl : public SolverBase {
       hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
       if (it == max_iters) break;  // the last pass only finalises (max-iterations termination)
       launch_step();
+      ph_begin(PH_REST);
       hipLaunchKernelGGL((k_update<T, false>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
       launch_cost(true, 0);
       hipLaunchKernelGGL((k_lm_control<T>), dim3(wb), dim3(64), 0, stream_, d);
       hipLaunchKernelGGL((k_update<T, true>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
+      ph_end();
       if ((it + 1) % check == 0 && it + 1 < max_iters) {
         int32_t na = 0;
         HIPCHK(hipMemcpyAsync(&na, d.n_active, sizeof na, hipMemcpyDeviceToHost, stream_));
@@ -453,8 +500,11 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipGetLastError());
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev_[8], ev_[9]));
-    std::fill(timing_, timing_ + 8, 0.0);
-    timing_[6] = ms; timing_[7] = it;
+    if (profiling_) ph_collect(); else { std::fill(ph_ms_, ph_ms_ + 8, 0.0); std::fill(ph_n_, ph_n_ + 8, 0); }
+    profiling_ = false;
+    std::copy(ph_ms_, ph_ms_ + 7, timing_);
+    timing_[7] = ms;
+    last_iters_ = it;
     if (d.dbg) {
       long long st[64];
       HIPCHK(hipMemcpy(st, d.dbg, sizeof st, hipMemcpyDeviceToHost));
@@ -494,6 +544,24 @@ template <class T> class SolverImpl : public SolverBase {
     if (rho && m.L) HIPCHK(hipMemcpyAsync(dev_.rho + m.lm0, rho, sizeof(double) * m.L, hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(dev_.ld + id, &ld, sizeof(double), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
+    return CTVIO_OK;
+  }
+
+  // device-side copy of the whole batch state (restore != 0: copy back)
+  int snapshot(int restore) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    Dev<T> &d = dev_;
+    HIPCHK(b_snap_.alloc((size_t)4 * d.Ktot + 3 * d.Ktot + 6 * d.Ftot + d.Ltot + d.nwin));
+    double *p = b_snap_.p;
+    double *parts[5] = {d.quat, d.pos, d.bias, d.rho, d.ld};
+    const size_t sz[5] = {(size_t)4 * d.Ktot, (size_t)3 * d.Ktot, (size_t)6 * d.Ftot, (size_t)d.Ltot, (size_t)d.nwin};
+    if (restore && !snap_valid_) return fail(CTVIO_ERR_STATE, "no snapshot taken");
+    for (int i = 0; i < 5; ++i) {
+      if (sz[i]) HIPCHK(hipMemcpyAsync(restore ? parts[i] : p, restore ? p : parts[i], sz[i] * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+      p += sz[i];
+    }
+    HIPCHK(hipStreamSynchronize(stream_));
+    snap_valid_ = true;
     return CTVIO_OK;
   }
 
@@ -596,17 +664,23 @@ template <class T> class SolverImpl : public SolverBase {
     if (err) return fail(CTVIO_ERR_INVALID, "query time outside the spline");
     return CTVIO_OK;
   }
-  int last_timing(double *ms8) override {
+  int last_timing(double *ms8, int32_t *n8) override {
     if (ms8) std::copy(timing_, timing_ + 8, ms8);
+    if (n8) { std::copy(ph_n_, ph_n_ + 7, n8); n8[7] = last_iters_; }
     return CTVIO_OK;
   }
+  int set_profiling(int on) override { profiling_requested_ = on != 0; return CTVIO_OK; }
 
  private:
   ctvio_options opt_;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool time_phases_ = false, uploaded_ = false;
-  double timing_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool uploaded_ = false, profiling_ = false, profiling_requested_ = false;
+  double timing_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t ph_n_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_iters_ = 0;
+  std::vector<hipEvent_t> pev_;
+  std::vector<int> pev_phase_;
+  size_t pev_used_ = 0;
   std::vector<HostWindow> wins_;
   std::vector<WinMeta> meta_;
   Dev<T> dev_;
@@ -624,6 +698,8 @@ template <class T> class SolverImpl : public SolverBase {
   DBuf<uint8_t> b_active_;
   DBuf<Lm> b_lm_;
   DBuf<long long> b_dbg_;
+  DBuf<double> b_snap_;
+  bool snap_valid_ = false;
 };
 
 template <> void SolverImpl<float>::launch_schur() {
@@ -707,7 +783,10 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) {
   CHK_S; return s->impl->spline_eval(id, n, t_ns, pose7, vel3, omega3, acc3);
 }
-int32_t ctvio_last_timing(ctvio_solver *s, double *ms8) { CHK_S; return s->impl->last_timing(ms8); }
+int32_t ctvio_last_timing(ctvio_solver *s, double *ms8, int32_t *launches8) { CHK_S; return s->impl->last_timing(ms8, launches8); }
+int32_t ctvio_snapshot_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(0); }
+int32_t ctvio_restore_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(1); }
+int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on) { CHK_S; return s->impl->set_profiling(on); }
 void *ctvio_stream(ctvio_solver *s) { return s ? s->impl->stream() : nullptr; }
 
 }  // extern "C"

@@ -106,6 +106,12 @@ class Solver:
         w.normalize()
         capi.check(self._lib.ctvio_set_state(self._h, wid, capi._p(w.quat), capi._p(w.pos), capi._p(w.bias), capi._p(w.rho), float(w.ld)))
 
+    def snapshot_state(self):
+        capi.check(self._lib.ctvio_snapshot_state(self._h))
+
+    def restore_state(self):
+        capi.check(self._lib.ctvio_restore_state(self._h))
+
     # ---- diagnostics
     def linearize(self, wid: int):
         w = self.windows[wid]
@@ -133,10 +139,16 @@ class Solver:
         capi.check(self._lib.ctvio_spline_eval(self._h, wid, n, capi._p(t), capi._p(pose), capi._p(vel), capi._p(om), capi._p(acc)))
         return pose, vel, om, acc
 
+    PHASES = ("k_imu_linearize", "k_vis_eval", "k_assemble_vis", "assemble_rest", "k_schur_mfma", "k_cholesky_solve", "rest", "solve")
+
+    def set_profiling(self, on: bool):
+        capi.check(self._lib.ctvio_set_profiling(self._h, int(bool(on))))
+
     def last_timing(self):
-        ms = np.zeros(8)
-        capi.check(self._lib.ctvio_last_timing(self._h, capi._p(ms)))
-        return ms
+        """(ms[8], launches[8]) of the last solve; see include/ctvio.h ctvio_last_timing."""
+        ms = np.zeros(8); n = np.zeros(8, np.int32)
+        capi.check(self._lib.ctvio_last_timing(self._h, capi._p(ms), capi._p(n)))
+        return ms, n
 
     @property
     def stream(self) -> int:

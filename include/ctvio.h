@@ -130,6 +130,11 @@ int32_t ctvio_get_state(ctvio_solver *s, int32_t id, double *quat, double *pos, 
 int32_t ctvio_set_state(ctvio_solver *s, int32_t id, const double *quat, const double *pos, const double *bias,
                         const double *rho, double ld);
 
+/* Keep / bring back a device-side copy of the whole batch state: re-solve the same windows from the same initial
+ * guess without touching the host (the reference rebuilds its estimator from live state every frame instead). */
+int32_t ctvio_snapshot_state(ctvio_solver *s);
+int32_t ctvio_restore_state(ctvio_solver *s);
+
 /* ---- diagnostics used by the per-kernel parity tests (ResidualSummary analogue,
  *      trajectory_estimator.h:37-59,168-171) ---- */
 /* Linearise window id at its current state: Hpp (P*P row-major, symmetric filled), W (P*L row-major,
@@ -146,9 +151,15 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3,
                           double *omega3, double *acc3);
 
-/* Wall-clock of the last ctvio_solve split per phase [ms]: 0 linearise 1 assemble 2 schur 3 cholesky
- * 4 update+cost 5 control, plus [6] = total and [7] = LM iterations launched.  From HIP events. */
-int32_t ctvio_last_timing(ctvio_solver *s, double *ms8);
+/* Kernel timing of the next ctvio_solve calls with HIP events recorded on the solver's stream around every
+ * launch group (adds a few microseconds per launch: use a dedicated profiling solve, not the timed one). */
+int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on);
+/* Timing of the last ctvio_solve.  ms8: accumulated device time [ms] per launch group
+ *   0 k_imu_linearize  1 k_vis_eval (linearise)  2 k_assemble_vis  3 zero + k_assemble_imu + k_misc + k_post_linearize
+ *   4 Schur SYRK (k_schur_mfma)  5 k_cholesky_solve  6 everything else (damping, rhs, backsub, update, cost, control)
+ *   7 whole solve (always measured).  launches8: number of launches of each group, [7] = LM passes launched.
+ * Groups 0..6 are zero unless profiling was on. */
+int32_t ctvio_last_timing(ctvio_solver *s, double *ms8, int32_t *launches8);
 /* The HIP stream every kernel of this solver is launched on (hipStream_t), for external event timing. */
 void *ctvio_stream(ctvio_solver *s);
 
