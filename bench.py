@@ -106,8 +106,6 @@ def main():
         tt = torch.tensor([t_total], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_total = float(tt.item())
-    # results of the last step: fixed-size per-window records gathered on every rank (RCCL all-gather, outside the timed region)
-    sms_last = solver.solve(args.iters, writeback=False) if False else None
     n_solved = args.windows * world * args.steps
     out = {
         "metric": "sliding-window solves/sec (10 KF, 200 lm, 2000 IMU)", "value": n_solved / t_total, "unit": "solves/s",
@@ -120,6 +118,7 @@ def main():
     }
     if rank == 0:
         # ---- quality of what was timed: the solved batch against the fp64 oracle on the distinct windows
+        solver.restore_state()
         sms = solver.solve(args.iters, writeback=False)
         out["solve_summary"] = {"iterations_mean": float(np.mean([m["iterations"] for m in sms])),
                                 "terminations": sorted({m["termination"] for m in sms})}
