@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="solver handles (HIP streams) per GPU; the windows are split evenly among them")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,9 +79,27 @@ def main():
 
     # synthetic windows, seeds 1000 + rank*unique + i; a few distinct ones replicated to fill the batch
     uniq = [cv.synth.make_window(args.config, seed=1000 + rank * args.unique + i) for i in range(min(args.unique, args.windows))]
-    solver = cv.Solver(device=local, precision=args.precision)
-    solver.set_windows([uniq[i % len(uniq)].copy() for i in range(args.windows)])
-    solver.snapshot_state()
+    import threading
+    nstream = max(1, args.streams)
+    per = [args.windows // nstream + (1 if i < args.windows % nstream else 0) for i in range(nstream)]
+    solvers = []
+    for si_, cnt in enumerate(per):
+        sv = cv.Solver(device=local, precision=args.precision)
+        sv.set_windows([uniq[(i + si_) % len(uniq)].copy() for i in range(cnt)])
+        sv.snapshot_state()
+        solvers.append(sv)
+    solver = solvers[0]
+
+    def solve_all():
+        if nstream == 1:
+            solver.solve_raw(args.iters)
+            return
+        th = [threading.Thread(target=sv.solve_raw, args=(args.iters,)) for sv in solvers]
+        for t in th: t.start()
+        for t in th: t.join()
+
+    def restore_all():
+        for sv in solvers: sv.restore_state()
 
     def barrier():
         torch.cuda.synchronize()
@@ -89,15 +108,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        solver.restore_state()
-        solver.solve_raw(args.iters)
+        restore_all()
+        solve_all()
     t_total = 0.0
     dev_ms = []
     for _ in range(args.steps):
-        solver.restore_state()
+        restore_all()
         barrier()
         t0 = time.perf_counter()
-        solver.solve_raw(args.iters)          # returns after the stream is drained (summaries copied back)
+        solve_all()                           # returns after every stream is drained (summaries copied back)
         torch.cuda.synchronize()
         t_total += time.perf_counter() - t0
         dev_ms.append(solver.last_timing()[0][7])
@@ -113,7 +132,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
         "config": {"workload": f"{args.config}: 10 KF / 200 landmarks / 2000 IMU sliding window, <= {args.iters} LM iterations",
-                   "windows_per_gpu": args.windows, "sharding": f"independent windows, {world} rank(s), no data-path collective"},
+                   "windows_per_gpu": args.windows, "streams_per_gpu": nstream, "sharding": f"independent windows, {world} rank(s), no data-path collective"},
         "device_ms_per_step": float(np.mean(dev_ms)),
     }
     if rank == 0:

@@ -100,7 +100,8 @@ template <class T> class SolverImpl : public SolverBase {
     for (auto &e : ev_) HIPCHK(hipEventCreate(&e));
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int clear() override { wins_.clear(); uploaded_ = false; return CTVIO_OK; }
@@ -164,7 +165,9 @@ template <class T> class SolverImpl : public SolverBase {
     std::vector<int64_t> v_ti, v_tj;
     std::vector<ImuGroup> groups;
     std::vector<VisItem> vitems;
-    size_t vis_lds_bytes = vis_stage_bytes();
+    std::vector<int32_t> lm_blk_off, lm_blk;
+    int maxL = 0, maxLdw = 0;
+    size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     std::vector<T> imu_u;
     std::vector<uint8_t> active;
     int64_t H0 = 0, W0 = 0, pH0 = 0;
@@ -241,11 +244,21 @@ template <class T> class SolverImpl : public SolverBase {
         v_obs[(size_t)2 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v]; v_obs[(size_t)3 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v + 1];
       }
       m.nvitem = (int)vitems.size() - m.vitem0;
+      {  // CSR landmark -> blocks (positions in the sorted order)
+        std::vector<std::vector<int>> per(w.L);
+        for (int i = 0; i < w.V; ++i) per[h.v_lm[vord[i]]].push_back(V0 + i);
+        for (int l = 0; l < w.L; ++l) {
+          lm_blk_off.push_back((int)lm_blk.size());
+          lm_blk.insert(lm_blk.end(), per[l].begin(), per[l].end());
+        }
+      }
       {
-        const size_t K6 = 6 * (size_t)w.K, nH = K6 * (K6 + 1) / 2 + K6 + 1;
+        const size_t K6 = 6 * (size_t)w.K, nG = K6 + 1, nH = K6 * (K6 + 1) / 2 + K6 + 1 + nG;
         const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(T) + vis_stage_bytes();
+        const size_t need_glb = ((nG + 3) & ~(size_t)3) * sizeof(T) + vis_stage_bytes();
         m.vis_lds = need <= 160 * 1024 ? 1 : 0;
-        vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : vis_stage_bytes());
+        vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : need_glb);
+        vis_glb_bytes = std::max(vis_glb_bytes, need_glb);
       }
       // bias chain
       for (int b = 0; b < w.NB; ++b) { bc_win.push_back(wi); bc_i.push_back(h.bc_i[b]); bc_j.push_back(h.bc_j[b]); }
@@ -316,6 +329,7 @@ template <class T> class SolverImpl : public SolverBase {
       K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += w.V; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += n; pb += w.pnb;
       H0 += (int64_t)m.P * m.P; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)n * n;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, n);
+      maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw);
     }
     const size_t chol_lds = (size_t)(32 * 34 + 32 + 34 + ((size_t)std::max(maxP - 32, 0) + 8) * 32) * sizeof(double);
     if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~640)");
@@ -342,7 +356,11 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_Jv_.alloc((size_t)100 * std::max(Vtot_, 1))); HIPCHK(b_rv_.alloc((size_t)2 * std::max(Vtot_, 1))); HIPCHK(b_vs_.alloc((size_t)2 * std::max(Vtot_, 1)));
     d.v_win = b_v_win_.p; d.v_lm = b_v_lm_.p; d.v_ti = b_v_ti_.p; d.v_tj = b_v_tj_.p; d.v_rowi = b_v_rowi_.p; d.v_rowj = b_v_rowj_.p;
     d.v_obs = b_v_obs_.p; d.Jv = b_Jv_.p; d.rv = b_rv_.p; d.vs = b_vs_.p;
+    HIPCHK(b_Wc_.alloc((size_t)52 * std::max(Vtot_, 1))); d.Wc = b_Wc_.p;
     HIPCHK(b_vitems_.upload(vitems, stream_)); d.vitems = b_vitems_.p;
+    lm_blk_off.push_back((int)lm_blk.size());
+    HIPCHK(b_lm_blk_off_.upload(lm_blk_off, stream_)); HIPCHK(b_lm_blk_.upload(lm_blk, stream_));
+    d.lm_blk_off = b_lm_blk_off_.p; d.lm_blk = b_lm_blk_.p; d.maxL = maxL; d.maxLdw = maxLdw;
     HIPCHK(b_bc_win_.upload(bc_win, stream_)); HIPCHK(b_bc_i_.upload(bc_i, stream_)); HIPCHK(b_bc_j_.upload(bc_j, stream_)); HIPCHK(b_bc_w_.upload(bc_w, stream_));
     d.bc_win = b_bc_win_.p; d.bc_i = b_bc_i_.p; d.bc_j = b_bc_j_.p; d.bc_w = b_bc_w_.p;
     HIPCHK(b_pH_.upload(pH, stream_)); HIPCHK(b_pb0_.upload(pb0, stream_)); HIPCHK(b_pc0_.upload(pc0, stream_)); HIPCHK(b_pcol_.upload(pcol, stream_));
@@ -356,12 +374,18 @@ template <class T> class SolverImpl : public SolverBase {
     d.Hpp = b_Hpp_.p; d.S = b_S_.p; d.W = b_W_.p; d.Hll = b_Hll_.p; d.g = b_g_.p; d.rhs = b_rhs_.p; d.dd = b_dd_.p; d.dinv = b_dinv_.p;
     d.cscale = b_cscale_.p; d.delta = b_delta_.p; d.active = b_active_.p; d.lm = b_lm_.p; d.n_active = b_nact_.p;
     HIPCHK(hipMemsetAsync(b_lm_.p, 0, sizeof(Lm) * nw, stream_));
+    HIPCHK(hipMemsetAsync(b_W_.p, 0, sizeof(T) * std::max<size_t>((size_t)W0, 1), stream_));
+    HIPCHK(hipMemsetAsync(b_Hll_.p, 0, sizeof(double) * std::max(L0, 1), stream_));
+    HIPCHK(hipMemsetAsync(b_g_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
     HIPCHK(hipMemsetAsync(b_delta_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
     HIPCHK(hipMemsetAsync(b_cscale_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     chol_lds_ = chol_lds;
     snap_valid_ = false;
+    any_vis_lds_ = any_vis_glb_ = false;
+    for (const auto &mm : meta_) { if (mm.vis_lds) any_vis_lds_ = true; else if (mm.V > 0) any_vis_glb_ = true; }
     vis_lds_ = vis_lds_bytes;
+    vis_glb_ = vis_glb_bytes;
     uploaded_ = true;
     return CTVIO_OK;
   }
@@ -408,7 +432,8 @@ template <class T> class SolverImpl : public SolverBase {
     hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d);
     ph_end();
     ph_begin(PH_IMU_LIN);
-    if (d.Gtot) hipLaunchKernelGGL((k_imu_linearize<T, CH>), dim3(d.Gtot), dim3(64), 32 * (6 * CH + 4) * sizeof(T), stream_, d);
+    if (d.Gtot) hipLaunchKernelGGL((k_imu_linearize<T, CH>), dim3(d.Gtot), dim3(64),
+                                   sizeof(T) == 4 ? (size_t)6 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T), stream_, d);
     ph_end();
     ph_begin(PH_VIS_LIN);
     if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T, true>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
@@ -418,9 +443,11 @@ template <class T> class SolverImpl : public SolverBase {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
     ph_begin(PH_ASM_VIS);
-    if (d.Vtot) {  // few windows: split each window's items over several workgroups to fill the chip
+    {  // few windows: split each window's items over several workgroups to fill the chip
       const int parts = std::min(8, std::max(1, 256 / nw));
-      hipLaunchKernelGGL((k_assemble_vis<T, VCH>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
+      if (any_vis_lds_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, true>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
+      if (any_vis_glb_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, false>), dim3(nw, parts), dim3(512), vis_glb_, stream_, d);
+      if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(nblk(d.maxL, 4), nw), dim3(256), (size_t)4 * d.maxLdw * sizeof(T), stream_, d);
     }
     ph_end();
     ph_begin(PH_ASM_REST);
@@ -510,6 +537,10 @@ template <class T> class SolverImpl : public SolverBase {
       HIPCHK(hipMemcpy(st, d.dbg, sizeof st, hipMemcpyDeviceToHost));
       std::fprintf(stderr, "[ctvio] cholesky clock64 deltas:");
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n[ctvio] imu_linearize clock64 deltas:");
+      for (int i = 33; i < 48; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (stage | tile | scatter | round-sync ...):");
+      for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n");
     }
     if (out)
@@ -685,8 +716,9 @@ template <class T> class SolverImpl : public SolverBase {
   std::vector<WinMeta> meta_;
   Dev<T> dev_;
   int Mtot_ = 0, Vtot_ = 0;
-  size_t chol_lds_ = 0, vis_lds_ = 0;
+  size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0;
   DBuf<VisItem> b_vitems_;
+  DBuf<int32_t> b_lm_blk_off_, b_lm_blk_;
   DBuf<WinMeta> b_meta_;
   DBuf<double> b_quat_, b_pos_, b_bias_, b_rho_, b_ld_, b_cquat_, b_cpos_, b_cbias_, b_crho_, b_cld_, b_bc_w_, b_pH_, b_pb0_, b_pc0_, b_p_x0_;
   DBuf<double> b_Hpp_, b_S_, b_Hll_, b_g_, b_rhs_, b_dd_, b_dinv_, b_cscale_, b_delta_;
@@ -694,12 +726,12 @@ template <class T> class SolverImpl : public SolverBase {
       b_p_kind_, b_p_index_, b_p_off_, b_vs_, b_nact_;
   DBuf<int64_t> b_v_ti_, b_v_tj_;
   DBuf<ImuGroup> b_groups_;
-  DBuf<T> b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_;
+  DBuf<T> b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_, b_Wc_;
   DBuf<uint8_t> b_active_;
   DBuf<Lm> b_lm_;
   DBuf<long long> b_dbg_;
   DBuf<double> b_snap_;
-  bool snap_valid_ = false;
+  bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
 };
 
 template <> void SolverImpl<float>::launch_schur() {

@@ -71,8 +71,11 @@ template <class T> struct Dev {
   const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
   T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
   T *rv;                 // [2][Vtot]
+  T *Wc;                 // [Vtot][52] per block: J~_rho^T J~_c (49 pose columns), J~_rho^T J~_rho, J~_rho^T r~
   int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
   const VisItem *vitems;
+  const int32_t *lm_blk_off, *lm_blk;   // CSR landmark -> its visual blocks (global indices), [Ltot+1], [Vtot]
+  int32_t maxL, maxLdw;
   // bias chain
   const int32_t *bc_win, *bc_i, *bc_j;
   const double *bc_w;    // [NBtot][6]

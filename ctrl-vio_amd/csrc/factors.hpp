@@ -34,10 +34,16 @@ template <class T> CTV_DI void seg_const(const Knots4<T> &k, SegConst<T> &sc, bo
 
 // ------------------------------------------------------------------------------------------------
 // IMU block.  Local column order of J (6 x 30): rot k0..k3 (12) | pos k0..k3 (12) | bg (3) | ba (3).
-// Sink::put(row, col, value) receives the non-zero Jacobian entries; r[6] is returned whitened.
+// Sink::put_col(col, v[6]) receives every column of J (all 6 rows, structural zeros included);
+// r[6] is returned whitened.
+//
+// Local frame (fp32 accuracy): the caller passes the knots expressed relative to a reference knot,
+// q'_k = q_ref^-1 q_k, p'_k = R_ref^T (p_k - p_ref), and gravity as R_ref^T g.  Residuals are invariant under this
+// change of gauge and right-perturbation rotation Jacobians are unchanged; only the position Jacobians need
+// J_p = J_p' R_ref^T (RrefT).  Rotations near identity keep ~10x more significant digits in fp32.
 template <class T, class Sink>
 CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T> gravity, const T bias[6],
-                     const T gyro[3], const T acc[3], const T w[6], T r[6], bool want_jac, Sink &sink) {
+                     const T gyro[3], const T acc[3], const T w[6], const M3<T> &RrefT, T r[6], bool want_jac, Sink &sink) {
   T lamA[4], lamR[4], lamW[4];
   basis<T, false, 2>(u, idt * idt, lamA);
   basis<T, true, 0>(u, T(1), lamR);
@@ -88,6 +94,7 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
   }
   // accel rows, split_spline_view.h:183-211 (three R_accum entries: the reference's 2-entry array is a bug)
   const M3<T> Rinv = q2R(Rinv_q);
+  const M3<T> Rinv_g = mul(Rinv, RrefT);  // R(t)^T in the global frame, for the position-knot columns
   {
     const M3<T> lhs = mul_hat(Rinv, ag);
     M3<T> Racc = q2R(k.q[0]);
@@ -100,19 +107,30 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
       Ja[i + 1] = add(Ja[i + 1], mul(dad, sc.JrI[i]));
     }
   }
-  // trajectory_value_factor.h:198-245
+  // trajectory_value_factor.h:198-245, column by column
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      T c6[6], p6[6];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        sink.put(a, 3 * kk + b, w[a] * Jw[kk].m[3 * a + b]);
-        sink.put(3 + a, 3 * kk + b, w[3 + a] * Ja[kk].m[3 * a + b]);
-        sink.put(3 + a, 12 + 3 * kk + b, w[3 + a] * lamA[kk] * Rinv.m[3 * a + b]);
+      for (int a = 0; a < 3; ++a) {
+        c6[a] = w[a] * Jw[kk].m[3 * a + b];
+        c6[3 + a] = w[3 + a] * Ja[kk].m[3 * a + b];
+        p6[a] = T(0);
+        p6[3 + a] = w[3 + a] * lamA[kk] * Rinv_g.m[3 * a + b];
       }
+      sink.put_col(3 * kk + b, c6);
+      sink.put_col(12 + 3 * kk + b, p6);
+    }
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { sink.put(a, 24 + a, w[a]); sink.put(3 + a, 27 + a, w[3 + a]); }
+  for (int a = 0; a < 3; ++a) {
+    T g6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, h6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    g6[a] = w[a];
+    h6[3 + a] = w[3 + a];
+    sink.put_col(24 + a, g6);
+    sink.put_col(27 + a, h6);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -196,8 +214,8 @@ template <class T> struct Calib {
 // Outputs are already robust-corrected (r~ = sqrt(rho') r, J~ = sqrt(rho')(J - alpha/s r r^T J)); returns
 // the block's cost contribution rho(s)/2.  Emit::put(col, j0, j1) receives column `col` of J~ (both rows).
 template <class T, class Emit>
-CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt, const Calib<T> &cal, T pix, T piy, T pjx,
-                     T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac, Emit &emit) {
+CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt, const Calib<T> &cal, const M3<T> &RrefT, T pix,
+                     T piy, T pjx, T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac, Emit &emit) {
   SegConst<T> sci, scj;
   seg_const(ki, sci, want_jac);
   seg_const(kj, scj, want_jac);
@@ -251,6 +269,12 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt
   const T Jv[6] = {dji, T(0), -dji * dji * x_j.x, T(0), dji, -dji * dji * x_j.y};
   const M3<T> RGCj = q2R(S_GtoCj), RIiG = q2R(S_IitoG);
   const M3<T> RGCjRi = mul(RGCj, RIiG);
+  // inverse depth (image_feature_factor.h:239-248) -- emitted first: sinks that form J_rho^T J_c need it up front
+  {
+    const V3<T> y = mul(RGCjRi, qrot(cal.q_CI, x_ci));
+    const T f = -inv_d * sw;
+    out(48, f * (Jv[0] * y.x + Jv[2] * y.z), f * (Jv[4] * y.y + Jv[5] * y.z));
+  }
   {
     const M3<T> t0 = mul_hat(RGCjRi, p_Ii), t1 = mul_hat(RGCj, dpg);
     T lhsR0[6], lhsP0[6], lhsR1[6];  // :192-197 (lhsP1 = -lhsP0)
@@ -265,6 +289,16 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt
         }
         lhsR0[3 * a + b] = -s0; lhsP0[3 * a + b] = s1; lhsR1[3 * a + b] = s2;
       }
+    {  // position columns back to the global frame: J_p = J_p' R_ref^T (see imu_eval)
+      T g6[6];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          g6[3 * a + b] = lhsP0[3 * a] * RrefT.m[b] + lhsP0[3 * a + 1] * RrefT.m[3 + b] + lhsP0[3 * a + 2] * RrefT.m[6 + b];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) lhsP0[i] = g6[i];
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -280,12 +314,6 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt
         out(12 + 3 * kk + b, sw * cp0[kk] * lhsP0[b], sw * cp0[kk] * lhsP0[3 + b]);
         out(36 + 3 * kk + b, -sw * cp1[kk] * lhsP0[b], -sw * cp1[kk] * lhsP0[3 + b]);
       }
-  }
-  // inverse depth (image_feature_factor.h:239-248)
-  {
-    const V3<T> y = mul(RGCjRi, qrot(cal.q_CI, x_ci));
-    const T f = -inv_d * sw;
-    out(48, f * (Jv[0] * y.x + Jv[2] * y.z), f * (Jv[4] * y.y + Jv[5] * y.z));
   }
   // line delay (image_feature_factor.h:251-264)
   {

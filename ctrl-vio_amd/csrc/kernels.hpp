@@ -39,6 +39,44 @@ template <class T> __device__ __forceinline__ void load_knots(const double *quat
   }
 }
 
+// Knots k0..k0+3 in the local frame of the reference knot `kref` (fp64 arithmetic, then cast):
+//   q'_k = q_ref^-1 q_k (near identity), p'_k = R_ref^T (p_k - p_ref).
+template <class T> struct LocalFrame {
+  Q4<double> qref_inv;
+  M3<double> RT;      // R_ref^T
+  double o[3];
+  __device__ __forceinline__ void init(const double *quat, const double *pos, int kref) {
+    const double *q = quat + 4 * kref, *p = pos + 3 * kref;
+    qref_inv = qmk<double>(-q[0], -q[1], -q[2], q[3]);
+    const M3<double> R = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) RT.m[3 * i + j] = R.m[3 * j + i];
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+  }
+  __device__ __forceinline__ void load(const double *quat, const double *pos, int k0, Knots4<T> &k) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double *q = quat + 4 * (k0 + i), *p = pos + 3 * (k0 + i);
+      const Q4<double> ql = qmul(qref_inv, qmk<double>(q[0], q[1], q[2], q[3]));
+      const V3<double> pl = mul(RT, mk<double>(p[0] - o[0], p[1] - o[1], p[2] - o[2]));
+      k.q[i] = qmk<T>((T)ql.x, (T)ql.y, (T)ql.z, (T)ql.w);
+      k.p[i] = mk<T>((T)pl.x, (T)pl.y, (T)pl.z);
+    }
+  }
+  __device__ __forceinline__ V3<T> rotate(const double *v) const {  // R_ref^T v
+    const V3<double> r = mul(RT, mk<double>(v[0], v[1], v[2]));
+    return mk<T>((T)r.x, (T)r.y, (T)r.z);
+  }
+  __device__ __forceinline__ M3<T> RrefT() const {
+    M3<T> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.m[i] = (T)RT.m[i];
+    return r;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ control
 template <class T> __global__ void k_lm_init(Dev<T> d, double mu, int keep_scale) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,34 +148,45 @@ template <class T> __global__ void k_zero_normal(Dev<T> d) {
   const int w = blockIdx.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
-  const long long nH = (long long)m.P * m.P, nW = (long long)m.Lpad * m.ldw;
+  const long long nH = (long long)m.P * m.P;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nW; i += stride) d.W[m.W0 + i] = T(0);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.N; i += stride) d.g[m.u0 + i] = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.L; i += stride) d.Hll[m.lm0 + i] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) d.g[m.u0 + i] = 0.0;
+  // W, Hll and g[P..N) are written (not accumulated) by k_build_W
   if (blockIdx.x == 0 && threadIdx.x == 0) d.lm[w].gmax_bits = 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------ IMU
 template <class T, int N> struct alignas(N * sizeof(T)) VecN { T v[N]; };
 
-template <class T> struct ImuLdsSink {
-  T *base;  // &A[0*KS + 6*lane]
-  int ks;
-  __device__ __forceinline__ void put(int row, int col, T v) { base[col * ks + row] = v; }
+// LDS layouts of the staged IMU rows (row k = 6 * lane + r of A = [J | r], 32 columns):
+//   MFMA path (float): row-major A[k][33]  -- v_mfma_f32_32x32x2_f32 reads 2 rows x 32 columns per instruction
+//   VALU path        : column-major A^T[32][KS] -- 4 consecutive k per ds_read for the register-tile reduction
+template <class T, bool ROWMAJOR> struct ImuLdsSink {
+  T *A;
+  int lane, stride;
+  __device__ __forceinline__ void put_col(int col, const T v[6]) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (ROWMAJOR) A[(6 * lane + r) * stride + col] = v[r];
+      else A[col * stride + 6 * lane + r] = v[r];
+    }
+  }
 };
 template <class T> struct NullSink {
-  __device__ __forceinline__ void put(int, int, T) {}
+  __device__ __forceinline__ void put_col(int, const T *) {}
 };
 
 // One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane
-// evaluates one sample, writes its 6 Jacobian rows + residual as columns of A^T into LDS ([32][KS],
-// column-major in k so that the reduction reads 4 consecutive k per ds_read), then the wave forms the
-// group's 31x31 block A^T A = [J^T J, J^T r; r^T J, r^T r] with a 4x4 register tile per lane
-// (rows {ti+8a}, cols {tj+8b}: conflict-free LDS reads) and stores it -- no atomics, deterministic.
+// evaluates one sample and writes its 6 Jacobian rows + residual (all 32 columns, zeros included: no separate
+// zero pass) into LDS; then the wave forms the group's 31x31 block A^T A = [J^T J, J^T r; r^T J, r^T r]:
+//   float : on the matrix cores, v_mfma_f32_32x32x2_f32 with A and B operand the same LDS value (2 rows / instr);
+//   double: 4x4 register tile per lane (rows {ti+8a}, cols {tj+8b}: conflict-free LDS reads).
+// The tile is stored, not accumulated -- no atomics, deterministic.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <class T, int CHUNK> __global__ __launch_bounds__(64) void k_imu_linearize(Dev<T> d) {
-  constexpr int KCH = 6 * CHUNK, KS = KCH + 4;
+  constexpr bool MFMA = sizeof(T) == 4;
+  constexpr int KCH = 6 * CHUNK, KS = MFMA ? 33 : KCH + 4;
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   T *A = reinterpret_cast<T *>(smraw);
   const ImuGroup grp = d.groups[blockIdx.x];
@@ -146,59 +195,86 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) void k_imu_linear
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x;
   Knots4<T> k;
-  load_knots<T>(d.quat, d.pos, m.knot0 + grp.s, d.pos + 3 * (m.knot0 + grp.s), k);
+  LocalFrame<T> lf;
+  lf.init(d.quat, d.pos, m.knot0 + grp.s);
+  lf.load(d.quat, d.pos, m.knot0 + grp.s, k);
+  const M3<T> RrefT = lf.RrefT();
   SegConst<T> sc;
   seg_const(k, sc, true);
   T bias[6], wgt[6];
   const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { bias[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
-  const V3<T> grav = mk<T>((T)m.gravity[0], (T)m.gravity[1], (T)m.gravity[2]);
+  const V3<T> grav = lf.rotate(m.gravity);
   const T idt = (T)m.inv_dt;
-  const int ti = lane >> 3, tj = lane & 7;
+  const int ti = lane >> 3, tj = lane & 7, half = lane >> 5, l31 = lane & 31;
   T acc[4][4];
+  f32x16 macc;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
-
+#pragma unroll
+  for (int r = 0; r < 16; ++r) macc[r] = 0.0f;
+  long long *dbg = (d.dbg && blockIdx.x == 0) ? d.dbg + 32 : nullptr;
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && lane == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
   for (int c0 = 0; c0 < grp.count; c0 += CHUNK) {
     const int nval = min(CHUNK, grp.count - c0);
     const int kmax = (6 * nval + 3) & ~3;
-    for (int e = lane; e < 32 * kmax; e += 64) A[(e / kmax) * KS + (e % kmax)] = T(0);
-    __syncthreads();
+    ImuLdsSink<T, MFMA> sink{A, lane, KS};
+    const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     if (lane < nval) {
       const int idx = m.imu0 + grp.start + c0 + lane;
       T gy[3], ac[3], r[6];
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
-      ImuLdsSink<T> sink{A + 6 * lane, KS};
-      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, r, true, sink);
+      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
+      sink.put_col(30, r);
+      sink.put_col(31, zero6);
+    } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
 #pragma unroll
-      for (int i = 0; i < 6; ++i) A[30 * KS + 6 * lane + i] = r[i];
+      for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
     }
     __syncthreads();
-    for (int k0 = 0; k0 < kmax; k0 += 4) {
-      VecN<T, 4> av[4], bv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        av[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (ti + 8 * a) * KS + k0);
-        bv[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (tj + 8 * a) * KS + k0);
+    CTV_STAMP();
+    if constexpr (MFMA) {
+#pragma unroll 8
+      for (int k0 = 0; k0 < kmax; k0 += 2) {
+        const float v = A[(k0 + half) * KS + l31];
+        macc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, macc, 0, 0, 0);
       }
+    } else {
+      for (int k0 = 0; k0 < kmax; k0 += 4) {
+        VecN<T, 4> av[4], bv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+          av[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (ti + 8 * a) * KS + k0);
+          bv[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (tj + 8 * a) * KS + k0);
+        }
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
+      }
     }
     __syncthreads();
+    CTV_STAMP();
   }
+#undef CTV_STAMP
   T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
+  if constexpr (MFMA) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = macc[r];
+  } else {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
+  }
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
@@ -213,6 +289,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
     const double v = (double)tile[a * 32 + b];
     const int ga = imu_col(a, grp.s, m.K, grp.bias);
     if (b == 30) { atomicAdd(&d.g[m.u0 + ga], v); continue; }
+    if (m.vis_lds && a < 24 && b < 24) continue;  // knot x knot: accumulated in LDS by k_assemble_vis
     const int gb = imu_col(b, grp.s, m.K, grp.bias);
     if (ga >= gb) atomicAdd(&d.Hpp[m.H0 + (long long)ga * m.P + gb], v);
   }
@@ -229,7 +306,9 @@ template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, c
     if (d.lm[w].status == 0 && (d.lm[w].step_valid || force)) {
       const WinMeta &m = d.wins[w];
       Knots4<T> k;
-      load_knots<T>(quat, pos, m.knot0 + grp.s, pos + 3 * (m.knot0 + grp.s), k);
+      LocalFrame<T> lf;
+      lf.init(quat, pos, m.knot0 + grp.s);
+      lf.load(quat, pos, m.knot0 + grp.s, k);
       SegConst<T> sc;
       seg_const(k, sc, false);
       T b[6], wgt[6], gy[3], ac[3], r[6];
@@ -239,7 +318,7 @@ template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, c
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
       NullSink<T> ns;
-      imu_eval<T>(k, sc, d.imu_u[idx], (T)m.inv_dt, mk<T>((T)m.gravity[0], (T)m.gravity[1], (T)m.gravity[2]), b, gy, ac, wgt, r, false, ns);
+      imu_eval<T>(k, sc, d.imu_u[idx], (T)m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, ns);
       T s = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) s += r[i] * r[i];
@@ -262,7 +341,13 @@ template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, c
 template <class T> struct VisGlobalSink {
   T *J;        // &Jv[v]
   size_t stride;
-  __device__ __forceinline__ void put(int col, T j0, T j1) { J[(size_t)(2 * col) * stride] = j0; J[(size_t)(2 * col + 1) * stride] = j1; }
+  T *wc;       // LDS row of this lane: J_rho^T J_c for the 49 pose columns (slot 48 = line delay), then Hll, g_rho
+  T jr0, jr1;
+  __device__ __forceinline__ void put(int col, T j0, T j1) {
+    J[(size_t)(2 * col) * stride] = j0; J[(size_t)(2 * col + 1) * stride] = j1;
+    if (col == 48) { jr0 = j0; jr1 = j1; }                       // visual_eval emits the inverse-depth column first
+    else wc[col < 48 ? col : 48] = jr0 * j0 + jr1 * j1;
+  }
 };
 template <class T> struct VisNullSink {
   __device__ __forceinline__ void put(int, T, T) {}
@@ -282,6 +367,9 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 template <class T, bool LIN>
 __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ T wcs[LIN ? 64 * 53 : 1];   // per-lane W contributions, written out coalesced at the end
+  __shared__ int wcs_on[LIN ? 64 : 1];
+  if (LIN) wcs_on[threadIdx.x] = 0;
   double c = 0.0;
   int w = -1;
   if (v < d.Vtot) {
@@ -298,10 +386,12 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
       vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
       si = max(0, min(si, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
       sj = max(0, min(sj, m.K - 4));
-      const double *origin = pos + 3 * (m.knot0 + si);
       Knots4<T> ki, kj;
-      load_knots<T>(quat, pos, m.knot0 + si, origin, ki);
-      load_knots<T>(quat, pos, m.knot0 + sj, origin, kj);
+      LocalFrame<T> lf;
+      lf.init(quat, pos, m.knot0 + si);       // both ends relative to the first active knot of the anchor end
+      lf.load(quat, pos, m.knot0 + si, ki);
+      lf.load(quat, pos, m.knot0 + sj, kj);
+      const M3<T> RrefT = lf.RrefT();
       Calib<T> cal;
       cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
       cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
@@ -311,21 +401,31 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisGlobalSink<T> sink{d.Jv + v, V};
-        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v], d.v_obs[3 * V + v],
-                                   (T)rowi, (T)rowj, d_inv, r, true, sink);
+        VisGlobalSink<T> sink{d.Jv + v, V, wcs + 53 * threadIdx.x, T(0), T(0)};
+        wcs_on[threadIdx.x] = 1;
+        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
+                                   d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
+        sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
+        sink.wc[50] = sink.jr0 * r[0] + sink.jr1 * r[1];
         d.rv[v] = r[0]; d.rv[V + v] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
       } else {
         VisNullSink<T> sink;
-        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v], d.v_obs[3 * V + v],
-                                   (T)rowi, (T)rowj, d_inv, r, false, sink);
+        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
+                                   d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, false, sink);
       }
     } else {
       w = -1;
     }
   }
-  if (!LIN) {
+  if (LIN) {
+    __syncthreads();
+    const long long vbase = (long long)blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 52; i += 64) {
+      const int bl = i / 52, cc = i % 52;
+      if (wcs_on[bl] && cc < 51) d.Wc[(size_t)52 * (vbase + bl) + cc] = wcs[53 * bl + cc];
+    }
+  } else {
     const int w0 = __shfl(w, 0);
     if (__all(w == w0)) {
       for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -346,16 +446,19 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
 // knots (reference image_feature_factor.h:165-180,215,233): every ordered column pair whose unknowns satisfy
 // g(a) >= g(b) is added, so shared knots sum correctly.  Landmark terms (W row, Hll, g_rho) stay per block.
 // Windows whose packed Hessian does not fit in LDS (vis_lds = 0) add straight into Hpp.
-template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d) {
+template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d) {
   constexpr int CHP = CH + 1, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
-  if (m.V == 0) return;
+  if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
+  if (m.V == 0 && !LDSH) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
   T *Hs = reinterpret_cast<T *>(smv);
   const int K6 = 6 * m.K, tri = K6 * (K6 + 1) / 2;
-  const int nH = m.vis_lds ? tri + K6 + 1 : 0;
+  const int nHh = LDSH ? tri + K6 + 1 : 0;     // packed Hessian entries
+  const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay), always in LDS
+  T *gs = Hs + nHh;
   T *stage = Hs + ((nH + 3) & ~3);                                    // [NW][102][CHP]
   int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -376,6 +479,10 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
     rowa[a] = ca < 48 ? 2 * ca : (ca == 48 ? 98 : (ca == 49 ? 100 : -1));
     rowb[a] = cb < 48 ? 2 * cb : (cb == 48 ? 98 : (cb == 49 ? 100 : -1));
   }
+  long long *dbg = (d.dbg && w == 0 && part == 0) ? d.dbg + 48 : nullptr;
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 15) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
   for (int r = 0; r < rounds; ++r) {
     const int it = (r * nparts + part) * NW + wave;
     int n = 0, v0 = 0;
@@ -397,6 +504,7 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
     }
     if (lane < n) { ks[lane] = d.vs[v0 + lane]; ks[CH + lane] = d.vs[V + v0 + lane]; }
     __syncthreads();
+    CTV_STAMP();
     int start = 0;
     while (start < n) {
       const int si = ks[start], sj = ks[CH + start];
@@ -423,6 +531,7 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
             for (int b = 0; b < 7; ++b) acc[a][b] += av[a] * bv[b];
         }
       }
+      CTV_STAMP();
       int ga[7], gb[7];
 #pragma unroll
       for (int a = 0; a < 7; ++a) {
@@ -434,39 +543,36 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
       for (int a = 0; a < 7; ++a)
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-          if (ga[a] < 0 || gb[b] == -1) continue;
-          if (gb[b] == -2) { atomicAdd(&d.g[m.u0 + ga[a]], (double)acc[a][b]); continue; }  // J~^T r~
-          if (ga[a] < gb[b]) continue;
-          if (m.vis_lds) {
-            const int idx = (ga[a] == m.P - 1) ? tri + (gb[b] == m.P - 1 ? K6 : gb[b]) : ga[a] * (ga[a] + 1) / 2 + gb[b];
-            atomicAdd(&Hs[idx], acc[a][b]);
-          } else {
-            atomicAdd(&Hg[(long long)ga[a] * m.P + gb[b]], (double)acc[a][b]);
+          const int gA = ga[a], gB = gb[b];
+          if (gB == -2) {                     // column 49 = residual: J~^T r~ (only the 8 lanes with tj == 1, b == 6)
+            if (gA >= 0) atomicAdd(&gs[gA == m.P - 1 ? K6 : gA], acc[a][b]);
+          } else if (gA >= 0 && gB >= 0 && gA >= gB) {
+            if (LDSH) atomicAdd(&Hs[(gA == m.P - 1) ? tri + (gB == m.P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], acc[a][b]);
+            else atomicAdd(&Hg[(long long)gA * m.P + gB], (double)acc[a][b]);
           }
         }
-      // landmark terms per block: W row (49), Hll, g_rho
-      for (int e = lane; e < (end - start) * 51; e += 64) {
-        const int v = start + e / 51, b = e % 51;
-        const int l = d.v_lm[v0 + v];
-        const T jr0 = Js[96 * CHP + v], jr1 = Js[97 * CHP + v];
-        if (b < 49) {
-          const int cb = b < 48 ? b : 49;
-          const T h = jr0 * Js[(2 * cb) * CHP + v] + jr1 * Js[(2 * cb + 1) * CHP + v];
-          atomicAdd(&d.W[m.W0 + (long long)l * m.ldw + vis_col(cb, si, sj, m.P)], h);
-        } else if (b == 49) {
-          atomicAdd(&d.Hll[m.lm0 + l], (double)(jr0 * jr0 + jr1 * jr1));
-        } else {
-          atomicAdd(&d.g[m.u0 + m.P + l], (double)(jr0 * Js[100 * CHP + v] + jr1 * Js[101 * CHP + v]));
-        }
-      }
       start = end;
+      CTV_STAMP();
     }
     __syncthreads();
+    CTV_STAMP();
   }
-  if (m.vis_lds) {
-    for (int i = tid; i < nH; i += 512) {
+#undef CTV_STAMP
+  if (LDSH) {
+    // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments)
+    for (int gi = part * NW + wave; gi < m.ngrp; gi += per_round) {
+      const ImuGroup grp = d.groups[m.grp0 + gi];
+      const T *tile = d.imu_tiles + (size_t)(m.grp0 + gi) * 1024;
+      for (int e = lane; e < 24 * 24; e += 64) {
+        const int a = e / 24, b = e % 24;
+        const int ga = imu_col(a, grp.s, m.K, grp.bias), gb = imu_col(b, grp.s, m.K, grp.bias);
+        if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], tile[a * 32 + b]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nHh; i += 512) {
       const T hv = Hs[i];
-      if (hv == T(0)) continue;
+      if (nparts > 1 && hv == T(0)) continue;
       int ga, gb;
       if (i < tri) {
         ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
@@ -477,8 +583,61 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
         ga = m.P - 1;
         gb = (i - tri) < K6 ? (i - tri) : m.P - 1;
       }
-      atomicAdd(&Hg[(long long)ga * m.P + gb], (double)hv);
+      if (nparts > 1) atomicAdd(&Hg[(long long)ga * m.P + gb], (double)hv);
+      else Hg[(long long)ga * m.P + gb] = (double)hv;  // first writer after k_zero_normal; later kernels add atomically
     }
+  }
+  if (!LDSH) __syncthreads();
+  for (int i = tid; i < K6 + 1; i += 512) {
+    const T gv = gs[i];
+    if (gv != T(0)) atomicAdd(&d.g[m.u0 + (i < K6 ? i : m.P - 1)], (double)gv);
+  }
+}
+
+// W row, Hll and g_rho of every landmark, gathered (no atomics, no zero pass): one wave per landmark walks the
+// landmark's visual blocks (CSR built at upload) and accumulates J~_rho^T J~_pose into a row buffer in LDS.
+template <class T> __global__ __launch_bounds__(256) void k_build_W(Dev<T> d) {
+  const int w = blockIdx.y;
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T *row = reinterpret_cast<T *>(smw) + (size_t)wave * m.ldw;
+  const int l = blockIdx.x * 4 + wave;
+  const bool valid = l < m.L;
+  if ((int)blockIdx.x * 4 >= m.L) return;  // whole block idle (uniform)
+  for (int i = lane; i < m.ldw; i += 64) row[i] = T(0);
+  __syncthreads();
+  double hll = 0.0, gl = 0.0;
+  if (valid) {
+    const size_t V = (size_t)d.Vtot;
+    const int b0 = d.lm_blk_off[m.lm0 + l], b1 = d.lm_blk_off[m.lm0 + l + 1];
+    for (int bb = b0; bb < b1; bb += 8) {  // 8 blocks per pass: all loads of the pass in flight together
+      T wv[8];
+      int si[8], sj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool on = bb + u < b1;
+        const int v = on ? d.lm_blk[bb + u] : 0;
+        wv[u] = (on && lane < 51) ? d.Wc[(size_t)52 * v + lane] : T(0);
+        si[u] = on ? d.vs[v] : 0;
+        sj[u] = on ? d.vs[V + v] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (bb + u >= b1) continue;
+        if (lane < 49) atomicAdd(&row[vis_col(lane < 48 ? lane : 49, si[u], sj[u], m.P)], wv[u]);  // ends may share knots
+        else if (lane == 49) hll += (double)wv[u];
+        else if (lane == 50) gl += (double)wv[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    T *Wr = d.W + m.W0 + (long long)l * m.ldw;
+    for (int i = lane; i < m.ldw; i += 64) Wr[i] = row[i];
+    if (lane == 49) d.Hll[m.lm0 + l] = hll;
+    if (lane == 50) d.g[m.u0 + m.P + l] = gl;
   }
 }
 
@@ -643,7 +802,6 @@ __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> 
 // S = Hpp + D^2 - W^T diag(dinv) W (lower triangle) on the matrix cores: one wave per 32x32 tile,
 // v_mfma_f32_32x32x2_f32 over the landmark dimension (2 landmarks per instruction), operands read
 // straight from the landmark-major W (32 consecutive floats per half-wave: coalesced).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
   const int w = blockIdx.y;
   if (d.lm[w].status) return;
@@ -661,7 +819,13 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  for (int l0 = 0; l0 < m.Lpad; l0 += 2) {
+  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
+  const int K6 = 6 * m.K;
+  const bool nz_i = (32 * bi < K6) || (m.P - 1 >= 32 * bi && m.P - 1 < 32 * bi + 32);
+  const bool nz_j = (32 * bj < K6) || (m.P - 1 >= 32 * bj && m.P - 1 < 32 * bj + 32);
+  const int lend = (nz_i && nz_j) ? m.Lpad : 0;
+#pragma unroll 8
+  for (int l0 = 0; l0 < lend; l0 += 2) {
     const int l = l0 + half;
     const float di = (l < m.L) ? (float)dinv[l] : 0.0f;
     const float a = Wp[(long long)l * m.ldw + i] * ai;
@@ -805,7 +969,7 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
     }
     __syncthreads();
     CTV_STAMP();
-    for (int r = tid; r < ntr4; r += 256) {  // panel rows (and the rhs row): L21 = A21 L11^-T, in place in the LDS panel
+    for (int r = tid; r < ntr4; r += 256) {  // panel rows (and the rhs row): L21 = A21 L11^-T, row kept in the LDS panel
       double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + jb : y + jb;
       const bool live = r < ntr;
       double *lr = LpT + r;  // element j of this row lives at lr[j * RS]: consecutive lanes -> consecutive addresses
@@ -816,12 +980,17 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
 #pragma unroll
         for (int j = 0; j < 32; ++j) lr[j * RS] = tmp[j];
       }
-      for (int k = 0; k < nb; ++k) {  // column sweep: entry k becomes final, then the columns to its right are updated
-        const double lk = lr[k * RS] * dinvs[k];
-        lr[k * RS] = lk;
-        const double *dk = Dt + k * 34;
-#pragma unroll 4
-        for (int j = k + 1; j < nb; ++j) lr[j * RS] -= lk * dk[j];
+      for (int j = 0; j < nb; ++j) {  // x_j = (a_j - sum_{k<j} x_k L11[j][k]) / L11[j][j]; 4 independent partial sums
+        double s0 = lr[j * RS], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 3 < j; k += 4) {
+          s0 -= lr[k * RS] * Dt[k * 34 + j];
+          s1 -= lr[(k + 1) * RS] * Dt[(k + 1) * 34 + j];
+          s2 -= lr[(k + 2) * RS] * Dt[(k + 2) * 34 + j];
+          s3 -= lr[(k + 3) * RS] * Dt[(k + 3) * 34 + j];
+        }
+        for (; k < j; ++k) s0 -= lr[k * RS] * Dt[k * 34 + j];
+        lr[j * RS] = ((s0 + s1) + (s2 + s3)) * dinvs[j];
       }
       if (live) {
         double tmp[32];
@@ -847,6 +1016,17 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
       const double *pr = LpT + 4 * tr, *pc = LpT + 4 * tc;
+      double sv[4][4];  // current values, requested before the k loop so their latency hides under it
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * tr + i;
+        const double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + r0 : y + r0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = 4 * tc + j;
+          sv[i][j] = (r < ntr && c < nt && c <= r) ? Srow[c] : 0.0;
+        }
+      }
 #pragma unroll 8
       for (int k = 0; k < 32; ++k) {
         const VecN<double, 4> rv = *reinterpret_cast<const VecN<double, 4> *>(pr + k * RS);
@@ -864,7 +1044,7 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int c = 4 * tc + j;
-          if (c < nt && (c <= r)) Srow[c] -= acc[i][j];
+          if (c < nt && (c <= r)) Srow[c] = sv[i][j] - acc[i][j];
         }
       }
     }

@@ -9,21 +9,40 @@ using namespace ctv;
 namespace {
 template <class T> struct ImuSink {
   T *J;
-  void put(int row, int col, T v) { J[row * 30 + col] = v; }
+  void put_col(int col, const T v[6]) { for (int r = 0; r < 6; ++r) J[r * 30 + col] = v[r]; }
 };
 template <class T> struct VisSink {
   T *J;
   void put(int col, T j0, T j1) { J[col] = j0; J[50 + col] = j1; }
 };
 
+// local frame of the reference knot (q_ref, p_ref): the same preparation the kernels do (LocalFrame in kernels.hpp)
+template <class T> struct HostLocalFrame {
+  Q4<double> qi; M3<double> RT; double o[3];
+  HostLocalFrame(const double *q, const double *p) {
+    qi = qmk<double>(-q[0], -q[1], -q[2], q[3]);
+    const M3<double> R = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RT.m[3 * i + j] = R.m[3 * j + i];
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+  }
+  void load(const double *q, const double *p, Knots4<T> &k) const {
+    for (int i = 0; i < 4; ++i) {
+      const Q4<double> ql = qmul(qi, qmk<double>(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]));
+      const V3<double> pl = mul(RT, mk<double>(p[3 * i] - o[0], p[3 * i + 1] - o[1], p[3 * i + 2] - o[2]));
+      k.q[i] = qmk<T>((T)ql.x, (T)ql.y, (T)ql.z, (T)ql.w);
+      k.p[i] = mk<T>((T)pl.x, (T)pl.y, (T)pl.z);
+    }
+  }
+  M3<T> RrefT() const { M3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = (T)RT.m[i]; return r; }
+  V3<T> rotate(const double *v) const { const V3<double> r = mul(RT, mk<double>(v[0], v[1], v[2])); return mk<T>((T)r.x, (T)r.y, (T)r.z); }
+};
+
 template <class T>
 void imu_eval_t(const double *q, const double *p, double u, double idt, const double *g, const double *bias,
                 const double *gyro, const double *acc, const double *w, double *r, double *J) {
   Knots4<T> k;
-  for (int i = 0; i < 4; ++i) {
-    k.q[i] = qmk<T>((T)q[4 * i], (T)q[4 * i + 1], (T)q[4 * i + 2], (T)q[4 * i + 3]);
-    k.p[i] = mk<T>((T)(p[3 * i] - p[0]), (T)(p[3 * i + 1] - p[1]), (T)(p[3 * i + 2] - p[2]));
-  }
+  HostLocalFrame<T> lf(q, p);
+  lf.load(q, p, k);
   SegConst<T> sc;
   seg_const(k, sc, true);
   T b[6], gy[3], ac[3], ww[6], rr[6], JJ[180];
@@ -31,7 +50,7 @@ void imu_eval_t(const double *q, const double *p, double u, double idt, const do
   for (int i = 0; i < 3; ++i) { gy[i] = (T)gyro[i]; ac[i] = (T)acc[i]; }
   for (int i = 0; i < 180; ++i) JJ[i] = 0;
   ImuSink<T> sink{JJ};
-  imu_eval<T>(k, sc, (T)u, (T)idt, mk<T>((T)g[0], (T)g[1], (T)g[2]), b, gy, ac, ww, rr, true, sink);
+  imu_eval<T>(k, sc, (T)u, (T)idt, lf.rotate(g), b, gy, ac, ww, lf.RrefT(), rr, true, sink);
   for (int i = 0; i < 6; ++i) r[i] = rr[i];
   for (int i = 0; i < 180; ++i) J[i] = JJ[i];
 }
@@ -41,13 +60,9 @@ double visual_eval_t(const double *qi, const double *pi, const double *qj, const
                      double idt, const double *q_CI, const double *p_CI, double img_w, double cauchy_a, const double *obs,
                      double rowi, double rowj, double d_inv, double *r, double *J) {
   Knots4<T> ki, kj;
-  for (int i = 0; i < 4; ++i) {
-    ki.q[i] = qmk<T>((T)qi[4 * i], (T)qi[4 * i + 1], (T)qi[4 * i + 2], (T)qi[4 * i + 3]);
-    kj.q[i] = qmk<T>((T)qj[4 * i], (T)qj[4 * i + 1], (T)qj[4 * i + 2], (T)qj[4 * i + 3]);
-    // common origin = first knot of the i-end
-    ki.p[i] = mk<T>((T)(pi[3 * i] - pi[0]), (T)(pi[3 * i + 1] - pi[1]), (T)(pi[3 * i + 2] - pi[2]));
-    kj.p[i] = mk<T>((T)(pj[3 * i] - pi[0]), (T)(pj[3 * i + 1] - pi[1]), (T)(pj[3 * i + 2] - pi[2]));
-  }
+  HostLocalFrame<T> lf(qi, pi);   // both ends relative to the first knot of the i-end
+  lf.load(qi, pi, ki);
+  lf.load(qj, pj, kj);
   Calib<T> cal;
   cal.q_CI = qmk<T>((T)q_CI[0], (T)q_CI[1], (T)q_CI[2], (T)q_CI[3]);
   cal.p_CI = mk<T>((T)p_CI[0], (T)p_CI[1], (T)p_CI[2]);
@@ -56,7 +71,7 @@ double visual_eval_t(const double *qi, const double *pi, const double *qj, const
   T rr[2], JJ[100];
   for (int i = 0; i < 100; ++i) JJ[i] = 0;
   VisSink<T> sink{JJ};
-  T cost = visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)idt, cal, (T)obs[0], (T)obs[1], (T)obs[2], (T)obs[3], (T)rowi, (T)rowj,
+  T cost = visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)idt, cal, lf.RrefT(), (T)obs[0], (T)obs[1], (T)obs[2], (T)obs[3], (T)rowi, (T)rowj,
                           (T)d_inv, rr, true, sink);
   r[0] = rr[0]; r[1] = rr[1];
   for (int i = 0; i < 100; ++i) J[i] = JJ[i];
