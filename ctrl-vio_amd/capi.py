@@ -38,7 +38,7 @@ class Options(C.Structure):
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("max_consecutive_invalid_steps", C.c_int32), ("reserved", C.c_int32)]
+                ("max_consecutive_invalid_steps", C.c_int32), ("fp64_residuals", C.c_int32)]
 
 
 class CWindow(C.Structure):

@@ -88,7 +88,7 @@ template <class T> class SolverImpl : public SolverBase {
  public:
   static constexpr int VCH = sizeof(T) == 4 ? 32 : 16;   // visual blocks per work item (k_assemble_vis)
   static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 1) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
-  explicit SolverImpl(const ctvio_options &o) : opt_(o) {}
+  explicit SolverImpl(const ctvio_options &o) : opt_(o), mixed_(sizeof(T) == 4 && o.fp64_residuals != 0) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
@@ -169,6 +169,7 @@ template <class T> class SolverImpl : public SolverBase {
     int maxL = 0, maxLdw = 0;
     size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     std::vector<T> imu_u;
+    std::vector<double> imu_ud;
     std::vector<uint8_t> active;
     int64_t H0 = 0, W0 = 0, pH0 = 0;
     int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0;
@@ -176,6 +177,7 @@ template <class T> class SolverImpl : public SolverBase {
     Mtot_ = 0; Vtot_ = 0;
     for (const auto &h : wins_) { Mtot_ += h.w.M; Vtot_ += h.w.V; }
     std::vector<T> imu_meas((size_t)6 * std::max(Mtot_, 1)), v_obs((size_t)4 * std::max(Vtot_, 1));
+    std::vector<double> imu_meas_d((size_t)6 * std::max(Mtot_, 1)), v_obs_d((size_t)4 * std::max(Vtot_, 1));
     for (int wi = 0; wi < nw; ++wi) {
       const HostWindow &h = wins_[wi];
       const ctvio_window &w = h.w;
@@ -216,9 +218,12 @@ template <class T> class SolverImpl : public SolverBase {
         groups.back().count++;
         imu_grp.push_back((int)groups.size() - 1);
         imu_u.push_back((T)uu[src]);
+        imu_ud.push_back(uu[src]);
         for (int c = 0; c < 3; ++c) {
           imu_meas[(size_t)c * Mtot_ + M0 + i] = (T)h.imu_gyro[3 * src + c];
           imu_meas[(size_t)(3 + c) * Mtot_ + M0 + i] = (T)h.imu_acc[3 * src + c];
+          imu_meas_d[(size_t)c * Mtot_ + M0 + i] = h.imu_gyro[3 * src + c];
+          imu_meas_d[(size_t)(3 + c) * Mtot_ + M0 + i] = h.imu_acc[3 * src + c];
         }
       }
       m.ngrp = (int)groups.size() - m.grp0;
@@ -242,6 +247,8 @@ template <class T> class SolverImpl : public SolverBase {
         v_rowi.push_back(h.v_rowi[v]); v_rowj.push_back(h.v_rowj[v]);
         v_obs[(size_t)0 * Vtot_ + V0 + i] = (T)h.v_pi[2 * v]; v_obs[(size_t)1 * Vtot_ + V0 + i] = (T)h.v_pi[2 * v + 1];
         v_obs[(size_t)2 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v]; v_obs[(size_t)3 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v + 1];
+        v_obs_d[(size_t)0 * Vtot_ + V0 + i] = h.v_pi[2 * v]; v_obs_d[(size_t)1 * Vtot_ + V0 + i] = h.v_pi[2 * v + 1];
+        v_obs_d[(size_t)2 * Vtot_ + V0 + i] = h.v_pj[2 * v]; v_obs_d[(size_t)3 * Vtot_ + V0 + i] = h.v_pj[2 * v + 1];
       }
       m.nvitem = (int)vitems.size() - m.vitem0;
       {  // CSR landmark -> blocks (positions in the sorted order)
@@ -350,6 +357,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_groups_.upload(groups, stream_)); HIPCHK(b_imu_grp_.upload(imu_grp, stream_)); HIPCHK(b_imu_u_.upload(imu_u, stream_));
     HIPCHK(b_imu_meas_.upload(imu_meas, stream_)); HIPCHK(b_tiles_.alloc(groups.size() * 1024));
     d.groups = b_groups_.p; d.imu_grp = b_imu_grp_.p; d.imu_u = b_imu_u_.p; d.imu_meas = b_imu_meas_.p; d.imu_tiles = b_tiles_.p;
+    HIPCHK(b_imu_ud_.upload(imu_ud, stream_)); HIPCHK(b_imu_meas_d_.upload(imu_meas_d, stream_)); HIPCHK(b_v_obs_d_.upload(v_obs_d, stream_));
+    d.imu_ud = b_imu_ud_.p; d.imu_meas_d = b_imu_meas_d_.p; d.v_obs_d = b_v_obs_d_.p;
     HIPCHK(b_v_win_.upload(v_win, stream_)); HIPCHK(b_v_lm_.upload(v_lm, stream_)); HIPCHK(b_v_ti_.upload(v_ti, stream_));
     HIPCHK(b_v_tj_.upload(v_tj, stream_)); HIPCHK(b_v_rowi_.upload(v_rowi, stream_)); HIPCHK(b_v_rowj_.upload(v_rowj, stream_));
     HIPCHK(b_v_obs_.upload(v_obs, stream_));
@@ -432,11 +441,17 @@ template <class T> class SolverImpl : public SolverBase {
     hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d);
     ph_end();
     ph_begin(PH_IMU_LIN);
-    if (d.Gtot) hipLaunchKernelGGL((k_imu_linearize<T, CH>), dim3(d.Gtot), dim3(64),
-                                   sizeof(T) == 4 ? (size_t)6 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T), stream_, d);
+    const size_t imu_lds = (sizeof(T) == 4 ? (size_t)6 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 40 * sizeof(double);
+    if (d.Gtot) {
+      if (mixed_) hipLaunchKernelGGL((k_imu_linearize<T, CH, double>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
+      else hipLaunchKernelGGL((k_imu_linearize<T, CH, T>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
+    }
     ph_end();
     ph_begin(PH_VIS_LIN);
-    if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T, true>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
+    if (d.Vtot) {
+      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, true, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
+      else hipLaunchKernelGGL((k_vis_eval<T, true, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
+    }
     ph_end();
   }
   void launch_assemble() {
@@ -480,8 +495,14 @@ template <class T> class SolverImpl : public SolverBase {
     const Dev<T> &d = dev_;
     const double *q = candidate ? d.cquat : d.quat, *p = candidate ? d.cpos : d.pos, *b = candidate ? d.cbias : d.bias;
     const double *r = candidate ? d.crho : d.rho, *l = candidate ? d.cld : d.ld;
-    if (d.Mtot) hipLaunchKernelGGL((k_imu_cost<T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, force);
-    if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T, false>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, force);
+    if (d.Mtot) {
+      if (mixed_) hipLaunchKernelGGL((k_imu_cost<T, double>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, force);
+      else hipLaunchKernelGGL((k_imu_cost<T, T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, force);
+    }
+    if (d.Vtot) {
+      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, false, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, force);
+      else hipLaunchKernelGGL((k_vis_eval<T, false, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, force);
+    }
     hipLaunchKernelGGL((k_misc<T, false>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, q, p, b, l, force);
   }
   int n_state() const { return dev_.Ktot + dev_.Ftot + dev_.Ltot + dev_.nwin; }
@@ -706,7 +727,7 @@ template <class T> class SolverImpl : public SolverBase {
   ctvio_options opt_;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool uploaded_ = false, profiling_ = false, profiling_requested_ = false;
+  bool uploaded_ = false, profiling_ = false, profiling_requested_ = false, mixed_ = false;
   double timing_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int32_t ph_n_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_iters_ = 0;
   std::vector<hipEvent_t> pev_;
@@ -730,7 +751,7 @@ template <class T> class SolverImpl : public SolverBase {
   DBuf<uint8_t> b_active_;
   DBuf<Lm> b_lm_;
   DBuf<long long> b_dbg_;
-  DBuf<double> b_snap_;
+  DBuf<double> b_snap_, b_imu_ud_, b_imu_meas_d_, b_v_obs_d_;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
 };
 
@@ -759,6 +780,7 @@ void ctvio_default_options(ctvio_options *o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32; o->min_relative_decrease = 1e-3;
   o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->max_consecutive_invalid_steps = 5;
+  o->fp64_residuals = 1;
 }
 const char *ctvio_status_string(int32_t s) {
   switch (s) {

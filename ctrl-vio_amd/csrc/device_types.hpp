@@ -63,12 +63,14 @@ template <class T> struct Dev {
   const int32_t *imu_grp;
   const T *imu_u;        // [Mtot] normalised time in the segment
   const T *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
+  const double *imu_ud, *imu_meas_d;   // the same in fp64, read by the residual path of the mixed mode
   T *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
   // visual factors
   const int32_t *v_win, *v_lm;
   const int64_t *v_ti, *v_tj;   // relative to the window's t0
   const int32_t *v_rowi, *v_rowj;
   const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
+  const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
   T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
   T *rv;                 // [2][Vtot]
   T *Wc;                 // [Vtot][52] per block: J~_rho^T J~_c (49 pose columns), J~_rho^T J~_rho, J~_rho^T r~

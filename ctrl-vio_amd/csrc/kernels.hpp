@@ -184,11 +184,16 @@ template <class T> struct NullSink {
 //   double: 4x4 register tile per lane (rows {ti+8a}, cols {tj+8b}: conflict-free LDS reads).
 // The tile is stored, not accumulated -- no atomics, deterministic.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <class T, int CHUNK> __global__ __launch_bounds__(64) void k_imu_linearize(Dev<T> d) {
+// RT = scalar of the RESIDUAL (and of the cost kernels).  RT = double with T = float is the mixed mode: Jacobians,
+// J^T J and the Schur complement stay in fp32, but r (hence the gradient J^T r and every cost) is evaluated in fp64
+// from fp64 inputs, which removes the fp32 residual noise (~5e-5 sigma) from the LM decisions and the fixed point.
+template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_imu_linearize(Dev<T> d) {
   constexpr bool MFMA = sizeof(T) == 4;
+  constexpr bool MIXED = sizeof(RT) != sizeof(T);
   constexpr int KCH = 6 * CHUNK, KS = MFMA ? 33 : KCH + 4;
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   T *A = reinterpret_cast<T *>(smraw);
+  RT *gsh = reinterpret_cast<RT *>(smraw + (MFMA ? (size_t)KCH * KS : (size_t)32 * KS) * sizeof(T));  // [40] group constants (MIXED)
   const ImuGroup grp = d.groups[blockIdx.x];
   const int w = grp.win;
   if (!lin_needed(d.lm[w])) return;
@@ -207,6 +212,24 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) void k_imu_linear
   for (int i = 0; i < 6; ++i) { bias[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
   const V3<T> grav = lf.rotate(m.gravity);
   const T idt = (T)m.inv_dt;
+  if (MIXED) {  // the group's knots, d_i = log(R_i^-1 R_{i+1}) and gravity in RT, computed once and parked in LDS
+    Knots4<RT> kd;
+    LocalFrame<RT> lfd;
+    lfd.init(d.quat, d.pos, m.knot0 + grp.s);
+    lfd.load(d.quat, d.pos, m.knot0 + grp.s, kd);
+    SegConst<RT> scd;
+    seg_const(kd, scd, false);
+    const V3<RT> gd = lfd.rotate(m.gravity);
+    if (lane == 0) {
+      for (int i = 0; i < 4; ++i) {
+        gsh[4 * i] = kd.q[i].x; gsh[4 * i + 1] = kd.q[i].y; gsh[4 * i + 2] = kd.q[i].z; gsh[4 * i + 3] = kd.q[i].w;
+        gsh[16 + 3 * i] = kd.p[i].x; gsh[16 + 3 * i + 1] = kd.p[i].y; gsh[16 + 3 * i + 2] = kd.p[i].z;
+      }
+      for (int i = 0; i < 3; ++i) { gsh[28 + 3 * i] = scd.d[i].x; gsh[28 + 3 * i + 1] = scd.d[i].y; gsh[28 + 3 * i + 2] = scd.d[i].z; }
+      gsh[37] = gd.x; gsh[38] = gd.y; gsh[39] = gd.z;
+    }
+    __syncthreads();
+  }
   const int ti = lane >> 3, tj = lane & 7, half = lane >> 5, l31 = lane & 31;
   T acc[4][4];
   f32x16 macc;
@@ -231,6 +254,27 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) void k_imu_linear
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
       imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
+      if (MIXED) {  // residual again, in RT from RT inputs (no Jacobian)
+        Knots4<RT> kd;
+        SegConst<RT> scd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          kd.q[i] = qmk<RT>(gsh[4 * i], gsh[4 * i + 1], gsh[4 * i + 2], gsh[4 * i + 3]);
+          kd.p[i] = mk<RT>(gsh[16 + 3 * i], gsh[16 + 3 * i + 1], gsh[16 + 3 * i + 2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) scd.d[i] = mk<RT>(gsh[28 + 3 * i], gsh[28 + 3 * i + 1], gsh[28 + 3 * i + 2]);
+        RT bd[6], wd[6], gyd[3], acd[3], rd[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { bd[i] = (RT)bp[i]; wd[i] = (RT)m.imu_w[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gyd[i] = d.imu_meas_d[(size_t)i * d.Mtot + idx]; acd[i] = d.imu_meas_d[(size_t)(3 + i) * d.Mtot + idx]; }
+        NullSink<RT> ns;
+        M3<RT> unused = m3_id<RT>();
+        imu_eval<RT>(kd, scd, (RT)d.imu_ud[idx], (RT)m.inv_dt, mk<RT>(gsh[37], gsh[38], gsh[39]), bd, gyd, acd, wd, unused, rd, false, ns);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = (T)rd[i];
+      }
       sink.put_col(30, r);
       sink.put_col(31, zero6);
     } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
@@ -296,7 +340,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
 }
 
 // Residual-only pass: one lane per IMU sample, cost accumulated in fp64.
-template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, int force) {
+template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, int force) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   double c = 0.0;
   int w = -1;
@@ -305,21 +349,25 @@ template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, c
     w = grp.win;
     if (d.lm[w].status == 0 && (d.lm[w].step_valid || force)) {
       const WinMeta &m = d.wins[w];
-      Knots4<T> k;
-      LocalFrame<T> lf;
+      Knots4<RT> k;
+      LocalFrame<RT> lf;
       lf.init(quat, pos, m.knot0 + grp.s);
       lf.load(quat, pos, m.knot0 + grp.s, k);
-      SegConst<T> sc;
+      SegConst<RT> sc;
       seg_const(k, sc, false);
-      T b[6], wgt[6], gy[3], ac[3], r[6];
+      RT b[6], wgt[6], gy[3], ac[3], r[6];
       const double *bp = bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { b[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
+      for (int i = 0; i < 6; ++i) { b[i] = (RT)bp[i]; wgt[i] = (RT)m.imu_w[i]; }
+      constexpr bool RD = sizeof(RT) == 8;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
-      NullSink<T> ns;
-      imu_eval<T>(k, sc, d.imu_u[idx], (T)m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, ns);
-      T s = 0;
+      for (int i = 0; i < 3; ++i) {
+        gy[i] = RD ? (RT)d.imu_meas_d[(size_t)i * d.Mtot + idx] : (RT)d.imu_meas[(size_t)i * d.Mtot + idx];
+        ac[i] = RD ? (RT)d.imu_meas_d[(size_t)(3 + i) * d.Mtot + idx] : (RT)d.imu_meas[(size_t)(3 + i) * d.Mtot + idx];
+      }
+      NullSink<RT> ns;
+      imu_eval<RT>(k, sc, RD ? (RT)d.imu_ud[idx] : (RT)d.imu_u[idx], (RT)m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, ns);
+      RT s = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) s += r[i] * r[i];
       c = 0.5 * (double)s;
@@ -364,7 +412,30 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 
 // One lane per visual block.  LIN: evaluate r~, J~ (robust-corrected) and materialise them (SoA, coalesced);
 // otherwise residual only.  Cost contributions are reduced per wave and added in fp64.
-template <class T, bool LIN>
+template <class RT, class TD>
+__device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, int v, int si, int sj, double ui, double uj, int rowi, int rowj,
+                                               const double *quat, const double *pos, double rho_l, RT r[2]) {
+  Knots4<RT> ki, kj;
+  LocalFrame<RT> lf;
+  lf.init(quat, pos, m.knot0 + si);
+  lf.load(quat, pos, m.knot0 + si, ki);
+  lf.load(quat, pos, m.knot0 + sj, kj);
+  Calib<RT> cal;
+  cal.q_CI = qmk<RT>((RT)m.q_CI[0], (RT)m.q_CI[1], (RT)m.q_CI[2], (RT)m.q_CI[3]);
+  cal.p_CI = mk<RT>((RT)m.p_CI[0], (RT)m.p_CI[1], (RT)m.p_CI[2]);
+  cal.img_w = (RT)m.img_w;
+  cal.cauchy_a = (RT)m.cauchy_a;
+  const size_t V = (size_t)d.Vtot;
+  constexpr bool RD = sizeof(RT) == 8;
+  RT o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = RD ? (RT)d.v_obs_d[(size_t)i * V + v] : (RT)d.v_obs[(size_t)i * V + v];
+  VisNullSink<RT> sink;
+  return (double)visual_eval<RT>(ki, kj, (RT)ui, (RT)uj, (RT)m.inv_dt, cal, lf.RrefT(), o[0], o[1], o[2], o[3], (RT)rowi, (RT)rowj, (RT)rho_l, r,
+                                 false, sink);
+}
+
+template <class T, bool LIN, class RT>
 __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ T wcs[LIN ? 64 * 53 : 1];   // per-lane W contributions, written out coalesced at the end
@@ -405,14 +476,18 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
         wcs_on[threadIdx.x] = 1;
         c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
+        if (sizeof(RT) != sizeof(T)) {  // mixed mode: residual (and its cost) again in RT; J~ keeps the fp32 corrector scale
+          RT rd[2];
+          c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, rho[m.lm0 + d.v_lm[v]], rd);
+          r[0] = (T)rd[0]; r[1] = (T)rd[1];
+        }
         sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
         sink.wc[50] = sink.jr0 * r[0] + sink.jr1 * r[1];
         d.rv[v] = r[0]; d.rv[V + v] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
       } else {
-        VisNullSink<T> sink;
-        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
-                                   d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, false, sink);
+        RT rd[2];
+        c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, rho[m.lm0 + d.v_lm[v]], rd);
       }
     } else {
       w = -1;

@@ -17,7 +17,8 @@ from .window import Window
 class Solver:
     """One handle = one HIP stream + the HBM buffers of a batch of windows."""
 
-    def __init__(self, device: int = 0, precision: str = "fp32", use_mfma: bool = True, check_every: int = 4, **tolerances):
+    def __init__(self, device: int = 0, precision: str = "fp32", use_mfma: bool = True, check_every: int = 4,
+                 fp64_residuals: bool = True, **tolerances):
         self._lib = capi.load_library()
         if self._lib.ctvio_device_count() <= 0:
             raise capi.CtvioError("no HIP device: ctrl-vio_amd has no CPU fallback")
@@ -27,6 +28,7 @@ class Solver:
         opt.precision = capi.FP64 if precision in ("fp64", capi.FP64) else capi.FP32
         opt.use_mfma = int(bool(use_mfma))
         opt.check_every = int(check_every)
+        opt.fp64_residuals = int(bool(fp64_residuals))
         for k, v in tolerances.items():
             if not hasattr(opt, k):
                 raise TypeError(f"unknown option {k}")

@@ -58,7 +58,8 @@ typedef struct ctvio_options {
   double min_relative_decrease; /* 1e-3 */
   double min_lm_diagonal, max_lm_diagonal; /* 1e-6, 1e32 */
   int32_t max_consecutive_invalid_steps;   /* 5 */
-  int32_t reserved;
+  int32_t fp64_residuals;       /* FP32 only, default 1: residuals, gradient right-hand sides and costs are evaluated in fp64
+                                   (Jacobians, J^T J and the Schur complement stay fp32) */
 } ctvio_options;
 
 /* One sliding window = what TrajectoryManager::UpdateTrajectory feeds a fresh TrajectoryEstimator

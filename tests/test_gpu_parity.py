@@ -3,9 +3,9 @@ the committed golden fixtures, and size-independent properties at BASELINE.json'
 
 Tolerances.  precision="fp64" runs the same kernels in double: it must reproduce the oracle to rounding, which
 validates kernel logic (indexing, reductions, Schur, Cholesky, LM control).  precision="fp32" is the product:
-  linearisation (Jacobi-normalised H, W, g)        <= 2e-4
+  linearisation (Jacobi-normalised H, W, g)        <= 2e-4   (fp32 Jacobians; residuals, J^T r inputs and costs in fp64)
   one LM step (relative, max-norm)                 <= 5e-3
-  converged state (relative L2 over the whole state, BASELINE target)  <= 1e-4
+  final state vs the fp64 reference solve at Ceres' own tolerances (BASELINE target)  <= 1e-4
 """
 import os
 
@@ -80,39 +80,28 @@ def test_solve_fp64_reproduces_oracle_iterates(cv, oracle):
         assert cv.rel_state_error(wg, wo)["state"] < 1e-6
 
 
-@pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config1", 1001), ("config2", 1000), ("config2", 1001)])
+@pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config1", 1001), ("config2", 1000), ("config2", 1001), ("config2", 1002)])
 def test_solve_fp32_vs_oracle_at_ceres_tolerances(cv, oracle, cfg, seed):
-    """Product precision (fp32 linearisation) against the fp64 reference solve with identical Ceres settings
-    (15 iterations, function tolerance 1e-6).  These windows are ill-conditioned (Jacobi-scaled Hessian
-    cond ~1e10), so Ceres' own stopping rule leaves the state undetermined at the 2e-4..2e-3 level: that
-    stopping slop is measured here (oracle at Ceres tolerances vs oracle converged tightly) and the fp32
-    result must agree with the reference within it (factor 3), with the cost agreeing to the function tolerance."""
+    """BASELINE target.  Product precision (fp32 Jacobians / normal equations / Schur, fp64 residuals and costs)
+    against the fp64 reference solve with identical Ceres settings (15 iterations, function tolerance 1e-6):
+    same iteration count, cost to 1e-7, final state within 1e-4 relative (measured 6e-6 .. 6e-5)."""
     w0 = cv.synth.make_window(cfg, seed=seed)
     wo = w0.copy()
     sm_o = oracle.OracleWindow(wo).solve(15)
-    oracle.set_tolerances(1e-13, 1e-14, 1e-13)
-    try:
-        wt = w0.copy()
-        oracle.OracleWindow(wt).solve(200)
-    finally:
-        oracle.set_tolerances()
-    slop = cv.rel_state_error(wo, wt)["state"]
     with cv.Solver(precision="fp32") as s:
         wg = w0.copy()
         s.set_windows([wg])
         sm = s.solve(15)[0]
-    assert abs(sm["iterations"] - sm_o.iterations) <= 2
-    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=3e-6)
+    assert abs(sm["iterations"] - sm_o.iterations) <= 1
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-7)
     err = cv.rel_state_error(wg, wo)
-    assert err["state"] < max(3.0 * slop, 1e-4), (err, slop)
-    assert err["state"] < 5e-3
+    assert err["state"] < 1e-4, err
 
 
 @pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config2", 1000), ("config2", 1002)])
 def test_solve_fp32_precision_floor(cv, oracle, cfg, seed):
-    """Both solvers converged tightly (tolerances 1e-13): what is left is the fp32 residual/Jacobian noise
-    propagated through the ill-conditioned normal equations.  BASELINE's 1e-4 target is met for most windows
-    (measured 2e-5..5e-4 over seeds); the bound asserted here is the worst case seen, 1e-3."""
+    """Both solvers converged tightly (tolerances 1e-13): what is left is the fp32 Jacobian noise in J^T r propagated
+    through the ill-conditioned normal equations (Jacobi-scaled cond ~1e10): measured 2e-6 .. 2e-5, asserted 5e-5."""
     w0 = cv.synth.make_window(cfg, seed=seed)
     oracle.set_tolerances(1e-13, 1e-14, 1e-13)
     try:
@@ -124,10 +113,31 @@ def test_solve_fp32_precision_floor(cv, oracle, cfg, seed):
         wg = w0.copy()
         s.set_windows([wg])
         sm = s.solve(200)[0]
-    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=3e-6)
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-8)
     err = cv.rel_state_error(wg, wt)
-    assert err["state"] < 1e-3, err
-    assert err["quat"] < 2e-4 and err["ld"] < 1e-4, err
+    assert err["state"] < 5e-5, err
+
+
+def test_pure_fp32_residuals_within_stopping_slop(cv, oracle):
+    """fp64_residuals = 0 (everything in fp32): the residual noise (~5e-5 sigma) perturbs Ceres' accept / terminate
+    decisions, so the result is only guaranteed to lie within the reference solve's own stopping slop (oracle at Ceres
+    tolerances vs oracle converged tightly), which is measured here."""
+    w0 = cv.synth.make_window("config2", seed=1000)
+    wo = w0.copy()
+    sm_o = oracle.OracleWindow(wo).solve(15)
+    oracle.set_tolerances(1e-13, 1e-14, 1e-13)
+    try:
+        wt = w0.copy()
+        oracle.OracleWindow(wt).solve(200)
+    finally:
+        oracle.set_tolerances()
+    slop = cv.rel_state_error(wo, wt)["state"]
+    with cv.Solver(precision="fp32", fp64_residuals=False) as s:
+        wg = w0.copy()
+        s.set_windows([wg])
+        sm = s.solve(15)[0]
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=3e-6)
+    assert cv.rel_state_error(wg, wo)["state"] < max(3.0 * slop, 1e-4)
 
 
 def test_golden_converged_state(cv, golden_dir):
@@ -138,8 +148,10 @@ def test_golden_converged_state(cv, golden_dir):
     with cv.Solver(precision="fp32") as s:
         s.set_windows([w])
         sm = s.solve(50)[0]
-    assert sm["final_cost"] == pytest.approx(float(d["final_cost"]), rel=5e-6)
-    assert cv.rel_state_error(w, wf)["state"] < 1e-3   # stopping slop of the Ceres tolerances, see the test above
+    assert sm["final_cost"] == pytest.approx(float(d["final_cost"]), rel=2e-6)
+    # the fixture is scipy's tightly converged minimiser; Ceres' function tolerance stops ~2.5e-4 short of it on this
+    # window (the oracle does too: tests/test_oracle_golden.py), so the bound is the stopping slop, not a precision
+    assert cv.rel_state_error(w, wf)["state"] < 1e-3
 
 
 def test_spline_eval(cv, oracle, win_cfg1):
