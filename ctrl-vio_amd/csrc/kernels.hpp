@@ -603,7 +603,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 #pragma unroll
           for (int a = 0; a < 7; ++a)
 #pragma unroll
-            for (int b = 0; b < 7; ++b) acc[a][b] += av[a] * bv[b];
+            for (int b = 0; b <= a; ++b) acc[a][b] += av[a] * bv[b];   // symmetric product: only column blocks a >= b
         }
       }
       CTV_STAMP();
@@ -611,19 +611,27 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 #pragma unroll
       for (int a = 0; a < 7; ++a) {
         const int ca = ti + 8 * a, cb = tj + 8 * a;
-        ga[a] = ca < 48 ? vis_col(ca, si, sj, m.P) : (ca == 48 ? m.P - 1 : -1);
+        ga[a] = ca < 48 ? vis_col(ca, si, sj, m.P) : (ca == 48 ? m.P - 1 : (ca == 49 ? -2 : -1));
         gb[a] = cb < 48 ? vis_col(cb, si, sj, m.P) : (cb == 48 ? m.P - 1 : (cb == 49 ? -2 : -1));
       }
+      // Each unordered column pair {ca, cb} is held exactly once: blocks a > b by this lane, and for a == b by the lane
+      // with ti >= tj.  It goes to H[max(g)][min(g)]; two different local columns that map to the same unknown (ends
+      // sharing a knot) contribute twice to the diagonal entry.
 #pragma unroll
       for (int a = 0; a < 7; ++a)
 #pragma unroll
-        for (int b = 0; b < 7; ++b) {
-          const int gA = ga[a], gB = gb[b];
-          if (gB == -2) {                     // column 49 = residual: J~^T r~ (only the 8 lanes with tj == 1, b == 6)
-            if (gA >= 0) atomicAdd(&gs[gA == m.P - 1 ? K6 : gA], acc[a][b]);
-          } else if (gA >= 0 && gB >= 0 && gA >= gB) {
-            if (LDSH) atomicAdd(&Hs[(gA == m.P - 1) ? tri + (gB == m.P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], acc[a][b]);
-            else atomicAdd(&Hg[(long long)gA * m.P + gB], (double)acc[a][b]);
+        for (int b = 0; b <= a; ++b) {
+          if (a == b && ti < tj) continue;
+          int gA = ga[a], gB = gb[b];
+          T hv = acc[a][b];
+          if (gA == -2 || gB == -2) {         // column 49 = residual: J~^T r~ (r~^T r~ itself is not needed)
+            const int gX = gA == -2 ? gB : gA;
+            if (gX >= 0) atomicAdd(&gs[gX == m.P - 1 ? K6 : gX], hv);
+          } else if (gA >= 0 && gB >= 0) {
+            if (gA == gB && !(a == b && ti == tj)) hv *= T(2);
+            if (gA < gB) { const int t = gA; gA = gB; gB = t; }
+            if (LDSH) atomicAdd(&Hs[(gA == m.P - 1) ? tri + (gB == m.P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], hv);
+            else atomicAdd(&Hg[(long long)gA * m.P + gB], (double)hv);
           }
         }
       start = end;
