@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="solver handles (HIP streams) per GPU; the windows are split evenly among them")
+    ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams) per GPU; the windows are split evenly among them")
     args = ap.parse_args()
 
     import numpy as np

@@ -25,7 +25,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     deps = SRC + [HDR]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(f) for f in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize",
            "-o", LIB_PATH, SRC[0]]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

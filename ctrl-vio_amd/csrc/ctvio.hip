@@ -87,7 +87,7 @@ static int prior_block_size(int kind) { return kind == CTVIO_PK_LD ? 1 : 3; }
 template <class T> class SolverImpl : public SolverBase {
  public:
   static constexpr int VCH = sizeof(T) == 4 ? 32 : 16;   // visual blocks per work item (k_assemble_vis)
-  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 1) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
+  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
   explicit SolverImpl(const ctvio_options &o) : opt_(o), mixed_(sizeof(T) == 4 && o.fp64_residuals != 0) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -185,7 +185,7 @@ template <class T> class SolverImpl : public SolverBase {
       m.K = w.K; m.F = w.F; m.L = w.L; m.M = w.M; m.NB = w.NB; m.V = w.V;
       m.P = 6 * w.K + 6 * w.F + 1; m.N = m.P + w.L; m.pn = w.pn; m.pnb = w.pnb;
       m.knot0 = K0; m.bias0 = F0; m.lm0 = L0; m.imu0 = M0; m.vis0 = V0; m.bc0 = B0; m.u0 = U0; m.p0 = Pp0;
-      m.ldw = (m.P + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
+      m.ldw = (m.P + 1 + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
       m.pv0 = pv0; m.pblk0 = pb; m.fix_ld = w.fix_ld; m.lock_bg = w.lock_bg; m.lock_ba = w.lock_ba; m.fixed_upto = w.fixed_upto;
       m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
       for (int i = 0; i < 4; ++i) m.q_CI[i] = w.q_CI[i];
@@ -401,6 +401,7 @@ template <class T> class SolverImpl : public SolverBase {
 
   // ---------------------------------------------------------------------------------------- launches
   static int nblk(long long n, int b) { return (int)std::max<long long>((n + b - 1) / b, 1); }
+  int vis_parts() const { return std::min(8, std::max(1, 256 / std::max(dev_.nwin, 1))); }
   void set_params(int max_iters) {
     LmParams &p = dev_.prm;
     p.ftol = opt_.function_tolerance; p.gtol = opt_.gradient_tolerance; p.ptol = opt_.parameter_tolerance;
@@ -438,7 +439,7 @@ template <class T> class SolverImpl : public SolverBase {
     const int nw = d.nwin;
     constexpr int CH = sizeof(T) == 4 ? 64 : 32;
     ph_begin(PH_ASM_REST);
-    hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0);
     ph_end();
     ph_begin(PH_IMU_LIN);
     const size_t imu_lds = (sizeof(T) == 4 ? (size_t)6 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 40 * sizeof(double);
@@ -459,7 +460,7 @@ template <class T> class SolverImpl : public SolverBase {
     const int nw = d.nwin;
     ph_begin(PH_ASM_VIS);
     {  // few windows: split each window's items over several workgroups to fill the chip
-      const int parts = std::min(8, std::max(1, 256 / nw));
+      const int parts = vis_parts();
       if (any_vis_lds_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, true>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
       if (any_vis_glb_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, false>), dim3(nw, parts), dim3(512), vis_glb_, stream_, d);
       if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(nblk(d.maxL, 4), nw), dim3(256), (size_t)4 * d.maxLdw * sizeof(T), stream_, d);
@@ -480,9 +481,11 @@ template <class T> class SolverImpl : public SolverBase {
     ph_begin(PH_SCHUR);
     launch_schur();
     ph_end();
-    ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_rhs<T>), dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
-    ph_end();
+    if (!schur_makes_rhs()) {
+      ph_begin(PH_REST);
+      hipLaunchKernelGGL((k_rhs<T>), dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
+      ph_end();
+    }
     ph_begin(PH_CHOL);
     hipLaunchKernelGGL((k_cholesky_solve<T>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
@@ -491,6 +494,7 @@ template <class T> class SolverImpl : public SolverBase {
     ph_end();
   }
   void launch_schur();
+  bool schur_makes_rhs() const { return sizeof(T) == 4 && opt_.use_mfma != 0; }
   void launch_cost(bool candidate, int force) {
     const Dev<T> &d = dev_;
     const double *q = candidate ? d.cquat : d.quat, *p = candidate ? d.cpos : d.pos, *b = candidate ? d.cbias : d.bias;
@@ -757,7 +761,7 @@ template <class T> class SolverImpl : public SolverBase {
 
 template <> void SolverImpl<float>::launch_schur() {
   const Dev<float> &d = dev_;
-  const int nt = (d.maxP + 31) / 32;
+  const int nt = (d.maxP + 1 + 31) / 32;
   if (opt_.use_mfma) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2, d.nwin), dim3(64), 0, stream_, d);
   else hipLaunchKernelGGL((k_schur_generic<float>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
 }

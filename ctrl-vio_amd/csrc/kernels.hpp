@@ -144,13 +144,16 @@ template <class T> __global__ void k_lm_control(Dev<T> d) {
 }
 
 // ------------------------------------------------------------------------------------------------ zero
-template <class T> __global__ void k_zero_normal(Dev<T> d) {
+template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part) {
   const int w = blockIdx.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
   const long long nH = (long long)m.P * m.P;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
+  // with a single k_assemble_vis part the LDS path overwrites the whole knot x knot block and the line-delay row
+  // (plain stores, issued after this kernel), so only the bias rows and the line-delay row need zeroing
+  const long long first = (m.vis_lds && single_part) ? (long long)6 * m.K * m.P : 0;
+  for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) d.g[m.u0 + i] = 0.0;
   // W, Hll and g[P..N) are written (not accumulated) by k_build_W
   if (blockIdx.x == 0 && threadIdx.x == 0) d.lm[w].gmax_bits = 0ull;
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
 // g(a) >= g(b) is added, so shared knots sum correctly.  Landmark terms (W row, Hll, g_rho) stay per block.
 // Windows whose packed Hessian does not fit in LDS (vis_lds = 0) add straight into Hpp.
 template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d) {
-  constexpr int CHP = CH + 1, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;
+  constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;   // even row stride: 8-byte aligned pairs
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
@@ -591,19 +594,23 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       for (int a = 0; a < 7; ++a)
 #pragma unroll
         for (int b = 0; b < 7; ++b) acc[a][b] = T(0);
-      for (int v = start; v < end; ++v) {
+      // two blocks per step (one 8-byte LDS read per operand); blocks outside [start, end) are masked to zero
+      for (int v2 = start & ~1; v2 < end; v2 += 2) {
+        const T m0 = (v2 >= start) ? T(1) : T(0), m1 = (v2 + 1 < end) ? T(1) : T(0);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-          T av[7], bv[7];
+          VecN<T, 2> av[7], bv[7];
 #pragma unroll
           for (int a = 0; a < 7; ++a) {
-            av[a] = rowa[a] >= 0 ? Js[(rowa[a] + rr) * CHP + v] : T(0);
-            bv[a] = rowb[a] >= 0 ? Js[(rowb[a] + rr) * CHP + v] : T(0);
+            av[a].v[0] = av[a].v[1] = bv[a].v[0] = bv[a].v[1] = T(0);
+            if (rowa[a] >= 0) av[a] = *reinterpret_cast<const VecN<T, 2> *>(Js + (rowa[a] + rr) * CHP + v2);
+            if (rowb[a] >= 0) bv[a] = *reinterpret_cast<const VecN<T, 2> *>(Js + (rowb[a] + rr) * CHP + v2);
+            av[a].v[0] *= m0; av[a].v[1] *= m1;
           }
 #pragma unroll
           for (int a = 0; a < 7; ++a)
 #pragma unroll
-            for (int b = 0; b <= a; ++b) acc[a][b] += av[a] * bv[b];   // symmetric product: only column blocks a >= b
+            for (int b = 0; b <= a; ++b) acc[a][b] += av[a].v[0] * bv[b].v[0] + av[a].v[1] * bv[b].v[1];   // symmetric: blocks a >= b
         }
       }
       CTV_STAMP();
@@ -885,11 +892,13 @@ __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> 
 // S = Hpp + D^2 - W^T diag(dinv) W (lower triangle) on the matrix cores: one wave per 32x32 tile,
 // v_mfma_f32_32x32x2_f32 over the landmark dimension (2 landmarks per instruction), operands read
 // straight from the landmark-major W (32 consecutive floats per half-wave: coalesced).
+// The right-hand side rides along: index P (< ldw, a padding column of W) is fed with g_l on the A side, so the tiles
+// of the last tile row also produce W^T diag(dinv) g_l, i.e. rhs_p = -g_p + W^T dinv g_l, at no extra cost.
 __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
   const int w = blockIdx.y;
   if (d.lm[w].status) return;
   const WinMeta &m = d.wins[w];
-  const int nt = (m.P + 31) / 32;
+  const int nt = (m.P + 1 + 31) / 32;  // index P (the rhs row) included
   if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;
   int bi, bj;
   tile_decode(blockIdx.x, bi, bj);
@@ -897,21 +906,24 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
   const int i = 32 * bi + l31, j = 32 * bj + l31;
   const float ai = (i < m.P && d.active[m.u0 + i]) ? 1.0f : 0.0f;
   const float aj = (j < m.P && d.active[m.u0 + j]) ? 1.0f : 0.0f;
+  const bool rhs_lane = (i == m.P);
   const float *Wp = d.W + m.W0;
-  const double *dinv = d.dinv + m.lm0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.g + m.u0 + m.P;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
+  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P):
+  // tiles over bias columns skip the loop
   const int K6 = 6 * m.K;
-  const bool nz_i = (32 * bi < K6) || (m.P - 1 >= 32 * bi && m.P - 1 < 32 * bi + 32);
+  const bool nz_i = (32 * bi < K6) || (m.P >= 32 * bi && m.P - 1 < 32 * bi + 32);
   const bool nz_j = (32 * bj < K6) || (m.P - 1 >= 32 * bj && m.P - 1 < 32 * bj + 32);
   const int lend = (nz_i && nz_j) ? m.Lpad : 0;
 #pragma unroll 8
   for (int l0 = 0; l0 < lend; l0 += 2) {
     const int l = l0 + half;
-    const float di = (l < m.L) ? (float)dinv[l] : 0.0f;
-    const float a = Wp[(long long)l * m.ldw + i] * ai;
+    const bool lv = l < m.L;
+    const float di = lv ? (float)dinv[l] : 0.0f;
+    const float a = rhs_lane ? (lv ? (float)gl[l] : 0.0f) : Wp[(long long)l * m.ldw + i] * ai;
     const float b = Wp[(long long)l * m.ldw + j] * aj * di;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
   }
@@ -927,6 +939,8 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
       if (on) val = H[(long long)ii * m.P + jj] - (double)acc[r] + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
       else val = (ii == jj) ? 1.0 : 0.0;
       S[(long long)ii * m.P + jj] = val;
+    } else if (ii == m.P && jj < m.P) {
+      d.rhs[m.p0 + jj] = d.active[m.u0 + jj] ? (double)acc[r] - d.g[m.u0 + jj] : 0.0;
     }
   }
 }
