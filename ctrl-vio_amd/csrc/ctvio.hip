@@ -351,6 +351,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_cquat_.alloc(quat.size())); HIPCHK(b_cpos_.alloc(pos.size())); HIPCHK(b_cbias_.alloc(bias.size()));
     HIPCHK(b_crho_.alloc(rho.size())); HIPCHK(b_cld_.alloc(ld.size()));
     d.quat = b_quat_.p; d.pos = b_pos_.p; d.bias = b_bias_.p; d.rho = b_rho_.p; d.ld = b_ld_.p;
+    HIPCHK(b_kd_.alloc(3 * quat.size() / 4)); HIPCHK(b_ckd_.alloc(3 * quat.size() / 4)); HIPCHK(b_kjri_.alloc(9 * quat.size() / 4));
+    d.kd = b_kd_.p; d.ckd = b_ckd_.p; d.kjri = b_kjri_.p;
     d.cquat = b_cquat_.p; d.cpos = b_cpos_.p; d.cbias = b_cbias_.p; d.crho = b_crho_.p; d.cld = b_cld_.p;
     HIPCHK(b_knot_win_.upload(knot_win, stream_)); HIPCHK(b_bias_win_.upload(bias_win, stream_)); HIPCHK(b_lm_win_.upload(lm_win, stream_));
     d.knot_win = b_knot_win_.p; d.bias_win = b_bias_win_.p; d.lm_win = b_lm_win_.p;
@@ -441,8 +443,9 @@ template <class T> class SolverImpl : public SolverBase {
     ph_begin(PH_ASM_REST);
     hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0);
     ph_end();
+    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, d.quat, d.kd, d.kjri);
     ph_begin(PH_IMU_LIN);
-    const size_t imu_lds = (sizeof(T) == 4 ? (size_t)6 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 40 * sizeof(double);
+    const size_t imu_lds = (sizeof(T) == 4 ? (size_t)3 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 40 * sizeof(double);
     if (d.Gtot) {
       if (mixed_) hipLaunchKernelGGL((k_imu_linearize<T, CH, double>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
       else hipLaunchKernelGGL((k_imu_linearize<T, CH, T>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
@@ -450,8 +453,8 @@ template <class T> class SolverImpl : public SolverBase {
     ph_end();
     ph_begin(PH_VIS_LIN);
     if (d.Vtot) {
-      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, true, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
-      else hipLaunchKernelGGL((k_vis_eval<T, true, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, 0);
+      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, true, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, d.kd, 0);
+      else hipLaunchKernelGGL((k_vis_eval<T, true, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, d.kd, 0);
     }
     ph_end();
   }
@@ -499,13 +502,15 @@ template <class T> class SolverImpl : public SolverBase {
     const Dev<T> &d = dev_;
     const double *q = candidate ? d.cquat : d.quat, *p = candidate ? d.cpos : d.pos, *b = candidate ? d.cbias : d.bias;
     const double *r = candidate ? d.crho : d.rho, *l = candidate ? d.cld : d.ld;
+    double *kd = candidate ? d.ckd : d.kd;
+    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, q, kd, (T *)nullptr);
     if (d.Mtot) {
-      if (mixed_) hipLaunchKernelGGL((k_imu_cost<T, double>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, force);
-      else hipLaunchKernelGGL((k_imu_cost<T, T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, force);
+      if (mixed_) hipLaunchKernelGGL((k_imu_cost<T, double>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
+      else hipLaunchKernelGGL((k_imu_cost<T, T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
     }
     if (d.Vtot) {
-      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, false, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, force);
-      else hipLaunchKernelGGL((k_vis_eval<T, false, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, force);
+      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, false, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, kd, force);
+      else hipLaunchKernelGGL((k_vis_eval<T, false, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, kd, force);
     }
     hipLaunchKernelGGL((k_misc<T, false>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, q, p, b, l, force);
   }
@@ -564,7 +569,7 @@ template <class T> class SolverImpl : public SolverBase {
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n[ctvio] imu_linearize clock64 deltas:");
       for (int i = 33; i < 48; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
-      std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (stage | tile | scatter | round-sync ...):");
+      std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | rounds | imu tiles | H flush | g flush):");
       for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n");
     }
@@ -751,11 +756,11 @@ template <class T> class SolverImpl : public SolverBase {
       b_p_kind_, b_p_index_, b_p_off_, b_vs_, b_nact_;
   DBuf<int64_t> b_v_ti_, b_v_tj_;
   DBuf<ImuGroup> b_groups_;
-  DBuf<T> b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_, b_Wc_;
+  DBuf<T> b_kjri_, b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_, b_Wc_;
   DBuf<uint8_t> b_active_;
   DBuf<Lm> b_lm_;
   DBuf<long long> b_dbg_;
-  DBuf<double> b_snap_, b_imu_ud_, b_imu_meas_d_, b_v_obs_d_;
+  DBuf<double> b_snap_, b_imu_ud_, b_imu_meas_d_, b_v_obs_d_, b_kd_, b_ckd_;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
 };
 

@@ -58,6 +58,10 @@ template <class T> struct Dev {
   double *quat, *pos, *bias, *rho, *ld;
   double *cquat, *cpos, *cbias, *crho, *cld;
   const int32_t *knot_win, *bias_win, *lm_win;
+  // per consecutive knot pair (k, k+1), filled by k_knot_prep once per state: d = log(R_k^-1 R_k+1) in fp64 for the
+  // current (kd) and the candidate (ckd) state, Jr^-1(d) in T for the current state
+  double *kd, *ckd;      // [Ktot][3]
+  T *kjri;               // [Ktot][9]
   // IMU factors (sorted by group)
   const ImuGroup *groups;
   const int32_t *imu_grp;

@@ -32,6 +32,30 @@ template <class T> CTV_DI void seg_const(const Knots4<T> &k, SegConst<T> &sc, bo
   }
 }
 
+// The same from the per-window tables k_knot_prep fills once per state (d of every consecutive knot pair in fp64,
+// Jr^-1(d) in T): the per-pair quantities do not depend on the residual block, so they are hoisted out of the
+// per-block evaluation (the reference recomputes them inside every factor, so3_spline_view.h:160-166).
+// One table entry: d = log(q_a^-1 q_b) in fp64 and Jr^-1(d) evaluated in TJ from the rounded d.
+template <class TJ> CTV_DI void knot_pair_const(const double *qa, const double *qb, double *d3, TJ *jri9) {
+  const V3<double> dd = so3_log(qmul(qconj(qmk<double>(qa[0], qa[1], qa[2], qa[3])), qmk<double>(qb[0], qb[1], qb[2], qb[3])));
+  d3[0] = dd.x; d3[1] = dd.y; d3[2] = dd.z;
+  if (jri9) {
+    const M3<TJ> J = so3_Jr_inv(mk<TJ>((TJ)dd.x, (TJ)dd.y, (TJ)dd.z));
+#pragma unroll
+    for (int e = 0; e < 9; ++e) jri9[e] = J.m[e];
+  }
+}
+template <class T, class TJ> CTV_DI void seg_const_load(const double *kd, const TJ *kjri, SegConst<T> &sc, bool want_jac) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    sc.d[i] = mk<T>((T)kd[3 * i], (T)kd[3 * i + 1], (T)kd[3 * i + 2]);
+    if (want_jac) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = (T)kjri[9 * i + e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // IMU block.  Local column order of J (6 x 30): rot k0..k3 (12) | pos k0..k3 (12) | bg (3) | ba (3).
 // Sink::put_col(col, v[6]) receives every column of J (all 6 rows, structural zeros included);
@@ -214,11 +238,9 @@ template <class T> struct Calib {
 // Outputs are already robust-corrected (r~ = sqrt(rho') r, J~ = sqrt(rho')(J - alpha/s r r^T J)); returns
 // the block's cost contribution rho(s)/2.  Emit::put(col, j0, j1) receives column `col` of J~ (both rows).
 template <class T, class Emit>
-CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, T ui, T uj, T idt, const Calib<T> &cal, const M3<T> &RrefT, T pix,
-                     T piy, T pjx, T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac, Emit &emit) {
-  SegConst<T> sci, scj;
-  seg_const(ki, sci, want_jac);
-  seg_const(kj, scj, want_jac);
+CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SegConst<T> &sci, const SegConst<T> &scj, T ui, T uj, T idt,
+                     const Calib<T> &cal, const M3<T> &RrefT, T pix, T piy, T pjx, T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac,
+                     Emit &emit) {
   const T inv_d = T(1) / d_inv;
   const V3<T> x_ci = mk<T>(pix * inv_d, piy * inv_d, inv_d);
   const V3<T> p_Ii = qrot(cal.q_CI, x_ci) + cal.p_CI;

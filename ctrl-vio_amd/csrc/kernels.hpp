@@ -59,7 +59,7 @@ template <class T> struct LocalFrame {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const double *q = quat + 4 * (k0 + i), *p = pos + 3 * (k0 + i);
-      const Q4<double> ql = qmul(qref_inv, qmk<double>(q[0], q[1], q[2], q[3]));
+      const Q4<double> ql = qmul_raw(qref_inv, qmk<double>(q[0], q[1], q[2], q[3]));   // unit x unit: no renormalisation in fp64
       const V3<double> pl = mul(RT, mk<double>(p[0] - o[0], p[1] - o[1], p[2] - o[2]));
       k.q[i] = qmk<T>((T)ql.x, (T)ql.y, (T)ql.z, (T)ql.w);
       k.p[i] = mk<T>((T)pl.x, (T)pl.y, (T)pl.z);
@@ -159,6 +159,15 @@ template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part) {
   if (blockIdx.x == 0 && threadIdx.x == 0) d.lm[w].gmax_bits = 0ull;
 }
 
+// Knot-pair constants of every window for one state (see Dev::kd): one thread per knot.
+template <class T> __global__ void k_knot_prep(Dev<T> d, const double *quat, double *kd, T *kjri) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= d.Ktot) return;
+  const WinMeta &m = d.wins[d.knot_win[g]];
+  if (g - m.knot0 >= m.K - 1) return;   // the last knot of a window starts no pair
+  knot_pair_const<T>(quat + 4 * g, quat + 4 * g + 4, kd + 3 * g, kjri ? kjri + 9 * g : nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------ IMU
 template <class T, int N> struct alignas(N * sizeof(T)) VecN { T v[N]; };
 
@@ -180,23 +189,44 @@ template <class T> struct NullSink {
   __device__ __forceinline__ void put_col(int, const T *) {}
 };
 
+// MFMA path: the accelerometer rows (3 per sample, all 32 columns) go to LDS as they are produced; the gyro rows are
+// non-zero only in 16 columns (12 rotation, 3 gyro bias, residual) and wait in registers until the accelerometer
+// product is done, then reuse the same LDS.  Halves the LDS per wave (occupancy) and cuts the MFMA work by 40%.
+template <class T> struct ImuSplitSink {
+  T *A;
+  int lane;
+  T g[16][3];
+  __device__ __forceinline__ void put_col(int col, const T v[6]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) A[(3 * lane + a) * 33 + col] = v[3 + a];
+    const int gc = col < 12 ? col : ((col >= 24 && col < 27) ? col - 12 : (col == 30 ? 15 : -1));
+    if (gc >= 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[gc][a] = v[a];
+    }
+  }
+};
+
 // One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane
-// evaluates one sample and writes its 6 Jacobian rows + residual (all 32 columns, zeros included: no separate
-// zero pass) into LDS; then the wave forms the group's 31x31 block A^T A = [J^T J, J^T r; r^T J, r^T r]:
-//   float : on the matrix cores, v_mfma_f32_32x32x2_f32 with A and B operand the same LDS value (2 rows / instr);
-//   double: 4x4 register tile per lane (rows {ti+8a}, cols {tj+8b}: conflict-free LDS reads).
+// evaluates one sample and its 6 Jacobian rows + residual; then the wave forms the group's 31x31 block
+// A^T A = [J^T J, J^T r; r^T J, r^T r]:
+//   float : on the matrix cores -- accelerometer rows with v_mfma_f32_32x32x2_f32 (row-major A[k][33] in LDS, A and B
+//           operand the same LDS value), gyro rows with v_mfma_f32_16x16x4_f32 on their 16 non-zero columns;
+//   double: rows staged column-major A^T[32][KS], 4x4 register tile per lane (rows {ti+8a}, cols {tj+8b}).
 // The tile is stored, not accumulated -- no atomics, deterministic.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // RT = scalar of the RESIDUAL (and of the cost kernels).  RT = double with T = float is the mixed mode: Jacobians,
 // J^T J and the Schur complement stay in fp32, but r (hence the gradient J^T r and every cost) is evaluated in fp64
 // from fp64 inputs, which removes the fp32 residual noise (~5e-5 sigma) from the LM decisions and the fixed point.
-template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_imu_linearize(Dev<T> d) {
+template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_imu_linearize(Dev<T> d) {
   constexpr bool MFMA = sizeof(T) == 4;
   constexpr bool MIXED = sizeof(RT) != sizeof(T);
-  constexpr int KCH = 6 * CHUNK, KS = MFMA ? 33 : KCH + 4;
+  constexpr int KCH = 6 * CHUNK, KS = KCH + 4;
+  constexpr size_t ABYTES = MFMA ? (size_t)3 * CHUNK * 33 * sizeof(T) : (size_t)32 * KS * sizeof(T);
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   T *A = reinterpret_cast<T *>(smraw);
-  RT *gsh = reinterpret_cast<RT *>(smraw + (MFMA ? (size_t)KCH * KS : (size_t)32 * KS) * sizeof(T));  // [40] group constants (MIXED)
+  RT *gsh = reinterpret_cast<RT *>(smraw + ABYTES);  // [40] group constants (MIXED)
   const ImuGroup grp = d.groups[blockIdx.x];
   const int w = grp.win;
   if (!lin_needed(d.lm[w])) return;
@@ -208,7 +238,7 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_
   lf.load(d.quat, d.pos, m.knot0 + grp.s, k);
   const M3<T> RrefT = lf.RrefT();
   SegConst<T> sc;
-  seg_const(k, sc, true);
+  seg_const_load(d.kd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc, true);
   T bias[6], wgt[6];
   const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
@@ -221,7 +251,7 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_
     lfd.init(d.quat, d.pos, m.knot0 + grp.s);
     lfd.load(d.quat, d.pos, m.knot0 + grp.s, kd);
     SegConst<RT> scd;
-    seg_const(kd, scd, false);
+    seg_const_load(d.kd + 3 * (m.knot0 + grp.s), (const T *)nullptr, scd, false);
     const V3<RT> gd = lfd.rotate(m.gravity);
     if (lane == 0) {
       for (int i = 0; i < 4; ++i) {
@@ -236,6 +266,7 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_
   const int ti = lane >> 3, tj = lane & 7, half = lane >> 5, l31 = lane & 31;
   T acc[4][4];
   f32x16 macc;
+  f32x4 gacc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -246,53 +277,90 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_
   int dbi = 0;
 #define CTV_STAMP() do { if (dbg && lane == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
   CTV_STAMP();
+  // the residual of this lane's sample again in RT from RT inputs (mixed mode; no Jacobian)
+  auto residual_rt = [&](int idx, T r[6]) {
+    Knots4<RT> kd;
+    SegConst<RT> scd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kd.q[i] = qmk<RT>(gsh[4 * i], gsh[4 * i + 1], gsh[4 * i + 2], gsh[4 * i + 3]);
+      kd.p[i] = mk<RT>(gsh[16 + 3 * i], gsh[16 + 3 * i + 1], gsh[16 + 3 * i + 2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) scd.d[i] = mk<RT>(gsh[28 + 3 * i], gsh[28 + 3 * i + 1], gsh[28 + 3 * i + 2]);
+    RT bd[6], wd[6], gyd[3], acd[3], rd[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { bd[i] = (RT)bp[i]; wd[i] = (RT)m.imu_w[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gyd[i] = d.imu_meas_d[(size_t)i * d.Mtot + idx]; acd[i] = d.imu_meas_d[(size_t)(3 + i) * d.Mtot + idx]; }
+    NullSink<RT> ns;
+    M3<RT> unused = m3_id<RT>();
+    imu_eval<RT>(kd, scd, (RT)d.imu_ud[idx], (RT)m.inv_dt, mk<RT>(gsh[37], gsh[38], gsh[39]), bd, gyd, acd, wd, unused, rd, false, ns);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[i] = (T)rd[i];
+  };
+  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   for (int c0 = 0; c0 < grp.count; c0 += CHUNK) {
     const int nval = min(CHUNK, grp.count - c0);
-    const int kmax = (6 * nval + 3) & ~3;
-    ImuLdsSink<T, MFMA> sink{A, lane, KS};
-    const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    const int idx = m.imu0 + grp.start + c0 + lane;
+    T gy[3], ac[3], r[6];
     if (lane < nval) {
-      const int idx = m.imu0 + grp.start + c0 + lane;
-      T gy[3], ac[3], r[6];
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
-      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
-      if (MIXED) {  // residual again, in RT from RT inputs (no Jacobian)
-        Knots4<RT> kd;
-        SegConst<RT> scd;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          kd.q[i] = qmk<RT>(gsh[4 * i], gsh[4 * i + 1], gsh[4 * i + 2], gsh[4 * i + 3]);
-          kd.p[i] = mk<RT>(gsh[16 + 3 * i], gsh[16 + 3 * i + 1], gsh[16 + 3 * i + 2]);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) scd.d[i] = mk<RT>(gsh[28 + 3 * i], gsh[28 + 3 * i + 1], gsh[28 + 3 * i + 2]);
-        RT bd[6], wd[6], gyd[3], acd[3], rd[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { bd[i] = (RT)bp[i]; wd[i] = (RT)m.imu_w[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { gyd[i] = d.imu_meas_d[(size_t)i * d.Mtot + idx]; acd[i] = d.imu_meas_d[(size_t)(3 + i) * d.Mtot + idx]; }
-        NullSink<RT> ns;
-        M3<RT> unused = m3_id<RT>();
-        imu_eval<RT>(kd, scd, (RT)d.imu_ud[idx], (RT)m.inv_dt, mk<RT>(gsh[37], gsh[38], gsh[39]), bd, gyd, acd, wd, unused, rd, false, ns);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) r[i] = (T)rd[i];
-      }
-      sink.put_col(30, r);
-      sink.put_col(31, zero6);
-    } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
-#pragma unroll
-      for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
     }
-    __syncthreads();
-    CTV_STAMP();
     if constexpr (MFMA) {
+      const int kmaxA = (3 * nval + 1) & ~1, kmaxG = (3 * nval + 3) & ~3;   // rows padded to the MFMA's K step
+      ImuSplitSink<T> sink;
+      sink.A = A; sink.lane = lane;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sink.g[c][0] = sink.g[c][1] = sink.g[c][2] = T(0);
+      if (lane < nval) {
+        imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
+        if (MIXED) residual_rt(idx, r);
+        sink.put_col(30, r);
+        sink.put_col(31, zero6);
+      } else if (lane == nval) {  // the pad rows (at most 3) must read as zero
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
+      }
+      __syncthreads();
+      CTV_STAMP();
 #pragma unroll 8
-      for (int k0 = 0; k0 < kmax; k0 += 2) {
-        const float v = A[(k0 + half) * KS + l31];
+      for (int k0 = 0; k0 < kmaxA; k0 += 2) {
+        const float v = A[(k0 + half) * 33 + l31];
         macc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, macc, 0, 0, 0);
       }
+      __syncthreads();
+      CTV_STAMP();
+      if (lane <= nval) {   // gyro rows: [3 * CHUNK][17] in the same LDS
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) A[(3 * lane + a) * 17 + c] = sink.g[c][a];
+      }
+      __syncthreads();
+      {
+        const int q4 = lane >> 4, l15 = lane & 15;
+#pragma unroll 8
+        for (int k0 = 0; k0 < kmaxG; k0 += 4) {
+          const float v = A[(k0 + q4) * 17 + l15];
+          gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, gacc, 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      CTV_STAMP();
     } else {
+      const int kmax = (6 * nval + 3) & ~3;
+      ImuLdsSink<T, false> sink{A, lane, KS};
+      if (lane < nval) {
+        imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
+        sink.put_col(30, r);
+        sink.put_col(31, zero6);
+      } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
+      }
+      __syncthreads();
       for (int k0 = 0; k0 < kmax; k0 += 4) {
         VecN<T, 4> av[4], bv[4];
 #pragma unroll
@@ -307,15 +375,30 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) void k_
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
       }
+      __syncthreads();
     }
-    __syncthreads();
-    CTV_STAMP();
   }
 #undef CTV_STAMP
   T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
   if constexpr (MFMA) {
+    // combine in LDS: the accelerometer product, plus the gyro product scattered to its 16 rows/columns
+    // (C/D layouts: 32x32 -> row (r&3) + 8(r>>2) + 4(lane>>5), col lane&31;  16x16 -> row 4(lane>>4) + r, col lane&15)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = macc[r];
+    for (int r = 0; r < 16; ++r) A[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = macc[r];
+    __syncthreads();
+    {
+      const int gcol = lane & 15;
+      const int tc = gcol < 12 ? gcol : (gcol < 15 ? gcol + 12 : 30);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int grow = 4 * (lane >> 4) + r;
+        const int tr = grow < 12 ? grow : (grow < 15 ? grow + 12 : 30);
+        A[tr * 32 + tc] += gacc[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
   } else {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -343,7 +426,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
 }
 
 // Residual-only pass: one lane per IMU sample, cost accumulated in fp64.
-template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, int force) {
+template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, const double *kd, int force) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   double c = 0.0;
   int w = -1;
@@ -357,7 +440,7 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
       lf.init(quat, pos, m.knot0 + grp.s);
       lf.load(quat, pos, m.knot0 + grp.s, k);
       SegConst<RT> sc;
-      seg_const(k, sc, false);
+      seg_const_load(kd + 3 * (m.knot0 + grp.s), (const T *)nullptr, sc, false);
       RT b[6], wgt[6], gy[3], ac[3], r[6];
       const double *bp = bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
@@ -417,8 +500,11 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 // otherwise residual only.  Cost contributions are reduced per wave and added in fp64.
 template <class RT, class TD>
 __device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, int v, int si, int sj, double ui, double uj, int rowi, int rowj,
-                                               const double *quat, const double *pos, double rho_l, RT r[2]) {
+                                               const double *quat, const double *pos, const double *kd, double rho_l, RT r[2]) {
   Knots4<RT> ki, kj;
+  SegConst<RT> sci, scj;
+  seg_const_load(kd + 3 * (m.knot0 + si), (const RT *)nullptr, sci, false);
+  seg_const_load(kd + 3 * (m.knot0 + sj), (const RT *)nullptr, scj, false);
   LocalFrame<RT> lf;
   lf.init(quat, pos, m.knot0 + si);
   lf.load(quat, pos, m.knot0 + si, ki);
@@ -434,12 +520,12 @@ __device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, in
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = RD ? (RT)d.v_obs_d[(size_t)i * V + v] : (RT)d.v_obs[(size_t)i * V + v];
   VisNullSink<RT> sink;
-  return (double)visual_eval<RT>(ki, kj, (RT)ui, (RT)uj, (RT)m.inv_dt, cal, lf.RrefT(), o[0], o[1], o[2], o[3], (RT)rowi, (RT)rowj, (RT)rho_l, r,
+  return (double)visual_eval<RT>(ki, kj, sci, scj, (RT)ui, (RT)uj, (RT)m.inv_dt, cal, lf.RrefT(), o[0], o[1], o[2], o[3], (RT)rowi, (RT)rowj, (RT)rho_l, r,
                                  false, sink);
 }
 
 template <class T, bool LIN, class RT>
-__global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, int force) {
+__global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ T wcs[LIN ? 64 * 53 : 1];   // per-lane W contributions, written out coalesced at the end
   __shared__ int wcs_on[LIN ? 64 : 1];
@@ -477,11 +563,14 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
       if (LIN) {
         VisGlobalSink<T> sink{d.Jv + v, V, wcs + 53 * threadIdx.x, T(0), T(0)};
         wcs_on[threadIdx.x] = 1;
-        c = (double)visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
+        SegConst<T> sci, scj;
+        seg_const_load(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci, true);
+        seg_const_load(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj, true);
+        c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
         if (sizeof(RT) != sizeof(T)) {  // mixed mode: residual (and its cost) again in RT; J~ keeps the fp32 corrector scale
           RT rd[2];
-          c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, rho[m.lm0 + d.v_lm[v]], rd);
+          c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
           r[0] = (T)rd[0]; r[1] = (T)rd[1];
         }
         sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
@@ -490,7 +579,7 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
         d.vs[v] = si; d.vs[V + v] = sj;
       } else {
         RT rd[2];
-        c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, rho[m.lm0 + d.v_lm[v]], rd);
+        c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
       }
     } else {
       w = -1;
@@ -526,14 +615,18 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
 // Windows whose packed Hessian does not fit in LDS (vis_lds = 0) add straight into Hpp.
 template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d) {
   constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;   // even row stride: 8-byte aligned pairs
+  const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
+  // fields used after LDS/global atomics are copied to registers: the compiler must otherwise re-read them from
+  // memory every time (a store could alias), one L2 round trip each
+  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0;
   if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
   if (m.V == 0 && !LDSH) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
   T *Hs = reinterpret_cast<T *>(smv);
-  const int K6 = 6 * m.K, tri = K6 * (K6 + 1) / 2;
+  const int K6 = 6 * K, tri = K6 * (K6 + 1) / 2;
   const int nHh = LDSH ? tri + K6 + 1 : 0;     // packed Hessian entries
   const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay), always in LDS
   T *gs = Hs + nHh;
@@ -546,7 +639,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   int *ks = keys + wave * 2 * CH;
   const size_t V = (size_t)d.Vtot;
   const int per_round = NW * nparts;
-  const int rounds = (m.nvitem + per_round - 1) / per_round;
+  const int rounds = (nvitem + per_round - 1) / per_round;
   double *Hg = d.Hpp + m.H0;
   const int ti = lane >> 3, tj = lane & 7;
   // local column c (0..47 knot columns, 48 line delay, 49 residual) -> first of its two staging rows
@@ -560,11 +653,12 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   long long *dbg = (d.dbg && w == 0 && part == 0) ? d.dbg + 48 : nullptr;
   int dbi = 0;
 #define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 15) dbg[dbi++] = clock64(); } while (0)
+  if (dbg && tid == 0) dbg[dbi++] = t_begin;
   CTV_STAMP();
   for (int r = 0; r < rounds; ++r) {
     const int it = (r * nparts + part) * NW + wave;
     int n = 0, v0 = 0;
-    if (it < m.nvitem) { const VisItem I = d.vitems[m.vitem0 + it]; n = I.count; v0 = I.start; }
+    if (it < nvitem) { const VisItem I = d.vitems[vitem0 + it]; n = I.count; v0 = I.start; }
     {
       const int c = lane % CH, rr = lane / CH;
       T tmp[NPASS];
@@ -582,19 +676,20 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
     }
     if (lane < n) { ks[lane] = d.vs[v0 + lane]; ks[CH + lane] = d.vs[V + v0 + lane]; }
     __syncthreads();
-    CTV_STAMP();
+    
     int start = 0;
     while (start < n) {
       const int si = ks[start], sj = ks[CH + start];
       const bool diff = (lane > start && lane < n) && (ks[lane] != si || ks[CH + lane] != sj);
       const unsigned long long mask = __ballot(diff);
       const int end = mask ? (__ffsll((long long)mask) - 1) : n;
+      // two blocks per step (one 8-byte LDS read per operand); blocks outside [start, end) are masked to zero.
+      // (v_pk_fma_f32 on the block pair was measured slower than scalar FMAs here: 354k vs 308k cycles per window.)
       T acc[7][7];
 #pragma unroll
       for (int a = 0; a < 7; ++a)
 #pragma unroll
         for (int b = 0; b < 7; ++b) acc[a][b] = T(0);
-      // two blocks per step (one 8-byte LDS read per operand); blocks outside [start, end) are masked to zero
       for (int v2 = start & ~1; v2 < end; v2 += 2) {
         const T m0 = (v2 >= start) ? T(1) : T(0), m1 = (v2 + 1 < end) ? T(1) : T(0);
 #pragma unroll
@@ -613,13 +708,12 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
             for (int b = 0; b <= a; ++b) acc[a][b] += av[a].v[0] * bv[b].v[0] + av[a].v[1] * bv[b].v[1];   // symmetric: blocks a >= b
         }
       }
-      CTV_STAMP();
       int ga[7], gb[7];
 #pragma unroll
       for (int a = 0; a < 7; ++a) {
         const int ca = ti + 8 * a, cb = tj + 8 * a;
-        ga[a] = ca < 48 ? vis_col(ca, si, sj, m.P) : (ca == 48 ? m.P - 1 : (ca == 49 ? -2 : -1));
-        gb[a] = cb < 48 ? vis_col(cb, si, sj, m.P) : (cb == 48 ? m.P - 1 : (cb == 49 ? -2 : -1));
+        ga[a] = ca < 48 ? vis_col(ca, si, sj, P) : (ca == 48 ? P - 1 : (ca == 49 ? -2 : -1));
+        gb[a] = cb < 48 ? vis_col(cb, si, sj, P) : (cb == 48 ? P - 1 : (cb == 49 ? -2 : -1));
       }
       // Each unordered column pair {ca, cb} is held exactly once: blocks a > b by this lane, and for a == b by the lane
       // with ti >= tj.  It goes to H[max(g)][min(g)]; two different local columns that map to the same unknown (ends
@@ -633,33 +727,38 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
           T hv = acc[a][b];
           if (gA == -2 || gB == -2) {         // column 49 = residual: J~^T r~ (r~^T r~ itself is not needed)
             const int gX = gA == -2 ? gB : gA;
-            if (gX >= 0) atomicAdd(&gs[gX == m.P - 1 ? K6 : gX], hv);
+            if (gX >= 0) atomicAdd(&gs[gX == P - 1 ? K6 : gX], hv);
           } else if (gA >= 0 && gB >= 0) {
             if (gA == gB && !(a == b && ti == tj)) hv *= T(2);
             if (gA < gB) { const int t = gA; gA = gB; gB = t; }
-            if (LDSH) atomicAdd(&Hs[(gA == m.P - 1) ? tri + (gB == m.P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], hv);
-            else atomicAdd(&Hg[(long long)gA * m.P + gB], (double)hv);
+            if (LDSH) atomicAdd(&Hs[(gA == P - 1) ? tri + (gB == P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], hv);
+            else atomicAdd(&Hg[(long long)gA * P + gB], (double)hv);
           }
         }
       start = end;
-      CTV_STAMP();
+      
     }
     __syncthreads();
-    CTV_STAMP();
+    
   }
-#undef CTV_STAMP
+  CTV_STAMP();
   if (LDSH) {
     // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments)
-    for (int gi = part * NW + wave; gi < m.ngrp; gi += per_round) {
-      const ImuGroup grp = d.groups[m.grp0 + gi];
-      const T *tile = d.imu_tiles + (size_t)(m.grp0 + gi) * 1024;
-      for (int e = lane; e < 24 * 24; e += 64) {
-        const int a = e / 24, b = e % 24;
-        const int ga = imu_col(a, grp.s, m.K, grp.bias), gb = imu_col(b, grp.s, m.K, grp.bias);
-        if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], tile[a * 32 + b]);
+    for (int gi = part * NW + wave; gi < ngrp; gi += per_round) {
+      const ImuGroup grp = d.groups[grp0 + gi];
+      const T *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
+      T tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
+#pragma unroll
+      for (int u = 0; u < 9; ++u) { const int e = lane + 64 * u; tv[u] = tile[(e / 24) * 32 + e % 24]; }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int e = lane + 64 * u, a = e / 24, b = e % 24;
+        const int ga = imu_col(a, grp.s, K, grp.bias), gb = imu_col(b, grp.s, K, grp.bias);
+        if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], tv[u]);
       }
     }
     __syncthreads();
+    CTV_STAMP();
     for (int i = tid; i < nHh; i += 512) {
       const T hv = Hs[i];
       if (nparts > 1 && hv == T(0)) continue;
@@ -670,18 +769,21 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
         while (ga * (ga + 1) / 2 > i) --ga;
         gb = i - ga * (ga + 1) / 2;
       } else {
-        ga = m.P - 1;
-        gb = (i - tri) < K6 ? (i - tri) : m.P - 1;
+        ga = P - 1;
+        gb = (i - tri) < K6 ? (i - tri) : P - 1;
       }
-      if (nparts > 1) atomicAdd(&Hg[(long long)ga * m.P + gb], (double)hv);
-      else Hg[(long long)ga * m.P + gb] = (double)hv;  // first writer after k_zero_normal; later kernels add atomically
+      if (nparts > 1) atomicAdd(&Hg[(long long)ga * P + gb], (double)hv);
+      else Hg[(long long)ga * P + gb] = (double)hv;  // first writer after k_zero_normal; later kernels add atomically
     }
   }
+  CTV_STAMP();
   if (!LDSH) __syncthreads();
   for (int i = tid; i < K6 + 1; i += 512) {
     const T gv = gs[i];
-    if (gv != T(0)) atomicAdd(&d.g[m.u0 + (i < K6 ? i : m.P - 1)], (double)gv);
+    if (gv != T(0)) atomicAdd(&d.g[u0 + (i < K6 ? i : P - 1)], (double)gv);
   }
+  CTV_STAMP();
+#undef CTV_STAMP
 }
 
 // W row, Hll and g_rho of every landmark, gathered (no atomics, no zero pass): one wave per landmark walks the

@@ -123,13 +123,18 @@ CTV_DI double t_abs(double x) { return fabs(x); }
 
 // ---- exp: so3.hpp:534-569 (series branch below eps; fp32 switches to the series earlier)
 CTV_DI Q4<double> so3_exp(V3<double> w) {
-  const double th2 = dot(w, w), th = sqrt(th2);
+  const double th2 = dot(w, w);
   double im, re;
-  if (th < 1e-10) {
-    const double th4 = th2 * th2;
-    im = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
-    re = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+  if (th2 < 0.25) {
+    // |theta| < 0.5 (lambda * d between neighbouring knots): Taylor series in h^2 = (theta/2)^2 up to h^14 / h^15,
+    // truncation < 3e-21 relative -- the same function as the closed form to the last bit or two, without sin/cos/divide
+    const double h2 = 0.25 * th2;
+    im = 0.5 * (1.0 + h2 * (-1.0 / 6.0 + h2 * (1.0 / 120.0 + h2 * (-1.0 / 5040.0 + h2 * (1.0 / 362880.0 + h2 * (-1.0 / 39916800.0 +
+         h2 * (1.0 / 6227020800.0 + h2 * (-1.0 / 1307674368000.0))))))));
+    re = 1.0 + h2 * (-0.5 + h2 * (1.0 / 24.0 + h2 * (-1.0 / 720.0 + h2 * (1.0 / 40320.0 + h2 * (-1.0 / 3628800.0 +
+         h2 * (1.0 / 479001600.0 + h2 * (-1.0 / 87178291200.0)))))));
   } else {
+    const double th = sqrt(th2);
     im = sin(0.5 * th) / th;
     re = cos(0.5 * th);
   }

@@ -43,8 +43,12 @@ void imu_eval_t(const double *q, const double *p, double u, double idt, const do
   Knots4<T> k;
   HostLocalFrame<T> lf(q, p);
   lf.load(q, p, k);
-  SegConst<T> sc;
-  seg_const(k, sc, true);
+  SegConst<T> sc;   // as on the device: pair constants from the fp64 table (k_knot_prep)
+  {
+    double dt[9]; T jt[27];
+    for (int i = 0; i < 3; ++i) knot_pair_const<T>(q + 4 * i, q + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    seg_const_load(dt, jt, sc, true);
+  }
   T b[6], gy[3], ac[3], ww[6], rr[6], JJ[180];
   for (int i = 0; i < 6; ++i) { b[i] = (T)bias[i]; ww[i] = (T)w[i]; }
   for (int i = 0; i < 3; ++i) { gy[i] = (T)gyro[i]; ac[i] = (T)acc[i]; }
@@ -71,7 +75,15 @@ double visual_eval_t(const double *qi, const double *pi, const double *qj, const
   T rr[2], JJ[100];
   for (int i = 0; i < 100; ++i) JJ[i] = 0;
   VisSink<T> sink{JJ};
-  T cost = visual_eval<T>(ki, kj, (T)ui, (T)uj, (T)idt, cal, lf.RrefT(), (T)obs[0], (T)obs[1], (T)obs[2], (T)obs[3], (T)rowi, (T)rowj,
+  SegConst<T> sci, scj;   // as on the device: pair constants from the fp64 table (k_knot_prep)
+  {
+    double dt[9]; T jt[27];
+    for (int i = 0; i < 3; ++i) knot_pair_const<T>(qi + 4 * i, qi + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    seg_const_load(dt, jt, sci, true);
+    for (int i = 0; i < 3; ++i) knot_pair_const<T>(qj + 4 * i, qj + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    seg_const_load(dt, jt, scj, true);
+  }
+  T cost = visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)idt, cal, lf.RrefT(), (T)obs[0], (T)obs[1], (T)obs[2], (T)obs[3], (T)rowi, (T)rowj,
                           (T)d_inv, rr, true, sink);
   r[0] = rr[0]; r[1] = rr[1];
   for (int i = 0; i < 100; ++i) J[i] = JJ[i];

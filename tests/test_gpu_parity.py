@@ -102,9 +102,11 @@ def test_solve_fp32_vs_oracle_at_ceres_tolerances(cv, oracle, cfg, seed):
 
 @pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config2", 1000), ("config2", 1002)])
 def test_solve_fp32_precision_floor(cv, oracle, cfg, seed):
-    """Both solvers converged tightly (tolerances 1e-13): what is left is the fp32 Jacobian noise in J^T r propagated
-    through the ill-conditioned normal equations (Jacobi-scaled cond ~1e10): measured 1e-6 .. 4e-5 over 12 runs (run-to-run
-    spread from the order of the atomic additions), asserted 1e-4."""
+    """Both solvers run with tolerances 1e-13.  The fp32 Hessian is noisy in the weakly determined directions (Jacobi-scaled
+    cond ~1e10 against 2^-24), so the device LM creeps along them and stops on its function tolerance after a varying
+    number of iterations (40 .. 66): the distance left to the fp64 optimum was measured at 8e-7 .. 1.5e-4 over 24 runs
+    (tests/gpu_floor_study.py; run-to-run spread from the order of the atomic additions), cost equal to <= 1.3e-8 relative.
+    Asserted with a 3x margin over the worst run seen."""
     w0 = cv.synth.make_window(cfg, seed=seed)
     oracle.set_tolerances(1e-13, 1e-14, 1e-13)
     try:
@@ -118,7 +120,7 @@ def test_solve_fp32_precision_floor(cv, oracle, cfg, seed):
         sm = s.solve(200)[0]
     assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-7)
     err = cv.rel_state_error(wg, wt)
-    assert err["state"] < 1e-4, err
+    assert err["state"] < 5e-4, err
 
 
 def test_pure_fp32_residuals_within_stopping_slop(cv, oracle):
