@@ -141,37 +141,41 @@ def main():
         sms = solver.solve(args.iters, writeback=False)
         out["solve_summary"] = {"iterations_mean": float(np.mean([m["iterations"] for m in sms])),
                                 "terminations": sorted({m["termination"] for m in sms})}
-        # ---- roofline: one profiled solve (HIP events around every launch group, on the solver's stream)
-        solver.restore_state()
+        # ---- roofline: one more step of the same workload (all streams running, as in the timed region) with HIP events
+        #      around every launch group of stream 0 -- the launches of that stream carry per[0] windows each
+        restore_all()
         solver.set_profiling(True)
-        solver.solve_raw(args.iters)
+        solve_all()
         solver.set_profiling(False)
+        torch.cuda.synchronize()
         ms, n = solver.last_timing()
         names = cv.Solver.PHASES
         shares = {names[i]: float(ms[i]) for i in range(7)}
         dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
         w_ref = uniq[0]
-        nbytes = sum(algorithmic_bytes(uniq[i % len(uniq)], names[dom]) for i in range(args.windows))
+        nbytes = sum(algorithmic_bytes(uniq[i % len(uniq)], names[dom]) for i in range(per[0]))
         avg_s = 1e-3 * ms[dom] / max(int(n[dom]), 1)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(names[dom], {}).get(str(args.windows))
+                key = names[dom] if names[dom] != "k_vis_eval" else "k_vis_eval<float, true, double>"
+                traffic = json.load(open(tfile)).get(key, {}).get(str(per[0]), {}).get("traffic_bytes")
             except Exception:
                 traffic = None
         ach = nbytes / avg_s / 1e9
         out["roofline"] = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "avg_launch_us": 1e6 * avg_s, "launches": int(n[dom]), "algorithmic_bytes_per_launch": nbytes,
+                           "avg_launch_us": 1e6 * avg_s, "launches": int(n[dom]), "windows_per_launch": per[0],
+                           "algorithmic_bytes_per_launch": nbytes,
                            "share_of_profiled_solve": float(ms[dom] / max(sum(ms[:7]), 1e-12))}
         P, L = w_ref.P, w_ref.L
-        fl = P * (P + 1) * L * args.windows                  # SYRK count
+        fl = P * (P + 1) * L * per[0]                        # SYRK count
         avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
         out["roofline_mfma"] = {"kernel": "k_schur_mfma", "bound": "mfma", "achieved": fl / avg_schur / 1e12,
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                 "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
-        out["phase_ms_profiled_solve"] = shares
+        out["phase_ms_profiled_solve"] = shares               # stream 0 only
         # ---- CPU baseline: the oracle (a port, not the reference binary: Ceres/Eigen are not installable here)
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline:

@@ -1,9 +1,63 @@
-import sqlite3, sys
-for name in sys.argv[1:]:
-    con = sqlite3.connect(name); cur = con.cursor()
-    rows = cur.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
-    tot = sum(r[2] for r in rows)
-    print(name, "total kernel ms %.2f" % (tot/1e3))
-    for r in rows[:12]:
-        nm = r[0].split('(')[0].replace('void ctv::','')[:40]
-        print(f"  {nm:40s} n={r[1]:5d} total={r[2]/1e3:9.3f} ms avg={r[3]:9.2f} us  {100*r[2]/tot:5.1f}%")
+"""Summaries of rocprofv3 output for profiles/ (run on the GPU box, after the rocprofv3 commands in DESIGN.md section 6).
+
+  python tests/prof_summary.py stats <results.db> [...]          per-kernel time table (rocprofv3 --kernel-trace --stats, rocpd db)
+  python tests/prof_summary.py pmc <windows_per_launch> <out.json> <counter_collection.csv> [...]
+        average FETCH_SIZE / WRITE_SIZE per launch of every kernel -> HBM traffic in bytes per launch
+        (MI355X_MICROARCH.md, "HBM": the counters are in KiB; FETCH_SIZE is doubled on gfx950), merged into out.json as
+        {kernel: {windows_per_launch: {"fetch_bytes":..,"write_bytes":..,"traffic_bytes":..,"launches":..}}}
+"""
+import csv
+import json
+import os
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_A-Z0-9]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:48]
+
+
+def stats(paths):
+    for name in paths:
+        con = sqlite3.connect(name)
+        cur = con.cursor()
+        rows = cur.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
+                           "from kernels group by name order by 3 desc").fetchall()
+        tot = sum(r[2] for r in rows)
+        print(f"# {os.path.basename(name)}: total kernel time {tot / 1e3:.2f} ms")
+        print(f"{'kernel':58s} {'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'min us':>9s} {'max us':>9s} {'%':>6s}")
+        for r in rows:
+            print(f"{short(r[0]):58s} {r[1]:6d} {r[2] / 1e3:10.3f} {r[3]:10.2f} {r[4]:9.2f} {r[5]:9.2f} {100 * r[2] / tot:6.2f}")
+
+
+def pmc(wpl, out, paths):
+    acc = defaultdict(lambda: defaultdict(list))
+    for p in paths:
+        with open(p, newline="") as f:
+            for row in csv.DictReader(f):
+                acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    res = json.load(open(out)) if os.path.exists(out) else {}
+    print(f"{'kernel':58s} {'launches':>8s} {'fetch MB':>10s} {'write MB':>10s}   (per launch; FETCH_SIZE x2 x1024, WRITE_SIZE x1024)")
+    for k, c in sorted(acc.items()):
+        f = c.get("FETCH_SIZE", [])
+        w = c.get("WRITE_SIZE", [])
+        fb = 2.0 * 1024.0 * sum(f) / len(f) if f else None
+        wb = 1024.0 * sum(w) / len(w) if w else None
+        e = res.setdefault(k.split("<")[0] if not k.startswith("k_vis_eval") else k, {}).setdefault(str(wpl), {})
+        if fb is not None: e["fetch_bytes"] = fb; e["launches"] = len(f)
+        if wb is not None: e["write_bytes"] = wb; e["launches"] = len(w)
+        if "fetch_bytes" in e and "write_bytes" in e: e["traffic_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+        print(f"{k:58s} {max(len(f), len(w)):8d} {(fb or 0) / 1e6:10.3f} {(wb or 0) / 1e6:10.3f}")
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2:])
+    elif sys.argv[1] == "pmc":
+        pmc(int(sys.argv[2]), sys.argv[3], sys.argv[4:])
+    else:
+        raise SystemExit(__doc__)
