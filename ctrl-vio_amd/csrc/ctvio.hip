@@ -466,10 +466,10 @@ template <class T> class SolverImpl : public SolverBase {
       const int parts = vis_parts();
       if (any_vis_lds_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, true>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
       if (any_vis_glb_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, false>), dim3(nw, parts), dim3(512), vis_glb_, stream_, d);
-      if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(nblk(d.maxL, 4), nw), dim3(256), (size_t)4 * d.maxLdw * sizeof(T), stream_, d);
     }
     ph_end();
     ph_begin(PH_ASM_REST);
+    if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(nblk(d.maxL, 4), nw), dim3(256), (size_t)4 * d.maxLdw * sizeof(T), stream_, d);
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d);
     hipLaunchKernelGGL((k_misc<T, true>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, d.quat, d.pos, d.bias, d.ld, 0);
     hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
@@ -493,7 +493,7 @@ template <class T> class SolverImpl : public SolverBase {
     hipLaunchKernelGGL((k_cholesky_solve<T>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(1024), 0, stream_, d);
+    hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
     ph_end();
   }
   void launch_schur();
@@ -767,7 +767,7 @@ template <class T> class SolverImpl : public SolverBase {
 template <> void SolverImpl<float>::launch_schur() {
   const Dev<float> &d = dev_;
   const int nt = (d.maxP + 1 + 31) / 32;
-  if (opt_.use_mfma) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2, d.nwin), dim3(64), 0, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
   else hipLaunchKernelGGL((k_schur_generic<float>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
 }
 template <> void SolverImpl<double>::launch_schur() {

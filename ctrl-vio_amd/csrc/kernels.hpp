@@ -792,33 +792,38 @@ template <class T> __global__ __launch_bounds__(256) void k_build_W(Dev<T> d) {
   const int w = blockIdx.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, lm0 = m.lm0, u0 = m.u0;   // registers: not re-read after the LDS atomics
+  const long long W0 = m.W0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  T *row = reinterpret_cast<T *>(smw) + (size_t)wave * m.ldw;
+  T *row = reinterpret_cast<T *>(smw) + (size_t)wave * ldw;
   const int l = blockIdx.x * 4 + wave;
-  const bool valid = l < m.L;
-  if ((int)blockIdx.x * 4 >= m.L) return;  // whole block idle (uniform)
-  for (int i = lane; i < m.ldw; i += 64) row[i] = T(0);
+  const bool valid = l < L;
+  if ((int)blockIdx.x * 4 >= L) return;  // whole block idle (uniform)
+  for (int i = lane; i < ldw; i += 64) row[i] = T(0);
   __syncthreads();
   double hll = 0.0, gl = 0.0;
   if (valid) {
     const size_t V = (size_t)d.Vtot;
-    const int b0 = d.lm_blk_off[m.lm0 + l], b1 = d.lm_blk_off[m.lm0 + l + 1];
-    for (int bb = b0; bb < b1; bb += 8) {  // 8 blocks per pass: all loads of the pass in flight together
+    const int b0 = d.lm_blk_off[lm0 + l], b1 = d.lm_blk_off[lm0 + l + 1];
+    const int lc = min(lane, 50);
+    for (int bb = b0; bb < b1; bb += 8) {
+      // 8 blocks per pass, two rounds of unconditional (clamped) loads: block ids, then their W contributions and knot
+      // segments -- a predicated load would compile to branch + load + wait, one memory round trip per block
+      int v[8], si[8], sj[8];
       T wv[8];
-      int si[8], sj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = d.lm_blk[min(bb + u, b1 - 1)];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const bool on = bb + u < b1;
-        const int v = on ? d.lm_blk[bb + u] : 0;
-        wv[u] = (on && lane < 51) ? d.Wc[(size_t)52 * v + lane] : T(0);
-        si[u] = on ? d.vs[v] : 0;
-        sj[u] = on ? d.vs[V + v] : 0;
+        wv[u] = d.Wc[(size_t)52 * v[u] + lc];
+        si[u] = d.vs[v[u]];
+        sj[u] = d.vs[V + v[u]];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (bb + u >= b1) continue;
-        if (lane < 49) atomicAdd(&row[vis_col(lane < 48 ? lane : 49, si[u], sj[u], m.P)], wv[u]);  // ends may share knots
+        if (lane < 49) atomicAdd(&row[vis_col(lane < 48 ? lane : 49, si[u], sj[u], P)], wv[u]);  // ends may share knots
         else if (lane == 49) hll += (double)wv[u];
         else if (lane == 50) gl += (double)wv[u];
       }
@@ -826,10 +831,10 @@ template <class T> __global__ __launch_bounds__(256) void k_build_W(Dev<T> d) {
   }
   __syncthreads();
   if (valid) {
-    T *Wr = d.W + m.W0 + (long long)l * m.ldw;
-    for (int i = lane; i < m.ldw; i += 64) Wr[i] = row[i];
-    if (lane == 49) d.Hll[m.lm0 + l] = hll;
-    if (lane == 50) d.g[m.u0 + m.P + l] = gl;
+    T *Wr = d.W + W0 + (long long)l * ldw;
+    for (int i = lane; i < ldw; i += 64) Wr[i] = row[i];
+    if (lane == 49) d.Hll[lm0 + l] = hll;
+    if (lane == 50) d.g[u0 + P + l] = gl;
   }
 }
 
@@ -996,58 +1001,86 @@ __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> 
 // straight from the landmark-major W (32 consecutive floats per half-wave: coalesced).
 // The right-hand side rides along: index P (< ldw, a padding column of W) is fed with g_l on the A side, so the tiles
 // of the last tile row also produce W^T diag(dinv) g_l, i.e. rhs_p = -g_p + W^T dinv g_l, at no extra cost.
-__global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d) {
-  const int w = blockIdx.y;
+__global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) {
+  // XCD-aware tile -> workgroup map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the
+  // tiles of one window are given ids that are congruent mod 8: they all run on one XCD and the window's W (re-read by
+  // every tile) comes out of that L2 instead of being fetched 8 times over the fabric.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
+  if (w >= d.nwin) return;
   if (d.lm[w].status) return;
   const WinMeta &m = d.wins[w];
   const int nt = (m.P + 1 + 31) / 32;  // index P (the rhs row) included
-  if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;
+  if (tile >= nt * (nt + 1) / 2) return;
   int bi, bj;
-  tile_decode(blockIdx.x, bi, bj);
+  tile_decode(tile, bi, bj);
   const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
-  const int i = 32 * bi + l31, j = 32 * bj + l31;
-  const float ai = (i < m.P && d.active[m.u0 + i]) ? 1.0f : 0.0f;
-  const float aj = (j < m.P && d.active[m.u0 + j]) ? 1.0f : 0.0f;
-  const bool rhs_lane = (i == m.P);
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, Lpad = m.Lpad;
+  const int i = 32 * bi + l31, j = 32 * bj + l31;        // < ldw by construction (ldw = 32 nt)
+  // every load below is unconditional on a clamped address (a predicated load costs a branch and a full wait each)
+  const float ai = (i < P && d.active[u0 + min(i, P - 1)]) ? 1.0f : 0.0f;
+  const float aj = (j < P && d.active[u0 + min(j, P - 1)]) ? 1.0f : 0.0f;
+  const bool rhs_lane = (i == P);
   const float *Wp = d.W + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.g + m.u0 + m.P;
+  const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P):
   // tiles over bias columns skip the loop
-  const int K6 = 6 * m.K;
-  const bool nz_i = (32 * bi < K6) || (m.P >= 32 * bi && m.P - 1 < 32 * bi + 32);
-  const bool nz_j = (32 * bj < K6) || (m.P - 1 >= 32 * bj && m.P - 1 < 32 * bj + 32);
-  const int lend = (nz_i && nz_j) ? m.Lpad : 0;
-#pragma unroll 8
-  for (int l0 = 0; l0 < lend; l0 += 2) {
-    const int l = l0 + half;
-    const bool lv = l < m.L;
-    const float di = lv ? (float)dinv[l] : 0.0f;
-    const float a = rhs_lane ? (lv ? (float)gl[l] : 0.0f) : Wp[(long long)l * m.ldw + i] * ai;
-    const float b = Wp[(long long)l * m.ldw + j] * aj * di;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  const bool nz_i = (32 * bi < K6) || (P >= 32 * bi && P - 1 < 32 * bi + 32);
+  const bool nz_j = (32 * bj < K6) || (P - 1 >= 32 * bj && P - 1 < 32 * bj + 32);
+  const int lend = (nz_i && nz_j) ? Lpad : 0;
+  for (int l0 = 0; l0 < lend; l0 += 16) {   // 8 MFMA steps (2 landmarks each) per trip: 32 loads in flight, then the products
+    float wa[8], wb[8];
+    double dv[8], gv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int lc = min(l0 + 2 * s + half, L - 1);
+      wa[s] = Wp[(long long)lc * ldw + i];
+      wb[s] = Wp[(long long)lc * ldw + j];
+      dv[s] = dinv[lc];
+      gv[s] = gl[lc];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bool lv = l0 + 2 * s + half < L;
+      const float di = lv ? (float)dv[s] : 0.0f;
+      const float a = rhs_lane ? (float)gv[s] : wa[s] * ai;
+      const float b = wb[s] * aj * di;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
   }
-  double *S = d.S + m.H0;
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
   const double *H = d.Hpp + m.H0;
+  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
+  // All inputs are fetched first (clamped addresses), then the 16 rows are written.
+  const int jj = 32 * bj + l31, jc = min(jj, P - 1);
+  const bool act_j = d.active[u0 + jc] != 0;
+  const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
+  double hv[16];
+  unsigned char act_i[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const int ii = 32 * bi + row, jj = 32 * bj + l31;
-    if (ii < m.P && jj <= ii) {
-      const bool on = d.active[m.u0 + ii] && d.active[m.u0 + jj];
+    const int ii = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, ic = min(ii, P - 1);
+    act_i[r] = d.active[u0 + ic];
+    hv[r] = H[(long long)ic * P + min(jc, ic)];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ii = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (ii < P && jj <= ii) {
+      const bool on = act_i[r] && act_j;
       double val;
-      if (on) val = H[(long long)ii * m.P + jj] - (double)acc[r] + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
+      if (on) val = hv[r] - (double)acc[r] + (ii == jj ? dd_j : 0.0);
       else val = (ii == jj) ? 1.0 : 0.0;
-      S[(long long)ii * m.P + jj] = val;
-    } else if (ii == m.P && jj < m.P) {
-      d.rhs[m.p0 + jj] = d.active[m.u0 + jj] ? (double)acc[r] - d.g[m.u0 + jj] : 0.0;
+      S[(long long)ii * P + jj] = val;
+    } else if (ii == P && jj < P) {
+      rhs[jj] = act_j ? (double)acc[r] - g_j : 0.0;
     }
   }
 }
 
-// Same contraction on the vector ALU, any scalar type (fp64 debugging path / use_mfma = 0).
 template <class T> __global__ void k_schur_generic(Dev<T> d) {
   const int w = blockIdx.y;
   if (d.lm[w].status) return;
@@ -1294,47 +1327,76 @@ template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T
 // delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
 // model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres' -(J y)^T (r + J y / 2) when
 // (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
-template <class T> __global__ __launch_bounds__(1024) void k_backsub(Dev<T> d) {
+template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
   if (lm.status) return;
   const WinMeta &m = d.wins[w];
-  __shared__ double red[1024];
+  const int P = m.P, L = m.L, N = m.N, u0 = m.u0, lm0 = m.lm0, ldw = m.ldw;
+  extern __shared__ __attribute__((aligned(16))) double xs[];   // [P] pose step
+  __shared__ double red[4];
   __shared__ int bad;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double *x = d.delta + u0;
+  const double *g = d.g + u0, *dd = d.dd + u0;
+  const T *Wp = d.W + m.W0;
+  for (int i = tid; i < P; i += 256) xs[i] = x[i];
   if (tid == 0) bad = 0;
   __syncthreads();
-  double *x = d.delta + m.u0;
-  const double *g = d.g + m.u0, *dd = d.dd + m.u0;
-  const T *Wp = d.W + m.W0;
-  const int nwave = blockDim.x >> 6;
-  for (int l0 = 8 * wave; l0 < m.L; l0 += 8 * nwave) {  // 8 rows of W per pass: 8 independent loads per lane in flight
+  // delta_rho_l = -(g_l + W_l . delta_p) / (Hll_l + D_l): a wave takes 8 rows of W per pass, 32 loads per lane in flight
+  for (int l0 = 8 * wave; l0 < L; l0 += 32) {
     double acc8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
-    for (int i = lane; i < m.P; i += 64) {
-      const double xi = x[i];
+    // the row this lane will finish (see the reduction below): its g, 1/(Hll + D) and active flag travel with the W loads
+    const int lrow = min(l0 + (lane >> 3), L - 1);
+    const double g_l = g[P + lrow], dinv_l = d.dinv[lm0 + lrow];
+    const bool act_l = d.active[u0 + P + lrow] != 0;
+    for (int i0 = 0; i0 < P; i0 += 256) {
+      T wv[8][4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc8[u] += (l0 + u < m.L) ? (double)Wp[(long long)(l0 + u) * m.ldw + i] * xi : 0.0;
-    }
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      double sacc = acc8[u];
-      for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off);
-      const int l = l0 + u;
-      if (lane == 0 && l < m.L) x[m.P + l] = d.active[m.u0 + m.P + l] ? (-g[m.P + l] - sacc) * d.dinv[m.lm0 + l] : 0.0;
+        for (int k = 0; k < 4; ++k) {
+          // clamped, unconditional loads (a predicated load compiles to branch + load + s_waitcnt: one round trip EACH);
+          // out-of-range columns are masked through xi below, out-of-range rows are never written
+          const int i = min(i0 + lane + 64 * k, P - 1), l = min(l0 + u, L - 1);
+          wv[u][k] = Wp[(long long)l * ldw + i];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + lane + 64 * k;
+        const double xi = i < P ? xs[i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc8[u] += (double)wv[u][k] * xi;
+      }
     }
+    // 8 row sums over 64 lanes with 10 shuffles: each butterfly step halves the rows a lane carries (bit 5 of the lane
+    // picks rows 0-3 / 4-7, bit 4 the pair, bit 3 the row), then three plain steps; row u = lane >> 3 ends up in lane 8u
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    double v4[4], v2[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v4[q] = (b5 ? acc8[4 + q] : acc8[q]) + __shfl_xor(b5 ? acc8[q] : acc8[4 + q], 32);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v2[q] = (b4 ? v4[2 + q] : v4[q]) + __shfl_xor(b4 ? v4[q] : v4[2 + q], 16);
+    double v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+    v1 += __shfl_xor(v1, 4);
+    v1 += __shfl_xor(v1, 2);
+    v1 += __shfl_xor(v1, 1);
+    if ((lane & 7) == 0 && l0 + (lane >> 3) < L) x[P + l0 + (lane >> 3)] = act_l ? (-g_l - v1) * dinv_l : 0.0;
   }
   __syncthreads();
   double mc = 0.0;
-  for (int j = tid; j < m.N; j += blockDim.x) {
+  for (int j = tid; j < N; j += 256) {
     const double dj = x[j];
     if (!isfinite(dj)) bad = 1;
-    if (d.active[m.u0 + j]) mc += 0.5 * dj * (dd[j] * dj - g[j]);
+    if (d.active[u0 + j]) mc += 0.5 * dj * (dd[j] * dj - g[j]);
   }
-  red[tid] = mc;
+  for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off);
+  if (lane == 0) red[wave] = mc;
   __syncthreads();
-  for (int s = blockDim.x >> 1; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  if (tid == 0) red[0] = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
   if (tid == 0) {
     lm.model_change = red[0];
     const bool valid = !lm.chol_fail && !bad && (red[0] > 0.0);
