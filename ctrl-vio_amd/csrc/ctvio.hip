@@ -338,8 +338,8 @@ template <class T> class SolverImpl : public SolverBase {
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, n);
       maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw);
     }
-    const size_t chol_lds = (size_t)(32 * 34 + 32 + 34 + ((size_t)std::max(maxP - 32, 0) + 8) * 32) * sizeof(double);
-    if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~640)");
+    const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
+    if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
     // ---- device buffers
     Dev<T> &d = dev_;
     std::memset(&d, 0, sizeof d);
@@ -382,6 +382,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_cscale_.alloc((size_t)U0)); HIPCHK(b_delta_.alloc((size_t)U0)); HIPCHK(b_active_.upload(active, stream_));
     HIPCHK(b_lm_.alloc((size_t)nw)); HIPCHK(b_nact_.alloc(1)); HIPCHK(b_dbg_.alloc(64));
     d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? b_dbg_.p : nullptr;
+    d.chol_nblk = (maxP + 31) / 32; HIPCHK(b_chol_inv_.alloc((size_t)nw * d.chol_nblk * 1024)); d.chol_inv = b_chol_inv_.p;
     d.Hpp = b_Hpp_.p; d.S = b_S_.p; d.W = b_W_.p; d.Hll = b_Hll_.p; d.g = b_g_.p; d.rhs = b_rhs_.p; d.dd = b_dd_.p; d.dinv = b_dinv_.p;
     d.cscale = b_cscale_.p; d.delta = b_delta_.p; d.active = b_active_.p; d.lm = b_lm_.p; d.n_active = b_nact_.p;
     HIPCHK(hipMemsetAsync(b_lm_.p, 0, sizeof(Lm) * nw, stream_));
@@ -751,7 +752,7 @@ template <class T> class SolverImpl : public SolverBase {
   DBuf<int32_t> b_lm_blk_off_, b_lm_blk_;
   DBuf<WinMeta> b_meta_;
   DBuf<double> b_quat_, b_pos_, b_bias_, b_rho_, b_ld_, b_cquat_, b_cpos_, b_cbias_, b_crho_, b_cld_, b_bc_w_, b_pH_, b_pb0_, b_pc0_, b_p_x0_;
-  DBuf<double> b_Hpp_, b_S_, b_Hll_, b_g_, b_rhs_, b_dd_, b_dinv_, b_cscale_, b_delta_;
+  DBuf<double> b_chol_inv_, b_Hpp_, b_S_, b_Hll_, b_g_, b_rhs_, b_dd_, b_dinv_, b_cscale_, b_delta_;
   DBuf<int32_t> b_knot_win_, b_bias_win_, b_lm_win_, b_imu_grp_, b_v_win_, b_v_lm_, b_v_rowi_, b_v_rowj_, b_bc_win_, b_bc_i_, b_bc_j_, b_pcol_,
       b_p_kind_, b_p_index_, b_p_off_, b_vs_, b_nact_;
   DBuf<int64_t> b_v_ti_, b_v_tj_;

@@ -95,6 +95,8 @@ template <class T> struct Dev {
   T *W;                  // Hpl^T, landmark-major
   double *Hll, *g;       // [Ltot], [Utot]
   double *S, *rhs;       // Schur complement (lower) and its right-hand side [sum P]
+  double *chol_inv;      // [nwin][chol_nblk][32][32] inverses of the diagonal blocks of the Cholesky factor (row-major)
+  int32_t chol_nblk;
   double *dd, *dinv;     // LM damping per unknown [Utot]; 1/(Hll + dd) [Ltot]
   double *cscale;        // Jacobi scaling [Utot]
   double *delta;         // step [Utot]

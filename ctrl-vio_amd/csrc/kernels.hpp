@@ -7,6 +7,7 @@
 //   control   : k_lm_init, k_begin_iter, k_lm_control, k_accept   (Ceres 1.14 trust-region semantics)
 //   query     : k_spline_eval
 #pragma once
+#include <utility>
 #include "device_types.hpp"
 #include "factors.hpp"
 
@@ -1131,194 +1132,235 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// Dense fp64 Cholesky of the P x P reduced system + solve, one workgroup per window, right-looking with
-// 32-column panels:
-//   1. wave 0 holds the 32x32 diagonal block one row per lane in registers and factors it with
-//      v_readlane broadcasts (no LDS, no barriers inside the 32 pivot steps);
-//   2. every lane solves one panel row against the factored block (LDS broadcast reads);
-//   3. trailing update A22 -= L21 L21^T with 4x4 register tiles from the LDS-resident panel.
+// Dense fp64 Cholesky of the P x P reduced system + solve, one workgroup (4 waves) per window, right-looking with
+// 32-column panels, the matrix products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   1. wave 0 factors the 32 x 32 diagonal block, one row per lane in registers, with v_readlane broadcasts (no LDS,
+//      no barriers inside the 32 pivot steps) and forms L11^-1 in the same sweep (lane = column of the inverse).
+//      Meanwhile waves 1-3 stage the panel rows A21 (and the rhs row) into LDS, k-major.
+//   2. L21 = A21 L11^-T as an MFMA product, in place in the LDS panel (a 16-row tile is owned by one wave);
+//   3. trailing update A22 -= L21 L21^T: one 16 x 16 tile per wave at a time, 8 MFMAs, read-modify-write of S.
 // The right-hand side rides along as an extra matrix row (Cholesky of [S b; b^T .]), so y = L^-1 b needs no
 // separate forward substitution; only the block back-substitution L^T x = y remains.  Result in delta[0..P).
-template <class T> __global__ __launch_bounds__(256) void k_cholesky_solve(Dev<T> d) {
+// MFMA register layout (measured, tools/mfma_f64_layout.hip): A operand lane l = A[l%16][l/16], B operand lane l =
+// B[l/16][l%16], D register r of lane l = D[(l/16) + 4r][l%16].
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// One elimination step of the fused factorisation / inversion (see k_cholesky_solve): s = a_j of lane C (two
+// v_readlane into a fixed SGPR pair), then a_c -= a_j s and x_c -= x_j s.  Written as one asm block so the broadcast
+// value lives for exactly these instructions (left to the compiler, every broadcast was spilled and reloaded).
+template <int C> __device__ __forceinline__ void chol_bcast_update(double &ac, double &xc, double aj, double xj, int aj_lo, int aj_hi) {
+  asm volatile("v_readlane_b32 s96, %4, %6\n\tv_readlane_b32 s97, %5, %6\n\ts_nop 1\n\t"
+               "v_fma_f64 %0, -%2, s[96:97], %0\n\tv_fma_f64 %1, -%3, s[96:97], %1"
+               : "+v"(ac), "+v"(xc)
+               : "v"(aj), "v"(xj), "v"(aj_lo), "v"(aj_hi), "n"(C)
+               : "s96", "s97");
+}
+template <int J, int... Cs>
+__device__ __forceinline__ void chol_row_updates(double (&a)[32], double (&xa)[32], double xj, std::integer_sequence<int, Cs...>) {
+  const int lo = __double2loint(a[J]), hi = __double2hiint(a[J]);
+  (chol_bcast_update<J + 1 + Cs>(a[J + 1 + Cs], xa[J + 1 + Cs], a[J], xj, lo, hi), ...);
+}
+template <int J> __device__ __forceinline__ void chol_diag_step(double (&a)[32], double (&xa)[32], int &bad) {
+  const double pj = readlane_d(a[J], J);
+  const bool ok = (pj > 0.0) && isfinite(pj);
+  if (!ok) bad = 1;
+  // 1/sqrt(pj): hardware estimate + two Newton steps (short dependent chain instead of sqrt + divide)
+  const double ps = ok ? pj : 1.0;
+  double di = __builtin_amdgcn_rsq(ps);
+  const double hp = 0.5 * ps;
+  di = di * (1.5 - hp * di * di);
+  di = di * (1.5 - hp * di * di);
+  a[J] *= di;                     // lane J: sqrt(pj); lanes > J: L[i][J]  (lanes < J hold unused upper-triangle values)
+  const double xj = xa[J] * di;   // X[J][lane], final: every k < J has been eliminated
+  xa[J] = xj;
+  chol_row_updates<J>(a, xa, xj, std::make_integer_sequence<int, 31 - J>{});
+}
+template <int... Js> __device__ __forceinline__ void chol_diag_all(double (&a)[32], double (&xa)[32], int &bad, std::integer_sequence<int, Js...>) {
+  (chol_diag_step<Js>(a, xa, bad), ...);
+}
+template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
   if (lm.status) return;
   const WinMeta &m = d.wins[w];
-  const int P = m.P, tid = threadIdx.x;
+  const int P = m.P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) double smc[];
-  double *Dt = smc;               // [32][34] factored diagonal block, TRANSPOSED: Dt[k][j] = L[j][k]
-  double *dinvs = smc + 32 * 34;  // [32] 1 / L_jj
-  double *yb = dinvs + 32;        // [32]
+  double *Lb = smc;                 // [32][34] L11 row-major
+  double *LiT = Lb + 32 * 34;       // [32][34] L11^-1 transposed: LiT[k][j] = Linv[j][k]
+  double *dinvs = LiT + 32 * 34;    // [32] 1 / L_jj
+  double *yb = dinvs + 32;          // [32]
   int &s_fail = *reinterpret_cast<int *>(yb + 32);
-  double *LpT = yb + 34;          // [32][RS] panel (+ rhs row) TRANSPOSED: LpT[k][r], rows padded to a multiple of 4
+  double *LpT = yb + 34;            // [32][RS] panel (+ rhs row) k-major: LpT[k][r]
   double *S = d.S + m.H0;
-  double *y = d.rhs + m.p0;       // augmented row; becomes L^-1 rhs
+  double *y = d.rhs + m.p0;         // augmented row; becomes L^-1 rhs
   double *x = d.delta + m.u0;
   if (tid == 0) s_fail = 0;
   __syncthreads();
   long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;
   int dbi = 0;
-#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 60) dbg[dbi++] = clock64(); } while (0)
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
   CTV_STAMP();
+  const int q4 = lane >> 4, l15 = lane & 15;
   for (int jb = 0; jb < P; jb += 32) {
     const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0, ntr = nt + 1;  // ntr: trailing rows incl. the rhs row
-    const int ntr4 = (ntr + 3) & ~3, RS = ntr4;
-    if (tid < 64) {
-      const int lane = tid;
+    const int RS = (ntr + 15) & ~15, ntile = RS >> 4;
+    if (wave == 0) {
+      // ---- diagonal block: lanes >= nb (last, partial block) carry identity rows
       double a[32];
+      {
+        const int rr = min(jb + lane, P - 1);
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        double v = (c == lane) ? 1.0 : 0.0;
-        if (lane < nb && c < nb) v = (c <= lane) ? S[(long long)(jb + lane) * P + jb + c] : 0.0;
-        a[c] = v;
-      }
-      int bad = 0;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const double pj = readlane_d(a[j], j);
-        const bool ok = (pj > 0.0) && isfinite(pj);
-        if (!ok) bad = 1;
-        // 1/sqrt(pj): hardware estimate + two Newton steps (short dependent chain instead of sqrt + divide)
-        const double ps = ok ? pj : 1.0;
-        double di = __builtin_amdgcn_rsq(ps);
-        const double hp = 0.5 * ps;
-        di = di * (1.5 - hp * di * di);
-        di = di * (1.5 - hp * di * di);
-        a[j] *= di;  // lane j: sqrt(pj); lanes > j: L[i][j]
-        if (lane == j) dinvs[j] = di;
-#pragma unroll
-        for (int c = j + 1; c < 32; ++c) a[c] -= a[j] * readlane_d(a[j], c);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (lane < 32) {
+        for (int c = 0; c < 32; ++c) a[c] = S[(long long)rr * P + min(jb + c, P - 1)];   // unconditional, masked below
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
-          Dt[c * 34 + lane] = (c <= lane) ? a[c] : 0.0;
-          if (lane < nb && c <= lane && c < nb) S[(long long)(jb + lane) * P + jb + c] = a[c];
+          const bool in = lane < nb && c < nb && c <= lane;
+          a[c] = in ? a[c] : ((c == lane && lane < 32) ? 1.0 : 0.0);
+        }
+      }
+      int bad = 0;
+      // Right-looking factorisation fused with the inversion X = L11^-1 (lane = column of X, forward substitution):
+      // the multiplier L[c][j] = readlane(a[j], c) of the rank-1 update is also the coefficient of the substitution
+      // x_c -= L[c][j] x_j, so one v_readlane pair feeds two FMAs and no LDS round trip sits on the critical path.
+      double xa[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) xa[i] = (i == lane) ? 1.0 : 0.0;
+      chol_diag_all(a, xa, bad, std::make_integer_sequence<int, 32>{});
+      if (lane < nb) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+          if (c <= lane && c < nb) S[(long long)(jb + lane) * P + jb + c] = a[c];
+      }
+      if (lane < 32) {
+        double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;   // kept for the back-substitution
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          LiT[lane * 34 + i] = xa[i];   // LiT[k = lane][j = i] = Linv[i][lane]
+          gi[i * 32 + lane] = xa[i];    // row-major Linv[i][lane]
         }
       }
       if (lane == 0 && bad) s_fail = 1;
-    }
-    __syncthreads();
-    CTV_STAMP();
-    for (int r = tid; r < ntr4; r += 256) {  // panel rows (and the rhs row): L21 = A21 L11^-T, row kept in the LDS panel
-      double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + jb : y + jb;
-      const bool live = r < ntr;
-      double *lr = LpT + r;  // element j of this row lives at lr[j * RS]: consecutive lanes -> consecutive addresses
-      {
+    } else {
+      // ---- waves 1-3: panel rows (and the rhs row) into the LDS panel, LpT[k][r]
+      for (int r = tid - 64; r < RS; r += 192) {
+        const double *src = (r < nt) ? S + (long long)(r0 + r) * P + jb : y + jb;
         double tmp[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) tmp[j] = (live && j < nb) ? Srow[j] : 0.0;  // 32 independent loads in flight
+        for (int k = 0; k < 32; ++k) tmp[k] = src[min(k, nb - 1)];   // unconditional: 32 loads in flight
+        const bool live = r < ntr;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) lr[j * RS] = tmp[j];
-      }
-      for (int j = 0; j < nb; ++j) {  // x_j = (a_j - sum_{k<j} x_k L11[j][k]) / L11[j][j]; 4 independent partial sums
-        double s0 = lr[j * RS], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int k = 0;
-        for (; k + 3 < j; k += 4) {
-          s0 -= lr[k * RS] * Dt[k * 34 + j];
-          s1 -= lr[(k + 1) * RS] * Dt[(k + 1) * 34 + j];
-          s2 -= lr[(k + 2) * RS] * Dt[(k + 2) * 34 + j];
-          s3 -= lr[(k + 3) * RS] * Dt[(k + 3) * 34 + j];
-        }
-        for (; k < j; ++k) s0 -= lr[k * RS] * Dt[k * 34 + j];
-        lr[j * RS] = ((s0 + s1) + (s2 + s3)) * dinvs[j];
-      }
-      if (live) {
-        double tmp[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) tmp[j] = lr[j * RS];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) if (j < nb) Srow[j] = tmp[j];
+        for (int k = 0; k < 32; ++k) LpT[k * RS + r] = (live && k < nb) ? tmp[k] : 0.0;
       }
     }
     __syncthreads();
     CTV_STAMP();
-    // trailing update with 4x4 tiles over the lower triangle of the (nt + rhs row) x nt block;
-    // LpT is k-major, so a tile's 4 row values / 4 column values are one contiguous 32-byte LDS read each
-    const int mt = ntr4 / 4, ntile = mt * (mt + 1) / 2;
-    for (int t = tid; t < ntile; t += 256) {
-      int tr = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-      while (tr * (tr + 1) / 2 > t) --tr;
-      const int tc = t - tr * (tr + 1) / 2;
-      double acc[4][4];
+    // ---- L21 = A21 L11^-T, in place: Linv is lower triangular, so output columns 0..15 need k < 16 only
+    for (int tr = wave; tr < ntile; tr += 4) {
+      f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+      const double *pa = LpT + 16 * tr + l15;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = 4 * kk + q4;
+        const double av = pa[k * RS];
+        if (kk < 4) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LiT[k * 34 + l15], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LiT[k * 34 + 16 + l15], c1, 0, 0, 0);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-      const double *pr = LpT + 4 * tr, *pc = LpT + 4 * tc;
-      double sv[4][4];  // current values, requested before the k loop so their latency hides under it
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 4 * tr + i;
-        const double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + r0 : y + r0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = 4 * tc + j;
-          sv[i][j] = (r < ntr && c < nt && c <= r) ? Srow[c] : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tr + q4 + 4 * r;
+        LpT[l15 * RS + row] = c0[r];
+        LpT[(16 + l15) * RS + row] = c1[r];
+        if (row < ntr) {
+          double *dst = (row < nt) ? S + (long long)(r0 + row) * P + jb : y + jb;
+          if (l15 < nb) dst[l15] = c0[r];
+          if (16 + l15 < nb) dst[16 + l15] = c1[r];
         }
       }
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) {
-        const VecN<double, 4> rv = *reinterpret_cast<const VecN<double, 4> *>(pr + k * RS);
-        const VecN<double, 4> cv = *reinterpret_cast<const VecN<double, 4> *>(pc + k * RS);
+    }
+    __syncthreads();
+    CTV_STAMP();
+    // ---- trailing update A22 -= L21 L21^T on the lower triangle (16 x 16 tiles) and the rhs row
+    const int ntt = nt > 0 ? ntile * (ntile + 1) / 2 : 0;   // last panel: nothing left to update
+    // (requesting the next trip's S values before the current products was tried: register spills made it slower)
+    for (int tb = wave; tb < ntt; tb += 16) {   // 4 tiles per wave and trip: 16 loads in flight, 32 MFMAs, 16 stores
+      double sv[4][4];
+      int ti4[4], tj4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int u = 0; u < 4; ++u) {
+        tile_decode(min(tb + 4 * u, ntt - 1), ti4[u], tj4[u]);
+        const int col = 16 * tj4[u] + l15;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += rv.v[i] * cv.v[j];
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti4[u] + q4 + 4 * r;
+          const double *src = (row < nt) ? S + (long long)(r0 + row) * P + r0 : y + r0;
+          sv[u][r] = src[min(col, nt - 1)];
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 4 * tr + i;
-        if (r >= ntr) continue;
-        double *Srow = (r < nt) ? S + (long long)(r0 + r) * P + r0 : y + r0;
+      for (int u = 0; u < 4; ++u) {
+        f64x4 c = {0.0, 0.0, 0.0, 0.0};
+        const double *pa = LpT + 16 * ti4[u] + l15, *pb = LpT + 16 * tj4[u] + l15;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = 4 * tc + j;
-          if (c < nt && (c <= r)) Srow[c] = sv[i][j] - acc[i][j];
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = 4 * kk + q4;
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k * RS], pb[k * RS], c, 0, 0, 0);
+        }
+        const int col = 16 * tj4[u] + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti4[u] + q4 + 4 * r;
+          if (tb + 4 * u < ntt && col < nt && ((row < nt && col <= row) || row == nt)) {
+            double *dst = (row < nt) ? S + (long long)(r0 + row) * P + r0 : y + r0;
+            dst[col] = sv[u][r] - c[r];
+          }
         }
       }
     }
     __syncthreads();
     CTV_STAMP();
   }
-  // ---- block back-substitution L^T x = y
-  for (int i = tid; i < P; i += 256) x[i] = y[i];
+  // ---- block back-substitution L^T x = y with the stored block inverses: x_b = Linv_b^T t_b, then t_j -= L[b][j]^T x_b
+  //      for the rows above.  x lives in LDS; per block the loads of Linv_b (wave 0) and of the panel rows (everyone) do
+  //      not depend on x and are issued together, before the block solve.
+  double *xs = LpT;   // the panel is no longer needed
+  for (int i = tid; i < P; i += 256) xs[i] = y[i];
   __syncthreads();
   const int nblk = (P + 31) / 32;
   for (int b = nblk - 1; b >= 0; --b) {
     const int jb = 32 * b, nb = min(32, P - jb);
-    if (tid < 64) {
-      const int lane = tid;
-      double col[32];  // column `lane` of the diagonal block: L[jb+i][jb+lane], i >= lane
+    double lv[32];   // column j of the panel rows of this block: L[jb + ii][j]
+    const bool upd = tid < jb;
+    {
+      const int j = min(tid, max(jb - 1, 0));
 #pragma unroll
-      for (int i = 0; i < 32; ++i) col[i] = (lane < nb && i >= lane && i < nb) ? S[(long long)(jb + i) * P + jb + lane] : 0.0;
-      double bj = (lane < nb) ? x[jb + lane] : 0.0;
-      double rdj = 1.0;
+      for (int ii = 0; ii < 32; ++ii) lv[ii] = S[(long long)(jb + min(ii, nb - 1)) * P + j];
+    }
+    if (wave == 0) {
+      const double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + b) * 1024;
+      double li[32];
+      const int l31 = lane & 31;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) if (i == lane && lane < nb) rdj = 1.0 / col[i];
+      for (int i = 0; i < 32; ++i) li[i] = gi[i * 32 + l31];
+      double acc = 0.0;
 #pragma unroll
-      for (int i = 31; i >= 0; --i) {
-        const double xi = readlane_d(bj, i) * readlane_d(rdj, i);
-        if (lane < i) bj -= col[i] * xi;
-        if (lane == i) bj = xi;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (lane < nb) { x[jb + lane] = bj; yb[lane] = bj; }
+      for (int i = 0; i < 32; ++i) acc += li[i] * ((i < nb) ? xs[jb + i] : 0.0);   // Linv is lower triangular: rows i >= lane
+      __builtin_amdgcn_wave_barrier();
+      if (lane < nb) { xs[jb + lane] = acc; yb[lane] = acc; }
     }
     __syncthreads();
-    for (int j = tid; j < jb; j += 256) {
-      double lv[32];
-#pragma unroll
-      for (int ii = 0; ii < 32; ++ii) lv[ii] = (ii < nb) ? S[(long long)(jb + ii) * P + j] : 0.0;  // all loads in flight at once
+    if (upd) {
       double sacc = 0.0;
 #pragma unroll
       for (int ii = 0; ii < 32; ++ii) sacc += lv[ii] * ((ii < nb) ? yb[ii] : 0.0);
-      x[j] -= sacc;
+      xs[tid] -= sacc;
+    }
+    for (int j = tid + 256; j < jb; j += 256) {   // P > 256 + 32: remaining rows
+      double sacc = 0.0;
+      for (int ii = 0; ii < nb; ++ii) sacc += S[(long long)(jb + ii) * P + j] * yb[ii];
+      xs[j] -= sacc;
     }
     __syncthreads();
   }
+  for (int i = tid; i < P; i += 256) x[i] = xs[i];
   CTV_STAMP();
   if (tid == 0) lm.chol_fail = s_fail;
 #undef CTV_STAMP
