@@ -86,7 +86,7 @@ static int prior_block_size(int kind) { return kind == CTVIO_PK_LD ? 1 : 3; }
 
 template <class T> class SolverImpl : public SolverBase {
  public:
-  static constexpr int VCH = sizeof(T) == 4 ? 32 : 16;   // visual blocks per work item (k_assemble_vis)
+  static constexpr int VCH = 16;   // visual blocks per work item (k_assemble_vis): with the fp64 LDS accumulators 16 leaves room for 8 staging areas
   static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
   explicit SolverImpl(const ctvio_options &o) : opt_(o), mixed_(sizeof(T) == 4 && o.fp64_residuals != 0) {}
   ~SolverImpl() override {
@@ -102,6 +102,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int clear() override { wins_.clear(); uploaded_ = false; return CTVIO_OK; }
@@ -261,7 +262,7 @@ template <class T> class SolverImpl : public SolverBase {
       }
       {
         const size_t K6 = 6 * (size_t)w.K, nG = K6 + 1, nH = K6 * (K6 + 1) / 2 + K6 + 1 + nG;
-        const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(T) + vis_stage_bytes();
+        const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(double) + vis_stage_bytes();   // fp64 accumulators in LDS
         const size_t need_glb = ((nG + 3) & ~(size_t)3) * sizeof(T) + vis_stage_bytes();
         m.vis_lds = need <= 160 * 1024 ? 1 : 0;
         vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : need_glb);
@@ -367,7 +368,12 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_Jv_.alloc((size_t)100 * std::max(Vtot_, 1))); HIPCHK(b_rv_.alloc((size_t)2 * std::max(Vtot_, 1))); HIPCHK(b_vs_.alloc((size_t)2 * std::max(Vtot_, 1)));
     d.v_win = b_v_win_.p; d.v_lm = b_v_lm_.p; d.v_ti = b_v_ti_.p; d.v_tj = b_v_tj_.p; d.v_rowi = b_v_rowi_.p; d.v_rowj = b_v_rowj_.p;
     d.v_obs = b_v_obs_.p; d.Jv = b_Jv_.p; d.rv = b_rv_.p; d.vs = b_vs_.p;
-    HIPCHK(b_Wc_.alloc((size_t)52 * std::max(Vtot_, 1))); d.Wc = b_Wc_.p;
+    HIPCHK(b_Wc_.alloc((size_t)WC_STRIDE * std::max(Vtot_, 1))); d.Wc = b_Wc_.p;
+    {  // row of every block in landmark order = its position in the CSR list
+      std::vector<int32_t> v_slot(std::max(Vtot_, 1), 0);
+      for (size_t p = 0; p < lm_blk.size(); ++p) v_slot[lm_blk[p]] = (int32_t)p;
+      HIPCHK(b_v_slot_.upload(v_slot, stream_)); d.v_slot = b_v_slot_.p;
+    }
     HIPCHK(b_vitems_.upload(vitems, stream_)); d.vitems = b_vitems_.p;
     lm_blk_off.push_back((int)lm_blk.size());
     HIPCHK(b_lm_blk_off_.upload(lm_blk_off, stream_)); HIPCHK(b_lm_blk_.upload(lm_blk, stream_));
@@ -465,12 +471,12 @@ template <class T> class SolverImpl : public SolverBase {
     ph_begin(PH_ASM_VIS);
     {  // few windows: split each window's items over several workgroups to fill the chip
       const int parts = vis_parts();
-      if (any_vis_lds_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, true>), dim3(nw, parts), dim3(512), vis_lds_, stream_, d);
+      if (any_vis_lds_) launch_assemble_vis_lds(parts);
       if (any_vis_glb_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, false>), dim3(nw, parts), dim3(512), vis_glb_, stream_, d);
     }
     ph_end();
     ph_begin(PH_ASM_REST);
-    if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(nblk(d.maxL, 4), nw), dim3(256), (size_t)4 * d.maxLdw * sizeof(T), stream_, d);
+    if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(d.maxL, nw), dim3(64), (size_t)d.maxLdw * sizeof(double), stream_, d);
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d);
     hipLaunchKernelGGL((k_misc<T, true>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, d.quat, d.pos, d.bias, d.ld, 0);
     hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
@@ -498,6 +504,7 @@ template <class T> class SolverImpl : public SolverBase {
     ph_end();
   }
   void launch_schur();
+  void launch_assemble_vis_lds(int parts);
   bool schur_makes_rhs() const { return sizeof(T) == 4 && opt_.use_mfma != 0; }
   void launch_cost(bool candidate, int force) {
     const Dev<T> &d = dev_;
@@ -749,7 +756,7 @@ template <class T> class SolverImpl : public SolverBase {
   int Mtot_ = 0, Vtot_ = 0;
   size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0;
   DBuf<VisItem> b_vitems_;
-  DBuf<int32_t> b_lm_blk_off_, b_lm_blk_;
+  DBuf<int32_t> b_lm_blk_off_, b_lm_blk_, b_v_slot_;
   DBuf<WinMeta> b_meta_;
   DBuf<double> b_quat_, b_pos_, b_bias_, b_rho_, b_ld_, b_cquat_, b_cpos_, b_cbias_, b_crho_, b_cld_, b_bc_w_, b_pH_, b_pb0_, b_pc0_, b_p_x0_;
   DBuf<double> b_chol_inv_, b_Hpp_, b_S_, b_Hll_, b_g_, b_rhs_, b_dd_, b_dinv_, b_cscale_, b_delta_;
@@ -770,6 +777,15 @@ template <> void SolverImpl<float>::launch_schur() {
   const int nt = (d.maxP + 1 + 31) / 32;
   if (opt_.use_mfma) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
   else hipLaunchKernelGGL((k_schur_generic<float>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
+}
+template <> void SolverImpl<float>::launch_assemble_vis_lds(int parts) {
+  const Dev<float> &d = dev_;
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  else hipLaunchKernelGGL((k_assemble_vis<float, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+}
+template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
+  const Dev<double> &d = dev_;
+  hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
 }
 template <> void SolverImpl<double>::launch_schur() {
   const Dev<double> &d = dev_;

@@ -51,6 +51,7 @@ struct LmParams {
 };
 
 // Device pointers of one batch.  T = scalar of the linearisation kernels (float product / double debug).
+constexpr int WC_STRIDE = 54;
 template <class T> struct Dev {
   int32_t nwin, Ktot, Ftot, Ltot, Mtot, Gtot, Vtot, NBtot, Utot, maxN, maxP, maxPn;
   const WinMeta *wins;
@@ -77,7 +78,9 @@ template <class T> struct Dev {
   const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
   T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
   T *rv;                 // [2][Vtot]
-  T *Wc;                 // [Vtot][52] per block: J~_rho^T J~_c (49 pose columns), J~_rho^T J~_rho, J~_rho^T r~
+  T *Wc;                 // [Vtot][WC_STRIDE] per block, rows in LANDMARK order (row v_slot[v]): J~_rho^T J~_c (49 pose columns),
+                         // J~_rho^T J~_rho, J~_rho^T r~, then the block's knot segments si, sj
+  const int32_t *v_slot; // [Vtot] row of block v in Wc
   int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
   const VisItem *vitems;
   const int32_t *lm_blk_off, *lm_blk;   // CSR landmark -> its visual blocks (global indices), [Ltot+1], [Vtot]

@@ -414,15 +414,35 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
   const int w = grp.win;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
+  const int K = m.K, P = m.P, u0 = m.u0;
+  const long long H0 = m.H0;
   const T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
+  if (m.vis_lds) {
+    // the knot x knot part is accumulated in LDS by k_assemble_vis; what is left is the bias rows (6 x 24 against the
+    // knots, the 6 x 6 lower triangle) and the gradient: 195 entries, one per thread -- one load, one atomic
+    const int t = threadIdx.x;
+    int a, b;
+    if (t < 144) { a = 24 + t / 24; b = t % 24; }
+    else if (t < 165) {
+      const int q = t - 144;                     // lower triangle of the bias block, row-major
+      const int i = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : q < 10 ? 3 : q < 15 ? 4 : 5;
+      a = 24 + i; b = 24 + q - i * (i + 1) / 2;
+    } else if (t < 195) { a = t - 165; b = 30; }
+    else return;
+    const double v = (double)tile[a * 32 + b];
+    const int ga = imu_col(a, grp.s, K, grp.bias);
+    if (b == 30) { atomicAdd(&d.g[u0 + ga], v); return; }
+    const int gb = imu_col(b, grp.s, K, grp.bias);
+    atomicAdd(&d.Hpp[H0 + (long long)max(ga, gb) * P + min(ga, gb)], v);
+    return;
+  }
   for (int e = threadIdx.x; e < 31 * 30; e += blockDim.x) {
     const int b = e / 30, a = e % 30;  // a < 30 : unknown row; b <= 30
     const double v = (double)tile[a * 32 + b];
-    const int ga = imu_col(a, grp.s, m.K, grp.bias);
-    if (b == 30) { atomicAdd(&d.g[m.u0 + ga], v); continue; }
-    if (m.vis_lds && a < 24 && b < 24) continue;  // knot x knot: accumulated in LDS by k_assemble_vis
-    const int gb = imu_col(b, grp.s, m.K, grp.bias);
-    if (ga >= gb) atomicAdd(&d.Hpp[m.H0 + (long long)ga * m.P + gb], v);
+    const int ga = imu_col(a, grp.s, K, grp.bias);
+    if (b == 30) { atomicAdd(&d.g[u0 + ga], v); continue; }
+    const int gb = imu_col(b, grp.s, K, grp.bias);
+    if (ga >= gb) atomicAdd(&d.Hpp[H0 + (long long)ga * P + gb], v);
   }
 }
 
@@ -526,11 +546,11 @@ __device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, in
 }
 
 template <class T, bool LIN, class RT>
-__global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ T wcs[LIN ? 64 * 53 : 1];   // per-lane W contributions, written out coalesced at the end
-  __shared__ int wcs_on[LIN ? 64 : 1];
-  if (LIN) wcs_on[threadIdx.x] = 0;
+  __shared__ T wcs[LIN ? 64 * 55 : 1];   // per-lane W contributions (row of WC_STRIDE entries), written out coalesced at the end
+  __shared__ int wcs_on[LIN ? 64 : 1];   // destination row (slot in landmark order, see Dev::Wc) or -1
+  if (LIN) wcs_on[threadIdx.x] = -1;
   double c = 0.0;
   int w = -1;
   if (v < d.Vtot) {
@@ -562,8 +582,8 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisGlobalSink<T> sink{d.Jv + v, V, wcs + 53 * threadIdx.x, T(0), T(0)};
-        wcs_on[threadIdx.x] = 1;
+        VisGlobalSink<T> sink{d.Jv + v, V, wcs + 55 * threadIdx.x, T(0), T(0)};
+        wcs_on[threadIdx.x] = d.v_slot[v];
         SegConst<T> sci, scj;
         seg_const_load(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci, true);
         seg_const_load(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj, true);
@@ -576,6 +596,7 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
         }
         sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
         sink.wc[50] = sink.jr0 * r[0] + sink.jr1 * r[1];
+        sink.wc[51] = (T)si; sink.wc[52] = (T)sj;   // knot segments travel with the row (exact in fp32)
         d.rv[v] = r[0]; d.rv[V + v] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
       } else {
@@ -588,10 +609,9 @@ __global__ __launch_bounds__(64) void k_vis_eval(Dev<T> d, const double *quat, c
   }
   if (LIN) {
     __syncthreads();
-    const long long vbase = (long long)blockIdx.x * 64;
-    for (int i = threadIdx.x; i < 64 * 52; i += 64) {
-      const int bl = i / 52, cc = i % 52;
-      if (wcs_on[bl] && cc < 51) d.Wc[(size_t)52 * (vbase + bl) + cc] = wcs[53 * bl + cc];
+    for (int i = threadIdx.x; i < 64 * WC_STRIDE; i += 64) {
+      const int bl = i / WC_STRIDE, cc = i % WC_STRIDE, slot = wcs_on[bl];
+      if (slot >= 0 && cc < 53) d.Wc[(size_t)WC_STRIDE * slot + cc] = wcs[55 * bl + cc];
     }
   } else {
     const int w0 = __shfl(w, 0);
@@ -787,53 +807,275 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 #undef CTV_STAMP
 }
 
+// fp32 visual assembly on the matrix cores (windows whose packed Hessian is LDS resident).  Same decomposition as
+// k_assemble_vis (items of <= CH blocks per frame pair, runs of equal knot quadruples inside an item), but
+//   * the run's [J~_pose | r~]^T [J~_pose | r~] (50 x 50, padded to 64 = 4 x 4 tiles of 16; the lower 10 tiles) is formed
+//     with v_mfma_f32_16x16x4_f32: K = 4 is two blocks x two residual rows, the operands are plain LDS reads of the staged
+//     item ([102][CH + 2], row = 2 * column + residual row), the A and B operand of a tile pair are the same registers;
+//   * the staging area of a wave is private, so there is no workgroup barrier inside the item loop, and the next item's
+//     J~ (51 values per lane) is requested before the current item is processed: its latency hides under the products.
+// C/D layout of the 16x16x4 fp32 MFMA: register r of lane l = D[4 (l / 16) + r][l % 16].
+template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<float> d) {
+  constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;
+  const long long t_begin = d.dbg ? clock64() : 0;
+  const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0;
+  if (m.vis_lds == 0) return;   // those windows go through k_assemble_vis<float, CH, false>
+  extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
+  // fp64 accumulators: ds_add_f64 sustains ~8 cycles per wave instruction on gfx950, ds_add_f32 ~190 (measured,
+  // tools/lds_atomic_bench.hip) -- and the fp64 sums do not depend on the order of the additions to ~1e-16
+  double *Hs = reinterpret_cast<double *>(smv);
+  const int K6 = 6 * K, tri = K6 * (K6 + 1) / 2;
+  const int nHh = tri + K6 + 1;                // packed Hessian entries: knot x knot lower triangle, line-delay row
+  const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay)
+  double *gs = Hs + nHh;
+  float *stage = reinterpret_cast<float *>(Hs + ((nH + 3) & ~3));     // [NW][102][CHP]
+  int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < nH; i += 512) Hs[i] = 0.0;
+  __syncthreads();
+  float *Js = stage + wave * 102 * CHP;
+  int *ks = keys + wave * 2 * CH;
+  const size_t V = (size_t)d.Vtot;
+  const int per_round = NW * nparts;
+  const int rounds = (nvitem + per_round - 1) / per_round;
+  double *Hg = d.Hpp + m.H0;
+  const int q4 = lane >> 4, l15 = lane & 15, bsel = q4 >> 1, rr = q4 & 1;   // MFMA k index = 2 * (block of the pair) + residual row
+  const int sc = lane % CH, srr = lane / CH;                               // staging: column (block) and row parity of this lane
+  long long *dbg = (d.dbg && w == 0 && part == 0) ? d.dbg + 48 : nullptr;
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 15) dbg[dbi++] = clock64(); } while (0)
+  if (dbg && tid == 0) dbg[dbi++] = t_begin;
+  CTV_STAMP();
+  // MFMA operand row offsets of this lane: tile row I -> knot column 16 I + l15, at k = q4 (block bsel of the pair, residual
+  // row rr).  The line-delay column (staged rows 98, 99) and the residual (rows 100, 101) ride on the same operand
+  // values with plain FMAs: every lane multiplies its three J entries by J_ld[k] and r[k] of its own k; the four k
+  // groups (lanes l15 + 16 q4) are summed with two shuffles per value at the end of the run.
+  int orow[3];
+#pragma unroll
+  for (int I = 0; I < 3; ++I) orow[I] = (2 * (16 * I + l15) + rr) * CHP;
+  const int ldrow = (98 + rr) * CHP, rrow = (100 + rr) * CHP;
+  float tmp[NPASS];
+  int n = 0, v0 = 0, key_i = 0, key_j = 0;
+  // the (start, count) of this wave's items: lane r holds item r, read once -- a per-item load of the descriptor would put a
+  // full memory round trip in front of every item's J~ request
+  int my_start, my_count;
+  {
+    const int it = (lane * nparts + part) * NW + wave;
+    const VisItem I = d.vitems[vitem0 + min(it, max(nvitem - 1, 0))];   // clamped: always a valid descriptor
+    my_start = I.start;
+    my_count = (lane < rounds && it < nvitem) ? I.count : 0;
+  }
+  auto fetch = [&](int r) {   // request item r of this wave: unconditional loads on clamped addresses, masked when staged
+    int istart, icount;
+    if (r < 64) { istart = __shfl(my_start, r); icount = __shfl(my_count, r); }
+    else {
+      const int it = (r * nparts + part) * NW + wave;
+      const VisItem I = d.vitems[vitem0 + min(it, nvitem - 1)];
+      istart = I.start; icount = (r < rounds && it < nvitem) ? I.count : 0;
+    }
+    if (r >= rounds) icount = 0;
+    n = icount;
+    v0 = istart;
+    const int c = sc < icount ? sc : 0;
+    // address = uniform row base (SGPR pair) + one 32-bit lane offset shared by all passes: pass i covers staged rows
+    // RPP i .. RPP i + RPP - 1, the lane's row inside the pass is srr  (64-bit per-lane addresses would cost 2 VGPRs per load)
+    static_assert(100 % RPP == 0, "a pass must not straddle the J / residual boundary");
+    const unsigned loff = (unsigned)srr * (unsigned)V + (unsigned)(v0 + c);
+    const unsigned loff_r = (unsigned)min(srr, 1) * (unsigned)V + (unsigned)(v0 + c);   // the residual has 2 rows only
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) tmp[i] = (i * RPP < 100) ? (d.Jv + (size_t)(i * RPP) * V)[loff] : d.rv[loff_r];
+    const int kc = lane < icount ? lane : 0;
+    key_i = d.vs[v0 + kc];
+    key_j = d.vs[V + v0 + kc];
+  };
+  if (nvitem > 0) fetch(0);
+  for (int r = 0; r < rounds && nvitem > 0; ++r) {
+    // ---- stage the fetched item (LDS operations of one wave are ordered: no barrier), then request the next one
+    const int ncur = n;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int row = i * RPP + srr;
+      if (row < 102) Js[row * CHP + sc] = (sc < ncur) ? tmp[i] : 0.0f;
+    }
+    if (lane < CH) { ks[lane] = key_i; ks[CH + lane] = key_j; }
+    __builtin_amdgcn_wave_barrier();
+    fetch(r + 1);
+    int start = 0;
+    while (start < ncur) {
+      const int si = ks[start], sj = ks[CH + start];
+      const bool diff = (lane > start && lane < ncur) && (ks[lane] != si || ks[CH + lane] != sj);
+      const unsigned long long mask = __ballot(diff);
+      const int end = mask ? (__ffsll((long long)mask) - 1) : ncur;
+      f32x4 acc[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      float pl[3] = {0.0f, 0.0f, 0.0f}, pr[3] = {0.0f, 0.0f, 0.0f}, pll = 0.0f, prl = 0.0f;
+      // 4 K-steps (8 blocks) per trip: the operand reads first, then the products -- one LDS latency per trip
+      for (int v8 = start; v8 < end; v8 += 8) {
+        float a[4][3], ldv[4], rv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int blk = v8 + 2 * s + bsel;
+          const bool in = blk < end;
+          const int bc = min(blk, CH + 1);   // a valid LDS address even when past the run (value discarded)
+#pragma unroll
+          for (int I = 0; I < 3; ++I) a[s][I] = Js[orow[I] + bc];
+          ldv[s] = Js[ldrow + bc];
+          rv[s] = Js[rrow + bc];
+#pragma unroll
+          for (int I = 0; I < 3; ++I) a[s][I] = in ? a[s][I] : 0.0f;
+          ldv[s] = in ? ldv[s] : 0.0f;
+          rv[s] = in ? rv[s] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (v8 + 2 * s >= end) break;     // uniform
+          int q = 0;
+#pragma unroll
+          for (int I = 0; I < 3; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][I], a[s][J], acc[q], 0, 0, 0);
+#pragma unroll
+          for (int I = 0; I < 3; ++I) { pl[I] += a[s][I] * ldv[s]; pr[I] += a[s][I] * rv[s]; }
+          pll += ldv[s] * ldv[s];
+          prl += rv[s] * ldv[s];
+        }
+      }
+#pragma unroll
+      for (int I = 0; I < 3; ++I) {
+        pl[I] += __shfl_xor(pl[I], 16); pl[I] += __shfl_xor(pl[I], 32);
+        pr[I] += __shfl_xor(pr[I], 16); pr[I] += __shfl_xor(pr[I], 32);
+      }
+      pll += __shfl_xor(pll, 16); pll += __shfl_xor(pll, 32);
+      prl += __shfl_xor(prl, 16); prl += __shfl_xor(prl, 32);
+      // ---- scatter: local column -> unknown, each unordered local pair once; pairs of different local columns that map
+      //      to the same unknown (ends sharing a knot) count twice on the diagonal
+      int gcol[3];
+#pragma unroll
+      for (int J = 0; J < 3; ++J) gcol[J] = vis_col(16 * J + l15, si, sj, P);
+      {
+        int q = 0;
+#pragma unroll
+        for (int I = 0; I < 3; ++I)
+#pragma unroll
+          for (int J = 0; J <= I; ++J, ++q) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int ca = 16 * I + 4 * q4 + rg, cb = 16 * J + l15;
+              if (I == J && ca < cb) continue;
+              int gA = vis_col(ca, si, sj, P), gB = gcol[J];
+              float hv = acc[q][rg];
+              if (gA == gB && ca != cb) hv *= 2.0f;
+              if (gA < gB) { const int t = gA; gA = gB; gB = t; }
+              atomicAdd(&Hs[gA * (gA + 1) / 2 + gB], (double)hv);
+            }
+          }
+        // line-delay row of the Hessian and the pose gradient (every k group holds the totals; group q4 = 0 adds them)
+        if (q4 == 0) {
+#pragma unroll
+          for (int J = 0; J < 3; ++J) {
+            atomicAdd(&Hs[tri + gcol[J]], (double)pl[J]);
+            atomicAdd(&gs[gcol[J]], (double)pr[J]);
+          }
+          if (l15 == 0) { atomicAdd(&Hs[tri + K6], (double)pll); atomicAdd(&gs[K6], (double)prl); }   // (ld, ld) and r . J_ld
+        }
+      }
+      start = end;
+    }
+  }
+  __syncthreads();
+  CTV_STAMP();
+  // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments)
+  for (int gi = part * NW + wave; gi < ngrp; gi += per_round) {
+    const ImuGroup grp = d.groups[grp0 + gi];
+    const float *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
+    float tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
+#pragma unroll
+    for (int u = 0; u < 9; ++u) { const int e = lane + 64 * u; tv[u] = tile[(e / 24) * 32 + e % 24]; }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int e = lane + 64 * u, a = e / 24, b = e % 24;
+      const int ga = imu_col(a, grp.s, K, grp.bias), gb = imu_col(b, grp.s, K, grp.bias);
+      if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], (double)tv[u]);
+    }
+  }
+  __syncthreads();
+  CTV_STAMP();
+  for (int i = tid; i < nHh; i += 512) {
+    const double hv = Hs[i];
+    if (nparts > 1 && hv == 0.0) continue;
+    int ga, gb;
+    if (i < tri) {
+      ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
+      while ((ga + 1) * (ga + 2) / 2 <= i) ++ga;
+      while (ga * (ga + 1) / 2 > i) --ga;
+      gb = i - ga * (ga + 1) / 2;
+    } else {
+      ga = P - 1;
+      gb = (i - tri) < K6 ? (i - tri) : P - 1;
+    }
+    if (nparts > 1) atomicAdd(&Hg[(long long)ga * P + gb], hv);
+    else Hg[(long long)ga * P + gb] = hv;  // first writer after k_zero_normal; later kernels add atomically
+  }
+  CTV_STAMP();
+  for (int i = tid; i < K6 + 1; i += 512) {
+    const double gv = gs[i];
+    if (gv != 0.0) atomicAdd(&d.g[u0 + (i < K6 ? i : P - 1)], gv);
+  }
+  CTV_STAMP();
+#undef CTV_STAMP
+}
+
 // W row, Hll and g_rho of every landmark, gathered (no atomics, no zero pass): one wave per landmark walks the
 // landmark's visual blocks (CSR built at upload) and accumulates J~_rho^T J~_pose into a row buffer in LDS.
-template <class T> __global__ __launch_bounds__(256) void k_build_W(Dev<T> d) {
+template <class T> __global__ __launch_bounds__(64) void k_build_W(Dev<T> d) {
   const int w = blockIdx.y;
-  if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, ldw = m.ldw, lm0 = m.lm0, u0 = m.u0;   // registers: not re-read after the LDS atomics
   const long long W0 = m.W0;
+  if (!lin_needed(d.lm[w])) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  T *row = reinterpret_cast<T *>(smw) + (size_t)wave * ldw;
-  const int l = blockIdx.x * 4 + wave;
+  const int lane = threadIdx.x;
+  double *row = reinterpret_cast<double *>(smw);   // fp64: ds_add_f32 is ~20x slower than ds_add_f64 on gfx950
+  const int l = blockIdx.x;          // one wave per landmark: no workgroup barriers (LDS operations of a wave are ordered)
   const bool valid = l < L;
-  if ((int)blockIdx.x * 4 >= L) return;  // whole block idle (uniform)
-  for (int i = lane; i < ldw; i += 64) row[i] = T(0);
-  __syncthreads();
+  if (!valid) return;
+  for (int i = lane; i < ldw; i += 64) row[i] = 0.0;
+  __builtin_amdgcn_wave_barrier();
   double hll = 0.0, gl = 0.0;
-  if (valid) {
+  {
     const size_t V = (size_t)d.Vtot;
+    (void)V;
     const int b0 = d.lm_blk_off[lm0 + l], b1 = d.lm_blk_off[lm0 + l + 1];
     const int lc = min(lane, 50);
     for (int bb = b0; bb < b1; bb += 8) {
-      // 8 blocks per pass, two rounds of unconditional (clamped) loads: block ids, then their W contributions and knot
-      // segments -- a predicated load would compile to branch + load + wait, one memory round trip per block
-      int v[8], si[8], sj[8];
+      // the landmark's rows are consecutive in Wc (k_vis_eval stored them in landmark order); 8 rows per pass, all
+      // loads unconditional on clamped rows -- a predicated load would cost a branch and a full wait each
+      int si[8], sj[8];
       T wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = d.lm_blk[min(bb + u, b1 - 1)];
-#pragma unroll
       for (int u = 0; u < 8; ++u) {
-        wv[u] = d.Wc[(size_t)52 * v[u] + lc];
-        si[u] = d.vs[v[u]];
-        sj[u] = d.vs[V + v[u]];
+        const T *rowp = d.Wc + (size_t)WC_STRIDE * min(bb + u, b1 - 1);
+        wv[u] = rowp[lc];
+        si[u] = (int)rowp[51];
+        sj[u] = (int)rowp[52];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (bb + u >= b1) continue;
-        if (lane < 49) atomicAdd(&row[vis_col(lane < 48 ? lane : 49, si[u], sj[u], P)], wv[u]);  // ends may share knots
+        if (lane < 49) atomicAdd(&row[vis_col(lane < 48 ? lane : 49, si[u], sj[u], P)], (double)wv[u]);  // ends may share knots
         else if (lane == 49) hll += (double)wv[u];
         else if (lane == 50) gl += (double)wv[u];
       }
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   if (valid) {
     T *Wr = d.W + W0 + (long long)l * ldw;
-    for (int i = lane; i < ldw; i += 64) Wr[i] = row[i];
+    for (int i = lane; i < ldw; i += 64) Wr[i] = (T)row[i];
     if (lane == 49) d.Hll[lm0 + l] = hll;
     if (lane == 50) d.g[u0 + P + l] = gl;
   }
