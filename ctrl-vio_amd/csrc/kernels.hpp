@@ -494,12 +494,13 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
 
 // ------------------------------------------------------------------------------------------------ visual
 template <class T> struct VisGlobalSink {
-  T *J;        // &Jv[v]
+  T *J;        // Jv (uniform): row r of the materialised Jacobian starts at J + r * stride
   size_t stride;
   T *wc;       // LDS row of this lane: J_rho^T J_c for the 49 pose columns (slot 48 = line delay), then Hll, g_rho
   T jr0, jr1;
+  unsigned v;  // this lane's block: uniform row base + one 32-bit lane offset (no 64-bit address per store)
   __device__ __forceinline__ void put(int col, T j0, T j1) {
-    J[(size_t)(2 * col) * stride] = j0; J[(size_t)(2 * col + 1) * stride] = j1;
+    (J + (size_t)(2 * col) * stride)[v] = j0; (J + (size_t)(2 * col + 1) * stride)[v] = j1;
     if (col == 48) { jr0 = j0; jr1 = j1; }                       // visual_eval emits the inverse-depth column first
     else wc[col < 48 ? col : 48] = jr0 * j0 + jr1 * j1;
   }
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisGlobalSink<T> sink{d.Jv + v, V, wcs + 55 * threadIdx.x, T(0), T(0)};
+        VisGlobalSink<T> sink{d.Jv, V, wcs + 55 * threadIdx.x, T(0), T(0), (unsigned)v};
         wcs_on[threadIdx.x] = d.v_slot[v];
         SegConst<T> sci, scj;
         seg_const_load(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci, true);
