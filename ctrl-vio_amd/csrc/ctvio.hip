@@ -188,7 +188,7 @@ template <class T> class SolverImpl : public SolverBase {
       m.knot0 = K0; m.bias0 = F0; m.lm0 = L0; m.imu0 = M0; m.vis0 = V0; m.bc0 = B0; m.u0 = U0; m.p0 = Pp0;
       m.ldw = (m.P + 1 + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
       m.pv0 = pv0; m.pblk0 = pb; m.fix_ld = w.fix_ld; m.lock_bg = w.lock_bg; m.lock_ba = w.lock_ba; m.fixed_upto = w.fixed_upto;
-      m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
+      m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.ldh = (m.P + 15) / 16 * 16; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
       for (int i = 0; i < 4; ++i) m.q_CI[i] = w.q_CI[i];
       for (int i = 0; i < 3; ++i) { m.p_CI[i] = w.p_CI[i]; m.gravity[i] = w.gravity[i]; }
       for (int i = 0; i < 6; ++i) m.imu_w[i] = w.imu_w[i];
@@ -335,7 +335,7 @@ template <class T> class SolverImpl : public SolverBase {
       active.insert(active.end(), act.begin(), act.end());
       // advance offsets
       K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += w.V; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += n; pb += w.pnb;
-      H0 += (int64_t)m.P * m.P; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)n * n;
+      H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)n * n;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, n);
       maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw);
     }
@@ -648,7 +648,8 @@ template <class T> class SolverImpl : public SolverBase {
     const WinMeta &m = meta_[id];
     const int P = m.P;
     if (Hpp) {
-      HIPCHK(hipMemcpyAsync(Hpp, d.Hpp + m.H0, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipMemcpy2DAsync(Hpp, sizeof(double) * (size_t)P, d.Hpp + m.H0, sizeof(double) * (size_t)m.ldh, sizeof(double) * (size_t)P, (size_t)P,
+                              hipMemcpyDeviceToHost, stream_));
     }
     std::vector<T> Wh;
     if (W && m.L) {
@@ -775,7 +776,12 @@ template <class T> class SolverImpl : public SolverBase {
 template <> void SolverImpl<float>::launch_schur() {
   const Dev<float> &d = dev_;
   const int nt = (d.maxP + 1 + 31) / 32;
-  if (opt_.use_mfma) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
+  if (opt_.use_mfma) {
+    const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32) * sizeof(float);
+    if (d.maxLdw <= 224 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<7>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    else if (d.maxLdw <= 448 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    else hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
+  }
   else hipLaunchKernelGGL((k_schur_generic<float>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
 }
 template <> void SolverImpl<float>::launch_assemble_vis_lds(int parts) {

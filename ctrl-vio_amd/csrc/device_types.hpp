@@ -20,7 +20,8 @@ struct WinMeta {
   int32_t ldw, Lpad;           // W is [Lpad][ldw] (landmark-major, zero padded; ldw % 32 == 0, Lpad % 2 == 0)
   int32_t pv0, pblk0;          // prior vectors (sum pn) / prior blocks
   int32_t fix_ld, lock_bg, lock_ba, fixed_upto;
-  int64_t H0;                  // offset of the P*P block in Hpp / S (doubles)
+  int64_t H0;                  // offset of the window's [P][ldh] block in Hpp / S (doubles)
+  int32_t ldh;                 // row stride of Hpp / S: P rounded up to 16 doubles, so every row starts on a 128-byte line
   int64_t W0;                  // offset of W (elements)
   int64_t pH0;                 // offset of the prior's J0^T J0 (pn*pn doubles)
   int64_t dt_ns;

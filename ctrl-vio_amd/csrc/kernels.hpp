@@ -149,11 +149,11 @@ template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part) {
   const int w = blockIdx.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
-  const long long nH = (long long)m.P * m.P;
+  const long long nH = (long long)m.P * m.ldh;
   const long long stride = (long long)gridDim.x * blockDim.x;
   // with a single k_assemble_vis part the LDS path overwrites the whole knot x knot block and the line-delay row
   // (plain stores, issued after this kernel), so only the bias rows and the line-delay row need zeroing
-  const long long first = (m.vis_lds && single_part) ? (long long)6 * m.K * m.P : 0;
+  const long long first = (m.vis_lds && single_part) ? (long long)6 * m.K * m.ldh : 0;
   for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) d.g[m.u0 + i] = 0.0;
   // W, Hll and g[P..N) are written (not accumulated) by k_build_W
@@ -414,7 +414,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
   const int w = grp.win;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
-  const int K = m.K, P = m.P, u0 = m.u0;
+  const int K = m.K, P = m.P, u0 = m.u0, ldh = m.ldh;
   const long long H0 = m.H0;
   const T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
   if (m.vis_lds) {
@@ -433,7 +433,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
     const int ga = imu_col(a, grp.s, K, grp.bias);
     if (b == 30) { atomicAdd(&d.g[u0 + ga], v); return; }
     const int gb = imu_col(b, grp.s, K, grp.bias);
-    atomicAdd(&d.Hpp[H0 + (long long)max(ga, gb) * P + min(ga, gb)], v);
+    atomicAdd(&d.Hpp[H0 + (long long)max(ga, gb) * ldh + min(ga, gb)], v);
     return;
   }
   for (int e = threadIdx.x; e < 31 * 30; e += blockDim.x) {
@@ -442,7 +442,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
     const int ga = imu_col(a, grp.s, K, grp.bias);
     if (b == 30) { atomicAdd(&d.g[u0 + ga], v); continue; }
     const int gb = imu_col(b, grp.s, K, grp.bias);
-    if (ga >= gb) atomicAdd(&d.Hpp[H0 + (long long)ga * P + gb], v);
+    if (ga >= gb) atomicAdd(&d.Hpp[H0 + (long long)ga * ldh + gb], v);
   }
 }
 
@@ -643,7 +643,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   const WinMeta &m = d.wins[w];
   // fields used after LDS/global atomics are copied to registers: the compiler must otherwise re-read them from
   // memory every time (a store could alias), one L2 round trip each
-  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0;
+  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0, ldh = m.ldh;
   if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
   if (m.V == 0 && !LDSH) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
@@ -754,7 +754,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
             if (gA == gB && !(a == b && ti == tj)) hv *= T(2);
             if (gA < gB) { const int t = gA; gA = gB; gB = t; }
             if (LDSH) atomicAdd(&Hs[(gA == P - 1) ? tri + (gB == P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], hv);
-            else atomicAdd(&Hg[(long long)gA * P + gB], (double)hv);
+            else atomicAdd(&Hg[(long long)gA * ldh + gB], (double)hv);
           }
         }
       start = end;
@@ -794,8 +794,8 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
         ga = P - 1;
         gb = (i - tri) < K6 ? (i - tri) : P - 1;
       }
-      if (nparts > 1) atomicAdd(&Hg[(long long)ga * P + gb], (double)hv);
-      else Hg[(long long)ga * P + gb] = (double)hv;  // first writer after k_zero_normal; later kernels add atomically
+      if (nparts > 1) atomicAdd(&Hg[(long long)ga * ldh + gb], (double)hv);
+      else Hg[(long long)ga * ldh + gb] = (double)hv;  // first writer after k_zero_normal; later kernels add atomically
     }
   }
   CTV_STAMP();
@@ -822,7 +822,7 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
-  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0;
+  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0, ldh = m.ldh;
   if (m.vis_lds == 0) return;   // those windows go through k_assemble_vis<float, CH, false>
   extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
   // fp64 accumulators: ds_add_f64 sustains ~8 cycles per wave instruction on gfx950, ds_add_f32 ~190 (measured,
@@ -1018,8 +1018,8 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
       ga = P - 1;
       gb = (i - tri) < K6 ? (i - tri) : P - 1;
     }
-    if (nparts > 1) atomicAdd(&Hg[(long long)ga * P + gb], hv);
-    else Hg[(long long)ga * P + gb] = hv;  // first writer after k_zero_normal; later kernels add atomically
+    if (nparts > 1) atomicAdd(&Hg[(long long)ga * ldh + gb], hv);
+    else Hg[(long long)ga * ldh + gb] = hv;  // first writer after k_zero_normal; later kernels add atomically
   }
   CTV_STAMP();
   for (int i = tid; i < K6 + 1; i += 512) {
@@ -1118,10 +1118,10 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
       const int ii = 6 * m.K + 6 * bi + k, jj = 6 * m.K + 6 * bj + k;
       atomicAdd(&d.g[m.u0 + ii], -wv * r);
       atomicAdd(&d.g[m.u0 + jj], wv * r);
-      atomicAdd(&d.Hpp[m.H0 + (long long)ii * m.P + ii], wv * wv);
-      atomicAdd(&d.Hpp[m.H0 + (long long)jj * m.P + jj], wv * wv);
+      atomicAdd(&d.Hpp[m.H0 + (long long)ii * m.ldh + ii], wv * wv);
+      atomicAdd(&d.Hpp[m.H0 + (long long)jj * m.ldh + jj], wv * wv);
       const int hi = max(ii, jj), lo = min(ii, jj);
-      atomicAdd(&d.Hpp[m.H0 + (long long)hi * m.P + lo], -wv * wv);
+      atomicAdd(&d.Hpp[m.H0 + (long long)hi * m.ldh + lo], -wv * wv);
     }
   }
   const int n = m.pn;
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
       for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e % n;
         const int ci = pcol[i], cj = pcol[j];
-        if (ci >= 0 && cj >= 0 && ci >= cj) atomicAdd(&d.Hpp[m.H0 + (long long)ci * m.P + cj], pH[e]);
+        if (ci >= 0 && cj >= 0 && ci >= cj) atomicAdd(&d.Hpp[m.H0 + (long long)ci * m.ldh + cj], pH[e]);
       }
     }
   }
@@ -1176,7 +1176,7 @@ template <class T> __global__ void k_post_linearize(Dev<T> d) {
   if (j >= m.N) return;
   const bool act = d.active[m.u0 + j] != 0;
   if (!lm.scaled) {
-    const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.P + j] : d.Hll[m.lm0 + j - m.P];
+    const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.ldh + j] : d.Hll[m.lm0 + j - m.P];
     d.cscale[m.u0 + j] = act ? 1.0 / (1.0 + sqrt(fmax(h, 0.0))) : 1.0;
   }
   if (!act) return;
@@ -1227,7 +1227,7 @@ template <class T> __global__ void k_damping(Dev<T> d) {
   if (j >= m.N) return;
   const bool act = d.active[m.u0 + j] != 0;
   const double c = d.cscale[m.u0 + j];
-  const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.P + j] : d.Hll[m.lm0 + j - m.P];
+  const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.ldh + j] : d.Hll[m.lm0 + j - m.P];
   double s = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
   const double dd = act ? s / (lm.mu * c * c) : 0.0;
   d.dd[m.u0 + j] = dd;
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) 
   int bi, bj;
   tile_decode(tile, bi, bj);
   const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
-  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, Lpad = m.Lpad;
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, Lpad = m.Lpad, ldh = m.ldh;
   const int i = 32 * bi + l31, j = 32 * bj + l31;        // < ldw by construction (ldw = 32 nt)
   // every load below is unconditional on a clamped address (a predicated load costs a branch and a full wait each)
   const float ai = (i < P && d.active[u0 + min(i, P - 1)]) ? 1.0f : 0.0f;
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) 
   for (int r = 0; r < 16; ++r) {
     const int ii = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, ic = min(ii, P - 1);
     act_i[r] = d.active[u0 + ic];
-    hv[r] = H[(long long)ic * P + min(jc, ic)];
+    hv[r] = H[(long long)ic * ldh + min(jc, ic)];
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1318,9 +1318,133 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) 
       double val;
       if (on) val = hv[r] - (double)acc[r] + (ii == jj ? dd_j : 0.0);
       else val = (ii == jj) ? 1.0 : 0.0;
-      S[(long long)ii * P + jj] = val;
+      S[(long long)ii * ldh + jj] = val;
     } else if (ii == P && jj < P) {
       rhs[jj] = act_j ? (double)acc[r] - g_j : 0.0;
+    }
+  }
+}
+
+// Schur complement, one workgroup (8 waves) per window: W is read from HBM exactly ONCE per window.  The landmark rows
+// are staged through LDS in chunks of 16 (double buffered; the next chunk's loads are in flight while the current one is
+// multiplied), masked by the active flags, with the rhs row g_rho appended as column P; every wave owns up to 4 of the
+// 32 x 32 output tiles of the lower triangle and keeps their accumulators in registers across the whole landmark loop.
+// (The per-tile kernel above re-reads the two 32-column panels of W for every tile: 1.2 MB per window instead of 0.18.)
+// NPRE = elements of a chunk per thread (16 ldw / 512), so ldw <= 32 NPRE.
+template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_schur_window(Dev<float> d) {
+  const int w = blockIdx.x;
+  if (d.lm[w].status) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int nt = ldw >> 5, ntile = nt * (nt + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float sms[];
+  float *Wb = sms;                       // [2][16][ldw]
+  float *acts = Wb + 2 * 16 * ldw;       // [ldw] 1 / 0 (0 beyond P)
+  float *dch = acts + ldw;               // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const float *Wp = d.W + m.W0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
+  for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0f : 0.0f;
+  int bi[4], bj[4];
+  bool run[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = wave + 8 * q;
+    tile_decode(min(t, ntile - 1), bi[q], bj[q]);
+    // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P): tiles over
+    // bias columns skip the products
+    const bool nz_i = (32 * bi[q] < K6) || (P >= 32 * bi[q] && P - 1 < 32 * bi[q] + 32);
+    const bool nz_j = (32 * bj[q] < K6) || (P - 1 >= 32 * bj[q] && P - 1 < 32 * bj[q] + 32);
+    run[q] = t < ntile && nz_i && nz_j;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+  const int nchunk = (L + 15) >> 4, nel = 16 * ldw;
+  float pre[NPRE];
+  float pre_d = 0.0f;
+  auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = min(tid + 512 * k, nel - 1), l = min(16 * ch + e / ldw, L - 1), c = e % ldw;
+      pre[k] = (c == P) ? (float)gl[l] : Wp[(long long)l * ldw + c];
+    }
+    if (tid < 16) pre_d = (float)dinv[min(16 * ch + tid, L - 1)];
+  };
+  auto stash = [&](int ch, int buf) {   // branch-free: a clamped element index re-writes the last element with its own value
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = min(tid + 512 * k, nel - 1);
+      const int lr = e / ldw, c = e % ldw;
+      const bool lv = 16 * ch + lr < L;
+      Wb[buf * nel + e] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0f;
+    }
+    if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0f;
+  };
+  __syncthreads();   // acts
+  if (nchunk > 0) { fetch(0); stash(0, 0); }
+  __syncthreads();
+#ifdef CTV_EXP_NOLOOP
+  for (int ch = 0; ch < 1; ++ch) {
+#else
+  for (int ch = 0; ch < nchunk; ++ch) {
+#endif
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) fetch(ch + 1);
+    const float *B = Wb + buf * nel;
+    float dl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) dl[s] = dch[16 * buf + 2 * s + half];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!run[q]) continue;   // wave-uniform, once per chunk and tile: the 16 operand reads, then the 8 products
+      float a[8], b[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int l = 2 * s + half;
+        a[s] = B[l * ldw + 32 * bi[q] + l31];
+        b[s] = B[l * ldw + 32 * bj[q] + l31];
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
+    }
+    if (ch + 1 < nchunk) stash(ch + 1, buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
+  const double *H = d.Hpp + m.H0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#ifdef CTV_EXP_NOEPI
+    if (acc[q][0] != 123.0f) continue;
+#endif
+    if (wave + 8 * q >= ntile) continue;
+    const int jj = 32 * bj[q] + l31, jc = min(jj, P - 1);
+    const bool act_j = d.active[u0 + jc] != 0;
+    const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
+    double hv[16];
+    unsigned char act_i[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ii = 32 * bi[q] + (r & 3) + 8 * (r >> 2) + 4 * half, ic = min(ii, P - 1);
+      act_i[r] = d.active[u0 + ic];
+      hv[r] = H[(long long)ic * ldh + min(jc, ic)];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ii = 32 * bi[q] + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (ii < P && jj <= ii) {
+        const bool on = act_i[r] && act_j;
+        double val;
+        if (on) val = hv[r] - (double)acc[q][r] + (ii == jj ? dd_j : 0.0);
+        else val = (ii == jj) ? 1.0 : 0.0;
+        S[(long long)ii * ldh + jj] = val;
+      } else if (ii == P && jj < P) {
+        rhs[jj] = act_j ? (double)acc[q][r] - g_j : 0.0;
+      }
     }
   }
 }
@@ -1339,11 +1463,11 @@ template <class T> __global__ void k_schur_generic(Dev<T> d) {
     const T *Wp = d.W + m.W0;
     double acc = 0.0;
     for (int l = 0; l < m.L; ++l) acc += (double)Wp[(long long)l * m.ldw + ii] * (double)Wp[(long long)l * m.ldw + jj] * d.dinv[m.lm0 + l];
-    val = d.Hpp[m.H0 + (long long)ii * m.P + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
+    val = d.Hpp[m.H0 + (long long)ii * m.ldh + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
   } else {
     val = (ii == jj) ? 1.0 : 0.0;
   }
-  d.S[m.H0 + (long long)ii * m.P + jj] = val;
+  d.S[m.H0 + (long long)ii * m.ldh + jj] = val;
 }
 
 // rhs_p = -g_p + W^T diag(dinv) g_l.  256 threads = 64 unknowns x 4 landmark slices (coalesced over the unknowns).
@@ -1426,7 +1550,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
   Lm &lm = d.lm[w];
   if (lm.status) return;
   const WinMeta &m = d.wins[w];
-  const int P = m.P, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) double smc[];
   double *Lb = smc;                 // [32][34] L11 row-major
   double *LiT = Lb + 32 * 34;       // [32][34] L11^-1 transposed: LiT[k][j] = Linv[j][k]
@@ -1453,7 +1577,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
       {
         const int rr = min(jb + lane, P - 1);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) a[c] = S[(long long)rr * P + min(jb + c, P - 1)];   // unconditional, masked below
+        for (int c = 0; c < 32; ++c) a[c] = S[(long long)rr * ldh + min(jb + c, P - 1)];   // unconditional, masked below
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
           const bool in = lane < nb && c < nb && c <= lane;
@@ -1471,7 +1595,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
       if (lane < nb) {
 #pragma unroll
         for (int c = 0; c < 32; ++c)
-          if (c <= lane && c < nb) S[(long long)(jb + lane) * P + jb + c] = a[c];
+          if (c <= lane && c < nb) S[(long long)(jb + lane) * ldh + jb + c] = a[c];
       }
       if (lane < 32) {
         double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;   // kept for the back-substitution
@@ -1485,7 +1609,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     } else {
       // ---- waves 1-3: panel rows (and the rhs row) into the LDS panel, LpT[k][r]
       for (int r = tid - 64; r < RS; r += 192) {
-        const double *src = (r < nt) ? S + (long long)(r0 + r) * P + jb : y + jb;
+        const double *src = (r < nt) ? S + (long long)(r0 + r) * ldh + jb : y + jb;
         double tmp[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) tmp[k] = src[min(k, nb - 1)];   // unconditional: 32 loads in flight
@@ -1513,7 +1637,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
         LpT[l15 * RS + row] = c0[r];
         LpT[(16 + l15) * RS + row] = c1[r];
         if (row < ntr) {
-          double *dst = (row < nt) ? S + (long long)(r0 + row) * P + jb : y + jb;
+          double *dst = (row < nt) ? S + (long long)(r0 + row) * ldh + jb : y + jb;
           if (l15 < nb) dst[l15] = c0[r];
           if (16 + l15 < nb) dst[16 + l15] = c1[r];
         }
@@ -1534,7 +1658,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ti4[u] + q4 + 4 * r;
-          const double *src = (row < nt) ? S + (long long)(r0 + row) * P + r0 : y + r0;
+          const double *src = (row < nt) ? S + (long long)(r0 + row) * ldh + r0 : y + r0;
           sv[u][r] = src[min(col, nt - 1)];
         }
       }
@@ -1552,7 +1676,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ti4[u] + q4 + 4 * r;
           if (tb + 4 * u < ntt && col < nt && ((row < nt && col <= row) || row == nt)) {
-            double *dst = (row < nt) ? S + (long long)(r0 + row) * P + r0 : y + r0;
+            double *dst = (row < nt) ? S + (long long)(r0 + row) * ldh + r0 : y + r0;
             dst[col] = sv[u][r] - c[r];
           }
         }
@@ -1575,7 +1699,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     {
       const int j = min(tid, max(jb - 1, 0));
 #pragma unroll
-      for (int ii = 0; ii < 32; ++ii) lv[ii] = S[(long long)(jb + min(ii, nb - 1)) * P + j];
+      for (int ii = 0; ii < 32; ++ii) lv[ii] = S[(long long)(jb + min(ii, nb - 1)) * ldh + j];
     }
     if (wave == 0) {
       const double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + b) * 1024;
@@ -1598,7 +1722,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     }
     for (int j = tid + 256; j < jb; j += 256) {   // P > 256 + 32: remaining rows
       double sacc = 0.0;
-      for (int ii = 0; ii < nb; ++ii) sacc += S[(long long)(jb + ii) * P + j] * yb[ii];
+      for (int ii = 0; ii < nb; ++ii) sacc += S[(long long)(jb + ii) * ldh + j] * yb[ii];
       xs[j] -= sacc;
     }
     __syncthreads();
