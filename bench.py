@@ -27,6 +27,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# phase of the solver's event profile -> kernel name in the rocprofv3 tables (profiles/)
+KERNEL_OF_PHASE = {"k_imu_linearize": "k_imu_linearize", "k_vis_eval": "k_vis_eval<float, true, double>",
+                   "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve"}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
 
@@ -61,6 +64,7 @@ def main():
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inclusive", action="store_true", help="also time pack + H2D + solve + D2H of one batch (DESIGN.md section 6; never the headline value)")
     ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams) per GPU; the windows are split evenly among them")
     args = ap.parse_args()
 
@@ -159,12 +163,12 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                key = names[dom] if names[dom] != "k_vis_eval" else "k_vis_eval<float, true, double>"
+                key = KERNEL_OF_PHASE.get(names[dom], names[dom])
                 traffic = json.load(open(tfile)).get(key, {}).get(str(per[0]), {}).get("traffic_bytes")
             except Exception:
                 traffic = None
         ach = nbytes / avg_s / 1e9
-        out["roofline"] = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"kernel": KERNEL_OF_PHASE.get(names[dom], names[dom]).split("<")[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "avg_launch_us": 1e6 * avg_s, "launches": int(n[dom]), "windows_per_launch": per[0],
                            "algorithmic_bytes_per_launch": nbytes,
@@ -172,10 +176,23 @@ def main():
         P, L = w_ref.P, w_ref.L
         fl = P * (P + 1) * L * per[0]                        # SYRK count
         avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
-        out["roofline_mfma"] = {"kernel": "k_schur_mfma", "bound": "mfma", "achieved": fl / avg_schur / 1e12,
+        out["roofline_mfma"] = {"kernel": "k_schur_window", "bound": "mfma", "achieved": fl / avg_schur / 1e12,
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                 "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
         out["phase_ms_profiled_solve"] = shares               # stream 0 only
+        if args.host_inclusive:
+            # the C ABI takes host buffers: pack (host, 1 thread) + H2D + solve + D2H of the states, one solver, one batch
+            wl = [uniq[i % len(uniq)].copy() for i in range(args.windows)]
+            with cv.Solver(device=local, precision=args.precision) as hs:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                hs.set_windows(wl)                          # ctvio_add_window x N + ctvio_upload
+                t1 = time.perf_counter()
+                hs.solve(args.iters, writeback=True)        # ctvio_solve + ctvio_get_state x N
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            out["host_inclusive"] = {"windows": args.windows, "pack_upload_s": t1 - t0, "solve_readback_s": t2 - t1,
+                                     "solves_per_s": args.windows / (t2 - t0)}
         # ---- CPU baseline: the oracle (a port, not the reference binary: Ceres/Eigen are not installable here)
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline:

@@ -1386,11 +1386,7 @@ template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_wave
   __syncthreads();   // acts
   if (nchunk > 0) { fetch(0); stash(0, 0); }
   __syncthreads();
-#ifdef CTV_EXP_NOLOOP
-  for (int ch = 0; ch < 1; ++ch) {
-#else
   for (int ch = 0; ch < nchunk; ++ch) {
-#endif
     const int buf = ch & 1;
     if (ch + 1 < nchunk) fetch(ch + 1);
     const float *B = Wb + buf * nel;
@@ -1418,9 +1414,6 @@ template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_wave
   const double *H = d.Hpp + m.H0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-#ifdef CTV_EXP_NOEPI
-    if (acc[q][0] != 123.0f) continue;
-#endif
     if (wave + 8 * q >= ntile) continue;
     const int jj = 32 * bj[q] + l31, jc = min(jj, P - 1);
     const bool act_j = d.active[u0 + jc] != 0;

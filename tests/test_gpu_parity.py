@@ -172,6 +172,33 @@ def test_spline_eval(cv, oracle, win_cfg1):
             s.spline_eval(0, np.array([w.max_time_ns()], np.int64))
 
 
+def test_config3_rolling_shutter_stress(cv, oracle):
+    """BASELINE configs[3]: 300 landmarks, 640-row images, 30 us line delay (every block's two ends evaluate at their own
+    per-row times).  fp32 product path against the oracle at Ceres settings, the estimated line delay included; then the
+    spline evaluated at every row time of every frame (11 x 640 = 7040 timestamps) against the oracle's evaluator."""
+    w0 = cv.synth.make_window("config3", seed=1003)
+    wo = w0.copy()
+    sm_o = oracle.OracleWindow(wo).solve(15)
+    with cv.Solver(precision="fp32") as s:
+        wg = w0.copy()
+        s.set_windows([wg])
+        sm = s.solve(15)[0]
+        assert abs(sm["iterations"] - sm_o.iterations) <= 1
+        assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-7)
+        err = cv.rel_state_error(wg, wo)
+        assert err["state"] < 2e-4, err
+        assert abs(wg.ld - wo.ld) < 2e-4 * max(abs(wo.ld), 1e-6) + 1e-9
+        frames = np.unique(np.concatenate([wg.v_ti, wg.v_tj]))
+        ld_ns = int(wg.ld * 1e9)
+        t = (frames[:, None] + np.arange(640, dtype=np.int64)[None, :] * ld_ns).reshape(-1)
+        t = t[(t >= wg.t0_ns) & (t < wg.max_time_ns())]
+        assert t.size >= 6000
+        got = s.spline_eval(0, t)
+        ref = oracle.OracleWindow(wg.copy()).spline_eval(t)
+        for a, b in zip(got, ref):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-10)
+
+
 def test_ragged_batch_equals_single(cv):
     """Windows of different sizes in one batch; each must match its own single-window solve."""
     ws = [cv.synth.make_window("config1", seed=1000 + i) for i in range(3)] + [cv.synth.make_window("tiny", seed=5),
