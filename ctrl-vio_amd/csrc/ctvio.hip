@@ -365,6 +365,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_v_win_.upload(v_win, stream_)); HIPCHK(b_v_lm_.upload(v_lm, stream_)); HIPCHK(b_v_ti_.upload(v_ti, stream_));
     HIPCHK(b_v_tj_.upload(v_tj, stream_)); HIPCHK(b_v_rowi_.upload(v_rowi, stream_)); HIPCHK(b_v_rowj_.upload(v_rowj, stream_));
     HIPCHK(b_v_obs_.upload(v_obs, stream_));
+    if (mixed_) { HIPCHK(b_imu_rc_.alloc((size_t)6 * std::max(Mtot_, 1))); HIPCHK(b_vis_rc_.alloc((size_t)2 * std::max(Vtot_, 1))); d.imu_rc = b_imu_rc_.p; d.vis_rc = b_vis_rc_.p; }
     HIPCHK(b_Jv_.alloc((size_t)100 * std::max(Vtot_, 1))); HIPCHK(b_rv_.alloc((size_t)2 * std::max(Vtot_, 1))); HIPCHK(b_vs_.alloc((size_t)2 * std::max(Vtot_, 1)));
     d.v_win = b_v_win_.p; d.v_lm = b_v_lm_.p; d.v_ti = b_v_ti_.p; d.v_tj = b_v_tj_.p; d.v_rowi = b_v_rowi_.p; d.v_rowj = b_v_rowj_.p;
     d.v_obs = b_v_obs_.p; d.Jv = b_Jv_.p; d.rv = b_rv_.p; d.vs = b_vs_.p;
@@ -452,7 +453,7 @@ template <class T> class SolverImpl : public SolverBase {
     ph_end();
     hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, d.quat, d.kd, d.kjri);
     ph_begin(PH_IMU_LIN);
-    const size_t imu_lds = (sizeof(T) == 4 ? (size_t)3 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 40 * sizeof(double);
+    const size_t imu_lds = (sizeof(T) == 4 ? (size_t)3 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 0;
     if (d.Gtot) {
       if (mixed_) hipLaunchKernelGGL((k_imu_linearize<T, CH, double>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
       else hipLaunchKernelGGL((k_imu_linearize<T, CH, T>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
@@ -693,6 +694,7 @@ template <class T> class SolverImpl : public SolverBase {
     const int wb = nblk(d.nwin, 64);
     set_params(1);
     hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, mu, 0);
+    launch_cost(false, 1);   // mixed mode: the linearisation reuses the residuals of a cost pass at the same state
     launch_linearize();
     launch_assemble();
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
@@ -765,7 +767,7 @@ template <class T> class SolverImpl : public SolverBase {
       b_p_kind_, b_p_index_, b_p_off_, b_vs_, b_nact_;
   DBuf<int64_t> b_v_ti_, b_v_tj_;
   DBuf<ImuGroup> b_groups_;
-  DBuf<T> b_kjri_, b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_, b_Wc_;
+  DBuf<T> b_imu_rc_, b_vis_rc_, b_kjri_, b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_, b_Wc_;
   DBuf<uint8_t> b_active_;
   DBuf<Lm> b_lm_;
   DBuf<long long> b_dbg_;

@@ -70,6 +70,8 @@ template <class T> struct Dev {
   const T *imu_u;        // [Mtot] normalised time in the segment
   const T *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
   const double *imu_ud, *imu_meas_d;   // the same in fp64, read by the residual path of the mixed mode
+  T *imu_rc;             // [6][Mtot] mixed mode: whitened residuals of the last cost pass (fp64 evaluation, rounded once);
+                         // the linearisation always follows a cost pass at the same state and reuses them
   T *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
   // visual factors
   const int32_t *v_win, *v_lm;
@@ -79,6 +81,7 @@ template <class T> struct Dev {
   const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
   T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
   T *rv;                 // [2][Vtot]
+  T *vis_rc;             // [2][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc)
   T *Wc;                 // [Vtot][WC_STRIDE] per block, rows in LANDMARK order (row v_slot[v]): J~_rho^T J~_c (49 pose columns),
                          // J~_rho^T J~_rho, J~_rho^T r~, then the block's knot segments si, sj
   const int32_t *v_slot; // [Vtot] row of block v in Wc

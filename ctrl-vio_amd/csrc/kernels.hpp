@@ -227,7 +227,6 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
   constexpr size_t ABYTES = MFMA ? (size_t)3 * CHUNK * 33 * sizeof(T) : (size_t)32 * KS * sizeof(T);
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   T *A = reinterpret_cast<T *>(smraw);
-  RT *gsh = reinterpret_cast<RT *>(smraw + ABYTES);  // [40] group constants (MIXED)
   const ImuGroup grp = d.groups[blockIdx.x];
   const int w = grp.win;
   if (!lin_needed(d.lm[w])) return;
@@ -246,24 +245,6 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
   for (int i = 0; i < 6; ++i) { bias[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
   const V3<T> grav = lf.rotate(m.gravity);
   const T idt = (T)m.inv_dt;
-  if (MIXED) {  // the group's knots, d_i = log(R_i^-1 R_{i+1}) and gravity in RT, computed once and parked in LDS
-    Knots4<RT> kd;
-    LocalFrame<RT> lfd;
-    lfd.init(d.quat, d.pos, m.knot0 + grp.s);
-    lfd.load(d.quat, d.pos, m.knot0 + grp.s, kd);
-    SegConst<RT> scd;
-    seg_const_load(d.kd + 3 * (m.knot0 + grp.s), (const T *)nullptr, scd, false);
-    const V3<RT> gd = lfd.rotate(m.gravity);
-    if (lane == 0) {
-      for (int i = 0; i < 4; ++i) {
-        gsh[4 * i] = kd.q[i].x; gsh[4 * i + 1] = kd.q[i].y; gsh[4 * i + 2] = kd.q[i].z; gsh[4 * i + 3] = kd.q[i].w;
-        gsh[16 + 3 * i] = kd.p[i].x; gsh[16 + 3 * i + 1] = kd.p[i].y; gsh[16 + 3 * i + 2] = kd.p[i].z;
-      }
-      for (int i = 0; i < 3; ++i) { gsh[28 + 3 * i] = scd.d[i].x; gsh[28 + 3 * i + 1] = scd.d[i].y; gsh[28 + 3 * i + 2] = scd.d[i].z; }
-      gsh[37] = gd.x; gsh[38] = gd.y; gsh[39] = gd.z;
-    }
-    __syncthreads();
-  }
   const int ti = lane >> 3, tj = lane & 7, half = lane >> 5, l31 = lane & 31;
   T acc[4][4];
   f32x16 macc;
@@ -278,27 +259,11 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
   int dbi = 0;
 #define CTV_STAMP() do { if (dbg && lane == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
   CTV_STAMP();
-  // the residual of this lane's sample again in RT from RT inputs (mixed mode; no Jacobian)
+  // mixed mode: the whitened residual of this sample was evaluated in fp64 by the cost pass at this very state
+  // (k_imu_cost) and rounded once; the fp32 evaluation below only supplies the Jacobian
   auto residual_rt = [&](int idx, T r[6]) {
-    Knots4<RT> kd;
-    SegConst<RT> scd;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      kd.q[i] = qmk<RT>(gsh[4 * i], gsh[4 * i + 1], gsh[4 * i + 2], gsh[4 * i + 3]);
-      kd.p[i] = mk<RT>(gsh[16 + 3 * i], gsh[16 + 3 * i + 1], gsh[16 + 3 * i + 2]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) scd.d[i] = mk<RT>(gsh[28 + 3 * i], gsh[28 + 3 * i + 1], gsh[28 + 3 * i + 2]);
-    RT bd[6], wd[6], gyd[3], acd[3], rd[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { bd[i] = (RT)bp[i]; wd[i] = (RT)m.imu_w[i]; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { gyd[i] = d.imu_meas_d[(size_t)i * d.Mtot + idx]; acd[i] = d.imu_meas_d[(size_t)(3 + i) * d.Mtot + idx]; }
-    NullSink<RT> ns;
-    M3<RT> unused = m3_id<RT>();
-    imu_eval<RT>(kd, scd, (RT)d.imu_ud[idx], (RT)m.inv_dt, mk<RT>(gsh[37], gsh[38], gsh[39]), bd, gyd, acd, wd, unused, rd, false, ns);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r[i] = (T)rd[i];
+    for (int i = 0; i < 6; ++i) r[i] = d.imu_rc[(size_t)i * d.Mtot + idx];
   };
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   for (int c0 = 0; c0 < grp.count; c0 += CHUNK) {
@@ -478,6 +443,10 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
 #pragma unroll
       for (int i = 0; i < 6; ++i) s += r[i] * r[i];
       c = 0.5 * (double)s;
+      if (sizeof(RT) != sizeof(T)) {   // mixed mode: the next linearisation (same state, if this step is accepted) reuses them
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d.imu_rc[(size_t)i * d.Mtot + idx] = (T)r[i];
+      }
     } else {
       w = -1;
     }
@@ -590,10 +559,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
         seg_const_load(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj, true);
         c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
-        if (sizeof(RT) != sizeof(T)) {  // mixed mode: residual (and its cost) again in RT; J~ keeps the fp32 corrector scale
-          RT rd[2];
-          c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
-          r[0] = (T)rd[0]; r[1] = (T)rd[1];
+        if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state; J~ keeps the fp32 corrector scale
+          r[0] = d.vis_rc[v]; r[1] = d.vis_rc[V + v];
         }
         sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
         sink.wc[50] = sink.jr0 * r[0] + sink.jr1 * r[1];
@@ -603,6 +570,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
       } else {
         RT rd[2];
         c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
+        if (sizeof(RT) != sizeof(T)) {   // mixed mode: reused by the next linearisation (same state, if the step is accepted)
+          d.vis_rc[v] = (T)rd[0]; d.vis_rc[(size_t)d.Vtot + v] = (T)rd[1];
+        }
       }
     } else {
       w = -1;
