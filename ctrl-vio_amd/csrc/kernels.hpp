@@ -1515,7 +1515,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
   const WinMeta &m = d.wins[w];
   const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) double smc[];
-  double *Lb = smc;                 // [32][34] L11 row-major
+  double *Lb = smc;                 // [32][34] NEXT diagonal block (row-major), deposited by the trailing update of the current panel
   double *LiT = Lb + 32 * 34;       // [32][34] L11^-1 transposed: LiT[k][j] = Linv[j][k]
   double *dinvs = LiT + 32 * 34;    // [32] 1 / L_jj
   double *yb = dinvs + 32;          // [32]
@@ -1525,6 +1525,10 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
   double *y = d.rhs + m.p0;         // augmented row; becomes L^-1 rhs
   double *x = d.delta + m.u0;
   if (tid == 0) s_fail = 0;
+  for (int e = tid; e < 32 * 32; e += 256) {   // first diagonal block -> LDS (rows / columns clamped; masked when read)
+    const int r = e >> 5, c = e & 31;
+    Lb[r * 34 + c] = S[(long long)min(r, P - 1) * ldh + min(c, P - 1)];
+  }
   __syncthreads();
   long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;
   int dbi = 0;
@@ -1538,9 +1542,12 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
       // ---- diagonal block: lanes >= nb (last, partial block) carry identity rows
       double a[32];
       {
-        const int rr = min(jb + lane, P - 1);
+        // the block is in LDS: the first one staged below, the later ones left there by the previous trailing update
 #pragma unroll
-        for (int c = 0; c < 32; ++c) a[c] = S[(long long)rr * ldh + min(jb + c, P - 1)];   // unconditional, masked below
+        for (int c = 0; c < 32; c += 2) {
+          const VecN<double, 2> v2 = *reinterpret_cast<const VecN<double, 2> *>(Lb + (lane & 31) * 34 + c);
+          a[c] = v2.v[0]; a[c + 1] = v2.v[1];
+        }
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
           const bool in = lane < nb && c < nb && c <= lane;
@@ -1555,11 +1562,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
 #pragma unroll
       for (int i = 0; i < 32; ++i) xa[i] = (i == lane) ? 1.0 : 0.0;
       chol_diag_all(a, xa, bad, std::make_integer_sequence<int, 32>{});
-      if (lane < nb) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c)
-          if (c <= lane && c < nb) S[(long long)(jb + lane) * ldh + jb + c] = a[c];
-      }
+      // (L11 itself is not written back: the back-substitution uses the stored inverse, nothing else reads it)
       if (lane < 32) {
         double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;   // kept for the back-substitution
 #pragma unroll
@@ -1581,7 +1584,10 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
         for (int k = 0; k < 32; ++k) LpT[k * RS + r] = (live && k < nb) ? tmp[k] : 0.0;
       }
     }
-    __syncthreads();
+    // LDS-only barrier: what the next phase reads (LiT, LpT) is in LDS; wave 0's global stores of the block inverse may
+    // stay in flight (a full __syncthreads would wait for them; they are read after later full barriers only)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     CTV_STAMP();
     // ---- L21 = A21 L11^-T, in place: Linv is lower triangular, so output columns 0..15 need k < 16 only
     for (int tr = wave; tr < ntile; tr += 4) {
@@ -1640,7 +1646,9 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
           const int row = 16 * ti4[u] + q4 + 4 * r;
           if (tb + 4 * u < ntt && col < nt && ((row < nt && col <= row) || row == nt)) {
             double *dst = (row < nt) ? S + (long long)(r0 + row) * ldh + r0 : y + r0;
-            dst[col] = sv[u][r] - c[r];
+            const double nv = sv[u][r] - c[r];
+            dst[col] = nv;
+            if (row < 32 && row < nt) Lb[row * 34 + col] = nv;   // tiles (0,0), (1,0), (1,1): the next diagonal block
           }
         }
       }
