@@ -924,9 +924,18 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
       prl += __shfl_xor(prl, 16); prl += __shfl_xor(prl, 32);
       // ---- scatter: local column -> unknown, each unordered local pair once; pairs of different local columns that map
       //      to the same unknown (ends sharing a knot) count twice on the diagonal
-      int gcol[3];
+      // unknown index and triangular row offset g (g + 1) / 2 of this lane's 3 tile columns and 12 tile rows, once per run
+      int gcol[3], tcol[3], grow[3][4], trow[3][4];
 #pragma unroll
-      for (int J = 0; J < 3; ++J) gcol[J] = vis_col(16 * J + l15, si, sj, P);
+      for (int J = 0; J < 3; ++J) {
+        gcol[J] = vis_col(16 * J + l15, si, sj, P);
+        tcol[J] = gcol[J] * (gcol[J] + 1) / 2;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          grow[J][rg] = vis_col(16 * J + 4 * q4 + rg, si, sj, P);
+          trow[J][rg] = grow[J][rg] * (grow[J][rg] + 1) / 2;
+        }
+      }
       {
         int q = 0;
 #pragma unroll
@@ -937,11 +946,11 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
             for (int rg = 0; rg < 4; ++rg) {
               const int ca = 16 * I + 4 * q4 + rg, cb = 16 * J + l15;
               if (I == J && ca < cb) continue;
-              int gA = vis_col(ca, si, sj, P), gB = gcol[J];
+              const int gA = grow[I][rg], gB = gcol[J];
               float hv = acc[q][rg];
               if (gA == gB && ca != cb) hv *= 2.0f;
-              if (gA < gB) { const int t = gA; gA = gB; gB = t; }
-              atomicAdd(&Hs[gA * (gA + 1) / 2 + gB], (double)hv);
+              const bool ge = gA >= gB;
+              atomicAdd(&Hs[(ge ? trow[I][rg] : tcol[J]) + (ge ? gB : gA)], (double)hv);
             }
           }
         // line-delay row of the Hessian and the pose gradient (every k group holds the totals; group q4 = 0 adds them)
@@ -1806,7 +1815,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
       }
       return;
     }
-    if (lm.status || !lm.step_valid) return;
+    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
     const WinMeta &m = d.wins[w];
     const int k = t - m.knot0;
     const double *dl = d.delta + m.u0 + 6 * k;
@@ -1832,7 +1841,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
       if (lm.accept) for (int c = 0; c < 6; ++c) d.bias[6 * f + c] = d.cbias[6 * f + c];
       return;
     }
-    if (lm.status || !lm.step_valid) return;
+    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
     const WinMeta &m = d.wins[w];
     const int u = 6 * m.K + 6 * (f - m.bias0);
     for (int c = 0; c < 6; ++c) {
@@ -1849,7 +1858,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
       if (lm.accept) d.rho[l] = d.crho[l];
       return;
     }
-    if (lm.status || !lm.step_valid) return;
+    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
     const WinMeta &m = d.wins[w];
     const int u = m.P + (l - m.lm0);
     const bool a = d.active[m.u0 + u] != 0;
@@ -1863,7 +1872,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
       if (lm.accept) d.ld[w] = d.cld[w];
       return;
     }
-    if (lm.status || !lm.step_valid) return;
+    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
     const WinMeta &m = d.wins[w];
     const bool a = d.active[m.u0 + m.P - 1] != 0;
     const double l0 = d.ld[w];
@@ -1871,12 +1880,19 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
     if (a && !m.fix_ld) l1 = fmin(fmax(l1, m.ld_lo), m.ld_hi);
     d.cld[w] = l1;
     if (a) { step2 += (l1 - l0) * (l1 - l0); x2 += l1 * l1; }
-  } else {
-    return;
   }
-  if (!ACCEPT && w >= 0) {
-    atomicAdd(&d.lm[w].step2, step2);
-    atomicAdd(&d.lm[w].cand_xnorm2, x2);
+reduce:
+  if (!ACCEPT) {
+    // |step|^2 and |x|^2 per window: one atomic pair per wave when the wave lies inside one window (same-address atomics
+    // from every thread serialise in L2)
+    const int w0 = __shfl(w, 0);
+    if (__all(w == w0)) {
+      for (int off = 32; off > 0; off >>= 1) { step2 += __shfl_down(step2, off); x2 += __shfl_down(x2, off); }
+      if ((threadIdx.x & 63) == 0 && w0 >= 0) { atomicAdd(&d.lm[w0].step2, step2); atomicAdd(&d.lm[w0].cand_xnorm2, x2); }
+    } else if (w >= 0) {
+      atomicAdd(&d.lm[w].step2, step2);
+      atomicAdd(&d.lm[w].cand_xnorm2, x2);
+    }
   }
 }
 
