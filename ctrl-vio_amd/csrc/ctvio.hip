@@ -262,8 +262,8 @@ template <class T> class SolverImpl : public SolverBase {
       }
       {
         const size_t K6 = 6 * (size_t)w.K, nG = K6 + 1, nH = K6 * (K6 + 1) / 2 + K6 + 1 + nG;
-        const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(double) + vis_stage_bytes();   // fp64 accumulators in LDS
-        const size_t need_glb = ((nG + 3) & ~(size_t)3) * sizeof(T) + vis_stage_bytes();
+        const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(double) + 32 + vis_stage_bytes();   // fp64 accumulators in LDS
+        const size_t need_glb = ((nG + 3) & ~(size_t)3) * sizeof(double) + 16 + vis_stage_bytes();
         m.vis_lds = need <= 160 * 1024 ? 1 : 0;
         vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : need_glb);
         vis_glb_bytes = std::max(vis_glb_bytes, need_glb);
@@ -780,7 +780,11 @@ template <> void SolverImpl<float>::launch_schur() {
   const int nt = (d.maxP + 1 + 31) / 32;
   if (opt_.use_mfma) {
     const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32) * sizeof(float);
-    if (d.maxLdw <= 224 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<7>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    // few windows: one workgroup per window leaves the chip idle and serialises 13 chunk round trips -- the per-tile
+    // kernel (28 independent waves per window, W re-read per tile) has the shorter latency there
+    const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");   // measured crossover ~256 windows per launch
+    if (small) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
+    else if (d.maxLdw <= 224 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<7>), dim3(d.nwin), dim3(512), lds, stream_, d);
     else if (d.maxLdw <= 448 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<14>), dim3(d.nwin), dim3(512), lds, stream_, d);
     else hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
   }

@@ -617,15 +617,15 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
   if (m.V == 0 && !LDSH) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
-  T *Hs = reinterpret_cast<T *>(smv);
   const int K6 = 6 * K, tri = K6 * (K6 + 1) / 2;
   const int nHh = LDSH ? tri + K6 + 1 : 0;     // packed Hessian entries
-  const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay), always in LDS
-  T *gs = Hs + nHh;
-  T *stage = Hs + ((nH + 3) & ~3);                                    // [NW][102][CHP]
+  double *gs = reinterpret_cast<double *>(smv);                       // [K6 + 1] pose gradient, fp64 (ds_add_f32 is ~20x slower)
+  T *Hs = reinterpret_cast<T *>(gs + ((K6 + 2) & ~1));                // [nHh]
+  T *stage = Hs + ((nHh + 3) & ~3);                                   // [NW][102][CHP]
   int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < nH; i += 512) Hs[i] = T(0);
+  for (int i = tid; i < nHh; i += 512) Hs[i] = T(0);
+  for (int i = tid; i < K6 + 1; i += 512) gs[i] = 0.0;
   __syncthreads();
   T *Js = stage + wave * 102 * CHP;
   int *ks = keys + wave * 2 * CH;
@@ -719,7 +719,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
           T hv = acc[a][b];
           if (gA == -2 || gB == -2) {         // column 49 = residual: J~^T r~ (r~^T r~ itself is not needed)
             const int gX = gA == -2 ? gB : gA;
-            if (gX >= 0) atomicAdd(&gs[gX == P - 1 ? K6 : gX], hv);
+            if (gX >= 0) atomicAdd(&gs[gX == P - 1 ? K6 : gX], (double)hv);
           } else if (gA >= 0 && gB >= 0) {
             if (gA == gB && !(a == b && ti == tj)) hv *= T(2);
             if (gA < gB) { const int t = gA; gA = gB; gB = t; }
@@ -771,8 +771,8 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   CTV_STAMP();
   if (!LDSH) __syncthreads();
   for (int i = tid; i < K6 + 1; i += 512) {
-    const T gv = gs[i];
-    if (gv != T(0)) atomicAdd(&d.g[u0 + (i < K6 ? i : P - 1)], (double)gv);
+    const double gv = gs[i];
+    if (gv != 0.0) atomicAdd(&d.g[u0 + (i < K6 ? i : P - 1)], gv);
   }
   CTV_STAMP();
 #undef CTV_STAMP
