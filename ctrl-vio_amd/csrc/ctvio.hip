@@ -426,13 +426,13 @@ template <class T> class SolverImpl : public SolverBase {
     if (pev_used_ + 2 > pev_.size()) {
       for (int i = 0; i < 64; ++i) { hipEvent_t e; (void)hipEventCreate(&e); pev_.push_back(e); }
     }
-    hipEventRecord(pev_[pev_used_], stream_);
+    (void)hipEventRecord(pev_[pev_used_], stream_);
     pev_phase_.push_back(ph);
     pev_used_ += 2;
   }
   void ph_end() {
     if (!profiling_) return;
-    hipEventRecord(pev_[pev_used_ - 1], stream_);
+    (void)hipEventRecord(pev_[pev_used_ - 1], stream_);
   }
   void ph_collect() {
     std::fill(ph_ms_, ph_ms_ + 8, 0.0);
