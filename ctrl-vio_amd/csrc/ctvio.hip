@@ -76,6 +76,7 @@ struct SolverBase {
   virtual int cost(int id, double *cost) = 0;
   virtual int lm_step(int id, double mu, double *delta, double *mc) = 0;
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
+  virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
   virtual int snapshot(int restore) = 0;
   virtual int last_timing(double *ms8, int32_t *n8) = 0;
   virtual int set_profiling(int on) = 0;
@@ -709,6 +710,23 @@ template <class T> class SolverImpl : public SolverBase {
     if (mc) *mc = lm.step_valid ? lm.model_change : -1.0;
     return CTVIO_OK;
   }
+  int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    if (n < 0 || (n && (!ids || !knot || !q0 || !t0))) return fail(CTVIO_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < n; ++i) {
+      if (ids[i] < 0 || ids[i] >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
+      if (knot[i] < 0 || knot[i] >= meta_[ids[i]].K) return fail(CTVIO_ERR_INVALID, "knot index out of range");
+      for (int j = 0; j < i; ++j) if (ids[j] == ids[i]) return fail(CTVIO_ERR_INVALID, "window listed twice");
+    }
+    if (n == 0) return CTVIO_OK;
+    DBuf<int32_t> di, dk; DBuf<double> dq, dt;
+    HIPCHK(di.upload(std::vector<int32_t>(ids, ids + n), stream_)); HIPCHK(dk.upload(std::vector<int32_t>(knot, knot + n), stream_));
+    HIPCHK(dq.upload(std::vector<double>(q0, q0 + 4 * (size_t)n), stream_)); HIPCHK(dt.upload(std::vector<double>(t0, t0 + 3 * (size_t)n), stream_));
+    hipLaunchKernelGGL((k_gauge_restore<T>), dim3(n), dim3(64), 0, stream_, dev_, n, di.p, dk.p, dq.p, dt.p);
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    return CTVIO_OK;
+  }
   int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin || n < 0 || (n && !t_ns)) return fail(CTVIO_ERR_INVALID, "bad arguments");
@@ -871,6 +889,9 @@ int32_t ctvio_linearize(ctvio_solver *s, int32_t id, double *Hpp, double *W, dou
 int32_t ctvio_cost(ctvio_solver *s, int32_t id, double *cost) { CHK_S; return s->impl->cost(id, cost); }
 int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, double *model_cost_change) {
   CHK_S; return s->impl->lm_step(id, mu, delta, model_cost_change);
+}
+int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) {
+  CHK_S; return s->impl->gauge_restore(n, ids, knot, q0, t0);
 }
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) {
   CHK_S; return s->impl->spline_eval(id, n, t_ns, pose7, vel3, omega3, acc3);

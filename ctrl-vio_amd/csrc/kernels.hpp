@@ -1896,6 +1896,64 @@ reduce:
   }
 }
 
+// 4-DoF gauge restore after a solve (reference TrajectoryManager::double2vector, trajectory_manager.cpp:485-516): one rigid
+// transform puts the yaw and the position of knot `knot[w]` back to their pre-solve values (q0, t0) and is applied to
+// knots knot..K-1.  One workgroup per requested window; all fp64.  Utility::R2ypr / ypr2R: visual_odometry/utility.h:74-113.
+template <class T> __global__ void k_gauge_restore(Dev<T> d, int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const WinMeta &m = d.wins[ids[e]];
+  const int K = m.K, k0 = knot[e], base = m.knot0;
+  __shared__ double sh[16];   // Rd (9), td (3), qd (4)
+  if (threadIdx.x == 0) {
+    const double *qr = d.quat + 4 * (base + k0), *pr = d.pos + 3 * (base + k0);
+    const M3<double> R0 = q2R(qmk<double>(q0[4 * e], q0[4 * e + 1], q0[4 * e + 2], q0[4 * e + 3]));
+    const M3<double> R00 = q2R(qmk<double>(qr[0], qr[1], qr[2], qr[3]));
+    auto ypr = [](const M3<double> &R, double &y, double &p) {   // degrees
+      y = atan2(R.m[3], R.m[0]);
+      p = atan2(-R.m[6], R.m[0] * cos(y) + R.m[3] * sin(y)) / 3.14159265358979323846 * 180.0;
+      y = y / 3.14159265358979323846 * 180.0;
+    };
+    double y0, p0, y00, p00;
+    ypr(R0, y0, p0);
+    ypr(R00, y00, p00);
+    M3<double> Rd;
+    if (fabs(fabs(p0) - 90.0) < 1.0 || fabs(fabs(p00) - 90.0) < 1.0) {   // Euler singularity: R0 R00^T
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rd.m[3 * i + j] = R0.m[3 * i] * R00.m[3 * j] + R0.m[3 * i + 1] * R00.m[3 * j + 1] + R0.m[3 * i + 2] * R00.m[3 * j + 2];
+    } else {
+      const double y = (y0 - y00) / 180.0 * 3.14159265358979323846;
+      Rd = m3_id<double>();
+      Rd.m[0] = cos(y); Rd.m[1] = -sin(y); Rd.m[3] = sin(y); Rd.m[4] = cos(y);
+    }
+    for (int i = 0; i < 9; ++i) sh[i] = Rd.m[i];
+    for (int i = 0; i < 3; ++i) sh[9 + i] = t0[3 * e + i] - (Rd.m[3 * i] * pr[0] + Rd.m[3 * i + 1] * pr[1] + Rd.m[3 * i + 2] * pr[2]);
+    // unit quaternion of Rd (Eigen::Quaterniond(R): trace / largest-diagonal branches)
+    double qd[4];
+    const double *r = Rd.m, tr = r[0] + r[4] + r[8];
+    if (tr > 0) { const double s = sqrt(tr + 1.0) * 2; qd[3] = 0.25 * s; qd[0] = (r[7] - r[5]) / s; qd[1] = (r[2] - r[6]) / s; qd[2] = (r[3] - r[1]) / s; }
+    else if (r[0] > r[4] && r[0] > r[8]) { const double s = sqrt(1.0 + r[0] - r[4] - r[8]) * 2; qd[3] = (r[7] - r[5]) / s; qd[0] = 0.25 * s; qd[1] = (r[1] + r[3]) / s; qd[2] = (r[2] + r[6]) / s; }
+    else if (r[4] > r[8]) { const double s = sqrt(1.0 + r[4] - r[0] - r[8]) * 2; qd[3] = (r[2] - r[6]) / s; qd[0] = (r[1] + r[3]) / s; qd[1] = 0.25 * s; qd[2] = (r[5] + r[7]) / s; }
+    else { const double s = sqrt(1.0 + r[8] - r[0] - r[4]) * 2; qd[3] = (r[3] - r[1]) / s; qd[0] = (r[2] + r[6]) / s; qd[1] = (r[5] + r[7]) / s; qd[2] = 0.25 * s; }
+    for (int i = 0; i < 4; ++i) sh[12 + i] = qd[i];
+  }
+  __syncthreads();   // the reference knot is read before any knot is rewritten
+  for (int k = k0 + threadIdx.x; k < K; k += blockDim.x) {
+    double *qk = d.quat + 4 * (base + k), *pk = d.pos + 3 * (base + k);
+    const double *qd = sh + 12;
+    double q[4];
+    q[0] = qd[3] * qk[0] + qd[0] * qk[3] + qd[1] * qk[2] - qd[2] * qk[1];
+    q[1] = qd[3] * qk[1] - qd[0] * qk[2] + qd[1] * qk[3] + qd[2] * qk[0];
+    q[2] = qd[3] * qk[2] + qd[0] * qk[1] - qd[1] * qk[0] + qd[2] * qk[3];
+    q[3] = qd[3] * qk[3] - qd[0] * qk[0] - qd[1] * qk[1] - qd[2] * qk[2];
+    const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double pn[3];
+    for (int i = 0; i < 3; ++i) pn[i] = sh[3 * i] * pk[0] + sh[3 * i + 1] * pk[1] + sh[3 * i + 2] * pk[2] + sh[9 + i];
+    for (int i = 0; i < 4; ++i) qk[i] = q[i] / nq;
+    for (int i = 0; i < 3; ++i) pk[i] = pn[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ trajectory query
 // Se3Spline::poseNs / transVelWorld / rotVelBody / transAccelWorld (se3_spline.h:361-399), fp64, one lane per query.
 template <class T>

@@ -134,6 +134,14 @@ class Solver:
         capi.check(self._lib.ctvio_lm_step(self._h, wid, float(mu), capi._p(d), C.cast(C.byref(mc), C.c_void_p)))
         return d, float(mc.value)
 
+    def gauge_restore(self, wids, knots, q0, t0):
+        """4-DoF gauge restore (reference double2vector): windows `wids`, reference knot index per window, its pre-solve
+        quaternion (n,4) (x,y,z,w) and position (n,3).  Acts on the device state; read it back with get_state."""
+        ids = np.ascontiguousarray(wids, np.int32); kn = np.ascontiguousarray(knots, np.int32)
+        q = np.ascontiguousarray(q0, np.float64).reshape(-1, 4); t = np.ascontiguousarray(t0, np.float64).reshape(-1, 3)
+        assert ids.shape[0] == kn.shape[0] == q.shape[0] == t.shape[0]
+        capi.check(self._lib.ctvio_gauge_restore(self._h, int(ids.shape[0]), capi._p(ids), capi._p(kn), capi._p(q), capi._p(t)))
+
     def spline_eval(self, wid: int, t_ns):
         t = np.ascontiguousarray(t_ns, np.int64)
         n = t.shape[0]

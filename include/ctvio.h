@@ -152,12 +152,19 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3,
                           double *omega3, double *acc3);
 
+/* 4-DoF gauge restore after a solve, on the device, for n windows of the batch at once (reference
+ * TrajectoryManager::double2vector, src/estimator/trajectory_manager.cpp:485-516, called at :467 right after Solve):
+ * for window ids[i], the rigid transform that puts the yaw (full rotation near the Euler singularity) and the position
+ * of knot knot[i] back to the pre-solve pose q0[i] = (x,y,z,w), t0[i] is applied to knots knot[i] .. K-1.
+ * knot[i] = computeTIndexNs(timestamps[0]).second - index of the window's first knot (reference :324-329). */
+int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0);
+
 /* Kernel timing of the next ctvio_solve calls with HIP events recorded on the solver's stream around every
  * launch group (adds a few microseconds per launch: use a dedicated profiling solve, not the timed one). */
 int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on);
 /* Timing of the last ctvio_solve.  ms8: accumulated device time [ms] per launch group
  *   0 k_imu_linearize  1 k_vis_eval (linearise)  2 k_assemble_vis  3 zero + k_assemble_imu + k_misc + k_post_linearize
- *   4 Schur SYRK (k_schur_mfma)  5 k_cholesky_solve  6 everything else (damping, rhs, backsub, update, cost, control)
+ *   4 Schur SYRK (k_schur_window / k_schur_mfma)  5 k_cholesky_solve  6 everything else (damping, rhs, backsub, update, cost, control)
  *   7 whole solve (always measured).  launches8: number of launches of each group, [7] = LM passes launched.
  * Groups 0..6 are zero unless profiling was on. */
 int32_t ctvio_last_timing(ctvio_solver *s, double *ms8, int32_t *launches8);

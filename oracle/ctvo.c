@@ -1158,3 +1158,62 @@ void ctvo_spline_eval(const ctvo_window *w, int n, const int64_t *t_ns, double *
     if (omega3) eval_omega(q4, u, idt, omega3 + 3 * i);
   }
 }
+
+/* ------------------------------------------------------------------------------------------------ gauge restore
+ * reference trajectory_manager.cpp:485-516 (double2vector), utility.h:74-113 (R2ypr in degrees, ypr2R = Rz Ry Rx). */
+static void gr_q2R(const double q[4], double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void gr_R2ypr(const double R[9], double ypr[3]) {
+  const double n0 = R[0], n1 = R[3], n2 = R[6], o0 = R[1], o1 = R[4], a0 = R[2], a1 = R[5];
+  const double y = atan2(n1, n0);
+  const double p = atan2(-n2, n0 * cos(y) + n1 * sin(y));
+  const double r = atan2(a0 * sin(y) - a1 * cos(y), -o0 * sin(y) + o1 * cos(y));
+  ypr[0] = y / CTVO_PI * 180.0; ypr[1] = p / CTVO_PI * 180.0; ypr[2] = r / CTVO_PI * 180.0;
+}
+void ctvo_gauge_restore(int K, double *quat, double *pos, int knot, const double q0[4], const double t0[3]) {
+  double R0[9], R00[9], e0[3], e00[3], Rd[9], td[3];
+  gr_q2R(q0, R0);
+  gr_q2R(quat + 4 * knot, R00);
+  gr_R2ypr(R0, e0);
+  gr_R2ypr(R00, e00);
+  if (fabs(fabs(e0[1]) - 90.0) < 1.0 || fabs(fabs(e00[1]) - 90.0) < 1.0) {   /* Euler singularity: R0 R00^T */
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += R0[3 * i + k] * R00[3 * j + k];
+        Rd[3 * i + j] = s;
+      }
+  } else {
+    const double y = (e0[0] - e00[0]) / 180.0 * CTVO_PI;
+    Rd[0] = cos(y); Rd[1] = -sin(y); Rd[2] = 0; Rd[3] = sin(y); Rd[4] = cos(y); Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1;
+  }
+  const double *p00 = pos + 3 * knot;
+  for (int i = 0; i < 3; ++i) td[i] = t0[i] - (Rd[3 * i] * p00[0] + Rd[3 * i + 1] * p00[1] + Rd[3 * i + 2] * p00[2]);
+  /* rot_diff as a unit quaternion (Sophus SO3(matrix) -> Eigen::Quaterniond(R): trace / largest-diagonal branches) */
+  double qd[4];
+  {
+    const double tr = Rd[0] + Rd[4] + Rd[8];
+    if (tr > 0) { const double s = sqrt(tr + 1.0) * 2; qd[3] = 0.25 * s; qd[0] = (Rd[7] - Rd[5]) / s; qd[1] = (Rd[2] - Rd[6]) / s; qd[2] = (Rd[3] - Rd[1]) / s; }
+    else if (Rd[0] > Rd[4] && Rd[0] > Rd[8]) { const double s = sqrt(1.0 + Rd[0] - Rd[4] - Rd[8]) * 2; qd[3] = (Rd[7] - Rd[5]) / s; qd[0] = 0.25 * s; qd[1] = (Rd[1] + Rd[3]) / s; qd[2] = (Rd[2] + Rd[6]) / s; }
+    else if (Rd[4] > Rd[8]) { const double s = sqrt(1.0 + Rd[4] - Rd[0] - Rd[8]) * 2; qd[3] = (Rd[2] - Rd[6]) / s; qd[0] = (Rd[1] + Rd[3]) / s; qd[1] = 0.25 * s; qd[2] = (Rd[5] + Rd[7]) / s; }
+    else { const double s = sqrt(1.0 + Rd[8] - Rd[0] - Rd[4]) * 2; qd[3] = (Rd[3] - Rd[1]) / s; qd[0] = (Rd[2] + Rd[6]) / s; qd[1] = (Rd[5] + Rd[7]) / s; qd[2] = 0.25 * s; }
+  }
+  for (int k = knot; k < K; ++k) {   /* knot <- SE3(Rd, td) * knot : q <- qd * q (Hamilton, renormalised), p <- Rd p + td */
+    const double *qk = quat + 4 * k;
+    double q[4];
+    q[0] = qd[3] * qk[0] + qd[0] * qk[3] + qd[1] * qk[2] - qd[2] * qk[1];
+    q[1] = qd[3] * qk[1] - qd[0] * qk[2] + qd[1] * qk[3] + qd[2] * qk[0];
+    q[2] = qd[3] * qk[2] + qd[0] * qk[1] - qd[1] * qk[0] + qd[2] * qk[3];
+    q[3] = qd[3] * qk[3] - qd[0] * qk[0] - qd[1] * qk[1] - qd[2] * qk[2];
+    const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= nq;
+    double *pk = pos + 3 * k, pn[3];
+    for (int i = 0; i < 3; ++i) pn[i] = Rd[3 * i] * pk[0] + Rd[3 * i + 1] * pk[1] + Rd[3 * i + 2] * pk[2] + td[i];
+    for (int i = 0; i < 4; ++i) quat[4 * k + i] = q[i];
+    for (int i = 0; i < 3; ++i) pk[i] = pn[i];
+  }
+}

@@ -118,4 +118,11 @@ void ctvo_spline_eval(const ctvo_window *w, int n, const int64_t *t_ns, double *
 #ifdef __cplusplus
 }
 #endif
+
+/* 4-DoF gauge restore after a solve (reference TrajectoryManager::double2vector, trajectory_manager.cpp:485-516, with
+ * Utility::R2ypr / ypr2R, visual_odometry/utility.h:74-113): the yaw and the position of knot `knot` are put back to
+ * their pre-solve values (q0 = x,y,z,w; t0) by one rigid transform applied to knots knot..K-1.  Near the Euler
+ * singularity (|pitch| within 1 degree of 90) the full rotation difference R0 R00^T is used instead of the yaw. */
+void ctvo_gauge_restore(int K, double *quat, double *pos, int knot, const double q0[4], const double t0[3]);
+
 #endif

@@ -166,6 +166,14 @@ class OracleWindow:
         return pose, vel, om, acc
 
 
+def gauge_restore(quat, pos, knot, q0, t0):
+    """In place on (K,4) / (K,3) fp64 arrays: reference double2vector (trajectory_manager.cpp:485-516)."""
+    quat = np.ascontiguousarray(quat, np.float64); pos = np.ascontiguousarray(pos, np.float64)
+    q0 = np.ascontiguousarray(q0, np.float64); t0 = np.ascontiguousarray(t0, np.float64)
+    lib().ctvo_gauge_restore(int(quat.shape[0]), _p(quat), _p(pos), int(knot), _p(q0), _p(t0))
+    return quat, pos
+
+
 def so3_exp(w):
     q = np.zeros(4); w = np.ascontiguousarray(w, np.float64)
     lib().ctvo_so3_exp(_p(w), _p(q)); return q

@@ -199,6 +199,30 @@ def test_config3_rolling_shutter_stress(cv, oracle):
             np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-10)
 
 
+def test_gauge_restore(cv, oracle):
+    """ctvio_gauge_restore (reference double2vector, the step right after Solve) on two windows of a batch at once, against
+    the oracle: regular case (yaw only) and a reference pose pitched to the Euler singularity (full rotation)."""
+    from scipy.spatial.transform import Rotation as R
+    ws = [cv.synth.make_window("config1", seed=1000 + i) for i in range(3)]
+    with cv.Solver(precision="fp32") as s:
+        s.set_windows(ws)
+        q0 = np.stack([ws[0].quat[2], (R.from_euler("y", 89.7, degrees=True) * R.from_quat(ws[2].quat[5])).as_quat()])
+        t0 = np.stack([ws[0].pos[2], ws[2].pos[5] + 0.3])
+        s.solve(15)                                   # moves the knots away from their initial gauge
+        solved = [w.copy() for w in ws]
+        s.gauge_restore([0, 2], [2, 5], q0, t0)
+        out = [s.get_state(i) for i in range(3)]
+    for e, (wi, k) in enumerate(((0, 2), (2, 5))):
+        qo, po = oracle.gauge_restore(solved[wi].quat.copy(), solved[wi].pos.copy(), k, q0[e], t0[e])
+        np.testing.assert_allclose(out[wi].quat, qo, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(out[wi].pos, po, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out[wi].pos[k], t0[e], atol=1e-12)
+    np.testing.assert_array_equal(out[1].quat, solved[1].quat)            # window not listed: untouched
+    np.testing.assert_array_equal(out[0].quat[:2], solved[0].quat[:2])    # knots before the reference knot: untouched
+    with pytest.raises(cv.capi.CtvioError):
+        s2 = cv.Solver(); s2.set_windows([ws[0]]); s2.gauge_restore([0], [99], q0[:1], t0[:1])
+
+
 def test_ragged_batch_equals_single(cv):
     """Windows of different sizes in one batch; each must match its own single-window solve."""
     ws = [cv.synth.make_window("config1", seed=1000 + i) for i in range(3)] + [cv.synth.make_window("tiny", seed=5),

@@ -98,3 +98,32 @@ def test_schur_equals_full_dense(cv, oracle):
     d2, m2 = o.lm_step(1e4, use_schur=False)
     np.testing.assert_allclose(d1, d2, rtol=1e-6, atol=1e-9 * np.abs(d2).max())
     assert m1 == pytest.approx(m2, rel=1e-8)
+
+
+def test_gauge_restore_against_scipy():
+    """oracle/ctvo.c: ctvo_gauge_restore (reference double2vector) against an independent SciPy restatement: the yaw of
+    the reference knot and its position return to the pre-solve values, earlier knots are untouched, later knots move
+    rigidly with it; near the Euler singularity the full rotation is restored."""
+    from scipy.spatial.transform import Rotation as R
+    import pyctvo
+    rng = np.random.default_rng(3)
+    K = 9
+    q = R.random(K, random_state=5).as_quat()
+    p = rng.normal(size=(K, 3))
+    for case, q0 in (("yaw", R.random(1, random_state=7).as_quat()[0]), ("singular", R.from_euler("ZYX", [40.0, 89.6, 10.0], degrees=True).as_quat())):
+        t0 = rng.normal(size=3)
+        k = 3
+        qq, pp = pyctvo.gauge_restore(q.copy(), p.copy(), k, q0, t0)
+        R0, R00 = R.from_quat(q0), R.from_quat(q[k])
+        if case == "yaw":
+            dy = R0.as_euler("ZYX")[0] - R00.as_euler("ZYX")[0]
+            Rd = R.from_euler("Z", dy)
+        else:
+            Rd = R0 * R00.inv()
+        td = t0 - Rd.apply(p[k])
+        np.testing.assert_allclose(pp[k:], Rd.apply(p[k:]) + td, atol=1e-12)
+        for i in range(k, K):
+            assert (R.from_quat(qq[i]).inv() * (Rd * R.from_quat(q[i]))).magnitude() < 1e-12
+        np.testing.assert_array_equal(qq[:k], q[:k])
+        np.testing.assert_array_equal(pp[:k], p[:k])
+        np.testing.assert_allclose(pp[k], t0, atol=1e-12)
