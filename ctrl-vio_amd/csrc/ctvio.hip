@@ -366,7 +366,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(b_v_win_.upload(v_win, stream_)); HIPCHK(b_v_lm_.upload(v_lm, stream_)); HIPCHK(b_v_ti_.upload(v_ti, stream_));
     HIPCHK(b_v_tj_.upload(v_tj, stream_)); HIPCHK(b_v_rowi_.upload(v_rowi, stream_)); HIPCHK(b_v_rowj_.upload(v_rowj, stream_));
     HIPCHK(b_v_obs_.upload(v_obs, stream_));
-    if (mixed_) { HIPCHK(b_imu_rc_.alloc((size_t)6 * std::max(Mtot_, 1))); HIPCHK(b_vis_rc_.alloc((size_t)2 * std::max(Vtot_, 1))); d.imu_rc = b_imu_rc_.p; d.vis_rc = b_vis_rc_.p; }
+    if (mixed_) { HIPCHK(b_imu_rc_.alloc((size_t)6 * std::max(Mtot_, 1))); HIPCHK(b_vis_rc_.alloc((size_t)3 * std::max(Vtot_, 1))); d.imu_rc = b_imu_rc_.p; d.vis_rc = b_vis_rc_.p; }
     HIPCHK(b_Jv_.alloc((size_t)100 * std::max(Vtot_, 1))); HIPCHK(b_rv_.alloc((size_t)2 * std::max(Vtot_, 1))); HIPCHK(b_vs_.alloc((size_t)2 * std::max(Vtot_, 1)));
     d.v_win = b_v_win_.p; d.v_lm = b_v_lm_.p; d.v_ti = b_v_ti_.p; d.v_tj = b_v_tj_.p; d.v_rowi = b_v_rowi_.p; d.v_rowj = b_v_rowj_.p;
     d.v_obs = b_v_obs_.p; d.Jv = b_Jv_.p; d.rv = b_rv_.p; d.vs = b_vs_.p;

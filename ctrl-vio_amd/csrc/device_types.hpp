@@ -81,7 +81,8 @@ template <class T> struct Dev {
   const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
   T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
   T *rv;                 // [2][Vtot]
-  T *vis_rc;             // [2][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc)
+  T *vis_rc;             // [3][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc) and the block's
+                         // sqrt(rho') = exp(-cost / a^2) from that fp64 evaluation (row 2)
   T *Wc;                 // [Vtot][WC_STRIDE] per block, rows in LANDMARK order (row v_slot[v]): J~_rho^T J~_c (49 pose columns),
                          // J~_rho^T J~_rho, J~_rho^T r~, then the block's knot segments si, sj
   const int32_t *v_slot; // [Vtot] row of block v in Wc

@@ -554,12 +554,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
       if (LIN) {
         VisGlobalSink<T> sink{d.Jv, V, wcs + 55 * threadIdx.x, T(0), T(0), (unsigned)v};
         wcs_on[threadIdx.x] = d.v_slot[v];
+        if (sizeof(RT) != sizeof(T)) cal.sq_override = d.vis_rc[2 * V + v];   // robust scale of the fp64 residual pass
         SegConst<T> sci, scj;
         seg_const_load(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci, true);
         seg_const_load(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj, true);
         c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
-        if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state; J~ keeps the fp32 corrector scale
+        if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state
           r[0] = d.vis_rc[v]; r[1] = d.vis_rc[V + v];
         }
         sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
         c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
         if (sizeof(RT) != sizeof(T)) {   // mixed mode: reused by the next linearisation (same state, if the step is accepted)
           d.vis_rc[v] = (T)rd[0]; d.vis_rc[(size_t)d.Vtot + v] = (T)rd[1];
+          d.vis_rc[(size_t)2 * d.Vtot + v] = m.cauchy_a > 0.0 ? (T)exp(-c / (m.cauchy_a * m.cauchy_a)) : T(1);   // cost = b/2 log(1 + s/b)
         }
       }
     } else {

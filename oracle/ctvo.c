@@ -300,6 +300,23 @@ static void eval_rd(const double *p4, int deriv, double u, double idt_pow, doubl
   }
 }
 
+/* Sensitivity study only (tests/jacobian_noise_study.py): multiplies every Jacobian entry of the IMU / visual blocks
+ * by (1 + rel * xi), xi uniform in [-1, 1] from a fixed LCG -- emulates Jacobians evaluated in lower precision while
+ * residuals, accumulation and the solve stay fp64.  0 (default) = off. */
+static double g_jn_imu = 0.0, g_jn_vis = 0.0;
+static int g_round_products = 0;   /* 1: every block's J^T J / J^T r contribution is rounded to fp32 before it is added */
+void ctvo_set_product_rounding(int on) { g_round_products = on; }
+static unsigned long long g_jn_state = 88172645463325252ull;
+void ctvo_set_jacobian_noise(double imu_rel, double vis_rel) { g_jn_imu = imu_rel; g_jn_vis = vis_rel; g_jn_state = 88172645463325252ull; }
+static void jn_apply(double *J, int n, double rel) {
+  if (rel == 0.0) return;
+  for (int i = 0; i < n; ++i) {
+    g_jn_state ^= g_jn_state << 13; g_jn_state ^= g_jn_state >> 7; g_jn_state ^= g_jn_state << 17;
+    const double xi = (double)(g_jn_state >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+    J[i] *= 1.0 + rel * xi;
+  }
+}
+
 /* ------------------------------------------------------------------ IMU block
  * SplitSpineView::Evaluate (split_spline_view.h:67-214) fused with
  * IMUFactor::Evaluate (trajectory_value_factor.h:141-248).
@@ -675,12 +692,12 @@ static void scatter(double *H, double *g, int N, int nres, int ncol, const doubl
     if (idx[a] < 0) continue;
     double ga = 0;
     for (int i = 0; i < nres; ++i) ga += J[i * ncol + a] * r[i];
-    g[idx[a]] += ga;
+    g[idx[a]] += g_round_products ? (double)(float)ga : ga;
     for (int b = 0; b < ncol; ++b) {
       if (idx[b] < 0) continue;
       double h = 0;
       for (int i = 0; i < nres; ++i) h += J[i * ncol + a] * J[i * ncol + b];
-      H[(size_t)idx[a] * N + idx[b]] += h;
+      H[(size_t)idx[a] * N + idx[b]] += g_round_products ? (double)(float)h : h;
     }
   }
 }
@@ -695,6 +712,7 @@ double ctvo_build_normal(const ctvo_window *w, double *H, double *g) {
   for (int m = 0; m < w->M; ++m) {
     int32_t s;
     ctvo_imu_block(w, m, r, J, &s);
+    jn_apply(J, 6 * 30, g_jn_imu);
     for (int k = 0; k < 4; ++k)
       for (int c = 0; c < 3; ++c) { idx[3 * k + c] = 6 * (s + k) + c; idx[12 + 3 * k + c] = 6 * (s + k) + 3 + c; }
     for (int c = 0; c < 6; ++c) idx[24 + c] = 6 * K + 6 * w->imu_bias[m] + c;
@@ -705,6 +723,7 @@ double ctvo_build_normal(const ctvo_window *w, double *H, double *g) {
   for (int v = 0; v < w->V; ++v) {
     int32_t si, sj;
     ctvo_visual_block(w, v, r, Jv, &si, &sj);
+    jn_apply(Jv, 2 * 50, g_jn_vis);
     cost += robustify(w->cauchy_a, 2, 50, r, Jv);
     for (int k = 0; k < 4; ++k)
       for (int c = 0; c < 3; ++c) {

@@ -125,4 +125,8 @@ void ctvo_spline_eval(const ctvo_window *w, int n, const int64_t *t_ns, double *
  * singularity (|pitch| within 1 degree of 90) the full rotation difference R0 R00^T is used instead of the yaw. */
 void ctvo_gauge_restore(int K, double *quat, double *pos, int knot, const double q0[4], const double t0[3]);
 
+/* Jacobian-precision sensitivity study hook (not used by the parity tests); 0, 0 = off. */
+void ctvo_set_jacobian_noise(double imu_rel, double vis_rel);
+void ctvo_set_product_rounding(int on);
+
 #endif

@@ -166,6 +166,15 @@ class OracleWindow:
         return pose, vel, om, acc
 
 
+def set_jacobian_noise(imu_rel=0.0, vis_rel=0.0):
+    lib().ctvo_set_jacobian_noise.argtypes = [C.c_double, C.c_double]
+    lib().ctvo_set_jacobian_noise(float(imu_rel), float(vis_rel))
+
+
+def set_product_rounding(on):
+    lib().ctvo_set_product_rounding(int(bool(on)))
+
+
 def gauge_restore(quat, pos, knot, q0, t0):
     """In place on (K,4) / (K,3) fp64 arrays: reference double2vector (trajectory_manager.cpp:485-516)."""
     quat = np.ascontiguousarray(quat, np.float64); pos = np.ascontiguousarray(pos, np.float64)

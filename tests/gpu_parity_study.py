@@ -2,7 +2,9 @@
 settings (15 iterations, function tolerance 1e-6), over many synthetic windows and repeated runs.  Windows are split by
 how the ORACLE stopped: by a tolerance (converged) or by the iteration cap (not converged: the state is then only
 determined up to the solver's own stopping slop, printed as the distance between the oracle at 15 iterations and the
-oracle run to 1e-13).  Run on the GPU box: python tests/gpu_parity_study.py [n_seeds] [repeats]"""
+oracle run to 1e-13), and by whether the device LM took the same accept / reject decisions as the oracle (same numbers of
+successful and unsuccessful steps): a borderline step accepted by one and rejected by the other changes the trust-region
+sequence, after which the two solvers follow different -- equally valid -- paths.  Run on the GPU box: python tests/gpu_parity_study.py [n_seeds] [repeats]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
@@ -31,6 +33,7 @@ for cfg in ("config1", "config2", "config3"):
             for i, (w, sm) in enumerate(zip(wg, sms)):
                 wo, smo, slop = ref[i]
                 rows.append(dict(cfg=cfg, seed=2000 + i, prec=prec, rep=rep, capped=smo.termination == 0, slop=slop,
+                                 same=(sm["num_successful"] == smo.num_successful and sm["num_unsuccessful"] == smo.num_unsuccessful),
                                  dit=sm["iterations"] - smo.iterations, cost=abs(sm["final_cost"] - smo.final_cost) / smo.final_cost,
                                  state=cv.rel_state_error(w, wo)["state"]))
 
@@ -50,6 +53,9 @@ for cfg in ("config1", "config2", "config3"):
         r = [x for x in rows if x["cfg"] == cfg and x["prec"] == prec]
         line(f"{prec} oracle converged (tolerance)", [x for x in r if not x["capped"]])
         line(f"{prec} oracle hit the iteration cap", [x for x in r if x["capped"]])
+        if prec == "fp32":
+            line("fp32 same accept/reject sequence", [x for x in r if x["same"]])
+            line("fp32 one or more decisions differ", [x for x in r if not x["same"]])
 for x in sorted([x for x in rows if x["prec"] == "fp32"], key=lambda x: -x["state"])[:6]:
     print("worst fp32:", x["cfg"], "seed", x["seed"], "run", x["rep"], "capped" if x["capped"] else "converged", "iter diff", x["dit"],
           "cost rel %.1e" % x["cost"], "state %.2e" % x["state"], "oracle slop %.1e" % x["slop"])
