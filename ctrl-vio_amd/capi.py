@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libctvio.so")
-SRC = [os.path.join(_HERE, "csrc", f) for f in ("ctvio.hip", "kernels.hpp", "factors.hpp", "so3.hpp", "device_types.hpp")]
+SRC = [os.path.join(_HERE, "csrc", f) for f in ("ctvio.hip", "kernels.hpp", "factors.hpp", "so3.hpp", "device_types.hpp", "marginalize.hpp")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctvio.h")
 
 FP32, FP64 = 0, 1
@@ -74,7 +74,7 @@ class Summary(C.Structure):
 # every symbol include/ctvio.h declares (tests check the .so exports all of them)
 SYMBOLS = ["ctvio_default_options", "ctvio_status_string", "ctvio_last_error", "ctvio_device_count", "ctvio_create",
            "ctvio_destroy", "ctvio_clear", "ctvio_add_window", "ctvio_upload", "ctvio_num_windows", "ctvio_solve",
-           "ctvio_get_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_gauge_restore",
+           "ctvio_get_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_gauge_restore", "ctvio_marginalize",
            "ctvio_last_timing", "ctvio_set_profiling", "ctvio_stream"]
 
 _lib = None
@@ -102,6 +102,7 @@ def load_library():
         lib.ctvio_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.ctvio_lm_step.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
         lib.ctvio_spline_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
+        lib.ctvio_marginalize.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 4
         lib.ctvio_gauge_restore.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 4
         lib.ctvio_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ctvio_set_profiling.argtypes = [C.c_void_p, C.c_int32]

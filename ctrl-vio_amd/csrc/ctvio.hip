@@ -20,6 +20,7 @@
 
 #include "../../include/ctvio.h"
 #include "kernels.hpp"
+#include "marginalize.hpp"
 
 namespace ctv {
 
@@ -77,6 +78,7 @@ struct SolverBase {
   virtual int lm_step(int id, double mu, double *delta, double *mc) = 0;
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
   virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
+  virtual int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
   virtual int snapshot(int restore) = 0;
   virtual int last_timing(double *ms8, int32_t *n8) = 0;
   virtual int set_profiling(int on) = 0;
@@ -710,6 +712,33 @@ template <class T> class SolverImpl : public SolverBase {
     if (mc) *mc = lm.step_valid ? lm.model_change : -1.0;
     return CTVIO_OK;
   }
+  // Prior construction: A, b of the window's factors on the device (the linearise kernels), elimination of
+  // the marginalised unknowns and the factorisation into (J0, r0) on the host (csrc/marginalize.hpp).
+  int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    if (id < 0 || id >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
+    if (!role || !n_keep || !kept || !J0 || !r0 || !(eps >= 0)) return fail(CTVIO_ERR_INVALID, "bad arguments");
+    const WinMeta &m = meta_[id];
+    const int N = m.N, P = m.P, L = m.L;
+    for (int i = 0; i < N; ++i) if (role[i] < -1 || role[i] > 1) return fail(CTVIO_ERR_INVALID, "role must be -1, 0 or 1");
+    std::vector<double> Hpp((size_t)P * P), W((size_t)P * std::max(L, 1)), Hll(std::max(L, 1)), g(N);
+    const int rc = linearize(id, Hpp.data(), L ? W.data() : nullptr, L ? Hll.data() : nullptr, g.data(), nullptr);
+    if (rc != CTVIO_OK) return rc;
+    std::vector<double> A((size_t)N * N, 0.0);
+    for (int i = 0; i < P; ++i) {
+      for (int j = 0; j < P; ++j) A[(size_t)i * N + j] = Hpp[(size_t)i * P + j];
+      for (int l = 0; l < L; ++l) { A[(size_t)i * N + P + l] = W[(size_t)i * L + l]; A[(size_t)(P + l) * N + i] = W[(size_t)i * L + l]; }
+    }
+    for (int l = 0; l < L; ++l) A[(size_t)(P + l) * N + P + l] = Hll[l];
+    std::vector<int32_t> kv;
+    std::vector<double> Jv, rv;
+    const int n = marginalize_dense(N, A.data(), g.data(), role, eps, kv, Jv, rv);
+    *n_keep = n;
+    std::copy(kv.begin(), kv.end(), kept);
+    std::copy(Jv.begin(), Jv.end(), J0);
+    std::copy(rv.begin(), rv.end(), r0);
+    return CTVIO_OK;
+  }
   int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (n < 0 || (n && (!ids || !knot || !q0 || !t0))) return fail(CTVIO_ERR_INVALID, "bad arguments");
@@ -889,6 +918,9 @@ int32_t ctvio_linearize(ctvio_solver *s, int32_t id, double *Hpp, double *W, dou
 int32_t ctvio_cost(ctvio_solver *s, int32_t id, double *cost) { CHK_S; return s->impl->cost(id, cost); }
 int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, double *model_cost_change) {
   CHK_S; return s->impl->lm_step(id, mu, delta, model_cost_change);
+}
+int32_t ctvio_marginalize(ctvio_solver *s, int32_t id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) {
+  CHK_S; return s->impl->marginalize(id, role, eps, n_keep, kept, J0, r0);
 }
 int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) {
   CHK_S; return s->impl->gauge_restore(n, ids, knot, q0, t0);

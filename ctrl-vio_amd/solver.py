@@ -134,6 +134,17 @@ class Solver:
         capi.check(self._lib.ctvio_lm_step(self._h, wid, float(mu), capi._p(d), C.cast(C.byref(mc), C.c_void_p)))
         return d, float(mc.value)
 
+    def marginalize(self, wid: int, role, eps: float = 1e-8):
+        """Prior construction from window `wid` (ctvio_marginalize): role[N] 1 = marginalise, 0 = keep, -1 = not involved.
+        Returns (kept indices, J0 (n, n), r0 (n))."""
+        N = self.windows[wid].N
+        role = np.ascontiguousarray(role, np.int8)
+        assert role.shape == (N,)
+        kept = np.zeros(N, np.int32); J0 = np.zeros(N * N); r0 = np.zeros(N); n = C.c_int32(0)
+        capi.check(self._lib.ctvio_marginalize(self._h, wid, capi._p(role), float(eps), C.byref(n), capi._p(kept), capi._p(J0), capi._p(r0)))
+        n = n.value
+        return kept[:n].copy(), J0[: n * n].reshape(n, n).copy(), r0[:n].copy()
+
     def gauge_restore(self, wids, knots, q0, t0):
         """4-DoF gauge restore (reference double2vector): windows `wids`, reference knot index per window, its pre-solve
         quaternion (n,4) (x,y,z,w) and position (n,3).  Acts on the device state; read it back with get_state."""

@@ -152,6 +152,18 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3,
                           double *omega3, double *acc3);
 
+/* Prior construction for the next window (reference MarginalizationInfo::preMarginalize / marginalize,
+ * src/estimator/factor/analytic_diff/marginalization_factor.cpp:106-265, driven by TrajectoryEstimator::
+ * PrepareMarginalizationInfo / SaveMarginalizationInfo, trajectory_estimator.cpp:143-204).  Window `id` holds the factors
+ * to be dropped (IMU samples, visual blocks with cauchy_a = 1 as in the reference, bias chain, the previous prior) at the
+ * linearisation point; its normal equations A = sum J~^T J~, b = sum J~^T r~ are assembled on the device by the linearise
+ * kernels.  role[N] (N = 6K + 6F + 1 + L, the library's unknown order): 1 = marginalise, 0 = keep, -1 = not involved.
+ * Output: n_keep, kept[n_keep] (unknown indices, ascending), J0 (n_keep x n_keep row-major) and r0 (n_keep) such that the
+ * prior residual of the next window is r0 + J0 dx (ctvio_window.pJ0 / pr0, column j of J0 = unknown kept[j]).
+ * kept / J0 / r0 must have room for N, N*N and N entries.  eps = 1e-8 in the reference (:26).  Use a CTVIO_FP64 solver when
+ * the prior has to match an fp64 reference tightly: the elimination amplifies the fp32 noise of the default path. */
+int32_t ctvio_marginalize(ctvio_solver *s, int32_t id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0);
+
 /* 4-DoF gauge restore after a solve, on the device, for n windows of the batch at once (reference
  * TrajectoryManager::double2vector, src/estimator/trajectory_manager.cpp:485-516, called at :467 right after Solve):
  * for window ids[i], the rigid transform that puts the yaw (full rotation near the Euler singularity) and the position

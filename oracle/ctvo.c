@@ -1236,3 +1236,109 @@ void ctvo_gauge_restore(int K, double *quat, double *pos, int knot, const double
     for (int i = 0; i < 3; ++i) pk[i] = pn[i];
   }
 }
+
+/* ------------------------------------------------------------------------------------------------ marginalisation
+ * reference marginalization_factor.cpp:189-265 (MarginalizationInfo::marginalize); Eigen::SelfAdjointEigenSolver is
+ * restated as a cyclic Jacobi iteration (eigenvalues to ~1e-15 relative to the largest). */
+void ctvo_sym_eig(int n, double *A, double *ev, double *V) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, dia = 0;
+    for (int i = 0; i < n; ++i) {
+      dia += A[(size_t)i * n + i] * A[(size_t)i * n + i];
+      for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+    }
+    if (off <= 1e-60 || off <= 1e-32 * dia) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+        for (int k = 0; k < n; ++k) {   /* A <- A G (columns p, q) */
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {   /* A <- G^T A (rows p, q) */
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {   /* V <- V G */
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < n; ++i) ev[i] = A[(size_t)i * n + i];
+  for (int i = 0; i < n - 1; ++i) {   /* ascending order (selection sort, columns of V follow) */
+    int m = i;
+    for (int j = i + 1; j < n; ++j) if (ev[j] < ev[m]) m = j;
+    if (m != i) {
+      const double te = ev[i]; ev[i] = ev[m]; ev[m] = te;
+      for (int k = 0; k < n; ++k) { const double tv = V[(size_t)k * n + i]; V[(size_t)k * n + i] = V[(size_t)k * n + m]; V[(size_t)k * n + m] = tv; }
+    }
+  }
+}
+
+int ctvo_marginalize(const ctvo_window *w, const int8_t *role, double eps, int32_t *kept, double *J0, double *r0) {
+  const int N = nN(w);
+  int m = 0, n = 0;
+  int *im = (int *)malloc(sizeof(int) * N), *ik = (int *)malloc(sizeof(int) * N);
+  for (int i = 0; i < N; ++i) { if (role[i] == 1) im[m++] = i; else if (role[i] == 0) ik[n++] = i; }
+  if (n <= 0) { free(im); free(ik); return 0; }
+  double *H = (double *)malloc(sizeof(double) * (size_t)N * N), *g = (double *)malloc(sizeof(double) * N);
+  ctvo_build_normal(w, H, g);
+  /* Amm^+ (marginalization_factor.cpp:236-240) */
+  double *Amm = (double *)malloc(sizeof(double) * (size_t)(m ? m : 1) * (m ? m : 1)), *em = (double *)malloc(sizeof(double) * (m ? m : 1));
+  double *Vm = (double *)malloc(sizeof(double) * (size_t)(m ? m : 1) * (m ? m : 1));
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) Amm[(size_t)i * m + j] = 0.5 * (H[(size_t)im[i] * N + im[j]] + H[(size_t)im[j] * N + im[i]]);
+  if (m) ctvo_sym_eig(m, Amm, em, Vm);
+  /* T = Amm^+ [Amr | bm]  (m x (n + 1)) through the eigenbasis: V diag(1/e) V^T */
+  double *X = (double *)malloc(sizeof(double) * (size_t)(m ? m : 1) * (n + 1)), *Y = (double *)malloc(sizeof(double) * (size_t)(m ? m : 1) * (n + 1));
+  for (int a = 0; a < m; ++a)          /* Y = diag(1/e) V^T [Amr | bm] */
+    for (int c = 0; c <= n; ++c) {
+      double s = 0;
+      for (int i = 0; i < m; ++i) s += Vm[(size_t)i * m + a] * (c < n ? H[(size_t)im[i] * N + ik[c]] : g[im[i]]);
+      Y[(size_t)a * (n + 1) + c] = em[a] > eps ? s / em[a] : 0.0;
+    }
+  for (int i = 0; i < m; ++i)
+    for (int c = 0; c <= n; ++c) {
+      double s = 0;
+      for (int a = 0; a < m; ++a) s += Vm[(size_t)i * m + a] * Y[(size_t)a * (n + 1) + c];
+      X[(size_t)i * (n + 1) + c] = s;
+    }
+  /* A' = Arr - Arm X[:, :n],  b' = br - Arm X[:, n]  (:242-248) */
+  double *Ar = (double *)malloc(sizeof(double) * (size_t)n * n), *br = (double *)malloc(sizeof(double) * n);
+  for (int r = 0; r < n; ++r) {
+    for (int c = 0; c < n; ++c) {
+      double s = H[(size_t)ik[r] * N + ik[c]];
+      for (int i = 0; i < m; ++i) s -= H[(size_t)ik[r] * N + im[i]] * X[(size_t)i * (n + 1) + c];
+      Ar[(size_t)r * n + c] = s;
+    }
+    double s = g[ik[r]];
+    for (int i = 0; i < m; ++i) s -= H[(size_t)ik[r] * N + im[i]] * X[(size_t)i * (n + 1) + n];
+    br[r] = s;
+  }
+  /* A' = V S V^T; J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b'  (:250-262).  (The reference does not symmetrise A' first; it is
+   * symmetric up to rounding, and only its symmetric part enters an eigendecomposition.) */
+  for (int r = 0; r < n; ++r)
+    for (int c = r + 1; c < n; ++c) { const double s = 0.5 * (Ar[(size_t)r * n + c] + Ar[(size_t)c * n + r]); Ar[(size_t)r * n + c] = s; Ar[(size_t)c * n + r] = s; }
+  double *er = (double *)malloc(sizeof(double) * n), *Vr = (double *)malloc(sizeof(double) * (size_t)n * n);
+  ctvo_sym_eig(n, Ar, er, Vr);
+  for (int a = 0; a < n; ++a) {
+    const double S = er[a] > eps ? er[a] : 0.0, sq = sqrt(S), isq = S > 0 ? 1.0 / sqrt(S) : 0.0;
+    double s = 0;
+    for (int i = 0; i < n; ++i) { J0[(size_t)a * n + i] = sq * Vr[(size_t)i * n + a]; s += Vr[(size_t)i * n + a] * br[i]; }
+    r0[a] = isq * s;
+  }
+  for (int i = 0; i < n; ++i) kept[i] = ik[i];
+  free(im); free(ik); free(H); free(g); free(Amm); free(em); free(Vm); free(X); free(Y); free(Ar); free(br); free(er); free(Vr);
+  return n;
+}

@@ -129,4 +129,17 @@ void ctvo_gauge_restore(int K, double *quat, double *pos, int knot, const double
 void ctvo_set_jacobian_noise(double imu_rel, double vis_rel);
 void ctvo_set_product_rounding(int on);
 
+/* Prior construction = marginalisation of a window that holds the dropped factors (reference
+ * MarginalizationInfo::marginalize, factor/analytic_diff/marginalization_factor.cpp:189-265; the factor evaluation with
+ * the robust correction, :39-67, is ctvo_build_normal).  role[N]: 1 = marginalise, 0 = keep, -1 = not involved (its row
+ * and column of A are ignored).  A = H (all factors of w), b = g, reordered [marginalised | kept];
+ *   Amm^+ by symmetric eigendecomposition with eigenvalues <= eps dropped; A' = Arr - Arm Amm^+ Amr, b' = br - Arm Amm^+ bm;
+ *   A' = V S V^T (eigenvalues <= eps -> 0):  J0 = sqrt(S) V^T,  r0 = S^-1/2 V^T b'.
+ * kept[n] receives the unknown indices of the kept set in ascending order; J0 is n x n row-major (row i = sqrt(S_i) v_i^T,
+ * eigenvalues ascending), r0 has n entries.  Returns n (<= 0: nothing to keep). */
+int ctvo_marginalize(const ctvo_window *w, const int8_t *role, double eps, int32_t *kept, double *J0, double *r0);
+/* cyclic Jacobi eigen-solver of a symmetric n x n matrix (row-major, destroyed): eigenvalues ascending in ev,
+ * eigenvectors in the COLUMNS of V (row-major n x n). */
+void ctvo_sym_eig(int n, double *A, double *ev, double *V);
+
 #endif

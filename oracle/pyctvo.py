@@ -158,6 +158,17 @@ class OracleWindow:
         self._sync_out()
         return sm
 
+    def marginalize(self, role, eps=1e-8):
+        """role[N]: 1 marginalise, 0 keep, -1 not involved.  Returns kept indices, J0 (n x n), r0 (n)."""
+        self._sync_in()
+        role = np.ascontiguousarray(role, np.int8)
+        N = self.w.N
+        kept = np.zeros(N, np.int32); J0 = np.zeros(N * N); r0 = np.zeros(N)
+        lib().ctvo_marginalize.restype = C.c_int
+        lib().ctvo_marginalize.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = lib().ctvo_marginalize(C.byref(self.c), _p(role), float(eps), _p(kept), _p(J0), _p(r0))
+        return kept[:n].copy(), J0[: n * n].reshape(n, n).copy(), r0[:n].copy()
+
     def spline_eval(self, t_ns):
         t = np.ascontiguousarray(t_ns, np.int64)
         n = t.shape[0]

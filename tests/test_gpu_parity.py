@@ -229,6 +229,32 @@ def test_config3_rolling_shutter_stress(cv, oracle):
             np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-10)
 
 
+def test_marginalize_prior_construction(cv, oracle):
+    """ctvio_marginalize: A, b assembled on the device, eliminated and factored on the host, against the
+    oracle's restatement of MarginalizationInfo::marginalize.  J0 is unique only up to the eigenvector basis: what the next
+    window uses is compared -- J0^T J0, J0^T r0, |r0|^2 (measured: fp64 path 1e-11 .. 6e-9, default mixed path 7e-10 on
+    J0^T J0 and 2e-7 .. 5e-7 on J0^T r0, configs 1-2)."""
+    w = cv.synth.make_window("config1", seed=1000)
+    w.cauchy_a = 1.0                                   # the reference marginalises with CauchyLoss(1.0)
+    role = np.zeros(w.N, np.int8)
+    role[:12] = 1                                      # two oldest knots
+    role[6 * w.K:6 * w.K + 6] = 1                      # oldest bias state
+    role[w.P:w.P + w.L // 2] = 1                       # landmarks anchored in the dropped frame
+    ko, Jo, ro = oracle.OracleWindow(w.copy()).marginalize(role, 1e-8)
+    Ho, go, co = Jo.T @ Jo, Jo.T @ ro, ro @ ro
+    for prec, tol in (("fp64", 1e-7), ("fp32", 1e-5)):
+        with cv.Solver(precision=prec) as s:
+            s.set_windows([w.copy()])
+            kept, J0, r0 = s.marginalize(0, role, 1e-8)
+        assert np.array_equal(kept, ko)
+        assert np.abs(J0.T @ J0 - Ho).max() <= tol * np.abs(Ho).max(), prec
+        assert np.abs(J0.T @ r0 - go).max() <= tol * np.abs(go).max(), prec
+        assert abs(r0 @ r0 - co) <= tol * co, prec
+    with pytest.raises(cv.capi.CtvioError):
+        bad = role.copy(); bad[3] = 2
+        s2 = cv.Solver(); s2.set_windows([w.copy()]); s2.marginalize(0, bad)
+
+
 def test_gauge_restore(cv, oracle):
     """ctvio_gauge_restore (reference double2vector, the step right after Solve) on two windows of a batch at once, against
     the oracle: regular case (yaw only) and a reference pose pitched to the Euler singularity (full rotation)."""
