@@ -8,6 +8,7 @@ validates kernel logic (indexing, reductions, Schur, Cholesky, LM control).  pre
   final state vs the fp64 reference solve at Ceres' own tolerances (BASELINE target)  <= 1e-4
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -253,6 +254,32 @@ def test_marginalize_prior_construction(cv, oracle):
     with pytest.raises(cv.capi.CtvioError):
         bad = role.copy(); bad[3] = 2
         s2 = cv.Solver(); s2.set_windows([w.copy()]); s2.marginalize(0, bad)
+
+
+def test_prior_chain_on_device(cv):
+    """Windows can be chained on the device: ctvio_marginalize on the factors of a dropped landmark set, its (J0, r0) fed
+    to the window of the remaining factors as ctvio_window.pJ0 / pr0 -- the Gauss-Newton step of that window equals the
+    step of the full window on the shared unknowns (fp64 path; gauge fixed in both solves, see the CPU twin in
+    tests/test_marginalize_host.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from chain_helpers import chain_case, prior_arrays
+    w, wD, wR, mapR = chain_case("config1", 1000)
+    with cv.Solver(precision="fp64") as s:
+        s.set_windows([wD.copy()])
+        Hpp = s.linearize(0)[0]
+        role = np.where(np.arange(wD.N) >= wD.P, 1, np.where(np.concatenate([np.diag(Hpp), np.ones(wD.L)]) > 0, 0, -1)).astype(np.int8)
+        kept, J0, r0 = s.marginalize(0, role, 1e-8)
+    wR.pJ0, wR.pr0, wR.p_kind, wR.p_index, wR.p_off, wR.p_x0 = prior_arrays(wR, kept, J0, r0)
+    wR.normalize()
+    w.fixed_upto = 3
+    wR.fixed_upto = 3
+    with cv.Solver(precision="fp64") as s:
+        s.set_windows([w.copy(), wR.copy()])
+        d_full, _ = s.lm_step(0, 1e16)
+        d_red, _ = s.lm_step(1, 1e16)
+    P = w.P
+    assert np.abs(d_red[:P] - d_full[:P]).max() < 1e-6 * np.abs(d_full[:P]).max()
+    assert np.abs(d_red[P:] - d_full[P + mapR]).max() < 1e-6 * np.abs(d_full[P:]).max()
 
 
 def test_gauge_restore(cv, oracle):

@@ -100,3 +100,25 @@ def test_library_host_algebra(hostlib):
     invariants_close(J0[:n * n].reshape(n, n), r0[:n], Jo, ro, 1e-7)
     ik, Jn, rn = numpy_marginalize(H, g, role, 1e-8)
     invariants_close(J0[:n * n].reshape(n, n), r0[:n], Jn, rn, 1e-7)
+
+
+def test_prior_chain_consistency_oracle():
+    """End-to-end meaning of the prior (oracle only, CPU): marginalise the landmarks of a dropped set D out of their own
+    factors, hand (J0, r0) to the window of the remaining factors R as its prior -- the Gauss-Newton step of R + prior must
+    equal the step of the full window on every unknown they share (exact for the linearised system: Schur complement).
+    The gauge is fixed in both solves (first four knots constant, as InitTrajectory does); the marginalisation window is free."""
+    from chain_helpers import chain_case, prior_arrays
+    w, wD, wR, mapR = chain_case("config1", 1000)
+    oD = pyctvo.OracleWindow(wD.copy())
+    H, g, _ = oD.build_normal()
+    role = np.where(np.arange(wD.N) >= wD.P, 1, np.where(np.diag(H) > 0, 0, -1)).astype(np.int8)
+    kept, J0, r0 = oD.marginalize(role, 1e-8)
+    wR.pJ0, wR.pr0, wR.p_kind, wR.p_index, wR.p_off, wR.p_x0 = prior_arrays(wR, kept, J0, r0)
+    wR.normalize()
+    w.fixed_upto = 3
+    wR.fixed_upto = 3
+    d_full, _ = pyctvo.OracleWindow(w.copy()).lm_step(1e16)
+    d_red, _ = pyctvo.OracleWindow(wR.copy()).lm_step(1e16)
+    P = w.P
+    assert np.abs(d_red[:P] - d_full[:P]).max() < 1e-8 * np.abs(d_full[:P]).max()
+    assert np.abs(d_red[P:] - d_full[P + mapR]).max() < 1e-8 * np.abs(d_full[P:]).max()
