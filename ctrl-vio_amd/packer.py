@@ -36,3 +36,66 @@ def bias_chain_sqrt_info(imu_t: np.ndarray, frame_t: np.ndarray, sigma_bg: float
         cov = np.array([sigma_bg ** 2 * s2] * 3 + [sigma_ba ** 2 * s2] * 3)
         out[i] = 1.0 / np.sqrt(cov)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ visual factors, depths
+# (the rest of TrajectoryManager::UpdateTrajectory's packing around the solve)
+
+def is_landmark_candidate(n_obs: int, start_frame: int, window_size: int) -> bool:
+    """FeatureManager::isLandmarkCandidate (reference src/visual_odometry/feature_manager.h:58-65): a feature track
+    enters the window as a landmark iff it has >= 2 observations and starts before frame WINDOW_SIZE - 2."""
+    return n_obs >= 2 and start_frame < window_size - 2
+
+
+def pack_visual(tracks, timestamps, window_size: int):
+    """Visual blocks of a window, in the reference's order (trajectory_manager.cpp:358-383).
+
+    tracks: iterable of dicts {"start_frame": int, "points": (n,3) normalised-plane points (x, y, 1),
+    "uv": (n,2) pixel coordinates, "depth": estimated depth of the anchor observation}; observation k of a track belongs to
+    frame start_frame + k.  timestamps: (window_size + 1,) frame times [ns].
+    The first observation is the anchor (ti, rowi = round(v), pts_i); every later observation adds one block against it.
+    Returns a dict with v_lm, v_ti, v_tj, v_rowi, v_rowj, v_pi, v_pj, rho (inverse depths, getDepthVector:
+    feature_manager.cpp:110-123) and `track_of_landmark` (index into `tracks` of every landmark, for copy-back)."""
+    timestamps = np.asarray(timestamps, np.int64)
+    v_lm, v_ti, v_tj, v_rowi, v_rowj, v_pi, v_pj, rho, owner = [], [], [], [], [], [], [], [], []
+    for ti_idx, tr in enumerate(tracks):
+        pts = np.asarray(tr["points"], np.float64)
+        uv = np.asarray(tr["uv"], np.float64)
+        if not is_landmark_candidate(len(pts), int(tr["start_frame"]), window_size):
+            continue
+        lm = len(rho)
+        rho.append(1.0 / float(tr["depth"]))
+        owner.append(ti_idx)
+        i = int(tr["start_frame"])
+        rowi = int(np.floor(uv[0, 1] + 0.5))           # std::round: half away from zero (np.round rounds half to even); rows >= 0
+        for k in range(1, len(pts)):
+            j = i + k
+            v_lm.append(lm); v_ti.append(int(timestamps[i])); v_tj.append(int(timestamps[j]))
+            v_rowi.append(rowi); v_rowj.append(int(np.floor(uv[k, 1] + 0.5)))
+            v_pi.append(pts[0, :2] / pts[0, 2]); v_pj.append(pts[k, :2] / pts[k, 2])
+    return dict(v_lm=np.array(v_lm, np.int32), v_ti=np.array(v_ti, np.int64), v_tj=np.array(v_tj, np.int64),
+                v_rowi=np.array(v_rowi, np.int32), v_rowj=np.array(v_rowj, np.int32),
+                v_pi=np.array(v_pi, np.float64).reshape(-1, 2), v_pj=np.array(v_pj, np.float64).reshape(-1, 2),
+                rho=np.array(rho, np.float64), track_of_landmark=np.array(owner, np.int32))
+
+
+def imu_in_window(imu_t: np.ndarray, opt_min_time: int, opt_max_time: int) -> np.ndarray:
+    """Boolean mask of the IMU samples that get a factor (trajectory_manager.cpp:386-394): opt_min <= t < opt_max, where
+    opt_min = (index of the first knot active at timestamps[0]) * dt and opt_max = the spline's maxTimeNs (:322-325)."""
+    imu_t = np.asarray(imu_t, np.int64)
+    return (imu_t >= opt_min_time) & (imu_t < opt_max_time)
+
+
+def opt_min_time(t_first_frame: int, t0_ns: int, dt_ns: int) -> int:
+    """computeTIndexNs(timestamps[0]).second * getDtNs() (trajectory_manager.cpp:322; the reference's spline starts at 0):
+    the time of the first knot that is active at the first frame, relative to the same origin as t_first_frame."""
+    return t0_ns + ((int(t_first_frame) - int(t0_ns)) // int(dt_ns)) * int(dt_ns)
+
+
+def depths_from_solution(rho: np.ndarray):
+    """FeatureManager::setDepth after the solve (feature_manager.cpp:125-143): estimated_depth = 1 / rho per landmark and
+    the solve flag (True = SovelSucc, False = SolveFail when the depth came out negative)."""
+    rho = np.asarray(rho, np.float64)
+    with np.errstate(divide="ignore"):
+        depth = 1.0 / rho
+    return depth, ~(depth < 0)
