@@ -1,6 +1,6 @@
 """Repeat the parity-critical solves many times in one process, interleaved with the other API paths (different kernels,
 different allocations), to expose races and reads of stale memory: every solve must reproduce the oracle.
-Run on the GPU box: python tools/stress_repeat.py [repeats]"""
+Run on the GPU box: python tests/gpu_stress_repeat.py [repeats]"""
 import importlib, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'oracle')
