@@ -1,11 +1,14 @@
 // kernels.hpp -- gfx950 kernels of the sliding-window solve.  One launch covers a whole batch of windows.
 //
-//   linearise : k_imu_linearize (LDS-staged J, per-group A^T A tiles), k_vis_linearize (J materialised, SoA)
-//   assemble  : k_zero_normal, k_assemble_imu, k_assemble_vis, k_assemble_misc (bias chain + prior), k_post_linearize
-//   solve     : k_damping, k_schur_mfma / k_schur_generic, k_rhs, k_cholesky_solve, k_backsub
-//   update    : k_update, k_imu_cost, k_vis_cost, k_misc_cost
-//   control   : k_lm_init, k_begin_iter, k_lm_control, k_accept   (Ceres 1.14 trust-region semantics)
-//   query     : k_spline_eval
+//   per state : k_knot_prep (d = log(R_k^-1 R_k+1) and Jr^-1(d) of every knot pair, shared by all blocks)
+//   linearise : k_imu_linearize (LDS-staged J, per-group A^T A on MFMA fp32), k_vis_eval<LIN> (J~ materialised SoA, W rows)
+//   assemble  : k_zero_normal, k_assemble_vis_mfma (MFMA fp32 + fp64 LDS Hessian; k_assemble_vis = generic / fp64 variant),
+//               k_build_W, k_assemble_imu, k_misc<LIN> (bias chain + prior), k_post_linearize
+//   solve     : k_damping, k_schur_window (large batches) / k_schur_mfma (per tile) / k_schur_generic + k_rhs (fp64 path),
+//               k_cholesky_solve (fp64 MFMA), k_backsub
+//   update    : k_update<false|true>, k_imu_cost, k_vis_eval<cost>, k_misc<cost>
+//   control   : k_lm_init, k_set_initial_cost, k_begin_iter, k_lm_control   (Ceres 1.14 trust-region semantics)
+//   after     : k_gauge_restore (double2vector), k_spline_eval (trajectory query)
 #pragma once
 #include <utility>
 #include "device_types.hpp"
