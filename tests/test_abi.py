@@ -55,3 +55,15 @@ def test_struct_layout_matches_header(cv):
             if part:
                 names.append(part)
     assert names == [f[0] for f in cv.capi.CWindow._fields_]
+
+
+def test_adaptor_header_compiles_standalone():
+    """include/ctvio_estimator.hpp (the reference-shaped C++ adaptor) and the demo that uses it must compile with the host
+    compiler alone -- no HIP, no torch headers in the drop-in boundary."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "estimator_demo.cpp")])
+    src = open(os.path.join(root, "include", "ctvio.h")).read()
+    includes = re.findall(r"#\s*include\s*[<\"]([^>\"]+)[>\"]", src)
+    assert all(not inc.startswith(("hip", "torch", "ATen", "c10")) for inc in includes), includes
