@@ -195,7 +195,7 @@ def main():
                                      "solves_per_s": args.windows / (t2 - t0)}
         # ---- CPU baseline: the oracle (a port, not the reference binary: Ceres/Eigen are not installable here)
         out["cpu_baseline"] = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the scaling runs must not wait on a CPU loop
             import pyctvo
             t0 = time.perf_counter(); k = 0
             while time.perf_counter() - t0 < args.cpu_seconds:
