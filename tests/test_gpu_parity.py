@@ -81,15 +81,22 @@ def test_solve_fp64_reproduces_oracle_iterates(cv, oracle):
         assert cv.rel_state_error(wg, wo)["state"] < 1e-6
 
 
-def mixed_state_bound(sm, sm_o, cfg):
-    """Tolerance of the mixed fp32/fp64 path on the final state (profiles/r01_v5_parity_study.txt):
-    2e-4 (7e-4 on the rolling-shutter stress config) while the device LM takes the oracle's accept / reject decisions; if one
-    borderline step is accepted by one solver and rejected by the other, the trust-region sequences diverge and the two 15th
-    iterates differ by up to 7e-4 (configs 1-2) / 4.5e-3 (config 3): bounded here by 2e-3 / 1e-2."""
+def mixed_bounds(sm, sm_o, cfg):
+    """(state, cost) tolerances of the mixed fp32/fp64 path (profiles/r01_v5_parity_study.txt).
+    While the device LM takes the oracle's accept / reject decisions: state 2e-4 (configs 1-2; study max 2.1e-4 over 58
+    solves, 9e-5 on the seeds used here) / 1e-3 (rolling-shutter stress config; study max 6.9e-4), cost 2e-6.
+    If one borderline step is accepted by one solver and rejected by the other, the trust-region sequences diverge and the two
+    15th iterates differ by up to 7e-4 (configs 1-2) / 4.5e-3 (config 3), the cost by up to 1e-6 / 2.5e-5: bounded here by
+    2e-3 / 1e-2 and 1e-5 / 1e-4.  Global atomics make the last digits vary from run to run, so a flip can appear in one run and
+    not in the next; the looser branch keeps the test meaningful (and not flaky) in that case."""
     same = sm["num_successful"] == sm_o.num_successful and sm["num_unsuccessful"] == sm_o.num_unsuccessful
     if cfg == "config3":
-        return 7e-4 if same else 1e-2
-    return 2e-4 if same else 2e-3
+        return (1e-3, 1e-5) if same else (1e-2, 1e-4)
+    return (2e-4, 2e-6) if same else (2e-3, 1e-5)
+
+
+def mixed_state_bound(sm, sm_o, cfg):
+    return mixed_bounds(sm, sm_o, cfg)[0]
 
 
 @pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config1", 1001), ("config2", 1000), ("config2", 1001), ("config2", 1002)])
@@ -107,9 +114,10 @@ def test_solve_fp32_vs_oracle_at_ceres_tolerances(cv, oracle, cfg, seed):
         s.set_windows([wg])
         sm = s.solve(15)[0]
     assert abs(sm["iterations"] - sm_o.iterations) <= 1
-    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=2e-6)
+    sb, cb = mixed_bounds(sm, sm_o, cfg)
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=cb)
     err = cv.rel_state_error(wg, wo)
-    assert err["state"] < mixed_state_bound(sm, sm_o, cfg), err
+    assert err["state"] < sb, err
 
 
 @pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config2", 1000), ("config2", 1002)])
@@ -189,7 +197,7 @@ def test_config3_rolling_shutter_stress(cv, oracle):
     per-row times), line delay estimated from 0.  These windows are NOT converged after Ceres' 15 iterations, so the 15th
     iterate is only determined up to the solver's own stopping slop (oracle at 15 iterations vs oracle run to 1e-13):
       * the all-fp64 device path must reproduce the oracle's iterate itself (same decisions, state to 1e-6);
-      * the mixed fp32/fp64 product path: cost to 1e-4, state within mixed_state_bound (7e-4 with the oracle's accept /
+      * the mixed fp32/fp64 product path: cost to 1e-4, state within mixed_state_bound (1e-3 with the oracle's accept /
         reject sequence, 1e-2 after a decision flip -- profiles/r01_v5_parity_study.txt).
     Then the spline is evaluated at every row time of every frame (11 x 640 = 7040 timestamps) against the oracle."""
     w0 = cv.synth.make_window("config3", seed=1003)
