@@ -45,3 +45,52 @@ def test_imu_window_and_depth_copy_back():
     depth, ok = pk.depths_from_solution([0.5, -0.25, 2.0])
     np.testing.assert_allclose(depth, [2.0, -4.0, 0.5])
     assert ok.tolist() == [True, False, True]
+
+
+def test_cpp_packer_matches_python(tmp_path):
+    """include/ctvio_packer.hpp (what a C++ caller of the C ABI uses) against ctrl-vio_amd/packer.py on random inputs."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libhostpacker.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", so, os.path.join(root, "tests", "host_packer_check.cpp")])
+    lib = C.CDLL(so)
+    lib.hp_opt_min_time.restype = C.c_int64
+    lib.hp_opt_min_time.argtypes = [C.c_int64] * 3
+    rng = np.random.default_rng(11)
+    W = 10
+    frame_t = np.cumsum(rng.integers(80_000_000, 120_000_000, W + 1)).astype(np.int64)
+    imu_t = np.sort(rng.integers(frame_t[0] - 50_000_000, frame_t[-1] + 50_000_000, 500)).astype(np.int64)
+    idx = np.zeros(imu_t.size, np.int32)
+    lib.hp_bias_index(C.c_int(imu_t.size), imu_t.ctypes.data_as(C.c_void_p), C.c_int(frame_t.size), frame_t.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(idx, pk.imu_bias_index(imu_t, frame_t))
+    chain = np.zeros((W, 6))
+    lib.hp_bias_chain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    lib.hp_bias_chain(imu_t.size, imu_t.ctypes.data, frame_t.size, frame_t.ctypes.data, 1e-4, 2e-3, chain.ctypes.data)
+    np.testing.assert_allclose(chain, pk.bias_chain_sqrt_info(imu_t, frame_t, 1e-4, 2e-3), rtol=1e-12)
+    assert lib.hp_opt_min_time(123_456_789, 3_000_000, 50_000_000) == pk.opt_min_time(123_456_789, 3_000_000, 50_000_000)
+    tracks = []
+    for _ in range(60):
+        n = int(rng.integers(1, 7)); s = int(rng.integers(0, W)); n = min(n, W + 1 - s)
+        pts = np.concatenate([rng.normal(0, 0.3, (n, 2)), np.ones((n, 1))], axis=1) * rng.uniform(0.5, 2.0)
+        uvp = np.stack([rng.uniform(0, 640, n), rng.integers(0, 960, n) * 0.5], axis=1)   # half-pixel rows exercise the rounding rule
+        tracks.append(dict(start_frame=s, points=pts, uv=uvp, depth=float(rng.uniform(-1, 8) or 1.0)))
+    ref = pk.pack_visual(tracks, frame_t, W)
+    n_obs = np.array([len(t["points"]) for t in tracks], np.int32)
+    start = np.array([t["start_frame"] for t in tracks], np.int32)
+    depth = np.array([t["depth"] for t in tracks])
+    points = np.concatenate([t["points"] for t in tracks]).astype(np.float64)
+    uvs = np.concatenate([t["uv"] for t in tracks]).astype(np.float64)
+    cap = int(n_obs.sum())
+    v_lm = np.zeros(cap, np.int32); v_ti = np.zeros(cap, np.int64); v_tj = np.zeros(cap, np.int64); v_ri = np.zeros(cap, np.int32); v_rj = np.zeros(cap, np.int32)
+    v_pi = np.zeros((cap, 2)); v_pj = np.zeros((cap, 2)); rho = np.zeros(len(tracks)); owner = np.zeros(len(tracks), np.int32); n_lm = C.c_int32(0)
+    lib.hp_pack_visual.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 11
+    V = lib.hp_pack_visual(len(tracks), n_obs.ctypes.data, start.ctypes.data, depth.ctypes.data, points.ctypes.data, uvs.ctypes.data, W, frame_t.ctypes.data,
+                           v_lm.ctypes.data, v_ti.ctypes.data, v_tj.ctypes.data, v_ri.ctypes.data, v_rj.ctypes.data, v_pi.ctypes.data, v_pj.ctypes.data,
+                           rho.ctypes.data, owner.ctypes.data, C.addressof(n_lm))
+    assert V == len(ref["v_lm"]) and n_lm.value == len(ref["rho"]) and V > 20
+    for got, key in ((v_lm, "v_lm"), (v_ti, "v_ti"), (v_tj, "v_tj"), (v_ri, "v_rowi"), (v_rj, "v_rowj")):
+        assert np.array_equal(got[:V], ref[key]), key
+    np.testing.assert_allclose(v_pi[:V], ref["v_pi"], rtol=1e-15); np.testing.assert_allclose(v_pj[:V], ref["v_pj"], rtol=1e-15)
+    np.testing.assert_allclose(rho[:n_lm.value], ref["rho"], rtol=1e-15)
+    assert np.array_equal(owner[:n_lm.value], ref["track_of_landmark"])
