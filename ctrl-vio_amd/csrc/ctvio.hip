@@ -79,6 +79,7 @@ struct SolverBase {
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
   virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
   virtual int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
+  virtual int bind() = 0;   // make the solver's device current on the calling thread (every ABI entry: callers use threads)
   virtual int snapshot(int restore) = 0;
   virtual int last_timing(double *ms8, int32_t *n8) = 0;
   virtual int set_profiling(int on) = 0;
@@ -108,6 +109,7 @@ template <class T> class SolverImpl : public SolverBase {
     if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
+  int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
   int clear() override { wins_.clear(); uploaded_ = false; return CTVIO_OK; }
   int num_windows() const override { return (int)wins_.size(); }
   void *stream() override { return (void *)stream_; }
@@ -900,7 +902,9 @@ int32_t ctvio_create(const ctvio_options *opt, ctvio_solver **out) {
   return CTVIO_OK;
 }
 void ctvio_destroy(ctvio_solver *s) { delete s; }
-#define CHK_S if (!s) return ctv::fail(CTVIO_ERR_INVALID, "null solver")
+// every entry point: null check, then the solver's device becomes current on this thread -- HIP's current device is per thread
+// (default 0), and a multi-GPU rank that drives several solver handles from worker threads would otherwise launch on device 0
+#define CHK_S if (!s) return ctv::fail(CTVIO_ERR_INVALID, "null solver"); if (int rc_bind_ = s->impl->bind()) return rc_bind_
 int32_t ctvio_clear(ctvio_solver *s) { CHK_S; return s->impl->clear(); }
 int32_t ctvio_add_window(ctvio_solver *s, const ctvio_window *w, int32_t *id) { CHK_S; return s->impl->add_window(w, id); }
 int32_t ctvio_upload(ctvio_solver *s) { CHK_S; return s->impl->upload(); }
