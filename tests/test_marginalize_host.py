@@ -122,3 +122,36 @@ def test_prior_chain_consistency_oracle():
     P = w.P
     assert np.abs(d_red[:P] - d_full[:P]).max() < 1e-8 * np.abs(d_full[:P]).max()
     assert np.abs(d_red[P:] - d_full[P + mapR]).max() < 1e-8 * np.abs(d_full[P:]).max()
+
+
+def test_marginalize_edge_cases(hostlib):
+    """m = 0 (nothing to drop: the prior is the factorisation of A itself), uninvolved unknowns (-1) ignored, an exactly
+    singular Amm (a marginalised unknown no factor touches) handled by the eps cut -- oracle and library alike."""
+    rng = np.random.default_rng(9)
+    N = 14
+    B = rng.normal(size=(N, N + 3))
+    H = B @ B.T
+    g = rng.normal(size=N)
+
+    def lib_marg(Hm, gv, role, eps=1e-8):
+        kept = np.zeros(N, np.int32); J0 = np.zeros(N * N); r0 = np.zeros(N)
+        Hc = np.ascontiguousarray(Hm); role = np.ascontiguousarray(role, np.int8)
+        n = hostlib.hm_marginalize_dense(N, Hc.ctypes.data, gv.ctypes.data, role.ctypes.data, eps, kept.ctypes.data, J0.ctypes.data, r0.ctypes.data)
+        return kept[:n], J0[:n * n].reshape(n, n), r0[:n]
+
+    role = np.zeros(N, np.int8)                                   # m = 0
+    k, J0, r0 = lib_marg(H, g, role)
+    assert k.tolist() == list(range(N))
+    np.testing.assert_allclose(J0.T @ J0, H, atol=1e-10 * np.abs(H).max())
+    np.testing.assert_allclose(J0.T @ r0, g, atol=1e-9)
+    role = np.array([1, 1, 0, 0, -1, 0, -1, 1, 0, 0, 0, -1, 0, 1], np.int8)   # mixed roles
+    k, J0, r0 = lib_marg(H, g, role)
+    ik, Jn, rn = numpy_marginalize(H, g, role, 1e-8)
+    assert np.array_equal(k, ik)
+    invariants_close(J0, r0, Jn, rn, 1e-9)
+    H2 = H.copy(); H2[0, :] = 0; H2[:, 0] = 0                       # marginalised unknown 0 untouched by any factor: Amm singular
+    g2 = g.copy(); g2[0] = 0
+    k, J0, r0 = lib_marg(H2, g2, role)
+    ik, Jn, rn = numpy_marginalize(H2, g2, role, 1e-8)
+    invariants_close(J0, r0, Jn, rn, 1e-9)
+    assert np.all(np.isfinite(J0)) and np.all(np.isfinite(r0))
