@@ -850,7 +850,12 @@ template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
 }
 template <> void SolverImpl<double>::launch_schur() {
   const Dev<double> &d = dev_;
-  hipLaunchKernelGGL((k_schur_generic<double>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
+  if (opt_.use_mfma) {   // fp64 matrix cores, one wave per 16 x 16 tile; k_rhs forms the reduced right-hand side
+    const int nt = (d.maxP + 15) / 16, ntile = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile);
+  } else {
+    hipLaunchKernelGGL((k_schur_generic<double>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
+  }
 }
 
 }  // namespace ctv

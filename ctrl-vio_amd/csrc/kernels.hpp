@@ -220,6 +220,7 @@ template <class T> struct ImuSplitSink {
 // The tile is stored, not accumulated -- no atomics, deterministic.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 // RT = scalar of the RESIDUAL (and of the cost kernels).  RT = double with T = float is the mixed mode: Jacobians,
 // J^T J and the Schur complement stay in fp32, but r (hence the gradient J^T r and every cost) is evaluated in fp64
 // from fp64 inputs, which removes the fp32 residual noise (~5e-5 sigma) from the LM decisions and the fixed point.
@@ -1426,6 +1427,70 @@ template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_wave
   }
 }
 
+// fp64 path: the same SYRK on the fp64 matrix cores, one wave per 16 x 16 tile of the lower triangle
+// (v_mfma_f64_16x16x4_f64: A operand lane l = X[k = l/16][i = l%16], B operand lane l = Y[k = l/16][j = l%16],
+// D register r of lane l = D[(l/16) + 4r][l%16]; measured with tools/mfma_f64_layout.hip).  Operands straight from W,
+// 16 landmarks (4 products) per trip with all loads of a trip in flight; the reduced rhs is left to k_rhs.
+__global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_max) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;     // tiles of one window on one XCD (see k_schur_mfma)
+  const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
+  if (w >= d.nwin) return;
+  if (d.lm[w].status) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int nt = (P + 15) / 16;
+  if (tile >= nt * (nt + 1) / 2) return;
+  int bi, bj;
+  tile_decode(tile, bi, bj);
+  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
+  const int i = min(16 * bi + l15, ldw - 1), j = min(16 * bj + l15, ldw - 1);
+  const double ai = (16 * bi + l15 < P && d.active[u0 + min(i, P - 1)]) ? 1.0 : 0.0;
+  const double aj = (16 * bj + l15 < P && d.active[u0 + min(j, P - 1)]) ? 1.0 : 0.0;
+  const double *Wp = d.W + m.W0;
+  const double *dinv = d.dinv + m.lm0;
+  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
+  const bool nz_i = (16 * bi < K6) || (P - 1 >= 16 * bi && P - 1 < 16 * bi + 16);
+  const bool nz_j = (16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16);
+  const int lend = (nz_i && nz_j) ? L : 0;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int l0 = 0; l0 < lend; l0 += 16) {
+    double wa[4], wb[4], dv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {   // unconditional loads on clamped rows, masked below
+      const int lc = min(l0 + 4 * s + q4, L - 1);
+      wa[s] = Wp[(long long)lc * ldw + i];
+      wb[s] = Wp[(long long)lc * ldw + j];
+      dv[s] = dinv[lc];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool lv = l0 + 4 * s + q4 < L;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s] * ai, lv ? wb[s] * aj * dv[s] : 0.0, acc, 0, 0, 0);
+    }
+  }
+  double *S = d.S + m.H0;
+  const double *H = d.Hpp + m.H0;
+  const int jj = 16 * bj + l15, jc = min(jj, P - 1);
+  const bool act_j = d.active[u0 + jc] != 0;
+  const double dd_j = d.dd[u0 + jc];
+  double hv[4];
+  unsigned char act_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ic = min(16 * bi + q4 + 4 * r, P - 1);
+    act_i[r] = d.active[u0 + ic];
+    hv[r] = H[(long long)ic * ldh + min(jc, ic)];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ii = 16 * bi + q4 + 4 * r;
+    if (ii < P && jj <= ii) {
+      const bool on = act_i[r] && act_j;
+      S[(long long)ii * ldh + jj] = on ? hv[r] - acc[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+    }
+  }
+}
+
 template <class T> __global__ void k_schur_generic(Dev<T> d) {
   const int w = blockIdx.y;
   if (d.lm[w].status) return;
@@ -1487,7 +1552,6 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
 // separate forward substitution; only the block back-substitution L^T x = y remains.  Result in delta[0..P).
 // MFMA register layout (measured, tools/mfma_f64_layout.hip): A operand lane l = A[l%16][l/16], B operand lane l =
 // B[l/16][l%16], D register r of lane l = D[(l/16) + 4r][l%16].
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // One elimination step of the fused factorisation / inversion (see k_cholesky_solve): s = a_j of lane C (two
 // v_readlane into a fixed SGPR pair), then a_c -= a_j s and x_c -= x_j s.  Written as one asm block so the broadcast
