@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libctvio.so")
-SRC = [os.path.join(_HERE, "csrc", f) for f in ("ctvio.hip", "kernels.hpp", "factors.hpp", "so3.hpp", "device_types.hpp", "marginalize.hpp")]
+SRC = [os.path.join(_HERE, "csrc", f) for f in ("ctvio.hip", "kernels.hpp", "factors.hpp", "so3.hpp", "device_types.hpp", "marginalize.hpp", "host_pack.hpp")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctvio.h")
 
 FP32, FP64 = 0, 1
@@ -38,7 +38,8 @@ class Options(C.Structure):
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("max_consecutive_invalid_steps", C.c_int32), ("fp64_residuals", C.c_int32)]
+                ("max_consecutive_invalid_steps", C.c_int32), ("fp64_residuals", C.c_int32), ("host_threads", C.c_int32),
+                ("use_graph", C.c_int32), ("line_search", C.c_int32)]
 
 
 class CWindow(C.Structure):
@@ -63,18 +64,19 @@ class CWindow(C.Structure):
 class Summary(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("num_successful", C.c_int32), ("num_unsuccessful", C.c_int32),
                 ("termination", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
-                ("final_radius", C.c_double)]
+                ("final_radius", C.c_double), ("num_line_search_steps", C.c_int32), ("num_line_search_reduced", C.c_int32)]
 
     def as_dict(self):
         return dict(iterations=self.iterations, num_successful=self.num_successful, num_unsuccessful=self.num_unsuccessful,
                     termination=TERMINATION.get(self.termination, "?"), initial_cost=self.initial_cost,
-                    final_cost=self.final_cost, final_radius=self.final_radius)
+                    final_cost=self.final_cost, final_radius=self.final_radius,
+                    num_line_search_steps=self.num_line_search_steps, num_line_search_reduced=self.num_line_search_reduced)
 
 
 # every symbol include/ctvio.h declares (tests check the .so exports all of them)
 SYMBOLS = ["ctvio_default_options", "ctvio_status_string", "ctvio_last_error", "ctvio_device_count", "ctvio_create",
-           "ctvio_destroy", "ctvio_clear", "ctvio_add_window", "ctvio_upload", "ctvio_num_windows", "ctvio_solve",
-           "ctvio_get_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_gauge_restore", "ctvio_marginalize",
+           "ctvio_destroy", "ctvio_clear", "ctvio_add_window", "ctvio_upload", "ctvio_set_batch", "ctvio_num_windows", "ctvio_solve",
+           "ctvio_get_state", "ctvio_get_batch_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_gauge_restore", "ctvio_marginalize",
            "ctvio_last_timing", "ctvio_set_profiling", "ctvio_stream"]
 
 _lib = None
@@ -95,6 +97,8 @@ def load_library():
         for name in ("ctvio_clear", "ctvio_upload", "ctvio_num_windows", "ctvio_snapshot_state", "ctvio_restore_state"):
             getattr(lib, name).argtypes = [C.c_void_p]
         lib.ctvio_add_window.argtypes = [C.c_void_p, C.POINTER(CWindow), C.POINTER(C.c_int32)]
+        lib.ctvio_set_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.ctvio_get_batch_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         lib.ctvio_solve.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.ctvio_get_state.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
         lib.ctvio_set_state.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_double]

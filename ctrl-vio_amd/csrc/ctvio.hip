@@ -21,6 +21,7 @@
 #include "../../include/ctvio.h"
 #include "kernels.hpp"
 #include "marginalize.hpp"
+#include "host_pack.hpp"
 
 namespace ctv {
 
@@ -51,27 +52,43 @@ template <class U> struct DBuf {
   }
 };
 
-// Host copy of one window (caller buffers are only read inside ctvio_add_window).
+// Owning host copy of one window (ctvio_add_window: the caller's buffers are only read inside that call).
 struct HostWindow {
-  ctvio_window w;  // scalars; pointers unused
+  ctvio_window w;  // scalars + pointers into the vectors below
   std::vector<double> quat, pos, bias, rho, imu_gyro, imu_acc, bc_w, v_pi, v_pj, pJ0, pr0, p_x0;
   std::vector<int64_t> imu_t, v_ti, v_tj;
   std::vector<int32_t> imu_bias, bc_i, bc_j, v_lm, v_rowi, v_rowj, p_kind, p_index, p_off;
+  template <class U> static const U *own(std::vector<U> &dst, const U *src, size_t n) {
+    if (src) dst.assign(src, src + n); else dst.assign(n, U(0));
+    return dst.data();
+  }
+  explicit HostWindow(const ctvio_window &c) : w(c) {
+    w.quat = own(quat, c.quat, (size_t)4 * c.K); w.pos = own(pos, c.pos, (size_t)3 * c.K);
+    w.bias = own(bias, c.bias, (size_t)6 * c.F); w.rho = own(rho, c.rho, (size_t)c.L);
+    w.imu_t = own(imu_t, c.imu_t, (size_t)c.M); w.imu_gyro = own(imu_gyro, c.imu_gyro, (size_t)3 * c.M);
+    w.imu_acc = own(imu_acc, c.imu_acc, (size_t)3 * c.M); w.imu_bias = own(imu_bias, c.imu_bias, (size_t)c.M);
+    w.bc_i = own(bc_i, c.bc_i, (size_t)c.NB); w.bc_j = own(bc_j, c.bc_j, (size_t)c.NB); w.bc_w = own(bc_w, c.bc_w, (size_t)6 * c.NB);
+    w.v_lm = own(v_lm, c.v_lm, (size_t)c.V); w.v_ti = own(v_ti, c.v_ti, (size_t)c.V); w.v_tj = own(v_tj, c.v_tj, (size_t)c.V);
+    w.v_rowi = own(v_rowi, c.v_rowi, (size_t)c.V); w.v_rowj = own(v_rowj, c.v_rowj, (size_t)c.V);
+    w.v_pi = own(v_pi, c.v_pi, (size_t)2 * c.V); w.v_pj = own(v_pj, c.v_pj, (size_t)2 * c.V);
+    w.pJ0 = own(pJ0, c.pJ0, (size_t)c.pn * c.pn); w.pr0 = own(pr0, c.pr0, (size_t)c.pn);
+    w.p_kind = own(p_kind, c.p_kind, (size_t)c.pnb); w.p_index = own(p_index, c.p_index, (size_t)c.pnb);
+    w.p_off = own(p_off, c.p_off, (size_t)c.pnb); w.p_x0 = own(p_x0, c.p_x0, (size_t)4 * c.pnb);
+  }
+  HostWindow(const HostWindow &) = delete;
+  HostWindow &operator=(const HostWindow &) = delete;
 };
-
-template <class U> static void copy_in(std::vector<U> &dst, const U *src, size_t n) {
-  dst.assign(src ? src : nullptr, src ? src + n : nullptr);
-  if (!src) dst.assign(n, U(0));
-}
 
 struct SolverBase {
   virtual ~SolverBase() {}
   virtual int clear() = 0;
   virtual int add_window(const ctvio_window *w, int32_t *id) = 0;
   virtual int upload() = 0;
+  virtual int set_batch(int n, const ctvio_window *wins) = 0;
   virtual int num_windows() const = 0;
   virtual int solve(int max_iters, ctvio_summary *out) = 0;
   virtual int get_state(int id, double *quat, double *pos, double *bias, double *rho, double *ld) = 0;
+  virtual int get_batch_state(double *quat, double *pos, double *bias, double *rho, double *ld) = 0;
   virtual int set_state(int id, const double *quat, const double *pos, const double *bias, const double *rho, double ld) = 0;
   virtual int linearize(int id, double *Hpp, double *W, double *Hll, double *g, double *cost) = 0;
   virtual int cost(int id, double *cost) = 0;
@@ -86,8 +103,6 @@ struct SolverBase {
   virtual void *stream() = 0;
 };
 
-static int prior_block_size(int kind) { return kind == CTVIO_PK_LD ? 1 : 3; }
-
 template <class T> class SolverImpl : public SolverBase {
  public:
   static constexpr int VCH = 16;   // visual blocks per work item (k_assemble_vis): with the fp64 LDS accumulators 16 leaves room for 8 staging areas
@@ -97,6 +112,9 @@ template <class T> class SolverImpl : public SolverBase {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto &e : pev_) (void)hipEventDestroy(e);
+    if (lm_host_) (void)hipHostFree(lm_host_);
+    if (state_host_) (void)hipHostFree(state_host_);
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
   }
   int init() {
     HIPCHK(hipSetDevice(opt_.device));
@@ -110,87 +128,68 @@ template <class T> class SolverImpl : public SolverBase {
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
-  int clear() override { wins_.clear(); uploaded_ = false; return CTVIO_OK; }
-  int num_windows() const override { return (int)wins_.size(); }
+  int clear() override { own_.clear(); uploaded_ = false; return CTVIO_OK; }
+  int num_windows() const override { return uploaded_ ? (int)meta_.size() : (int)own_.size(); }
   void *stream() override { return (void *)stream_; }
 
   int add_window(const ctvio_window *w, int32_t *id) override {
-    if (!w) return fail(CTVIO_ERR_INVALID, "null window");
-    if (w->K < 4 || w->F < 1 || w->L < 0 || w->M < 0 || w->NB < 0 || w->V < 0 || w->dt_ns <= 0)
-      return fail(CTVIO_ERR_INVALID, "bad sizes (need K >= 4, F >= 1, dt_ns > 0)");
-    if (!w->quat || !w->pos || !w->bias || (w->L && !w->rho)) return fail(CTVIO_ERR_INVALID, "null state pointer");
-    HostWindow h;
-    h.w = *w;
-    copy_in(h.quat, w->quat, (size_t)4 * w->K); copy_in(h.pos, w->pos, (size_t)3 * w->K);
-    copy_in(h.bias, w->bias, (size_t)6 * w->F); copy_in(h.rho, w->rho, (size_t)w->L);
-    copy_in(h.imu_t, w->imu_t, (size_t)w->M); copy_in(h.imu_gyro, w->imu_gyro, (size_t)3 * w->M);
-    copy_in(h.imu_acc, w->imu_acc, (size_t)3 * w->M); copy_in(h.imu_bias, w->imu_bias, (size_t)w->M);
-    copy_in(h.bc_i, w->bc_i, (size_t)w->NB); copy_in(h.bc_j, w->bc_j, (size_t)w->NB); copy_in(h.bc_w, w->bc_w, (size_t)6 * w->NB);
-    copy_in(h.v_lm, w->v_lm, (size_t)w->V); copy_in(h.v_ti, w->v_ti, (size_t)w->V); copy_in(h.v_tj, w->v_tj, (size_t)w->V);
-    copy_in(h.v_rowi, w->v_rowi, (size_t)w->V); copy_in(h.v_rowj, w->v_rowj, (size_t)w->V);
-    copy_in(h.v_pi, w->v_pi, (size_t)2 * w->V); copy_in(h.v_pj, w->v_pj, (size_t)2 * w->V);
-    copy_in(h.pJ0, w->pJ0, (size_t)w->pn * w->pn); copy_in(h.pr0, w->pr0, (size_t)w->pn);
-    copy_in(h.p_kind, w->p_kind, (size_t)w->pnb); copy_in(h.p_index, w->p_index, (size_t)w->pnb);
-    copy_in(h.p_off, w->p_off, (size_t)w->pnb); copy_in(h.p_x0, w->p_x0, (size_t)4 * w->pnb);
-    // ---- validation (the reference asserts / prints: spline_segment.h:74-81)
-    const int64_t tmax = w->t0_ns + (int64_t)(w->K - 3) * w->dt_ns;
-    for (int m = 0; m < w->M; ++m) {
-      if (h.imu_t[m] < w->t0_ns || h.imu_t[m] >= tmax) return fail(CTVIO_ERR_INVALID, "IMU time outside the spline");
-      if (h.imu_bias[m] < 0 || h.imu_bias[m] >= w->F) return fail(CTVIO_ERR_INVALID, "IMU bias index out of range");
-    }
-    const int64_t ldmax_ns = (int64_t)((w->fix_ld ? w->ld : std::max(w->ld, w->ld_hi)) * 1e9);
-    for (int v = 0; v < w->V; ++v) {
-      if (h.v_lm[v] < 0 || h.v_lm[v] >= w->L) return fail(CTVIO_ERR_INVALID, "visual landmark index out of range");
-      if (h.v_rowi[v] < 0 || h.v_rowj[v] < 0) return fail(CTVIO_ERR_INVALID, "negative image row");
-      const int64_t a = h.v_ti[v], b = h.v_tj[v];
-      if (a < w->t0_ns || b < w->t0_ns || a + h.v_rowi[v] * ldmax_ns >= tmax || b + h.v_rowj[v] * ldmax_ns >= tmax)
-        return fail(CTVIO_ERR_INVALID, "visual time (+ row * line delay) outside the spline");
-    }
-    for (int b = 0; b < w->NB; ++b)
-      if (h.bc_i[b] < 0 || h.bc_i[b] >= w->F || h.bc_j[b] < 0 || h.bc_j[b] >= w->F) return fail(CTVIO_ERR_INVALID, "bias chain index out of range");
-    for (int b = 0; b < w->pnb; ++b) {
-      const int kind = h.p_kind[b], idx = h.p_index[b];
-      const int lim = (kind <= CTVIO_PK_POS) ? w->K : (kind <= CTVIO_PK_BA ? w->F : 1);
-      if (kind < 0 || kind > CTVIO_PK_LD || idx < 0 || idx >= lim || h.p_off[b] < 0 || h.p_off[b] + prior_block_size(kind) > w->pn)
-        return fail(CTVIO_ERR_INVALID, "prior block out of range");
-    }
-    if (!w->fix_ld) h.w.ld = std::min(std::max(w->ld, w->ld_lo), w->ld_hi);  // Ceres IterationZero: project on the feasible set
-    wins_.push_back(std::move(h));
-    if (id) *id = (int32_t)wins_.size() - 1;
+    std::string err;
+    if (!validate_window(w, err)) return fail(CTVIO_ERR_INVALID, err);
+    own_.emplace_back(new HostWindow(*w));
+    if (id) *id = (int32_t)own_.size() - 1;
     uploaded_ = false;
     return CTVIO_OK;
   }
+  int upload() override {
+    if (own_.empty()) return fail(CTVIO_ERR_STATE, "no windows");
+    std::vector<const ctvio_window *> ptr(own_.size());
+    for (size_t i = 0; i < own_.size(); ++i) ptr[i] = &own_[i]->w;
+    return pack_and_upload(ptr, false);
+  }
+  // ctvio_set_batch: the windows are read straight from the caller's buffers (no intermediate copy)
+  int set_batch(int n, const ctvio_window *wins) override {
+    if (n <= 0 || !wins) return fail(CTVIO_ERR_INVALID, "empty batch");
+    own_.clear();
+    uploaded_ = false;
+    std::vector<const ctvio_window *> ptr((size_t)n);
+    for (int i = 0; i < n; ++i) ptr[i] = wins + i;
+    return pack_and_upload(ptr, true);
+  }
 
   // ---------------------------------------------------------------------------------------- pack + upload
-  int upload() override {
-    const int nw = (int)wins_.size();
-    if (nw == 0) return fail(CTVIO_ERR_STATE, "no windows");
+  // Two passes over the windows, both spread over host threads: (1) validate, sort, count; (2) fill the pinned staging
+  // arena, which mirrors the device input arena byte for byte -- one hipMemcpyAsync carries the batch to HBM.  Work
+  // buffers live in a second, device-only arena.  Both arenas only ever grow, so a stream of equally sized batches
+  // allocates nothing after the first one.
+  int pack_and_upload(const std::vector<const ctvio_window *> &wins, bool validate) {
+    const int nw = (int)wins.size();
+    const int nth = host_threads(opt_.host_threads);
+    std::vector<PackTmp> tmp((size_t)nw);
+    std::atomic<int> first_bad{nw};
+    parallel_for(nw, nth, [&](int wi) {
+      if (validate && !validate_window(wins[wi], tmp[wi].err)) {
+        int cur = first_bad.load();
+        while (wi < cur && !first_bad.compare_exchange_weak(cur, wi)) {}
+        return;
+      }
+      plan_window(wins[wi], VCH, tmp[wi]);
+    });
+    if (first_bad.load() < nw) return fail(CTVIO_ERR_INVALID, "window " + std::to_string(first_bad.load()) + ": " + tmp[first_bad.load()].err);
+    // ---- offsets (serial prefix sums)
     meta_.assign(nw, WinMeta());
-    std::vector<double> quat, pos, bias, rho, ld, bc_w, pH, pb0, pc0(nw, 0.0), p_x0;
-    std::vector<int32_t> knot_win, bias_win, lm_win, imu_grp, v_win, v_lm, v_rowi, v_rowj, bc_win, bc_i, bc_j, pcol, p_kind, p_index, p_off;
-    std::vector<int64_t> v_ti, v_tj;
-    std::vector<ImuGroup> groups;
-    std::vector<VisItem> vitems;
-    std::vector<int32_t> lm_blk_off, lm_blk;
-    int maxL = 0, maxLdw = 0;
-    size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
-    std::vector<T> imu_u;
-    std::vector<double> imu_ud;
-    std::vector<uint8_t> active;
+    t0_.resize(nw);
     int64_t H0 = 0, W0 = 0, pH0 = 0;
-    int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0;
-    int maxN = 0, maxP = 0, maxPn = 0;
-    Mtot_ = 0; Vtot_ = 0;
-    for (const auto &h : wins_) { Mtot_ += h.w.M; Vtot_ += h.w.V; }
-    std::vector<T> imu_meas((size_t)6 * std::max(Mtot_, 1)), v_obs((size_t)4 * std::max(Vtot_, 1));
-    std::vector<double> imu_meas_d((size_t)6 * std::max(Mtot_, 1)), v_obs_d((size_t)4 * std::max(Vtot_, 1));
+    int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0;
+    int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0;
+    size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     for (int wi = 0; wi < nw; ++wi) {
-      const HostWindow &h = wins_[wi];
-      const ctvio_window &w = h.w;
+      const ctvio_window &w = *wins[wi];
       WinMeta &m = meta_[wi];
+      t0_[wi] = w.t0_ns;
       m.K = w.K; m.F = w.F; m.L = w.L; m.M = w.M; m.NB = w.NB; m.V = w.V;
       m.P = 6 * w.K + 6 * w.F + 1; m.N = m.P + w.L; m.pn = w.pn; m.pnb = w.pnb;
       m.knot0 = K0; m.bias0 = F0; m.lm0 = L0; m.imu0 = M0; m.vis0 = V0; m.bc0 = B0; m.u0 = U0; m.p0 = Pp0;
+      m.grp0 = G0; m.ngrp = tmp[wi].ngrp; m.vitem0 = I0; m.nvitem = tmp[wi].nvitem;
       m.ldw = (m.P + 1 + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
       m.pv0 = pv0; m.pblk0 = pb; m.fix_ld = w.fix_ld; m.lock_bg = w.lock_bg; m.lock_ba = w.lock_ba; m.fixed_upto = w.fixed_upto;
       m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.ldh = (m.P + 15) / 16 * 16; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
@@ -198,73 +197,6 @@ template <class T> class SolverImpl : public SolverBase {
       for (int i = 0; i < 3; ++i) { m.p_CI[i] = w.p_CI[i]; m.gravity[i] = w.gravity[i]; }
       for (int i = 0; i < 6; ++i) m.imu_w[i] = w.imu_w[i];
       m.img_w = w.img_w; m.cauchy_a = w.cauchy_a; m.ld_lo = w.ld_lo; m.ld_hi = w.ld_hi;
-      // state
-      quat.insert(quat.end(), h.quat.begin(), h.quat.end()); pos.insert(pos.end(), h.pos.begin(), h.pos.end());
-      bias.insert(bias.end(), h.bias.begin(), h.bias.end()); rho.insert(rho.end(), h.rho.begin(), h.rho.end());
-      ld.push_back(w.ld);
-      knot_win.insert(knot_win.end(), w.K, wi); bias_win.insert(bias_win.end(), w.F, wi); lm_win.insert(lm_win.end(), w.L, wi);
-      // IMU: sort by (segment, bias) and cut into groups
-      std::vector<int> order(w.M), seg(w.M);
-      std::vector<double> uu(w.M);
-      for (int i = 0; i < w.M; ++i) {
-        const int64_t st = h.imu_t[i] - w.t0_ns;
-        seg[i] = (int)(st / w.dt_ns);
-        uu[i] = (double)(st % w.dt_ns) / (double)w.dt_ns;
-        order[i] = i;
-      }
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (seg[a] != seg[b]) return seg[a] < seg[b];
-        return h.imu_bias[a] < h.imu_bias[b];
-      });
-      m.grp0 = (int)groups.size();
-      for (int i = 0; i < w.M; ++i) {
-        const int src = order[i];
-        if (i == 0 || seg[src] != seg[order[i - 1]] || h.imu_bias[src] != h.imu_bias[order[i - 1]])
-          groups.push_back(ImuGroup{wi, seg[src], h.imu_bias[src], i, 0});
-        groups.back().count++;
-        imu_grp.push_back((int)groups.size() - 1);
-        imu_u.push_back((T)uu[src]);
-        imu_ud.push_back(uu[src]);
-        for (int c = 0; c < 3; ++c) {
-          imu_meas[(size_t)c * Mtot_ + M0 + i] = (T)h.imu_gyro[3 * src + c];
-          imu_meas[(size_t)(3 + c) * Mtot_ + M0 + i] = (T)h.imu_acc[3 * src + c];
-          imu_meas_d[(size_t)c * Mtot_ + M0 + i] = h.imu_gyro[3 * src + c];
-          imu_meas_d[(size_t)(3 + c) * Mtot_ + M0 + i] = h.imu_acc[3 * src + c];
-        }
-      }
-      m.ngrp = (int)groups.size() - m.grp0;
-      // visual: sort by frame pair (then rows) so that consecutive blocks hit the same knot quadruples, cut into items
-      std::vector<int> vord(w.V);
-      std::iota(vord.begin(), vord.end(), 0);
-      std::stable_sort(vord.begin(), vord.end(), [&](int a, int b) {
-        if (h.v_ti[a] != h.v_ti[b]) return h.v_ti[a] < h.v_ti[b];
-        if (h.v_tj[a] != h.v_tj[b]) return h.v_tj[a] < h.v_tj[b];
-        if (h.v_rowi[a] != h.v_rowi[b]) return h.v_rowi[a] < h.v_rowi[b];
-        return h.v_rowj[a] < h.v_rowj[b];
-      });
-      m.vitem0 = (int)vitems.size();
-      for (int i = 0; i < w.V; ++i) {
-        const int v = vord[i];
-        const bool fresh = (i == 0) || h.v_ti[v] != h.v_ti[vord[i - 1]] || h.v_tj[v] != h.v_tj[vord[i - 1]] || vitems.back().count >= VCH;
-        if (fresh) vitems.push_back(VisItem{V0 + i, 0});
-        vitems.back().count++;
-        v_win.push_back(wi); v_lm.push_back(h.v_lm[v]);
-        v_ti.push_back(h.v_ti[v] - w.t0_ns); v_tj.push_back(h.v_tj[v] - w.t0_ns);
-        v_rowi.push_back(h.v_rowi[v]); v_rowj.push_back(h.v_rowj[v]);
-        v_obs[(size_t)0 * Vtot_ + V0 + i] = (T)h.v_pi[2 * v]; v_obs[(size_t)1 * Vtot_ + V0 + i] = (T)h.v_pi[2 * v + 1];
-        v_obs[(size_t)2 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v]; v_obs[(size_t)3 * Vtot_ + V0 + i] = (T)h.v_pj[2 * v + 1];
-        v_obs_d[(size_t)0 * Vtot_ + V0 + i] = h.v_pi[2 * v]; v_obs_d[(size_t)1 * Vtot_ + V0 + i] = h.v_pi[2 * v + 1];
-        v_obs_d[(size_t)2 * Vtot_ + V0 + i] = h.v_pj[2 * v]; v_obs_d[(size_t)3 * Vtot_ + V0 + i] = h.v_pj[2 * v + 1];
-      }
-      m.nvitem = (int)vitems.size() - m.vitem0;
-      {  // CSR landmark -> blocks (positions in the sorted order)
-        std::vector<std::vector<int>> per(w.L);
-        for (int i = 0; i < w.V; ++i) per[h.v_lm[vord[i]]].push_back(V0 + i);
-        for (int l = 0; l < w.L; ++l) {
-          lm_blk_off.push_back((int)lm_blk.size());
-          lm_blk.insert(lm_blk.end(), per[l].begin(), per[l].end());
-        }
-      }
       {
         const size_t K6 = 6 * (size_t)w.K, nG = K6 + 1, nH = K6 * (K6 + 1) / 2 + K6 + 1 + nG;
         const size_t need = ((nH + 3) & ~(size_t)3) * sizeof(double) + 32 + vis_stage_bytes();   // fp64 accumulators in LDS
@@ -273,15 +205,126 @@ template <class T> class SolverImpl : public SolverBase {
         vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : need_glb);
         vis_glb_bytes = std::max(vis_glb_bytes, need_glb);
       }
-      // bias chain
-      for (int b = 0; b < w.NB; ++b) { bc_win.push_back(wi); bc_i.push_back(h.bc_i[b]); bc_j.push_back(h.bc_j[b]); }
-      bc_w.insert(bc_w.end(), h.bc_w.begin(), h.bc_w.end());
+      K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += w.V; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += w.pn; pb += w.pnb;
+      G0 += m.ngrp; I0 += m.nvitem;
+      H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)w.pn * w.pn;
+      maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, w.pn);
+      maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw);
+    }
+    const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
+    if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
+    const size_t Mt = (size_t)std::max(M0, 1), Vt = (size_t)std::max(V0, 1);
+    Mtot_ = M0; Vtot_ = V0;
+    // ---- input arena layout (host mirror + device)
+    size_t off = 0;
+    auto seg = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_meta = seg(sizeof(WinMeta) * nw);
+    const size_t o_state = seg(sizeof(double) * ((size_t)7 * K0 + 6 * F0 + L0 + nw));   // quat | pos | bias | rho | ld, contiguous
+    const size_t o_knot_win = seg(4 * (size_t)K0), o_bias_win = seg(4 * (size_t)F0), o_lm_win = seg(4 * (size_t)L0);
+    const size_t o_groups = seg(sizeof(ImuGroup) * (size_t)G0), o_imu_grp = seg(4 * Mt);
+    const size_t o_imu_u = seg(sizeof(T) * Mt), o_imu_meas = seg(sizeof(T) * 6 * Mt);
+    const bool dup64 = sizeof(T) == 4;   // the mixed mode keeps an fp64 copy of the measurements for its residual pass
+    const size_t o_imu_ud = dup64 ? seg(8 * Mt) : o_imu_u, o_imu_meas_d = dup64 ? seg(8 * 6 * Mt) : o_imu_meas;
+    const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_rowi = seg(4 * Vt), o_v_rowj = seg(4 * Vt), o_v_slot = seg(4 * Vt);
+    const size_t o_v_ti = seg(8 * Vt), o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(T) * 4 * Vt);
+    const size_t o_v_obs_d = dup64 ? seg(8 * 4 * Vt) : o_v_obs;
+    const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_lm_blk_off = seg(4 * ((size_t)L0 + 1)), o_lm_blk = seg(4 * Vt);
+    const size_t o_bc_win = seg(4 * (size_t)B0), o_bc_i = seg(4 * (size_t)B0), o_bc_j = seg(4 * (size_t)B0), o_bc_w = seg(8 * 6 * (size_t)B0);
+    const size_t o_pH = seg(8 * (size_t)pH0), o_pb0 = seg(8 * (size_t)pv0), o_pc0 = seg(8 * (size_t)nw), o_p_x0 = seg(8 * 4 * (size_t)pb);
+    const size_t o_pcol = seg(4 * (size_t)pv0), o_p_kind = seg(4 * (size_t)pb), o_p_index = seg(4 * (size_t)pb), o_p_off = seg(4 * (size_t)pb);
+    const size_t o_active = seg((size_t)U0);
+    const size_t in_bytes = off;
+    bool grew = false;
+    HIPCHK(hipStreamSynchronize(stream_));   // the previous batch may still be reading the staging arena (H2D in flight)
+    HIPCHK(in_.reserve(in_bytes, true, &grew));
+    char *hb = in_.host, *db = in_.dev;
+#define CTV_H(type, o) reinterpret_cast<type *>(hb + (o))
+#define CTV_D(type, o) reinterpret_cast<type *>(db + (o))
+    std::memcpy(CTV_H(WinMeta, o_meta), meta_.data(), sizeof(WinMeta) * nw);
+    double *h_quat = CTV_H(double, o_state), *h_pos = h_quat + (size_t)4 * K0, *h_bias = h_pos + (size_t)3 * K0, *h_rho = h_bias + (size_t)6 * F0,
+           *h_ld = h_rho + L0;
+    int32_t *h_knot_win = CTV_H(int32_t, o_knot_win), *h_bias_win = CTV_H(int32_t, o_bias_win), *h_lm_win = CTV_H(int32_t, o_lm_win);
+    ImuGroup *h_groups = CTV_H(ImuGroup, o_groups);
+    int32_t *h_imu_grp = CTV_H(int32_t, o_imu_grp);
+    T *h_imu_u = CTV_H(T, o_imu_u), *h_imu_meas = CTV_H(T, o_imu_meas), *h_v_obs = CTV_H(T, o_v_obs);
+    double *h_imu_ud = CTV_H(double, o_imu_ud), *h_imu_meas_d = CTV_H(double, o_imu_meas_d), *h_v_obs_d = CTV_H(double, o_v_obs_d);
+    int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_rowi = CTV_H(int32_t, o_v_rowi), *h_v_rowj = CTV_H(int32_t, o_v_rowj),
+            *h_v_slot = CTV_H(int32_t, o_v_slot);
+    int64_t *h_v_ti = CTV_H(int64_t, o_v_ti), *h_v_tj = CTV_H(int64_t, o_v_tj);
+    VisItem *h_vitems = CTV_H(VisItem, o_vitems);
+    int32_t *h_lm_blk_off = CTV_H(int32_t, o_lm_blk_off), *h_lm_blk = CTV_H(int32_t, o_lm_blk);
+    int32_t *h_bc_win = CTV_H(int32_t, o_bc_win), *h_bc_i = CTV_H(int32_t, o_bc_i), *h_bc_j = CTV_H(int32_t, o_bc_j);
+    double *h_bc_w = CTV_H(double, o_bc_w), *h_pH = CTV_H(double, o_pH), *h_pb0 = CTV_H(double, o_pb0), *h_pc0 = CTV_H(double, o_pc0),
+           *h_p_x0 = CTV_H(double, o_p_x0);
+    int32_t *h_pcol = CTV_H(int32_t, o_pcol), *h_p_kind = CTV_H(int32_t, o_p_kind), *h_p_index = CTV_H(int32_t, o_p_index), *h_p_off = CTV_H(int32_t, o_p_off);
+    uint8_t *h_active = CTV_H(uint8_t, o_active);
+    h_lm_blk_off[L0] = V0;
+    // ---- second pass: every window fills its own slices
+    parallel_for(nw, nth, [&](int wi) {
+      const ctvio_window &w = *wins[wi];
+      const WinMeta &m = meta_[wi];
+      const PackTmp &t = tmp[wi];
+      std::memcpy(h_quat + (size_t)4 * m.knot0, w.quat, sizeof(double) * 4 * w.K);
+      std::memcpy(h_pos + (size_t)3 * m.knot0, w.pos, sizeof(double) * 3 * w.K);
+      std::memcpy(h_bias + (size_t)6 * m.bias0, w.bias, sizeof(double) * 6 * w.F);
+      if (w.L) std::memcpy(h_rho + m.lm0, w.rho, sizeof(double) * w.L);
+      h_ld[wi] = w.fix_ld ? w.ld : std::min(std::max(w.ld, w.ld_lo), w.ld_hi);   // Ceres IterationZero: project on the feasible set
+      std::fill(h_knot_win + m.knot0, h_knot_win + m.knot0 + w.K, wi);
+      std::fill(h_bias_win + m.bias0, h_bias_win + m.bias0 + w.F, wi);
+      std::fill(h_lm_win + m.lm0, h_lm_win + m.lm0 + w.L, wi);
+      // IMU samples in (segment, bias) order; groups = runs of equal (segment, bias)
+      int g = m.grp0 - 1;
+      for (int i = 0; i < w.M; ++i) {
+        const int src = t.iorder[i];
+        if (i == 0 || t.iseg[src] != t.iseg[t.iorder[i - 1]] || w.imu_bias[src] != w.imu_bias[t.iorder[i - 1]])
+          h_groups[++g] = ImuGroup{wi, t.iseg[src], w.imu_bias[src], i, 0};
+        h_groups[g].count++;
+        const size_t e = (size_t)m.imu0 + i;
+        h_imu_grp[e] = g;
+        const int64_t st = w.imu_t[src] - w.t0_ns;
+        const double uu = (double)(st % w.dt_ns) / (double)w.dt_ns;
+        h_imu_u[e] = (T)uu;
+        if (dup64) h_imu_ud[e] = uu;
+        for (int c = 0; c < 3; ++c) {
+          h_imu_meas[(size_t)c * Mt + e] = (T)w.imu_gyro[3 * src + c];
+          h_imu_meas[(size_t)(3 + c) * Mt + e] = (T)w.imu_acc[3 * src + c];
+          if (dup64) { h_imu_meas_d[(size_t)c * Mt + e] = w.imu_gyro[3 * src + c]; h_imu_meas_d[(size_t)(3 + c) * Mt + e] = w.imu_acc[3 * src + c]; }
+        }
+      }
+      // visual blocks in frame-pair order, items of <= VCH blocks
+      int it = m.vitem0 - 1;
+      for (int i = 0; i < w.V; ++i) {
+        const int v = t.vord[i];
+        const bool fresh = (i == 0) || w.v_ti[v] != w.v_ti[t.vord[i - 1]] || w.v_tj[v] != w.v_tj[t.vord[i - 1]] || h_vitems[it].count >= VCH;
+        if (fresh) h_vitems[++it] = VisItem{m.vis0 + i, 0};
+        h_vitems[it].count++;
+        const size_t e = (size_t)m.vis0 + i;
+        h_v_win[e] = wi; h_v_lm[e] = w.v_lm[v];
+        h_v_ti[e] = w.v_ti[v] - w.t0_ns; h_v_tj[e] = w.v_tj[v] - w.t0_ns;
+        h_v_rowi[e] = w.v_rowi[v]; h_v_rowj[e] = w.v_rowj[v];
+        const double o4[4] = {w.v_pi[2 * v], w.v_pi[2 * v + 1], w.v_pj[2 * v], w.v_pj[2 * v + 1]};
+        for (int c = 0; c < 4; ++c) { h_v_obs[(size_t)c * Vt + e] = (T)o4[c]; if (dup64) h_v_obs_d[(size_t)c * Vt + e] = o4[c]; }
+      }
+      {  // CSR landmark -> blocks (positions in the sorted order); v_slot = position of a block in the CSR list
+        std::vector<int32_t> cnt((size_t)w.L + 1, 0);
+        for (int i = 0; i < w.V; ++i) cnt[w.v_lm[t.vord[i]] + 1]++;
+        for (int l = 0; l < w.L; ++l) { cnt[l + 1] += cnt[l]; h_lm_blk_off[m.lm0 + l] = m.vis0 + cnt[l]; }
+        for (int i = 0; i < w.V; ++i) {
+          const int l = w.v_lm[t.vord[i]];
+          const int p = m.vis0 + cnt[l]++;
+          h_lm_blk[p] = m.vis0 + i;
+          h_v_slot[m.vis0 + i] = p;
+        }
+      }
+      for (int b = 0; b < w.NB; ++b) { h_bc_win[m.bc0 + b] = wi; h_bc_i[m.bc0 + b] = w.bc_i[b]; h_bc_j[m.bc0 + b] = w.bc_j[b]; }
+      if (w.NB) std::memcpy(h_bc_w + (size_t)6 * m.bc0, w.bc_w, sizeof(double) * 6 * w.NB);
       // prior: J0^T J0 (row-major n*n), J0^T r0, r0^T r0 in fp64; J0 is column-major (Eigen)
       const int n = w.pn;
+      h_pc0[wi] = 0.0;
+      int32_t *col = h_pcol + m.pv0;
       if (n > 0) {
-        std::vector<int32_t> col(n, -1);
         for (int b = 0; b < w.pnb; ++b) {
-          const int kind = h.p_kind[b], idx = h.p_index[b];
+          const int kind = w.p_kind[b], idx = w.p_index[b];
           int u0 = 0;
           switch (kind) {
             case CTVIO_PK_ROT: u0 = 6 * idx; break;
@@ -290,120 +333,88 @@ template <class T> class SolverImpl : public SolverBase {
             case CTVIO_PK_BA: u0 = 6 * w.K + 6 * idx + 3; break;
             default: u0 = m.P - 1;
           }
-          for (int k = 0; k < prior_block_size(kind); ++k) col[h.p_off[b] + k] = u0 + k;
+          for (int k = 0; k < prior_block_size(kind); ++k) col[w.p_off[b] + k] = u0 + k;
         }
-        pcol.insert(pcol.end(), col.begin(), col.end());
+        double *pH = h_pH + m.pH0, *pb0 = h_pb0 + m.pv0;
         for (int i = 0; i < n; ++i) {
+          const double *Ji = w.pJ0 + (size_t)i * n;
           double bi = 0;
-          for (int r = 0; r < n; ++r) bi += h.pJ0[(size_t)i * n + r] * h.pr0[r];
-          pb0.push_back(bi);
-          for (int j = 0; j < n; ++j) {
+          for (int r = 0; r < n; ++r) bi += Ji[r] * w.pr0[r];
+          pb0[i] = bi;
+          for (int j = 0; j <= i; ++j) {
+            const double *Jj = w.pJ0 + (size_t)j * n;
             double s = 0;
-            for (int r = 0; r < n; ++r) s += h.pJ0[(size_t)i * n + r] * h.pJ0[(size_t)j * n + r];
-            pH.push_back(s);
+            for (int r = 0; r < n; ++r) s += Ji[r] * Jj[r];
+            pH[(size_t)i * n + j] = s; pH[(size_t)j * n + i] = s;
           }
         }
         double c0 = 0;
-        for (int r = 0; r < n; ++r) c0 += h.pr0[r] * h.pr0[r];
-        pc0[wi] = c0;
+        for (int r = 0; r < n; ++r) c0 += w.pr0[r] * w.pr0[r];
+        h_pc0[wi] = c0;
+        std::memcpy(h_p_kind + m.pblk0, w.p_kind, 4 * (size_t)w.pnb); std::memcpy(h_p_index + m.pblk0, w.p_index, 4 * (size_t)w.pnb);
+        std::memcpy(h_p_off + m.pblk0, w.p_off, 4 * (size_t)w.pnb); std::memcpy(h_p_x0 + (size_t)4 * m.pblk0, w.p_x0, 8 * 4 * (size_t)w.pnb);
       }
-      p_kind.insert(p_kind.end(), h.p_kind.begin(), h.p_kind.end()); p_index.insert(p_index.end(), h.p_index.begin(), h.p_index.end());
-      p_off.insert(p_off.end(), h.p_off.begin(), h.p_off.end()); p_x0.insert(p_x0.end(), h.p_x0.begin(), h.p_x0.end());
-      // reduced program: referenced and not constant (trajectory_estimator.cpp:114-141, 236-245, 311-318)
-      std::vector<uint8_t> act(m.N, 0);
-      for (int i = 0; i < w.M; ++i) {
-        for (int c = 0; c < 24; ++c) act[6 * seg[i] + c] = 1;
-        for (int c = 0; c < 6; ++c) act[6 * w.K + 6 * h.imu_bias[i] + c] = 1;
-      }
-      const int64_t pad_ns = (int64_t)(0.039 * 1e9);  // AddImageFeatureDelayAnalytic spans [t, t + 0.039 s] (trajectory_estimator.cpp:299)
-      for (int v = 0; v < w.V; ++v) {
-        const int64_t tt[2] = {h.v_ti[v], h.v_tj[v]};
-        for (int e = 0; e < 2; ++e) {
-          const int s0 = (int)((tt[e] - w.t0_ns) / w.dt_ns), s1 = (int)((tt[e] + pad_ns - w.t0_ns) / w.dt_ns);
-          for (int k = s0; k < s1 + 4 && k < w.K; ++k)
-            for (int c = 0; c < 6; ++c) act[6 * k + c] = 1;
-        }
-        act[m.P + h.v_lm[v]] = 1;
-        act[m.P - 1] = 1;
-      }
-      for (int b = 0; b < w.NB; ++b)
-        for (int c = 0; c < 6; ++c) { act[6 * w.K + 6 * h.bc_i[b] + c] = 1; act[6 * w.K + 6 * h.bc_j[b] + c] = 1; }
-      for (int i = 0; i < n; ++i) act[pcol[pv0 + i]] = 1;
-      for (int k = 0; k <= w.fixed_upto && k < w.K; ++k)
-        for (int c = 0; c < 6; ++c) act[6 * k + c] = 0;
-      for (int f = 0; f < w.F; ++f)
-        for (int c = 0; c < 3; ++c) {
-          if (w.lock_bg) act[6 * w.K + 6 * f + c] = 0;
-          if (w.lock_ba) act[6 * w.K + 6 * f + 3 + c] = 0;
-        }
-      if (w.fix_ld) act[m.P - 1] = 0;
-      active.insert(active.end(), act.begin(), act.end());
-      // advance offsets
-      K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += w.V; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += n; pb += w.pnb;
-      H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)n * n;
-      maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, n);
-      maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw);
-    }
-    const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
-    if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
-    // ---- device buffers
+      active_mask(&w, t, m.P, col, h_active + m.u0);
+    });
+    // ---- device pointers of the input arena
     Dev<T> &d = dev_;
     std::memset(&d, 0, sizeof d);
-    d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = Mtot_; d.Gtot = (int)groups.size(); d.Vtot = Vtot_;
-    d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn;
-    HIPCHK(b_meta_.upload(meta_, stream_)); d.wins = b_meta_.p;
-    HIPCHK(b_quat_.upload(quat, stream_)); HIPCHK(b_pos_.upload(pos, stream_)); HIPCHK(b_bias_.upload(bias, stream_));
-    HIPCHK(b_rho_.upload(rho, stream_)); HIPCHK(b_ld_.upload(ld, stream_));
-    HIPCHK(b_cquat_.alloc(quat.size())); HIPCHK(b_cpos_.alloc(pos.size())); HIPCHK(b_cbias_.alloc(bias.size()));
-    HIPCHK(b_crho_.alloc(rho.size())); HIPCHK(b_cld_.alloc(ld.size()));
-    d.quat = b_quat_.p; d.pos = b_pos_.p; d.bias = b_bias_.p; d.rho = b_rho_.p; d.ld = b_ld_.p;
-    HIPCHK(b_kd_.alloc(3 * quat.size() / 4)); HIPCHK(b_ckd_.alloc(3 * quat.size() / 4)); HIPCHK(b_kjri_.alloc(9 * quat.size() / 4));
-    d.kd = b_kd_.p; d.ckd = b_ckd_.p; d.kjri = b_kjri_.p;
-    d.cquat = b_cquat_.p; d.cpos = b_cpos_.p; d.cbias = b_cbias_.p; d.crho = b_crho_.p; d.cld = b_cld_.p;
-    HIPCHK(b_knot_win_.upload(knot_win, stream_)); HIPCHK(b_bias_win_.upload(bias_win, stream_)); HIPCHK(b_lm_win_.upload(lm_win, stream_));
-    d.knot_win = b_knot_win_.p; d.bias_win = b_bias_win_.p; d.lm_win = b_lm_win_.p;
-    HIPCHK(b_groups_.upload(groups, stream_)); HIPCHK(b_imu_grp_.upload(imu_grp, stream_)); HIPCHK(b_imu_u_.upload(imu_u, stream_));
-    HIPCHK(b_imu_meas_.upload(imu_meas, stream_)); HIPCHK(b_tiles_.alloc(groups.size() * 1024));
-    d.groups = b_groups_.p; d.imu_grp = b_imu_grp_.p; d.imu_u = b_imu_u_.p; d.imu_meas = b_imu_meas_.p; d.imu_tiles = b_tiles_.p;
-    HIPCHK(b_imu_ud_.upload(imu_ud, stream_)); HIPCHK(b_imu_meas_d_.upload(imu_meas_d, stream_)); HIPCHK(b_v_obs_d_.upload(v_obs_d, stream_));
-    d.imu_ud = b_imu_ud_.p; d.imu_meas_d = b_imu_meas_d_.p; d.v_obs_d = b_v_obs_d_.p;
-    HIPCHK(b_v_win_.upload(v_win, stream_)); HIPCHK(b_v_lm_.upload(v_lm, stream_)); HIPCHK(b_v_ti_.upload(v_ti, stream_));
-    HIPCHK(b_v_tj_.upload(v_tj, stream_)); HIPCHK(b_v_rowi_.upload(v_rowi, stream_)); HIPCHK(b_v_rowj_.upload(v_rowj, stream_));
-    HIPCHK(b_v_obs_.upload(v_obs, stream_));
-    if (mixed_) { HIPCHK(b_imu_rc_.alloc((size_t)6 * std::max(Mtot_, 1))); HIPCHK(b_vis_rc_.alloc((size_t)3 * std::max(Vtot_, 1))); d.imu_rc = b_imu_rc_.p; d.vis_rc = b_vis_rc_.p; }
-    HIPCHK(b_Jv_.alloc((size_t)100 * std::max(Vtot_, 1))); HIPCHK(b_rv_.alloc((size_t)2 * std::max(Vtot_, 1))); HIPCHK(b_vs_.alloc((size_t)2 * std::max(Vtot_, 1)));
-    d.v_win = b_v_win_.p; d.v_lm = b_v_lm_.p; d.v_ti = b_v_ti_.p; d.v_tj = b_v_tj_.p; d.v_rowi = b_v_rowi_.p; d.v_rowj = b_v_rowj_.p;
-    d.v_obs = b_v_obs_.p; d.Jv = b_Jv_.p; d.rv = b_rv_.p; d.vs = b_vs_.p;
-    HIPCHK(b_Wc_.alloc((size_t)WC_STRIDE * std::max(Vtot_, 1))); d.Wc = b_Wc_.p;
-    {  // row of every block in landmark order = its position in the CSR list
-      std::vector<int32_t> v_slot(std::max(Vtot_, 1), 0);
-      for (size_t p = 0; p < lm_blk.size(); ++p) v_slot[lm_blk[p]] = (int32_t)p;
-      HIPCHK(b_v_slot_.upload(v_slot, stream_)); d.v_slot = b_v_slot_.p;
+    d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0;
+    d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw;
+    d.wins = CTV_D(WinMeta, o_meta);
+    d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
+    d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
+    d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(T, o_imu_u); d.imu_meas = CTV_D(T, o_imu_meas);
+    d.imu_ud = CTV_D(double, o_imu_ud); d.imu_meas_d = CTV_D(double, o_imu_meas_d); d.v_obs_d = CTV_D(double, o_v_obs_d);
+    d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_rowi = CTV_D(int32_t, o_v_rowi); d.v_rowj = CTV_D(int32_t, o_v_rowj);
+    d.v_slot = CTV_D(int32_t, o_v_slot); d.v_ti = CTV_D(int64_t, o_v_ti); d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
+    d.vitems = CTV_D(VisItem, o_vitems); d.lm_blk_off = CTV_D(int32_t, o_lm_blk_off); d.lm_blk = CTV_D(int32_t, o_lm_blk);
+    d.bc_win = CTV_D(int32_t, o_bc_win); d.bc_i = CTV_D(int32_t, o_bc_i); d.bc_j = CTV_D(int32_t, o_bc_j); d.bc_w = CTV_D(double, o_bc_w);
+    d.pH = CTV_D(double, o_pH); d.pb0 = CTV_D(double, o_pb0); d.pc0 = CTV_D(double, o_pc0); d.p_x0 = CTV_D(double, o_p_x0);
+    d.pcol = CTV_D(int32_t, o_pcol); d.p_kind = CTV_D(int32_t, o_p_kind); d.p_index = CTV_D(int32_t, o_p_index); d.p_off = CTV_D(int32_t, o_p_off);
+    d.active = CTV_D(uint8_t, o_active);
+#undef CTV_H
+#undef CTV_D
+    HIPCHK(hipMemcpyAsync(in_.dev, in_.host, in_bytes, hipMemcpyHostToDevice, stream_));
+    in_bytes_ = in_bytes;
+    // ---- work arena (device only)
+    state_doubles_ = (size_t)7 * K0 + 6 * F0 + L0 + nw;
+    off = 0;
+    const size_t o_cstate = seg(8 * state_doubles_), o_snap = seg(8 * state_doubles_);
+    const size_t o_kd = seg(8 * 3 * (size_t)K0), o_ckd = seg(8 * 3 * (size_t)K0), o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
+    const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
+    const size_t o_imu_rc = mixed_ ? seg(sizeof(T) * 6 * Mt) : 0, o_vis_rc = mixed_ ? seg(sizeof(T) * 3 * Vt) : 0;
+    const size_t o_Jv = seg(sizeof(T) * 100 * Vt), o_rv = seg(sizeof(T) * 2 * Vt), o_vs = seg(4 * 2 * Vt), o_Wc = seg(sizeof(T) * WC_STRIDE * Vt);
+    const size_t o_Hpp = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
+    const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
+    const size_t o_W = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_g = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
+                 o_cscale = seg(8 * (size_t)U0), o_lm = seg(sizeof(Lm) * (size_t)nw), o_nact = seg(16), o_dbg = seg(8 * 64);
+    const size_t o_zero1 = off;   // ---- ... to here
+    const size_t o_rhs = seg(8 * (size_t)Pp0), o_dd = seg(8 * (size_t)U0), o_dinv = seg(8 * (size_t)L0);
+    d.chol_nblk = (maxP + 31) / 32;
+    d.line_search = (sizeof(T) == 8 && opt_.line_search) ? 1 : 0;   // the mixed mode reuses cost-pass residuals: no trial-point linearisations
+    const size_t o_chol_inv = seg(8 * (size_t)nw * d.chol_nblk * 1024);
+    HIPCHK(work_.reserve(off, false, &grew));
+    if (grew) HIPCHK(hipMemsetAsync(work_.dev, 0, work_.cap, stream_));   // fresh memory may hold NaN patterns (0 * NaN in masked products)
+    char *wb = work_.dev;
+#define CTV_W(type, o) reinterpret_cast<type *>(wb + (o))
+    d.cquat = CTV_W(double, o_cstate); d.cpos = d.cquat + (size_t)4 * K0; d.cbias = d.cpos + (size_t)3 * K0; d.crho = d.cbias + (size_t)6 * F0; d.cld = d.crho + L0;
+    snap_ = CTV_W(double, o_snap);
+    d.kd = CTV_W(double, o_kd); d.ckd = CTV_W(double, o_ckd); d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
+    if (mixed_) { d.imu_rc = CTV_W(T, o_imu_rc); d.vis_rc = CTV_W(T, o_vis_rc); }
+    d.Jv = CTV_W(T, o_Jv); d.rv = CTV_W(T, o_rv); d.vs = CTV_W(int32_t, o_vs); d.Wc = CTV_W(T, o_Wc);
+    d.Hpp = CTV_W(double, o_Hpp); d.S = CTV_W(double, o_S); d.W = CTV_W(T, o_W); d.Hll = CTV_W(double, o_Hll); d.g = CTV_W(double, o_g);
+    d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
+    d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;
+    d.rhs = CTV_W(double, o_rhs); d.dd = CTV_W(double, o_dd); d.dinv = CTV_W(double, o_dinv); d.chol_inv = CTV_W(double, o_chol_inv);
+#undef CTV_W
+    HIPCHK(hipMemsetAsync(wb + o_zero0, 0, o_zero1 - o_zero0, stream_));
+    // pinned landing areas of the results
+    if ((size_t)nw > lm_host_cap_) {
+      if (lm_host_) (void)hipHostFree(lm_host_);
+      lm_host_cap_ = (size_t)nw + nw / 8 + 16;
+      HIPCHK(hipHostMalloc((void **)&lm_host_, sizeof(Lm) * lm_host_cap_, hipHostMallocDefault));
     }
-    HIPCHK(b_vitems_.upload(vitems, stream_)); d.vitems = b_vitems_.p;
-    lm_blk_off.push_back((int)lm_blk.size());
-    HIPCHK(b_lm_blk_off_.upload(lm_blk_off, stream_)); HIPCHK(b_lm_blk_.upload(lm_blk, stream_));
-    d.lm_blk_off = b_lm_blk_off_.p; d.lm_blk = b_lm_blk_.p; d.maxL = maxL; d.maxLdw = maxLdw;
-    HIPCHK(b_bc_win_.upload(bc_win, stream_)); HIPCHK(b_bc_i_.upload(bc_i, stream_)); HIPCHK(b_bc_j_.upload(bc_j, stream_)); HIPCHK(b_bc_w_.upload(bc_w, stream_));
-    d.bc_win = b_bc_win_.p; d.bc_i = b_bc_i_.p; d.bc_j = b_bc_j_.p; d.bc_w = b_bc_w_.p;
-    HIPCHK(b_pH_.upload(pH, stream_)); HIPCHK(b_pb0_.upload(pb0, stream_)); HIPCHK(b_pc0_.upload(pc0, stream_)); HIPCHK(b_pcol_.upload(pcol, stream_));
-    HIPCHK(b_p_kind_.upload(p_kind, stream_)); HIPCHK(b_p_index_.upload(p_index, stream_)); HIPCHK(b_p_off_.upload(p_off, stream_)); HIPCHK(b_p_x0_.upload(p_x0, stream_));
-    d.pH = b_pH_.p; d.pb0 = b_pb0_.p; d.pc0 = b_pc0_.p; d.pcol = b_pcol_.p; d.p_kind = b_p_kind_.p; d.p_index = b_p_index_.p; d.p_off = b_p_off_.p; d.p_x0 = b_p_x0_.p;
-    HIPCHK(b_Hpp_.alloc((size_t)H0)); HIPCHK(b_S_.alloc((size_t)H0)); HIPCHK(b_W_.alloc((size_t)W0)); HIPCHK(b_Hll_.alloc((size_t)L0));
-    HIPCHK(b_g_.alloc((size_t)U0)); HIPCHK(b_rhs_.alloc((size_t)Pp0)); HIPCHK(b_dd_.alloc((size_t)U0)); HIPCHK(b_dinv_.alloc((size_t)L0));
-    HIPCHK(b_cscale_.alloc((size_t)U0)); HIPCHK(b_delta_.alloc((size_t)U0)); HIPCHK(b_active_.upload(active, stream_));
-    HIPCHK(b_lm_.alloc((size_t)nw)); HIPCHK(b_nact_.alloc(1)); HIPCHK(b_dbg_.alloc(64));
-    d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? b_dbg_.p : nullptr;
-    d.chol_nblk = (maxP + 31) / 32; HIPCHK(b_chol_inv_.alloc((size_t)nw * d.chol_nblk * 1024)); d.chol_inv = b_chol_inv_.p;
-    d.Hpp = b_Hpp_.p; d.S = b_S_.p; d.W = b_W_.p; d.Hll = b_Hll_.p; d.g = b_g_.p; d.rhs = b_rhs_.p; d.dd = b_dd_.p; d.dinv = b_dinv_.p;
-    d.cscale = b_cscale_.p; d.delta = b_delta_.p; d.active = b_active_.p; d.lm = b_lm_.p; d.n_active = b_nact_.p;
-    HIPCHK(hipMemsetAsync(b_lm_.p, 0, sizeof(Lm) * nw, stream_));
-    HIPCHK(hipMemsetAsync(b_W_.p, 0, sizeof(T) * std::max<size_t>((size_t)W0, 1), stream_));
-    HIPCHK(hipMemsetAsync(b_Hll_.p, 0, sizeof(double) * std::max(L0, 1), stream_));
-    HIPCHK(hipMemsetAsync(b_g_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
-    HIPCHK(hipMemsetAsync(b_delta_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
-    HIPCHK(hipMemsetAsync(b_cscale_.p, 0, sizeof(double) * std::max(U0, 1), stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
     chol_lds_ = chol_lds;
     snap_valid_ = false;
     any_vis_lds_ = any_vis_glb_ = false;
@@ -456,7 +467,7 @@ template <class T> class SolverImpl : public SolverBase {
     ph_begin(PH_ASM_REST);
     hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0);
     ph_end();
-    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, d.quat, d.kd, d.kjri);
+    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, 2);
     ph_begin(PH_IMU_LIN);
     const size_t imu_lds = (sizeof(T) == 4 ? (size_t)3 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 0;
     if (d.Gtot) {
@@ -516,8 +527,8 @@ template <class T> class SolverImpl : public SolverBase {
     const Dev<T> &d = dev_;
     const double *q = candidate ? d.cquat : d.quat, *p = candidate ? d.cpos : d.pos, *b = candidate ? d.cbias : d.bias;
     const double *r = candidate ? d.crho : d.rho, *l = candidate ? d.cld : d.ld;
-    double *kd = candidate ? d.ckd : d.kd;
-    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, q, kd, (T *)nullptr);
+    const double *kd = candidate ? d.ckd : d.kd;
+    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, candidate ? 1 : 0);
     if (d.Mtot) {
       if (mixed_) hipLaunchKernelGGL((k_imu_cost<T, double>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
       else hipLaunchKernelGGL((k_imu_cost<T, T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
@@ -530,6 +541,42 @@ template <class T> class SolverImpl : public SolverBase {
   }
   int n_state() const { return dev_.Ktot + dev_.Ftot + dev_.Ltot + dev_.nwin; }
 
+  // One PASS of the device-resident LM: every running window advances by one phase -- a new trust-region iteration
+  // (linearise at x if a step was accepted, damp, Schur, Cholesky, back-substitute, candidate, cost, accept / reject), or,
+  // for a window inside Ceres' projected line search, one trial step (linearise at the candidate, interpolate alpha,
+  // candidate, cost, Armijo test).  The launch list is fixed: kernels skip windows that are not in the matching phase.
+  void launch_pass() {
+    Dev<T> &d = dev_;
+    const int nw = d.nwin, wb = nblk(nw, 64);
+    launch_linearize();
+    launch_assemble();
+    (void)hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_);
+    hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
+    if (d.line_search) hipLaunchKernelGGL((k_ls_step<T>), dim3(nw), dim3(64), 0, stream_, d);
+    launch_step();
+    ph_begin(PH_REST);
+    hipLaunchKernelGGL((k_update<T, false>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
+    launch_cost(true, 0);
+    hipLaunchKernelGGL((k_lm_control<T>), dim3(wb), dim3(64), 0, stream_, d);
+    hipLaunchKernelGGL((k_update<T, true>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
+    ph_end();
+  }
+  // The pass as a hipGraph (captured once per batch shape: the kernel arguments are the Dev struct, so equal shapes in the
+  // grow-only arenas give identical graphs), replayed instead of ~25 launches.
+  int ensure_graph() {
+    if (graph_exec_ && std::memcmp(&graph_dev_, &dev_, sizeof dev_) == 0) return CTVIO_OK;
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    launch_pass();
+    HIPCHK(hipStreamEndCapture(stream_, &g));
+    hipError_t e = hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { graph_exec_ = nullptr; return fail(CTVIO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    graph_dev_ = dev_;
+    return CTVIO_OK;
+  }
+
   int solve(int max_iters, ctvio_summary *out) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (max_iters < 0) return fail(CTVIO_ERR_INVALID, "max_iterations < 0");
@@ -538,35 +585,31 @@ template <class T> class SolverImpl : public SolverBase {
     set_params(max_iters);
     profiling_ = profiling_requested_;
     pev_phase_.clear(); pev_used_ = 0;
+    const bool graph = opt_.use_graph && !profiling_ && !d.dbg;
+    if (graph) { const int rc = ensure_graph(); if (rc != CTVIO_OK) return rc; }
     HIPCHK(hipEventRecord(ev_[8], stream_));
     hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 0);
     launch_cost(false, 1);
     hipLaunchKernelGGL((k_set_initial_cost<T>), dim3(wb), dim3(64), 0, stream_, d);
-    int it = 0;
+    // max_iters + 1 passes finish every window that never enters the line search (the last pass only finalises); the host
+    // looks at the "windows still running" counter every check_every passes and keeps launching while any is left
     const int check = std::max(1, opt_.check_every);
-    for (; it <= max_iters; ++it) {
-      launch_linearize();
-      launch_assemble();
-      HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
-      hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
-      if (it == max_iters) break;  // the last pass only finalises (max-iterations termination)
-      launch_step();
-      ph_begin(PH_REST);
-      hipLaunchKernelGGL((k_update<T, false>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
-      launch_cost(true, 0);
-      hipLaunchKernelGGL((k_lm_control<T>), dim3(wb), dim3(64), 0, stream_, d);
-      hipLaunchKernelGGL((k_update<T, true>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
-      ph_end();
-      if ((it + 1) % check == 0 && it + 1 < max_iters) {
-        int32_t na = 0;
-        HIPCHK(hipMemcpyAsync(&na, d.n_active, sizeof na, hipMemcpyDeviceToHost, stream_));
+    const int pass_cap = (max_iters + 1) * 22 + 4;   // every LM iteration may take up to 20 trial steps + 1 re-evaluation
+    int it = 0;
+    for (;;) {
+      if (graph) HIPCHK(hipGraphLaunch(graph_exec_, stream_)); else launch_pass();
+      ++it;
+      if (it >= pass_cap) break;
+      if (it > max_iters || it % check == 0) {
+        int32_t *na = reinterpret_cast<int32_t *>(lm_host_ + lm_host_cap_ - 1);   // pinned scratch word
+        HIPCHK(hipMemcpyAsync(na, d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
-        if (na == 0) { ++it; break; }
+        if (*na == 0) break;
       }
     }
     HIPCHK(hipEventRecord(ev_[9], stream_));
-    std::vector<Lm> lm(nw);
-    HIPCHK(hipMemcpyAsync(lm.data(), d.lm, sizeof(Lm) * nw, hipMemcpyDeviceToHost, stream_));
+    Lm *lm = lm_host_;   // pinned: the copy does not stage through a runtime bounce buffer
+    HIPCHK(hipMemcpyAsync(lm, d.lm, sizeof(Lm) * nw, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
     float ms = 0;
@@ -592,6 +635,7 @@ template <class T> class SolverImpl : public SolverBase {
         out[w].iterations = lm[w].iter; out[w].num_successful = lm[w].nsucc; out[w].num_unsuccessful = lm[w].nunsucc;
         out[w].termination = lm[w].status > 0 ? lm[w].status - 1 : 0;
         out[w].initial_cost = lm[w].initial_cost; out[w].final_cost = lm[w].cost; out[w].final_radius = lm[w].mu;
+        out[w].num_line_search_steps = lm[w].nls_steps; out[w].num_line_search_reduced = lm[w].nls_reduced;
       }
     return CTVIO_OK;
   }
@@ -622,21 +666,35 @@ template <class T> class SolverImpl : public SolverBase {
     return CTVIO_OK;
   }
 
-  // device-side copy of the whole batch state (restore != 0: copy back)
+  // device-side copy of the whole batch state (restore != 0: copy back); the state is one contiguous block
   int snapshot(int restore) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
-    Dev<T> &d = dev_;
-    HIPCHK(b_snap_.alloc((size_t)4 * d.Ktot + 3 * d.Ktot + 6 * d.Ftot + d.Ltot + d.nwin));
-    double *p = b_snap_.p;
-    double *parts[5] = {d.quat, d.pos, d.bias, d.rho, d.ld};
-    const size_t sz[5] = {(size_t)4 * d.Ktot, (size_t)3 * d.Ktot, (size_t)6 * d.Ftot, (size_t)d.Ltot, (size_t)d.nwin};
     if (restore && !snap_valid_) return fail(CTVIO_ERR_STATE, "no snapshot taken");
-    for (int i = 0; i < 5; ++i) {
-      if (sz[i]) HIPCHK(hipMemcpyAsync(restore ? parts[i] : p, restore ? p : parts[i], sz[i] * sizeof(double), hipMemcpyDeviceToDevice, stream_));
-      p += sz[i];
+    HIPCHK(hipMemcpyAsync(restore ? dev_.quat : snap_, restore ? snap_ : dev_.quat, state_doubles_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    if (!restore) { HIPCHK(hipStreamSynchronize(stream_)); snap_valid_ = true; }
+    return CTVIO_OK;
+  }
+  // every window's state in one device-to-host copy (concatenated in window order, like the device arrays)
+  int get_batch_state(double *quat, double *pos, double *bias, double *rho, double *ld) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    const Dev<T> &d = dev_;
+    if (state_doubles_ > state_host_cap_) {
+      if (state_host_) (void)hipHostFree(state_host_);
+      state_host_cap_ = state_doubles_ + state_doubles_ / 8;
+      HIPCHK(hipHostMalloc((void **)&state_host_, sizeof(double) * state_host_cap_, hipHostMallocDefault));
     }
+    HIPCHK(hipMemcpyAsync(state_host_, d.quat, state_doubles_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
-    snap_valid_ = true;
+    const double *p = state_host_;
+    if (quat) std::memcpy(quat, p, sizeof(double) * 4 * d.Ktot);
+    p += (size_t)4 * d.Ktot;
+    if (pos) std::memcpy(pos, p, sizeof(double) * 3 * d.Ktot);
+    p += (size_t)3 * d.Ktot;
+    if (bias) std::memcpy(bias, p, sizeof(double) * 6 * d.Ftot);
+    p += (size_t)6 * d.Ftot;
+    if (rho && d.Ltot) std::memcpy(rho, p, sizeof(double) * d.Ltot);
+    p += d.Ltot;
+    if (ld) std::memcpy(ld, p, sizeof(double) * d.nwin);
     return CTVIO_OK;
   }
 
@@ -763,7 +821,7 @@ template <class T> class SolverImpl : public SolverBase {
     if (id < 0 || id >= dev_.nwin || n < 0 || (n && !t_ns)) return fail(CTVIO_ERR_INVALID, "bad arguments");
     if (n == 0) return CTVIO_OK;
     std::vector<long long> rel(n);
-    for (int i = 0; i < n; ++i) rel[i] = (long long)(t_ns[i] - wins_[id].w.t0_ns);
+    for (int i = 0; i < n; ++i) rel[i] = (long long)(t_ns[i] - t0_[id]);
     DBuf<long long> dt; DBuf<double> dp, dv, dw, da; DBuf<int> derr;
     HIPCHK(dt.alloc(n)); HIPCHK(derr.alloc(1));
     HIPCHK(hipMemcpyAsync(dt.p, rel.data(), sizeof(long long) * n, hipMemcpyHostToDevice, stream_));
@@ -802,25 +860,18 @@ template <class T> class SolverImpl : public SolverBase {
   std::vector<hipEvent_t> pev_;
   std::vector<int> pev_phase_;
   size_t pev_used_ = 0;
-  std::vector<HostWindow> wins_;
+  std::vector<std::unique_ptr<HostWindow>> own_;   // windows recorded by ctvio_add_window (owning copies)
   std::vector<WinMeta> meta_;
+  std::vector<int64_t> t0_;
   Dev<T> dev_;
   int Mtot_ = 0, Vtot_ = 0;
-  size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0;
-  DBuf<VisItem> b_vitems_;
-  DBuf<int32_t> b_lm_blk_off_, b_lm_blk_, b_v_slot_;
-  DBuf<WinMeta> b_meta_;
-  DBuf<double> b_quat_, b_pos_, b_bias_, b_rho_, b_ld_, b_cquat_, b_cpos_, b_cbias_, b_crho_, b_cld_, b_bc_w_, b_pH_, b_pb0_, b_pc0_, b_p_x0_;
-  DBuf<double> b_chol_inv_, b_Hpp_, b_S_, b_Hll_, b_g_, b_rhs_, b_dd_, b_dinv_, b_cscale_, b_delta_;
-  DBuf<int32_t> b_knot_win_, b_bias_win_, b_lm_win_, b_imu_grp_, b_v_win_, b_v_lm_, b_v_rowi_, b_v_rowj_, b_bc_win_, b_bc_i_, b_bc_j_, b_pcol_,
-      b_p_kind_, b_p_index_, b_p_off_, b_vs_, b_nact_;
-  DBuf<int64_t> b_v_ti_, b_v_tj_;
-  DBuf<ImuGroup> b_groups_;
-  DBuf<T> b_imu_rc_, b_vis_rc_, b_kjri_, b_imu_u_, b_imu_meas_, b_tiles_, b_v_obs_, b_Jv_, b_rv_, b_W_, b_Wc_;
-  DBuf<uint8_t> b_active_;
-  DBuf<Lm> b_lm_;
-  DBuf<long long> b_dbg_;
-  DBuf<double> b_snap_, b_imu_ud_, b_imu_meas_d_, b_v_obs_d_, b_kd_, b_ckd_;
+  size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0, in_bytes_ = 0, state_doubles_ = 0;
+  Arena in_, work_;          // uploaded inputs (pinned mirror) / device-only work buffers
+  double *snap_ = nullptr;   // state snapshot (inside work_)
+  Lm *lm_host_ = nullptr; size_t lm_host_cap_ = 0;
+  hipGraphExec_t graph_exec_ = nullptr;   // one LM pass (launch_pass) as a graph, valid while dev_ == graph_dev_
+  Dev<T> graph_dev_;
+  double *state_host_ = nullptr; size_t state_host_cap_ = 0;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
 };
 
@@ -868,11 +919,11 @@ extern "C" {
 void ctvio_default_options(ctvio_options *o) {
   if (!o) return;
   std::memset(o, 0, sizeof *o);
-  o->device = 0; o->precision = CTVIO_FP32; o->use_mfma = 1; o->check_every = 4;
+  o->device = 0; o->precision = CTVIO_FP64; o->use_mfma = 1; o->check_every = 4;
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32; o->min_relative_decrease = 1e-3;
   o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->max_consecutive_invalid_steps = 5;
-  o->fp64_residuals = 1;
+  o->fp64_residuals = 1; o->host_threads = 0; o->use_graph = 1; o->line_search = 1;
 }
 const char *ctvio_status_string(int32_t s) {
   switch (s) {
@@ -913,10 +964,14 @@ void ctvio_destroy(ctvio_solver *s) { delete s; }
 int32_t ctvio_clear(ctvio_solver *s) { CHK_S; return s->impl->clear(); }
 int32_t ctvio_add_window(ctvio_solver *s, const ctvio_window *w, int32_t *id) { CHK_S; return s->impl->add_window(w, id); }
 int32_t ctvio_upload(ctvio_solver *s) { CHK_S; return s->impl->upload(); }
+int32_t ctvio_set_batch(ctvio_solver *s, int32_t n, const ctvio_window *wins) { CHK_S; return s->impl->set_batch(n, wins); }
 int32_t ctvio_num_windows(const ctvio_solver *s) { return s ? s->impl->num_windows() : 0; }
 int32_t ctvio_solve(ctvio_solver *s, int32_t max_iterations, ctvio_summary *out) { CHK_S; return s->impl->solve(max_iterations, out); }
 int32_t ctvio_get_state(ctvio_solver *s, int32_t id, double *quat, double *pos, double *bias, double *rho, double *ld) {
   CHK_S; return s->impl->get_state(id, quat, pos, bias, rho, ld);
+}
+int32_t ctvio_get_batch_state(ctvio_solver *s, double *quat, double *pos, double *bias, double *rho, double *ld) {
+  CHK_S; return s->impl->get_batch_state(quat, pos, bias, rho, ld);
 }
 int32_t ctvio_set_state(ctvio_solver *s, int32_t id, const double *quat, const double *pos, const double *bias, const double *rho, double ld) {
   CHK_S; return s->impl->set_state(id, quat, pos, bias, rho, ld);

@@ -44,6 +44,13 @@ struct Lm {
   int32_t iter, invalid, status; // status 0 = running, else 1 + termination code
   int32_t need_lin, scaled, last_ok, step_valid, chol_fail, accept;
   int32_t nsucc, nunsucc, pad;
+  // Ceres' projected Armijo line search of bounds-constrained problems (TrustRegionMinimizer::DoLineSearch, line_search.cc):
+  // ls_on = the reduced program has a bounded parameter (free line delay); ls_active 0 = not searching, 1 = searching (the
+  // next pass linearises at the CANDIDATE to get the directional derivative of the current trial), 2 = search failed, the full
+  // step is being re-evaluated.  alpha = step size of the candidate x (+) alpha * delta.
+  int32_t ls_on, ls_active, ls_iters, ls_prev_valid, ls_cur_valid, nls_steps, nls_reduced, pad2;
+  double alpha, ls_gd0, ls_dmax;          // g . delta at x (initial directional derivative), max-norm of delta
+  double ls_cur_x, ls_cur_v, ls_cur_g, ls_prev_x, ls_prev_v, ls_prev_g;
 };
 
 struct LmParams {
@@ -63,7 +70,8 @@ template <class T> struct Dev {
   // per consecutive knot pair (k, k+1), filled by k_knot_prep once per state: d = log(R_k^-1 R_k+1) in fp64 for the
   // current (kd) and the candidate (ckd) state, Jr^-1(d) in T for the current state
   double *kd, *ckd;      // [Ktot][3]
-  T *kjri;               // [Ktot][9]
+  double *lkd;           // [Ktot][3] the same at the state being LINEARISED (current, or the candidate of a window in line search)
+  T *kjri;               // [Ktot][9] Jr^-1(d) at the linearised state
   // IMU factors (sorted by group)
   const ImuGroup *groups;
   const int32_t *imu_grp;
@@ -112,6 +120,7 @@ template <class T> struct Dev {
   Lm *lm;
   int32_t *n_active;
   long long *dbg;        // optional clock64() stamps (profiling aid), may be null
+  int32_t line_search;   // 1: restate Ceres' projected line search (all-fp64 product path)
   LmParams prm;
 };
 

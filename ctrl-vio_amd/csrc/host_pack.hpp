@@ -1,0 +1,196 @@
+// host_pack.hpp -- host side of a batch upload: validation and packing of the caller's windows (the factor set of the
+// reference's TrajectoryManager::UpdateTrajectory, src/estimator/trajectory_manager.cpp:331-451) into ONE pinned staging
+// arena that mirrors the device input arena byte for byte, so that a whole batch reaches HBM with a single
+// hipMemcpyAsync.  Windows are independent: both passes (validate + count, then fill) run over the windows with a pool
+// of host threads.  No device code in this file.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ctvio.h"
+#include "device_types.hpp"
+
+namespace ctv {
+
+inline int host_threads(int requested) {
+  if (requested > 0) return requested;
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+}
+
+// f(i) for i in [0, n), dynamic distribution over `nthreads` threads (the calling thread included)
+template <class F> void parallel_for(int n, int nthreads, F &&f) {
+  if (nthreads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int> next{0};
+  auto worker = [&]() { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; f(i); } };
+  std::vector<std::thread> th;
+  const int extra = std::min(nthreads, n) - 1;
+  th.reserve(extra);
+  for (int t = 0; t < extra; ++t) th.emplace_back(worker);
+  worker();
+  for (auto &t : th) t.join();
+}
+
+// Grow-only device buffer, optionally mirrored by pinned host memory of the same size.
+struct Arena {
+  char *dev = nullptr, *host = nullptr;
+  size_t cap = 0;
+  bool mirrored = false;
+  ~Arena() { release(); }
+  void release() {
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+    dev = host = nullptr; cap = 0;
+  }
+  // returns hipSuccess; *grew tells the caller that the contents (and every pointer into the arena) are gone
+  hipError_t reserve(size_t bytes, bool mirror, bool *grew) {
+    if (grew) *grew = false;
+    if (bytes <= cap && dev && (!mirror || host)) return hipSuccess;
+    release();
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);   // headroom: a slightly larger next batch does not reallocate
+    hipError_t e = hipMalloc((void **)&dev, want);
+    if (e != hipSuccess) { dev = nullptr; return e; }
+    if (mirror) {
+      e = hipHostMalloc((void **)&host, want, hipHostMallocDefault);
+      if (e != hipSuccess) { host = nullptr; release(); return e; }
+    }
+    cap = want; mirrored = mirror;
+    if (grew) *grew = true;
+    return hipSuccess;
+  }
+};
+
+static inline int prior_block_size(int kind) { return kind == CTVIO_PK_LD ? 1 : 3; }
+
+// Per-window results of the first pass.
+struct PackTmp {
+  std::vector<int32_t> iorder, iseg;    // IMU: sample order by (segment, bias state); segment of every sample (input order)
+  std::vector<int32_t> vord;            // visual blocks: order by (ti, tj, rowi, rowj)
+  int32_t ngrp = 0, nvitem = 0;
+  std::string err;
+};
+
+// reference asserts / prints when a time falls outside the spline (spline_segment.h:74-81); here every input is checked
+inline bool validate_window(const ctvio_window *w, std::string &err) {
+  auto bad = [&](const char *m) { err = m; return false; };
+  if (!w) return bad("null window");
+  if (w->K < 4 || w->F < 1 || w->L < 0 || w->M < 0 || w->NB < 0 || w->V < 0 || w->dt_ns <= 0 || w->pn < 0 || w->pnb < 0)
+    return bad("bad sizes (need K >= 4, F >= 1, dt_ns > 0)");
+  if (!w->quat || !w->pos || !w->bias || (w->L && !w->rho)) return bad("null state pointer");
+  if (w->M && (!w->imu_t || !w->imu_gyro || !w->imu_acc || !w->imu_bias)) return bad("null IMU pointer");
+  if (w->NB && (!w->bc_i || !w->bc_j || !w->bc_w)) return bad("null bias-chain pointer");
+  if (w->V && (!w->v_lm || !w->v_ti || !w->v_tj || !w->v_rowi || !w->v_rowj || !w->v_pi || !w->v_pj)) return bad("null visual pointer");
+  const int64_t tmax = w->t0_ns + (int64_t)(w->K - 3) * w->dt_ns;
+  for (int m = 0; m < w->M; ++m) {
+    if (w->imu_t[m] < w->t0_ns || w->imu_t[m] >= tmax) return bad("IMU time outside the spline");
+    if (w->imu_bias[m] < 0 || w->imu_bias[m] >= w->F) return bad("IMU bias index out of range");
+  }
+  const int64_t ldmax_ns = (int64_t)((w->fix_ld ? w->ld : std::max(w->ld, w->ld_hi)) * 1e9);
+  for (int v = 0; v < w->V; ++v) {
+    if (w->v_lm[v] < 0 || w->v_lm[v] >= w->L) return bad("visual landmark index out of range");
+    if (w->v_rowi[v] < 0 || w->v_rowj[v] < 0) return bad("negative image row");
+    const int64_t a = w->v_ti[v], b = w->v_tj[v];
+    if (a < w->t0_ns || b < w->t0_ns || a + w->v_rowi[v] * ldmax_ns >= tmax || b + w->v_rowj[v] * ldmax_ns >= tmax)
+      return bad("visual time (+ row * line delay) outside the spline");
+  }
+  for (int b = 0; b < w->NB; ++b)
+    if (w->bc_i[b] < 0 || w->bc_i[b] >= w->F || w->bc_j[b] < 0 || w->bc_j[b] >= w->F) return bad("bias chain index out of range");
+  if (w->pn > 0) {
+    if (!w->pJ0 || !w->pr0 || !w->p_x0 || !w->p_kind || !w->p_index || !w->p_off) return bad("null prior pointer");
+    // the kept blocks must tile the prior's columns exactly once (a hole would leave an unmapped column)
+    std::vector<uint8_t> cover((size_t)w->pn, 0);
+    for (int b = 0; b < w->pnb; ++b) {
+      const int kind = w->p_kind[b], idx = w->p_index[b];
+      const int lim = (kind <= CTVIO_PK_POS) ? w->K : (kind <= CTVIO_PK_BA ? w->F : 1);
+      if (kind < 0 || kind > CTVIO_PK_LD || idx < 0 || idx >= lim || w->p_off[b] < 0 || w->p_off[b] + prior_block_size(kind) > w->pn)
+        return bad("prior block out of range");
+      for (int k = 0; k < prior_block_size(kind); ++k)
+        if (cover[w->p_off[b] + k]++) return bad("prior blocks overlap");
+    }
+    for (int i = 0; i < w->pn; ++i)
+      if (!cover[i]) return bad("prior column not covered by any kept block");
+  } else if (w->pnb != 0) {
+    return bad("prior blocks without a prior");
+  }
+  return true;
+}
+
+// first pass: IMU samples sorted by (segment, bias state) and cut into groups, visual blocks sorted by frame pair (then rows)
+// and cut into items of <= vch blocks -- only the orders and the counts are kept
+inline void plan_window(const ctvio_window *w, int vch, PackTmp &t) {
+  const int M = w->M, V = w->V;
+  t.iseg.resize(M); t.iorder.resize(M);
+  bool sorted = true;
+  for (int i = 0; i < M; ++i) {
+    t.iseg[i] = (int32_t)((w->imu_t[i] - w->t0_ns) / w->dt_ns);
+    t.iorder[i] = i;
+    if (i && (t.iseg[i] < t.iseg[i - 1] || (t.iseg[i] == t.iseg[i - 1] && w->imu_bias[i] < w->imu_bias[i - 1]))) sorted = false;
+  }
+  if (!sorted)
+    std::stable_sort(t.iorder.begin(), t.iorder.end(), [&](int a, int b) {
+      if (t.iseg[a] != t.iseg[b]) return t.iseg[a] < t.iseg[b];
+      return w->imu_bias[a] < w->imu_bias[b];
+    });
+  t.ngrp = 0;
+  for (int i = 0; i < M; ++i) {
+    const int s = t.iorder[i];
+    if (i == 0 || t.iseg[s] != t.iseg[t.iorder[i - 1]] || w->imu_bias[s] != w->imu_bias[t.iorder[i - 1]]) t.ngrp++;
+  }
+  t.vord.resize(V);
+  std::iota(t.vord.begin(), t.vord.end(), 0);
+  auto vless = [&](int a, int b) {
+    if (w->v_ti[a] != w->v_ti[b]) return w->v_ti[a] < w->v_ti[b];
+    if (w->v_tj[a] != w->v_tj[b]) return w->v_tj[a] < w->v_tj[b];
+    if (w->v_rowi[a] != w->v_rowi[b]) return w->v_rowi[a] < w->v_rowi[b];
+    return w->v_rowj[a] < w->v_rowj[b];
+  };
+  if (!std::is_sorted(t.vord.begin(), t.vord.end(), vless)) std::stable_sort(t.vord.begin(), t.vord.end(), vless);
+  t.nvitem = 0;
+  int cnt = 0;
+  for (int i = 0; i < V; ++i) {
+    const int v = t.vord[i];
+    const bool fresh = (i == 0) || w->v_ti[v] != w->v_ti[t.vord[i - 1]] || w->v_tj[v] != w->v_tj[t.vord[i - 1]] || cnt >= vch;
+    if (fresh) { t.nvitem++; cnt = 0; }
+    cnt++;
+  }
+}
+
+// Unknowns of Ceres' reduced program: referenced by some residual block and not constant
+// (trajectory_estimator.cpp:114-141, 236-245, 311-318).
+inline void active_mask(const ctvio_window *w, const PackTmp &t, int P, const int32_t *pcol, uint8_t *act) {
+  const int N = P + w->L, K = w->K;
+  std::memset(act, 0, (size_t)N);
+  for (int i = 0; i < w->M; ++i) {
+    std::memset(act + 6 * t.iseg[i], 1, 24);
+    std::memset(act + 6 * K + 6 * w->imu_bias[i], 1, 6);
+  }
+  const int64_t pad_ns = (int64_t)(0.039 * 1e9);  // AddImageFeatureDelayAnalytic spans [t, t + 0.039 s] (trajectory_estimator.cpp:299)
+  for (int v = 0; v < w->V; ++v) {
+    const int64_t tt[2] = {w->v_ti[v], w->v_tj[v]};
+    for (int e = 0; e < 2; ++e) {
+      const int s0 = (int)((tt[e] - w->t0_ns) / w->dt_ns), s1 = (int)((tt[e] + pad_ns - w->t0_ns) / w->dt_ns);
+      for (int k = s0; k < s1 + 4 && k < K; ++k) std::memset(act + 6 * k, 1, 6);
+    }
+    act[P + w->v_lm[v]] = 1;
+    act[P - 1] = 1;
+  }
+  for (int b = 0; b < w->NB; ++b) { std::memset(act + 6 * K + 6 * w->bc_i[b], 1, 6); std::memset(act + 6 * K + 6 * w->bc_j[b], 1, 6); }
+  for (int i = 0; i < w->pn; ++i) act[pcol[i]] = 1;
+  for (int k = 0; k <= w->fixed_upto && k < K; ++k) std::memset(act + 6 * k, 0, 6);
+  for (int f = 0; f < w->F; ++f) {
+    if (w->lock_bg) std::memset(act + 6 * K + 6 * f, 0, 3);
+    if (w->lock_ba) std::memset(act + 6 * K + 6 * f + 3, 0, 3);
+  }
+  if (w->fix_ld) act[P - 1] = 0;
+}
+
+}  // namespace ctv

@@ -16,7 +16,10 @@
 
 namespace ctv {
 
-__device__ __forceinline__ bool lin_needed(const Lm &lm) { return lm.status == 0 && lm.need_lin != 0; }
+// A window is (re)linearised when a step was accepted (need_lin) -- or, inside Ceres' projected line search, at the CANDIDATE
+// x (+) alpha delta, whose directional derivative the cubic interpolation of the next trial step needs (ls_active == 1).
+__device__ __forceinline__ bool lin_needed(const Lm &lm) { return lm.status == 0 && (lm.need_lin != 0 || lm.ls_active == 1); }
+__device__ __forceinline__ bool lin_at_candidate(const Lm &lm) { return lm.ls_active == 1; }
 
 // local column -> unknown index maps
 __device__ __forceinline__ int imu_col(int c, int s, int K, int bias) {
@@ -93,6 +96,11 @@ template <class T> __global__ void k_lm_init(Dev<T> d, double mu, int keep_scale
   lm.iter = 0; lm.invalid = 0; lm.status = 0;
   lm.need_lin = 1; lm.scaled = keep_scale ? lm.scaled : 0; lm.last_ok = 1; lm.step_valid = 0; lm.chol_fail = 0; lm.accept = 0;
   lm.nsucc = lm.nunsucc = 0;
+  const WinMeta &m = d.wins[w];
+  lm.ls_on = (d.line_search && !m.fix_ld && d.active[m.u0 + m.P - 1]) ? 1 : 0;   // Program::IsBoundsConstrained of the reduced program
+  lm.ls_active = 0; lm.ls_iters = 0; lm.ls_prev_valid = lm.ls_cur_valid = 0; lm.nls_steps = lm.nls_reduced = 0;
+  lm.alpha = 1.0; lm.ls_gd0 = 0; lm.ls_dmax = 0;
+  lm.ls_cur_x = lm.ls_cur_v = lm.ls_cur_g = lm.ls_prev_x = lm.ls_prev_v = lm.ls_prev_g = 0;
 }
 template <class T> __global__ void k_set_initial_cost(Dev<T> d) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,7 +111,7 @@ template <class T> __global__ void k_set_initial_cost(Dev<T> d) {
 }
 template <class T> __global__ void k_force_lin(Dev<T> d) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < d.nwin) { d.lm[w].need_lin = 1; d.lm[w].status = 0; }
+  if (w < d.nwin) { d.lm[w].need_lin = 1; d.lm[w].status = 0; d.lm[w].ls_active = 0; }
 }
 
 // FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration.
@@ -112,13 +120,14 @@ template <class T> __global__ void k_begin_iter(Dev<T> d) {
   if (w >= d.nwin) return;
   Lm &lm = d.lm[w];
   if (lm.status) return;
+  if (lm.ls_active) { atomicAdd(d.n_active, 1); return; }   // inside the line search: no new LM iteration (see k_ls_step)
   if (lm.need_lin) { lm.scaled = 1; lm.need_lin = 0; }
   if (lm.iter >= d.prm.max_iters) { lm.status = 1 + 0; return; }
   if (lm.last_ok && __longlong_as_double((long long)lm.gmax_bits) <= d.prm.gtol) { lm.status = 1 + 1; return; }
   if (lm.mu <= d.prm.min_radius) { lm.status = 1 + 4; return; }
   lm.iter += 1;
   lm.cand_cost = 0; lm.step2 = 0; lm.cand_xnorm2 = 0;
-  lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0;
+  lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0; lm.alpha = 1.0;
   atomicAdd(d.n_active, 1);
 }
 
@@ -128,6 +137,22 @@ template <class T> __global__ void k_lm_control(Dev<T> d) {
   if (w >= d.nwin) return;
   Lm &lm = d.lm[w];
   if (lm.status || !lm.step_valid) return;
+  lm.accept = 0;
+  if (lm.ls_on && lm.ls_active != 2) {
+    // ArmijoLineSearch::DoSearch (Ceres line_search.cc): the trial alpha is kept when
+    // f(alpha) <= f(0) + sufficient_decrease * alpha * f'(0); an invalid (non-finite) value counts as a failure
+    const bool valid = isfinite(lm.cand_cost);
+    const bool ok = valid && !(lm.cand_cost > lm.cost + 1e-4 * lm.ls_gd0 * lm.alpha);
+    if (!ok) {
+      if (!lm.ls_active) { lm.ls_active = 1; lm.ls_iters = 0; lm.ls_prev_valid = 0; lm.ls_cur_x = 1.0; }
+      lm.ls_cur_v = lm.cand_cost; lm.ls_cur_valid = valid ? 1 : 0;
+      if (++lm.ls_iters >= 20) { lm.ls_active = 2; lm.nls_steps += lm.ls_iters; }   // max_num_line_search_step_size_iterations: the full step is kept
+      return;   // next pass: gradient at this trial point, interpolated step, new candidate (k_ls_step)
+    }
+    if (lm.ls_active) { lm.nls_steps += lm.ls_iters; lm.nls_reduced += 1; }
+  }
+  const bool searched = lm.ls_active != 0;   // H and g were overwritten by the trial-point linearisations
+  lm.ls_active = 0;
   const double step_norm = sqrt(lm.step2), x_norm = sqrt(lm.xnorm2);
   if (step_norm <= d.prm.ptol * (x_norm + d.prm.ptol)) { lm.status = 1 + 2; return; }
   const double cost_change = lm.cost - lm.cand_cost;
@@ -144,7 +169,136 @@ template <class T> __global__ void k_lm_control(Dev<T> d) {
     lm.nu = 2.0; lm.last_ok = 1; lm.nsucc += 1; lm.need_lin = 1;
   } else {
     lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1;
+    if (searched) lm.need_lin = 1;   // back at x: its normal equations have to be rebuilt
   }
+}
+
+// ---- interpolation of the next trial step (Ceres polynomial.cc: FindInterpolatingPolynomial / MinimizePolynomial)
+struct LsSample { double x, v, g; };
+__device__ inline double ls_poly_eval(const double *p, int n, double x) {
+  double v = 0;
+  for (int i = 0; i < n; ++i) v = v * x + p[i];
+  return v;
+}
+__device__ inline double ls_ipow(double x, int e) { double r = 1.0; for (int i = 0; i < e; ++i) r *= x; return r; }
+// real parts of all (complex) roots of a polynomial of degree <= 4, coefficients highest power first
+__device__ inline int ls_root_real_parts(const double *p_in, int n, double *re) {
+  while (n > 0 && p_in[0] == 0.0) { ++p_in; --n; }
+  const int deg = n - 1;
+  if (deg <= 0) return 0;
+  if (deg == 1) { re[0] = -p_in[1] / p_in[0]; return 1; }
+  if (deg == 2) {
+    const double a = p_in[0], b = p_in[1], c = p_in[2], D = b * b - 4 * a * c, sD = sqrt(fabs(D));
+    if (D >= 0) {
+      if (b >= 0) { re[0] = (-b - sD) / (2.0 * a); re[1] = (2.0 * c) / (-b - sD); }
+      else { re[0] = (2.0 * c) / (-b + sD); re[1] = (-b + sD) / (2.0 * a); }
+    } else { re[0] = re[1] = -b / (2.0 * a); }
+    return 2;
+  }
+  double q[5], zr[4], zi[4];
+  for (int i = 0; i <= deg; ++i) q[i] = p_in[i] / p_in[0];
+  double rad = 0;
+  for (int i = 1; i <= deg; ++i) rad = fmax(rad, fabs(q[i]));
+  rad = 1.0 + rad;
+  for (int k = 0; k < deg; ++k) { const double ang = 2.0 * 3.14159265358979323846 * k / deg + 0.4; zr[k] = 0.5 * rad * cos(ang); zi[k] = 0.5 * rad * sin(ang); }
+  for (int it = 0; it < 500; ++it) {   // Durand-Kerner
+    double change = 0;
+    for (int k = 0; k < deg; ++k) {
+      double pr = 1.0, pi = 0.0;
+      for (int i = 1; i <= deg; ++i) { const double tr = pr * zr[k] - pi * zi[k] + q[i], ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti; }
+      double dr = 1.0, di = 0.0;
+      for (int j = 0; j < deg; ++j) {
+        if (j == k) continue;
+        const double ar = zr[k] - zr[j], ai = zi[k] - zi[j], tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+        dr = tr; di = ti;
+      }
+      const double den = dr * dr + di * di;
+      if (den == 0.0) continue;
+      const double cr = (pr * dr + pi * di) / den, ci = (pi * dr - pr * di) / den;
+      zr[k] -= cr; zi[k] -= ci;
+      change += fabs(cr) + fabs(ci);
+    }
+    if (change < 1e-15 * rad) break;
+  }
+  for (int k = 0; k < deg; ++k) re[k] = zr[k];
+  return deg;
+}
+__device__ inline double ls_minimize_interpolating(const LsSample *s, int ns, double x_min, double x_max) {
+  const int nc = 2 * ns, deg = nc - 1;
+  double A[6][7], coef[6], der[5], roots[4];
+  for (int i = 0; i < ns; ++i) {
+    for (int j = 0; j <= deg; ++j) A[2 * i][j] = ls_ipow(s[i].x, deg - j);
+    A[2 * i][nc] = s[i].v;
+    for (int j = 0; j < deg; ++j) A[2 * i + 1][j] = (deg - j) * ls_ipow(s[i].x, deg - j - 1);
+    A[2 * i + 1][deg] = 0.0;
+    A[2 * i + 1][nc] = s[i].g;
+  }
+  for (int c = 0; c < nc; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < nc; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    if (A[piv][c] == 0.0) return 0.5 * (x_min + x_max);
+    if (piv != c) for (int j = 0; j <= nc; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+    for (int r = 0; r < nc; ++r) {
+      if (r == c) continue;
+      const double f = A[r][c] / A[c][c];
+      for (int j = c; j <= nc; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  for (int c = 0; c < nc; ++c) coef[c] = A[c][nc] / A[c][c];
+  double best_x = 0.5 * (x_min + x_max), best = ls_poly_eval(coef, nc, best_x), v;
+  v = ls_poly_eval(coef, nc, x_min); if (v < best) { best = v; best_x = x_min; }
+  v = ls_poly_eval(coef, nc, x_max); if (v < best) { best = v; best_x = x_max; }
+  for (int i = 0; i < nc - 1; ++i) der[i] = (nc - 1 - i) * coef[i];
+  const int nr = ls_root_real_parts(der, nc - 1, roots);
+  for (int i = 0; i < nr; ++i) {
+    if (roots[i] < x_min || roots[i] > x_max) continue;
+    v = ls_poly_eval(coef, nc, roots[i]);
+    if (v < best) { best = v; best_x = roots[i]; }
+  }
+  for (int i = 0; i < ns; ++i) {
+    if (s[i].x < x_min || s[i].x > x_max) continue;
+    v = ls_poly_eval(coef, nc, s[i].x);
+    if (v < best) { best = v; best_x = s[i].x; }
+  }
+  return best_x;
+}
+
+// One line-search pass of a window, between its trial-point linearisation and the next candidate: directional derivative
+// g(x (+) alpha delta) . delta of the current trial, next alpha by cubic / quintic interpolation contracted into
+// [1e-3, 0.6] x alpha (ArmijoLineSearch::DoSearch + LineSearch::InterpolatingPolynomialMinimizingStepSize), min-step test.
+// One wave per window.
+template <class T> __global__ __launch_bounds__(64) void k_ls_step(Dev<T> d) {
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status || lm.ls_active == 0) return;
+  const WinMeta &m = d.wins[w];
+  const int lane = threadIdx.x;
+  double gd = 0.0;
+  if (lm.ls_active == 1)
+    for (int j = lane; j < m.N; j += 64)
+      if (d.active[m.u0 + j]) gd += d.g[m.u0 + j] * d.delta[m.u0 + j];
+  for (int off = 32; off > 0; off >>= 1) gd += __shfl_down(gd, off);
+  if (lane != 0) return;
+  lm.cand_cost = 0; lm.step2 = 0; lm.cand_xnorm2 = 0;
+  if (lm.ls_active == 2) { lm.alpha = 1.0; return; }   // failed search: Ceres keeps the full step
+  lm.ls_cur_g = gd;
+  const bool cur_ok = lm.ls_cur_valid && isfinite(gd);
+  const double lo = 1e-3 * lm.ls_cur_x, hi = 0.6 * lm.ls_cur_x;   // max_step_contraction, min_step_contraction
+  double step;
+  if (!cur_ok) {
+    step = fmin(fmax(lm.ls_cur_x * 0.5, lo), hi);
+  } else {
+    LsSample s[3];
+    int ns = 0;
+    s[ns++] = LsSample{0.0, lm.cost, lm.ls_gd0};
+    s[ns++] = LsSample{lm.ls_cur_x, lm.ls_cur_v, lm.ls_cur_g};
+    if (lm.ls_prev_valid) s[ns++] = LsSample{lm.ls_prev_x, lm.ls_prev_v, lm.ls_prev_g};
+    step = ls_minimize_interpolating(s, ns, lo, hi);
+  }
+  if (step * lm.ls_dmax < 1e-9) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return; }   // min_line_search_step_size
+  lm.ls_prev_x = lm.ls_cur_x; lm.ls_prev_v = lm.ls_cur_v; lm.ls_prev_g = lm.ls_cur_g; lm.ls_prev_valid = cur_ok ? 1 : 0;
+  lm.ls_cur_x = step;
+  lm.alpha = step;
 }
 
 // ------------------------------------------------------------------------------------------------ zero
@@ -160,16 +314,20 @@ template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part) {
   for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) d.g[m.u0 + i] = 0.0;
   // W, Hll and g[P..N) are written (not accumulated) by k_build_W
-  if (blockIdx.x == 0 && threadIdx.x == 0) d.lm[w].gmax_bits = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && !lin_at_candidate(d.lm[w])) d.lm[w].gmax_bits = 0ull;
 }
 
 // Knot-pair constants of every window for one state (see Dev::kd): one thread per knot.
-template <class T> __global__ void k_knot_prep(Dev<T> d, const double *quat, double *kd, T *kjri) {
+// mode 0: current state -> kd; 1: candidate -> ckd; 2: the state each window is about to be linearised at -> lkd, kjri.
+template <class T> __global__ void k_knot_prep(Dev<T> d, int mode) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= d.Ktot) return;
-  const WinMeta &m = d.wins[d.knot_win[g]];
+  const int w = d.knot_win[g];
+  const WinMeta &m = d.wins[w];
   if (g - m.knot0 >= m.K - 1) return;   // the last knot of a window starts no pair
-  knot_pair_const<T>(quat + 4 * g, quat + 4 * g + 4, kd + 3 * g, kjri ? kjri + 9 * g : nullptr);
+  const double *quat = mode == 0 ? d.quat : (mode == 1 ? d.cquat : (lin_at_candidate(d.lm[w]) ? d.cquat : d.quat));
+  double *kd = mode == 0 ? d.kd : (mode == 1 ? d.ckd : d.lkd);
+  knot_pair_const<T>(quat + 4 * g, quat + 4 * g + 4, kd + 3 * g, mode == 2 ? d.kjri + 9 * g : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ IMU
@@ -238,13 +396,15 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
   const int lane = threadIdx.x;
   Knots4<T> k;
   LocalFrame<T> lf;
-  lf.init(d.quat, d.pos, m.knot0 + grp.s);
-  lf.load(d.quat, d.pos, m.knot0 + grp.s, k);
+  const bool at_cand = lin_at_candidate(d.lm[w]);
+  const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
+  lf.init(s_quat, s_pos, m.knot0 + grp.s);
+  lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
   const M3<T> RrefT = lf.RrefT();
   SegConst<T> sc;
-  seg_const_load(d.kd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc, true);
+  seg_const_load(d.lkd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc, true);
   T bias[6], wgt[6];
-  const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
+  const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { bias[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
   const V3<T> grav = lf.rotate(m.gravity);
@@ -533,6 +693,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     const bool run = LIN ? lin_needed(lm) : (lm.status == 0 && (lm.step_valid || force));
     if (run) {
       const WinMeta &m = d.wins[w];
+      if (LIN) {   // the state this window is linearised at (its candidate while it is in the line search)
+        const bool at_cand = lin_at_candidate(lm);
+        quat = at_cand ? d.cquat : d.quat; pos = at_cand ? d.cpos : d.pos; rho = at_cand ? d.crho : d.rho; ldp = at_cand ? d.cld : d.ld;
+        kd = d.lkd;
+      }
       int si, sj;
       double ui, uj;
       const double ld = ldp[w];
@@ -1088,6 +1253,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
   const Lm &lm = d.lm[w];
   if (LIN ? !lin_needed(lm) : !(lm.status == 0 && (lm.step_valid || force))) return;
   const WinMeta &m = d.wins[w];
+  if (LIN && lin_at_candidate(lm)) { quat = d.cquat; pos = d.cpos; bias = d.cbias; ldp = d.cld; }
   extern __shared__ __attribute__((aligned(16))) double smd[];
   double *dx = smd;                 // [pn]
   __shared__ double red[256];
@@ -1111,6 +1277,8 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
   }
   const int n = m.pn;
   if (n > 0) {
+    for (int i = tid; i < n; i += 256) dx[i] = 0.0;
+    __syncthreads();
     for (int b = tid; b < m.pnb; b += 256) {
       const int kind = d.p_kind[m.pblk0 + b], idx = d.p_index[m.pblk0 + b], off = d.p_off[m.pblk0 + b];
       const double *x = prior_block_ptr(m, kind, idx, quat, pos, bias, ldp, w);
@@ -1155,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
 template <class T> __global__ void k_post_linearize(Dev<T> d) {
   const int w = blockIdx.y;
   Lm &lm = d.lm[w];
-  if (!lin_needed(lm)) return;
+  if (!lin_needed(lm) || lin_at_candidate(lm)) return;   // trial points of the line search only need g
   const WinMeta &m = d.wins[w];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m.N) return;
@@ -1206,7 +1374,7 @@ template <class T> __global__ void k_post_linearize(Dev<T> d) {
 template <class T> __global__ void k_damping(Dev<T> d) {
   const int w = blockIdx.y;
   const Lm &lm = d.lm[w];
-  if (lm.status) return;
+  if (lm.status || lm.ls_active) return;
   const WinMeta &m = d.wins[w];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m.N) return;
@@ -1237,7 +1405,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
   if (w >= d.nwin) return;
-  if (d.lm[w].status) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   const int nt = (m.P + 1 + 31) / 32;  // index P (the rhs row) included
   if (tile >= nt * (nt + 1) / 2) return;
@@ -1259,7 +1427,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) 
   // tiles over bias columns skip the loop
   const bool nz_i = (32 * bi < K6) || (P >= 32 * bi && P - 1 < 32 * bi + 32);
   const bool nz_j = (32 * bj < K6) || (P - 1 >= 32 * bj && P - 1 < 32 * bj + 32);
-  const int lend = (nz_i && nz_j) ? Lpad : 0;
+  const int lend = (nz_i && nz_j && L > 0) ? Lpad : 0;   // L == 0 (IMU-only window): nothing to eliminate, no row to clamp to
   for (int l0 = 0; l0 < lend; l0 += 16) {   // 8 MFMA steps (2 landmarks each) per trip: 32 loads in flight, then the products
     float wa[8], wb[8];
     double dv[8], gv[8];
@@ -1318,7 +1486,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) 
 // NPRE = elements of a chunk per thread (16 ldw / 512), so ldw <= 32 NPRE.
 template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_schur_window(Dev<float> d) {
   const int w = blockIdx.x;
-  if (d.lm[w].status) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
   const int nt = ldw >> 5, ntile = nt * (nt + 1) / 2;
@@ -1435,7 +1603,7 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;     // tiles of one window on one XCD (see k_schur_mfma)
   const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
   if (w >= d.nwin) return;
-  if (d.lm[w].status) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
   const int nt = (P + 15) / 16;
@@ -1451,7 +1619,7 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
   // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
   const bool nz_i = (16 * bi < K6) || (P - 1 >= 16 * bi && P - 1 < 16 * bi + 16);
   const bool nz_j = (16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16);
-  const int lend = (nz_i && nz_j) ? L : 0;
+  const int lend = (nz_i && nz_j) ? L : 0;   // L == 0: the loop (and its clamped row L - 1) is skipped
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
   for (int l0 = 0; l0 < lend; l0 += 16) {
     double wa[4], wb[4], dv[4];
@@ -1493,7 +1661,7 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
 
 template <class T> __global__ void k_schur_generic(Dev<T> d) {
   const int w = blockIdx.y;
-  if (d.lm[w].status) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long long)m.P * m.P) return;
@@ -1515,7 +1683,7 @@ template <class T> __global__ void k_schur_generic(Dev<T> d) {
 // rhs_p = -g_p + W^T diag(dinv) g_l.  256 threads = 64 unknowns x 4 landmark slices (coalesced over the unknowns).
 template <class T> __global__ __launch_bounds__(256) void k_rhs(Dev<T> d) {
   const int w = blockIdx.y;
-  if (d.lm[w].status) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   __shared__ double part[4][64];
   const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -1589,7 +1757,7 @@ template <int... Js> __device__ __forceinline__ void chol_diag_all(double (&a)[3
 template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
-  if (lm.status) return;
+  if (lm.status || lm.ls_active) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) double smc[];
@@ -1788,11 +1956,11 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
 template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
-  if (lm.status) return;
+  if (lm.status || lm.ls_active) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, N = m.N, u0 = m.u0, lm0 = m.lm0, ldw = m.ldw;
   extern __shared__ __attribute__((aligned(16))) double xs[];   // [P] pose step
-  __shared__ double red[4];
+  __shared__ double red[4], red_gd[4], red_dm[4];
   __shared__ int bad;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double *x = d.delta + u0;
@@ -1844,19 +2012,21 @@ template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
     if ((lane & 7) == 0 && l0 + (lane >> 3) < L) x[P + l0 + (lane >> 3)] = act_l ? (-g_l - v1) * dinv_l : 0.0;
   }
   __syncthreads();
-  double mc = 0.0;
+  double mc = 0.0, gd = 0.0, dm = 0.0;   // model change; g . delta and |delta|_inf for the projected line search
   for (int j = tid; j < N; j += 256) {
     const double dj = x[j];
     if (!isfinite(dj)) bad = 1;
-    if (d.active[u0 + j]) mc += 0.5 * dj * (dd[j] * dj - g[j]);
+    if (d.active[u0 + j]) { mc += 0.5 * dj * (dd[j] * dj - g[j]); gd += g[j] * dj; dm = fmax(dm, fabs(dj)); }
   }
-  for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off);
-  if (lane == 0) red[wave] = mc;
+  for (int off = 32; off > 0; off >>= 1) { mc += __shfl_down(mc, off); gd += __shfl_down(gd, off); dm = fmax(dm, __shfl_down(dm, off)); }
+  if (lane == 0) { red[wave] = mc; red_gd[wave] = gd; red_dm[wave] = dm; }
   __syncthreads();
   if (tid == 0) red[0] = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
   if (tid == 0) {
     lm.model_change = red[0];
+    lm.ls_gd0 = (red_gd[0] + red_gd[1]) + (red_gd[2] + red_gd[3]);
+    lm.ls_dmax = fmax(fmax(red_dm[0], red_dm[1]), fmax(red_dm[2], red_dm[3]));
     const bool valid = !lm.chol_fail && !bad && (red[0] > 0.0);
     if (valid) { lm.step_valid = 1; lm.invalid = 0; }
     else {
@@ -1887,7 +2057,9 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
     if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
     const WinMeta &m = d.wins[w];
     const int k = t - m.knot0;
-    const double *dl = d.delta + m.u0 + 6 * k;
+    const double al = lm.alpha;   // 1, or the trial step size of the projected line search
+    double dl[6];
+    for (int c = 0; c < 6; ++c) dl[c] = al * d.delta[m.u0 + 6 * k + c];
     const bool ar = d.active[m.u0 + 6 * k] != 0, ap = d.active[m.u0 + 6 * k + 3] != 0;
     const Q4<double> q0 = qmk<double>(d.quat[4 * t], d.quat[4 * t + 1], d.quat[4 * t + 2], d.quat[4 * t + 3]);
     Q4<double> q1 = q0;
@@ -1915,7 +2087,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
     const int u = 6 * m.K + 6 * (f - m.bias0);
     for (int c = 0; c < 6; ++c) {
       const bool a = d.active[m.u0 + u + c] != 0;
-      const double b0 = d.bias[6 * f + c], b1 = a ? b0 + d.delta[m.u0 + u + c] : b0;
+      const double b0 = d.bias[6 * f + c], b1 = a ? b0 + lm.alpha * d.delta[m.u0 + u + c] : b0;
       d.cbias[6 * f + c] = b1;
       if (a) { step2 += (b1 - b0) * (b1 - b0); x2 += b1 * b1; }
     }
@@ -1931,7 +2103,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
     const WinMeta &m = d.wins[w];
     const int u = m.P + (l - m.lm0);
     const bool a = d.active[m.u0 + u] != 0;
-    const double r0 = d.rho[l], r1 = a ? r0 + d.delta[m.u0 + u] : r0;
+    const double r0 = d.rho[l], r1 = a ? r0 + lm.alpha * d.delta[m.u0 + u] : r0;
     d.crho[l] = r1;
     if (a) { step2 += (r1 - r0) * (r1 - r0); x2 += r1 * r1; }
   } else if (t < d.Ktot + d.Ftot + d.Ltot + d.nwin) {
@@ -1945,7 +2117,7 @@ template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
     const WinMeta &m = d.wins[w];
     const bool a = d.active[m.u0 + m.P - 1] != 0;
     const double l0 = d.ld[w];
-    double l1 = a ? l0 + d.delta[m.u0 + m.P - 1] : l0;
+    double l1 = a ? l0 + lm.alpha * d.delta[m.u0 + m.P - 1] : l0;
     if (a && !m.fix_ld) l1 = fmin(fmax(l1, m.ld_lo), m.ld_hi);
     d.cld[w] = l1;
     if (a) { step2 += (l1 - l0) * (l1 - l0); x2 += l1 * l1; }

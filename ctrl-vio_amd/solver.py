@@ -17,8 +17,10 @@ from .window import Window
 class Solver:
     """One handle = one HIP stream + the HBM buffers of a batch of windows."""
 
-    def __init__(self, device: int = 0, precision: str = "fp32", use_mfma: bool = True, check_every: int = 4,
-                 fp64_residuals: bool = True, **tolerances):
+    def __init__(self, device: int = 0, precision: str = "fp64", use_mfma: bool = True, check_every: int = 4,
+                 fp64_residuals: bool = True, host_threads: int = 0, use_graph: bool = True, line_search: bool = True,
+                 **tolerances):
+        """precision "fp64" = the product (all-fp64, like the reference); "fp32" = the mixed fast mode."""
         self._lib = capi.load_library()
         if self._lib.ctvio_device_count() <= 0:
             raise capi.CtvioError("no HIP device: ctrl-vio_amd has no CPU fallback")
@@ -29,6 +31,9 @@ class Solver:
         opt.use_mfma = int(bool(use_mfma))
         opt.check_every = int(check_every)
         opt.fp64_residuals = int(bool(fp64_residuals))
+        opt.host_threads = int(host_threads)
+        opt.use_graph = int(bool(use_graph))
+        opt.line_search = int(bool(line_search))
         for k, v in tolerances.items():
             if not hasattr(opt, k):
                 raise TypeError(f"unknown option {k}")
@@ -71,10 +76,34 @@ class Solver:
         capi.check(self._lib.ctvio_upload(self._h))
 
     def set_windows(self, windows):
-        self.clear()
-        for w in windows:
-            self.add_window(w)
-        self.upload()
+        """ctvio_set_batch: validate + pack (C++ host threads) + one H2D copy of the whole batch."""
+        windows = list(windows)
+        keep = []
+        arr = (capi.CWindow * len(windows))()
+        for i, w in enumerate(windows):
+            arr[i] = capi.to_cwindow(w, keep)
+        capi.check(self._lib.ctvio_set_batch(self._h, len(windows), C.cast(arr, C.c_void_p)))
+        self.windows = windows
+
+    def set_cbatch(self, arr, n, windows=None):
+        """Same from a prebuilt (CWindow * n) array (bench.py keeps the ctypes marshalling out of the timed region)."""
+        capi.check(self._lib.ctvio_set_batch(self._h, int(n), C.cast(arr, C.c_void_p)))
+        self.windows = list(windows) if windows is not None else []
+
+    def get_batch_state(self):
+        """Every window's state with one D2H copy: (quat (sumK,4), pos (sumK,3), bias (sumF,6), rho (sumL,), ld (n,))."""
+        K = sum(w.K for w in self.windows); F = sum(w.F for w in self.windows); L = sum(w.L for w in self.windows); n = len(self.windows)
+        q = np.zeros((K, 4)); p = np.zeros((K, 3)); b = np.zeros((F, 6)); r = np.zeros(max(L, 1)); ld = np.zeros(n)
+        capi.check(self._lib.ctvio_get_batch_state(self._h, capi._p(q), capi._p(p), capi._p(b), capi._p(r), capi._p(ld)))
+        return q, p, b, r[:L], ld
+
+    def writeback_all(self):
+        """get_batch_state scattered into the Window objects of the batch (in place, like Ceres updates its double*)."""
+        q, p, b, r, ld = self.get_batch_state()
+        k = f = l = 0
+        for i, w in enumerate(self.windows):
+            w.quat[:] = q[k:k + w.K]; w.pos[:] = p[k:k + w.K]; w.bias[:] = b[f:f + w.F]; w.rho[:] = r[l:l + w.L]; w.ld = float(ld[i])
+            k += w.K; f += w.F; l += w.L
 
     @property
     def n(self) -> int:
@@ -88,9 +117,36 @@ class Solver:
         sm = (capi.Summary * n)()
         capi.check(self._lib.ctvio_solve(self._h, int(max_iterations), C.cast(sm, C.c_void_p)))
         if writeback:
-            for i, w in enumerate(self.windows):
-                self.get_state(i, into=w)
+            self.writeback_all()
         return [s.as_dict() for s in sm]
+
+    # ---- IMU-only predict (reference TrajectoryManager::InitTrajectory, src/estimator/trajectory_manager.cpp:288-315)
+    @staticmethod
+    def predict_window(w: Window, fixed_upto: int = -1) -> Window:
+        """The factor set of InitTrajectory for window w: IMU blocks only (no visual blocks, bias chain or prior), both biases
+        locked (option.lock_ab / lock_wb), knots 0..fixed_upto constant.  NB: the reference calls SetFixedIndex(max_bef_idx)
+        AFTER its AddIMUMeasurementAnalytic loop, and constancy is decided when a knot is added
+        (trajectory_estimator.cpp:134-138), so in the reference as written no knot is constant: pass fixed_upto = -1 for
+        that behaviour, max_bef_idx for what the call order suggests was intended."""
+        p = w.copy()
+        z = lambda a: a[:0]
+        p.v_lm, p.v_ti, p.v_tj, p.v_rowi, p.v_rowj, p.v_pi, p.v_pj = z(p.v_lm), z(p.v_ti), z(p.v_tj), z(p.v_rowi), z(p.v_rowj), z(p.v_pi), z(p.v_pj)
+        p.bc_i, p.bc_j, p.bc_w = z(p.bc_i), z(p.bc_j), z(p.bc_w)
+        p.pJ0 = np.zeros((0, 0)); p.pr0 = np.zeros(0)
+        p.p_kind, p.p_index, p.p_off, p.p_x0 = z(p.p_kind), z(p.p_index), z(p.p_off), z(p.p_x0)
+        p.lock_bg = p.lock_ba = True
+        p.fixed_upto = int(fixed_upto)
+        return p.normalize()
+
+    def predict(self, windows, fixed_upto=None, max_iterations: int = 8):
+        """InitTrajectory for a batch: Solve(8) of the IMU-only problems; the knots of `windows` are updated in place."""
+        fixed_upto = [-1] * len(windows) if fixed_upto is None else list(fixed_upto)
+        pw = [self.predict_window(w, f) for w, f in zip(windows, fixed_upto)]
+        self.set_windows(pw)
+        sms = self.solve(max_iterations)
+        for w, p in zip(windows, pw):
+            w.quat[:] = p.quat; w.pos[:] = p.pos
+        return sms
 
     def solve_raw(self, max_iterations: int = 15):
         """Solve without any host-side copy besides the summaries (used by bench.py)."""

@@ -80,53 +80,75 @@ def make_window(config: str = "config2", seed: int = 1000, *, with_prior: bool =
     cx, cy = W_img / 2.0, H_img / 2.0
 
     def cam_pose(tau_ns):
-        e = sp.eval_spline(quat, pos, 0, dt_ns, [tau_ns], want=("q", "p"))
-        R = sp.quat_to_R(e["q"][0])
-        return R, e["p"][0]
+        """spline pose at (n,) times: rotations (n,3,3), positions (n,3)."""
+        e = sp.eval_spline(quat, pos, 0, dt_ns, tau_ns, want=("q", "p"))
+        return sp.quat_to_R(e["q"]), e["p"]
 
     def project(Xw, t_frame):
-        """Rolling-shutter projection: returns (u, v) or None."""
-        v = cy
+        """Rolling-shutter projection of (n,3) world points into the frames starting at t_frame (n,): fixed point on the row
+        time (6 rounds; an element stops once its row moved by < 1e-7).  Returns u, v, valid."""
+        n = Xw.shape[0]
+        v = np.full(n, cy); u = np.zeros(n)
+        live = np.ones(n, bool); ok = np.ones(n, bool)
         for _ in range(6):
-            tau = int(t_frame + round(v * ld_true * 1e9))
-            R, p = cam_pose(tau)
-            Xc = R_CI.T @ (R.T @ (Xw - p) - _P_CI)
-            if Xc[2] < 0.3:
-                return None
-            u_new, v_new = f * Xc[0] / Xc[2] + cx, f * Xc[1] / Xc[2] + cy
-            if not (2 <= v_new < H_img - 2 and 2 <= u_new < W_img - 2):
-                return None
-            if abs(v_new - v) < 1e-7:
-                v = v_new
+            if not live.any():
                 break
-            v = v_new
-        return u_new, v
+            tau = t_frame[live] + np.round(v[live] * ld_true * 1e9).astype(np.int64)
+            R, p = cam_pose(tau)
+            Xc = np.einsum("ji,nj->ni", R_CI, np.einsum("nji,nj->ni", R, Xw[live] - p) - _P_CI)
+            z = np.where(Xc[:, 2] < 0.3, 1.0, Xc[:, 2])
+            un, vn = f * Xc[:, 0] / z + cx, f * Xc[:, 1] / z + cy
+            good = (Xc[:, 2] >= 0.3) & (vn >= 2) & (vn < H_img - 2) & (un >= 2) & (un < W_img - 2)
+            idx = np.flatnonzero(live)
+            done = good & (np.abs(vn - v[idx]) < 1e-7)
+            u[idx] = un; v[idx] = np.where(good, vn, v[idx])
+            ok[idx[~good]] = False
+            live[idx[~good | done]] = False
+        return u, v, ok
 
+    # landmarks are placed by rejection, all still-unplaced ones per round (vectorised; deterministic for a given seed)
+    anchors = np.arange(L) % min(8, max(F - 2, 1))               # anchor frame < WINDOW_SIZE-2 (feature_manager.h:58-65)
+    n_obs = np.minimum(F - anchors, 3 + (np.arange(L) % 6))
+    max_obs = int(n_obs.max()) if L else 0
     rho_true = np.zeros(L)
-    v_lm, v_ti, v_tj, v_rowi, v_rowj, v_pi, v_pj = [], [], [], [], [], [], []
+    anchor_uv = np.zeros((L, 2)); obs_uv = np.zeros((L, max(max_obs, 1), 2))
+    todo = np.arange(L)
+    for _attempt in range(200):
+        if todo.size == 0:
+            break
+        n = todo.size
+        dr = rng.uniform(size=(n, 3))
+        u0, v0, depth = 40 + (W_img - 80) * dr[:, 0], 40 + (H_img - 80) * dr[:, 1], 2.0 + 6.0 * dr[:, 2]
+        tau = frame_t[anchors[todo]] + np.round(v0 * ld_true * 1e9).astype(np.int64)
+        R, p = cam_pose(tau)
+        Xc = depth[:, None] * np.stack([(u0 - cx) / f, (v0 - cy) / f, np.ones(n)], 1)
+        Xw = np.einsum("nij,nj->ni", R, Xc @ R_CI.T + _P_CI) + p
+        good = np.ones(n, bool)
+        uvs = np.zeros((n, max(max_obs, 1), 2))
+        for k in range(1, max_obs):
+            sel = np.flatnonzero((k < n_obs[todo]) & good)
+            if sel.size == 0:
+                continue
+            uu, vv, ok = project(Xw[sel], frame_t[anchors[todo[sel]] + k])
+            uvs[sel, k, 0] = uu; uvs[sel, k, 1] = vv
+            good[sel[~ok]] = False
+        placed = todo[good]
+        rho_true[placed] = 1.0 / depth[good]
+        anchor_uv[placed, 0] = u0[good]; anchor_uv[placed, 1] = v0[good]
+        obs_uv[placed] = uvs[good]
+        todo = todo[~good]
+    if todo.size:
+        raise RuntimeError("could not place landmark")
     sig = cfg["pix_sigma"]
+    noise = rng.normal(0.0, sig, (L, max(max_obs, 1), 2))
+    v_lm, v_ti, v_tj, v_rowi, v_rowj, v_pi, v_pj = [], [], [], [], [], [], []
     for l in range(L):
-        a = l % min(8, max(F - 2, 1))                            # anchor frame < WINDOW_SIZE-2 (feature_manager.h:58-65)
-        n_obs = min(F - a, 3 + (l % 6))
-        for _attempt in range(200):
-            u0, v0 = rng.uniform(40, W_img - 40), rng.uniform(40, H_img - 40)
-            depth = rng.uniform(2.0, 8.0)
-            tau = int(frame_t[a] + round(v0 * ld_true * 1e9))
-            R, p = cam_pose(tau)
-            Xc = depth * np.array([(u0 - cx) / f, (v0 - cy) / f, 1.0])
-            Xw = R @ (R_CI @ Xc + _P_CI) + p
-            obs = [project(Xw, int(frame_t[b])) for b in range(a + 1, a + n_obs)]
-            if all(o is not None for o in obs):
-                break
-        else:
-            raise RuntimeError("could not place landmark")
-        rho_true[l] = 1.0 / depth
-        noise = rng.normal(0.0, sig, (n_obs, 2))
-        ua, va = u0 + noise[0, 0], v0 + noise[0, 1]
-        for k, o in enumerate(obs):
-            uo, vo = o[0] + noise[k + 1, 0], o[1] + noise[k + 1, 1]
+        a = int(anchors[l])
+        ua, va = anchor_uv[l, 0] + noise[l, 0, 0], anchor_uv[l, 1] + noise[l, 0, 1]
+        for k in range(1, int(n_obs[l])):
+            uo, vo = obs_uv[l, k, 0] + noise[l, k, 0], obs_uv[l, k, 1] + noise[l, k, 1]
             v_lm.append(l)
-            v_ti.append(frame_t[a]); v_tj.append(frame_t[a + 1 + k])
+            v_ti.append(frame_t[a]); v_tj.append(frame_t[a + k])
             v_rowi.append(int(round(va))); v_rowj.append(int(round(vo)))
             v_pi.append([(ua - cx) / f, (va - cy) / f]); v_pj.append([(uo - cx) / f, (vo - cy) / f])
 

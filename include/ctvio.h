@@ -36,7 +36,11 @@ enum ctvio_status {
   CTVIO_ERR_STATE = 4       /* call order violated (e.g. solve before upload) */
 };
 
-enum ctvio_precision { CTVIO_FP32 = 0 /* product */, CTVIO_FP64 = 1 /* debugging the kernels against the oracle */ };
+/* CTVIO_FP64 (default, the product): every residual, Jacobian, product and factorisation in fp64, like the reference
+ * (Ceres/Eigen are all double); reproduces the fp64 CPU reference's iterates, final state to ~1e-9.
+ * CTVIO_FP32: mixed "fast" mode -- Jacobians, J^T J and the Schur complement in fp32 (residuals, costs, Cholesky in fp64);
+ * the 15th iterate then agrees with the fp64 reference to ~1e-5 typically but NOT to 1e-4 on every window. */
+enum ctvio_precision { CTVIO_FP32 = 0, CTVIO_FP64 = 1 };
 
 /* Kinds of parameter blocks kept by a marginalisation prior (reference
  * marginalization_factor.h:115-129 keep_block_*; sizes 4->local 3, 3, 3, 3, 1). */
@@ -60,6 +64,10 @@ typedef struct ctvio_options {
   int32_t max_consecutive_invalid_steps;   /* 5 */
   int32_t fp64_residuals;       /* FP32 only, default 1: residuals, gradient right-hand sides and costs are evaluated in fp64
                                    (Jacobians, J^T J and the Schur complement stay fp32) */
+  int32_t host_threads;         /* host threads that validate / pack a batch (ctvio_set_batch, ctvio_upload); 0 = min(cores, 16) */
+  int32_t use_graph;            /* 1 (default): the launch sequence of one LM pass is captured into a hipGraph and replayed */
+  int32_t line_search;          /* 1 (default, CTVIO_FP64 only): Ceres' projected Armijo line search of bounds-constrained problems
+                                   (a free line delay has bounds: trajectory_estimator.cpp:311-318 => Minimizer is_constrained) */
 } ctvio_options;
 
 /* One sliding window = what TrajectoryManager::UpdateTrajectory feeds a fresh TrajectoryEstimator
@@ -101,6 +109,8 @@ typedef struct ctvio_summary {
   int32_t num_successful, num_unsuccessful;
   int32_t termination;          /* 0 max-iterations 1 gradient 2 parameter 3 function 4 min-radius 5 failure */
   double initial_cost, final_cost, final_radius;
+  int32_t num_line_search_steps;   /* ceres::Solver::Summary::num_line_search_steps: Armijo iterations beyond the first trial */
+  int32_t num_line_search_reduced; /* LM iterations whose step was shortened by the projected line search */
 } ctvio_summary;
 
 void ctvio_default_options(ctvio_options *opt);
@@ -119,6 +129,10 @@ int32_t ctvio_clear(ctvio_solver *s);
 int32_t ctvio_add_window(ctvio_solver *s, const ctvio_window *w, int32_t *id);
 /* Pack (sort IMU samples into (segment,bias) groups, prior J0^T J0, ...) and copy to HBM. */
 int32_t ctvio_upload(ctvio_solver *s);
+/* ctvio_clear + n x ctvio_add_window + ctvio_upload in one call, without the intermediate host copy: the n windows are
+ * validated and packed straight from the caller's buffers (read during this call only) by opt.host_threads threads into a
+ * pinned staging arena, which reaches HBM with a single asynchronous copy on the solver's stream.  Window ids = 0..n-1. */
+int32_t ctvio_set_batch(ctvio_solver *s, int32_t n, const ctvio_window *wins);
 int32_t ctvio_num_windows(const ctvio_solver *s);
 
 /* TrajectoryEstimator::Solve(max_iterations) (trajectory_estimator.cpp:367-408) for every window of the
@@ -127,6 +141,9 @@ int32_t ctvio_solve(ctvio_solver *s, int32_t max_iterations, ctvio_summary *out)
 
 /* Results back to the caller's live state (Ceres updates the double* in place; here explicit). */
 int32_t ctvio_get_state(ctvio_solver *s, int32_t id, double *quat, double *pos, double *bias, double *rho, double *ld);
+/* The state of EVERY window of the batch with one device-to-host copy: quat (sum K x 4), pos (sum K x 3), bias (sum F x 6),
+ * rho (sum L), ld (n), each concatenated in window order.  Any pointer may be NULL. */
+int32_t ctvio_get_batch_state(ctvio_solver *s, double *quat, double *pos, double *bias, double *rho, double *ld);
 /* Overwrite the state of an uploaded window (re-solve the same factors from another initial guess). */
 int32_t ctvio_set_state(ctvio_solver *s, int32_t id, const double *quat, const double *pos, const double *bias,
                         const double *rho, double ld);

@@ -1052,12 +1052,136 @@ static double gradient_max_norm(ctvo_window *w, const double *g_unscaled, const 
   return dinf;
 }
 
+/* ------------------------------------------------------------------ Ceres' projected line search
+ * When any parameter block of the reduced program has bounds (the line delay, trajectory_estimator.cpp:311-318)
+ * Ceres 1.14 sets Minimizer::Options::is_constrained and TrustRegionMinimizer::Minimize runs DoLineSearch(x, gradient,
+ * cost, &delta) between ComputeTrustRegionStep and ComputeCandidatePointAndEvaluateCost (external source:
+ * internal/ceres/trust_region_minimizer.cc, line_search.cc, polynomial.cc; restated from their published algorithm):
+ * an ARMIJO search along Plus(x, alpha * delta) (Plus projects onto the box) starting at alpha = 1 with
+ * sufficient_decrease 1e-4, CUBIC interpolation (value AND gradient at every trial point), step contraction limited to
+ * [1e-3, 0.6] x the current alpha, at most 20 iterations, min step 1e-9.  On success delta *= alpha; on failure delta is
+ * left unchanged.  model_cost_change stays the one of the unscaled step.                                             */
+typedef struct { double x, value, gradient; int value_is_valid, gradient_is_valid; } ls_sample;
+
+static double poly_eval(const double *p, int n /* coefficients, highest first */, double x) {
+  double v = 0;
+  for (int i = 0; i < n; ++i) v = v * x + p[i];
+  return v;
+}
+/* FindInterpolatingPolynomial: values and gradients of the samples -> coefficients (highest power first). */
+static int poly_interpolate(const ls_sample *s, int ns, double *coef) {
+  int nc = 0;
+  for (int i = 0; i < ns; ++i) nc += (s[i].value_is_valid != 0) + (s[i].gradient_is_valid != 0);
+  const int deg = nc - 1;
+  double A[6][7];
+  int row = 0;
+  for (int i = 0; i < ns; ++i) {
+    if (s[i].value_is_valid) {
+      for (int j = 0; j <= deg; ++j) A[row][j] = pow(s[i].x, deg - j);
+      A[row][nc] = s[i].value; ++row;
+    }
+    if (s[i].gradient_is_valid) {
+      for (int j = 0; j < deg; ++j) A[row][j] = (deg - j) * pow(s[i].x, deg - j - 1);
+      A[row][deg] = 0.0;
+      A[row][nc] = s[i].gradient; ++row;
+    }
+  }
+  for (int c = 0; c < nc; ++c) { /* Gauss-Jordan with partial pivoting (Ceres: Eigen fullPivLu, same solution) */
+    int piv = c;
+    for (int r = c + 1; r < nc; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    if (A[piv][c] == 0.0) return 0;
+    if (piv != c) for (int j = 0; j <= nc; ++j) { double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+    for (int r = 0; r < nc; ++r) {
+      if (r == c) continue;
+      const double f = A[r][c] / A[c][c];
+      for (int j = c; j <= nc; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  for (int c = 0; c < nc; ++c) coef[c] = A[c][nc] / A[c][c];
+  return nc;
+}
+/* real parts of all (complex) roots of a polynomial of degree <= 4 (Ceres FindPolynomialRoots: closed forms up to degree 2,
+ * companion-matrix eigenvalues above; here Durand-Kerner, same roots to rounding).  Returns the number of roots. */
+static int poly_root_real_parts(const double *p_in, int n, double *re) {
+  while (n > 0 && p_in[0] == 0.0) { ++p_in; --n; }   /* RemoveLeadingZeros */
+  const int deg = n - 1;
+  if (deg <= 0) return 0;
+  if (deg == 1) { re[0] = -p_in[1] / p_in[0]; return 1; }
+  if (deg == 2) {
+    const double a = p_in[0], b = p_in[1], c = p_in[2], D = b * b - 4 * a * c, sD = sqrt(fabs(D));
+    if (D >= 0) {
+      if (b >= 0) { re[0] = (-b - sD) / (2.0 * a); re[1] = (2.0 * c) / (-b - sD); }
+      else { re[0] = (2.0 * c) / (-b + sD); re[1] = (-b + sD) / (2.0 * a); }
+    } else { re[0] = re[1] = -b / (2.0 * a); }
+    return 2;
+  }
+  double q[5], zr[4], zi[4];
+  for (int i = 0; i <= deg; ++i) q[i] = p_in[i] / p_in[0];
+  double rad = 0;
+  for (int i = 1; i <= deg; ++i) if (fabs(q[i]) > rad) rad = fabs(q[i]);
+  rad = 1.0 + rad;
+  for (int k = 0; k < deg; ++k) { const double ang = 2.0 * 3.14159265358979323846 * k / deg + 0.4; zr[k] = 0.5 * rad * cos(ang); zi[k] = 0.5 * rad * sin(ang); }
+  for (int it = 0; it < 500; ++it) {
+    double change = 0;
+    for (int k = 0; k < deg; ++k) {
+      double pr = 1.0, pi = 0.0;   /* p(z_k) by Horner */
+      for (int i = 1; i <= deg; ++i) { const double tr = pr * zr[k] - pi * zi[k] + q[i], ti = pr * zi[k] + pi * zr[k]; pr = tr; pi = ti; }
+      double dr = 1.0, di = 0.0;   /* prod_{j != k} (z_k - z_j) */
+      for (int j = 0; j < deg; ++j) {
+        if (j == k) continue;
+        const double ar = zr[k] - zr[j], ai = zi[k] - zi[j], tr = dr * ar - di * ai, ti = dr * ai + di * ar;
+        dr = tr; di = ti;
+      }
+      const double den = dr * dr + di * di;
+      if (den == 0.0) continue;
+      const double cr = (pr * dr + pi * di) / den, ci = (pi * dr - pr * di) / den;
+      zr[k] -= cr; zi[k] -= ci;
+      change += fabs(cr) + fabs(ci);
+    }
+    if (change < 1e-15 * rad) break;
+  }
+  for (int k = 0; k < deg; ++k) re[k] = zr[k];
+  return deg;
+}
+/* MinimizeInterpolatingPolynomial (polynomial.cc): minimum over [x_min, x_max] of the interpolating polynomial, candidates =
+ * midpoint, both ends, the real part of every root of the derivative inside the interval, the sample points inside it. */
+static double poly_minimize_interpolating(const ls_sample *s, int ns, double x_min, double x_max) {
+  double coef[6], der[5], roots[4];
+  const int nc = poly_interpolate(s, ns, coef);
+  if (nc <= 0) return 0.5 * (x_min + x_max);
+  double best_x = 0.5 * (x_min + x_max), best = poly_eval(coef, nc, best_x), v;
+  v = poly_eval(coef, nc, x_min); if (v < best) { best = v; best_x = x_min; }
+  v = poly_eval(coef, nc, x_max); if (v < best) { best = v; best_x = x_max; }
+  if (nc > 2) {
+    for (int i = 0; i < nc - 1; ++i) der[i] = (nc - 1 - i) * coef[i];
+    const int nr = poly_root_real_parts(der, nc - 1, roots);
+    for (int i = 0; i < nr; ++i) {
+      if (roots[i] < x_min || roots[i] > x_max) continue;
+      v = poly_eval(coef, nc, roots[i]);
+      if (v < best) { best = v; best_x = roots[i]; }
+    }
+  }
+  for (int i = 0; i < ns; ++i) {
+    if (s[i].x < x_min || s[i].x > x_max) continue;
+    v = poly_eval(coef, nc, s[i].x);
+    if (v < best) { best = v; best_x = s[i].x; }
+  }
+  return best_x;
+}
+/* test hook: exercise the interpolation machinery from Python */
+double ctvo_ls_interpolate(int ns, const double *x, const double *value, const double *gradient, double x_min, double x_max) {
+  ls_sample s[3];
+  for (int i = 0; i < ns && i < 3; ++i) { s[i].x = x[i]; s[i].value = value[i]; s[i].gradient = gradient[i]; s[i].value_is_valid = s[i].gradient_is_valid = 1; }
+  return poly_minimize_interpolating(s, ns, x_min, x_max);
+}
+
 /* TrustRegionMinimizer::Minimize of Ceres 1.14 as configured at trajectory_estimator.cpp:371-398
- * (external source, restated from its documentation).  The bounded
- * line search Ceres runs when a parameter has bounds is restated only for its alpha = 1
- * outcome (step kept, projection into the box applied by Plus).                       */
+ * (external source, restated from its documentation and published algorithm), including the
+ * projected Armijo line search of bounds-constrained problems (above).                                        */
 static double g_ftol = 1e-6, g_gtol = 1e-10, g_ptol = 1e-8; /* Ceres defaults */
 void ctvo_set_tolerances(double ftol, double gtol, double ptol) { g_ftol = ftol; g_gtol = gtol; g_ptol = ptol; }
+static int g_line_search = 1;
+void ctvo_set_line_search(int on) { g_line_search = on; }
 
 int ctvo_solve(ctvo_window *w, int max_iters, int use_schur, ctvo_summary *out) {
   const int N = nN(w), P = nP(w);
@@ -1065,10 +1189,12 @@ int ctvo_solve(ctvo_window *w, int max_iters, int use_schur, ctvo_summary *out) 
   const double max_radius = 1e16, min_radius = 1e-32;
   double *H = (double *)malloc(sizeof(double) * (size_t)N * N), *g = (double *)malloc(sizeof(double) * N);
   double *c = (double *)malloc(sizeof(double) * N), *delta = (double *)malloc(sizeof(double) * N);
+  double *H2 = NULL, *g2 = (double *)malloc(sizeof(double) * N), *dtrial = (double *)malloc(sizeof(double) * N);
   uint8_t *act = (uint8_t *)malloc(N);
   ctvo_summary sm;
   memset(&sm, 0, sizeof sm);
   ctvo_active_mask(w, act);
+  const int constrained = g_line_search && !w->fix_ld && act[P - 1];   /* Program::IsBoundsConstrained of the reduced program */
   /* IterationZero: project onto the feasible set, evaluate */
   if (!w->fix_ld) {
     if (w->ld < w->ld_lo) w->ld = w->ld_lo;
@@ -1101,8 +1227,58 @@ int ctvo_solve(ctvo_window *w, int max_iters, int use_schur, ctvo_summary *out) 
     invalid = 0;
     state_copy xs;
     state_save(w, &xs);
-    ctvo_plus(w, delta);
-    const double cand_cost = ctvo_cost(w);
+    double cand_cost;
+    if (constrained) {
+      /* DoLineSearch: g here is the Jacobi-scaled gradient gs = c .* g and delta = c .* y, so g^T delta = sum gs_i delta_i / c_i */
+      double gd = 0, dmax = 0;
+      for (int i = 0; i < N; ++i)
+        if (act[i]) { gd += g[i] * delta[i] / c[i]; if (fabs(delta[i]) > dmax) dmax = fabs(delta[i]); }
+      ls_sample initial = {0.0, cost, gd, 1, 1}, previous = {0, 0, 0, 0, 0}, current = {1.0, 0, 0, 0, 0};
+      ctvo_plus(w, delta);
+      if (!H2) H2 = (double *)malloc(sizeof(double) * (size_t)N * N);
+      current.value = ctvo_build_normal(w, H2, g2);   /* CUBIC interpolation: value and gradient at every trial point */
+      current.gradient = 0;
+      for (int i = 0; i < N; ++i) if (act[i]) current.gradient += g2[i] * delta[i];
+      current.value_is_valid = isfinite(current.value) && isfinite(current.gradient);
+      current.gradient_is_valid = current.value_is_valid;
+      int ls_iters = 0, ls_ok = 1;
+      while (!current.value_is_valid || current.value > cost + 1e-4 * gd * current.x) {
+        if (++ls_iters >= 20) { ls_ok = 0; break; }
+        double step;
+        if (!current.value_is_valid) {
+          step = fmin(fmax(current.x * 0.5, 1e-3 * current.x), 0.6 * current.x);
+        } else {
+          ls_sample smp[3];
+          int ns = 0;
+          smp[ns++] = initial; smp[ns++] = current;
+          if (previous.value_is_valid) smp[ns++] = previous;
+          step = poly_minimize_interpolating(smp, ns, 1e-3 * current.x, 0.6 * current.x);
+        }
+        if (step * dmax < 1e-9) { ls_ok = 0; break; }
+        previous = current;
+        current.x = step;
+        state_restore(w, &xs);
+        for (int i = 0; i < N; ++i) dtrial[i] = step * delta[i];
+        ctvo_plus(w, dtrial);
+        current.value = ctvo_build_normal(w, H2, g2);
+        current.gradient = 0;
+        for (int i = 0; i < N; ++i) if (act[i]) current.gradient += g2[i] * delta[i];
+        current.value_is_valid = isfinite(current.value) && isfinite(current.gradient);
+        current.gradient_is_valid = current.value_is_valid;
+      }
+      sm.num_line_search_steps += ls_iters;
+      const double alpha = ls_ok ? current.x : 1.0;
+      if (alpha != 1.0) {
+        sm.num_line_search_reduced++;
+        for (int i = 0; i < N; ++i) delta[i] *= alpha;
+      }
+      state_restore(w, &xs);
+      ctvo_plus(w, delta);
+      cand_cost = ctvo_cost(w);
+    } else {
+      ctvo_plus(w, delta);
+      cand_cost = ctvo_cost(w);
+    }
     double d2;
     state_norms(w, &xs, act, NULL, &d2, NULL);
     const double step_norm = sqrt(d2);
@@ -1141,7 +1317,7 @@ int ctvo_solve(ctvo_window *w, int max_iters, int use_schur, ctvo_summary *out) 
   sm.final_cost = cost;
   sm.final_radius = mu;
   if (out) *out = sm;
-  free(H); free(g); free(c); free(delta); free(act);
+  free(H); free(g); free(c); free(delta); free(act); free(g2); free(dtrial); free(H2);
   return term;
 }
 

@@ -71,6 +71,8 @@ typedef struct ctvo_summary {
   double initial_cost, final_cost;
   double final_radius;
   double cost_hist[64];     /* x_cost after each iteration (index = iteration) */
+  int32_t num_line_search_steps;   /* Ceres Summary::num_line_search_steps: Armijo iterations beyond the first trial (alpha = 1) */
+  int32_t num_line_search_reduced; /* LM iterations whose step was shortened by the projected line search (alpha < 1) */
 } ctvo_summary;
 
 /* --- Lie primitives (src/sophus_lib/so3.hpp:220-262,534-569; src/utils/sophus_utils.hpp:166-242) */
@@ -100,6 +102,9 @@ void ctvo_active_mask(const ctvo_window *w, uint8_t *active);
 /* LM solve with Ceres-1.14 semantics.  Updates the state in place.
  * use_schur: 1 = eliminate landmarks then dense P*P Cholesky; 0 = dense Cholesky on all N. */
 int ctvo_solve(ctvo_window *w, int max_iters, int use_schur, ctvo_summary *out);
+/* Test hooks: projected line search on/off (default on, as Ceres does for bounded problems); the interpolation step. */
+void ctvo_set_line_search(int on);
+double ctvo_ls_interpolate(int ns, const double *x, const double *value, const double *gradient, double x_min, double x_max);
 /* Test hook: override function/gradient/parameter tolerances (Ceres defaults 1e-6, 1e-10, 1e-8). */
 void ctvo_set_tolerances(double ftol, double gtol, double ptol);
 

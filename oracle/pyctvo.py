@@ -45,7 +45,8 @@ class _CWindow(C.Structure):
 class Summary(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("num_successful", C.c_int32), ("num_unsuccessful", C.c_int32),
                 ("termination", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
-                ("final_radius", C.c_double), ("cost_hist", C.c_double * 64)]
+                ("final_radius", C.c_double), ("cost_hist", C.c_double * 64),
+                ("num_line_search_steps", C.c_int32), ("num_line_search_reduced", C.c_int32)]
 
 
 _lib = None
@@ -60,6 +61,9 @@ def lib():
         _lib.ctvo_lm_step.restype = C.c_double
         _lib.ctvo_lm_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p]
         _lib.ctvo_set_tolerances.argtypes = [C.c_double, C.c_double, C.c_double]
+        _lib.ctvo_set_line_search.argtypes = [C.c_int]
+        _lib.ctvo_ls_interpolate.restype = C.c_double
+        _lib.ctvo_ls_interpolate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
     return _lib
 
 
@@ -217,3 +221,14 @@ def so3_Jr_inv(phi):
 def set_tolerances(ftol=1e-6, gtol=1e-10, ptol=1e-8):
     """Test hook; defaults are Ceres' (function, gradient, parameter) tolerances."""
     lib().ctvo_set_tolerances(float(ftol), float(gtol), float(ptol))
+
+
+def set_line_search(on=True):
+    """Test hook: Ceres' projected Armijo line search of bounded problems (default on)."""
+    lib().ctvo_set_line_search(int(bool(on)))
+
+
+def ls_interpolate(x, value, gradient, x_min, x_max):
+    """Minimiser over [x_min, x_max] of the polynomial interpolating (x, value, gradient) samples (2 -> cubic, 3 -> quintic)."""
+    x = np.ascontiguousarray(x, np.float64); v = np.ascontiguousarray(value, np.float64); g = np.ascontiguousarray(gradient, np.float64)
+    return float(lib().ctvo_ls_interpolate(int(x.shape[0]), _p(x), _p(v), _p(g), float(x_min), float(x_max)))

@@ -22,7 +22,7 @@ def test_default_options_and_strings(cv):
     o = cv.capi.Options()
     lib.ctvio_default_options(C.byref(o))
     assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
-    assert o.initial_radius == 1e4 and o.max_consecutive_invalid_steps == 5 and o.precision == cv.capi.FP32
+    assert o.initial_radius == 1e4 and o.max_consecutive_invalid_steps == 5 and o.precision == cv.capi.FP64 and o.use_graph == 1 and o.host_threads == 0
     assert lib.ctvio_status_string(0) == b"ok"
     assert b"no CPU fallback" in lib.ctvio_status_string(2)
 

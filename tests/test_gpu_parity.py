@@ -1,11 +1,9 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against the fp64 oracle on the same seeded windows,
 the committed golden fixtures, and size-independent properties at BASELINE.json's full sizes.
 
-Tolerances.  precision="fp64" runs the same kernels in double: it must reproduce the oracle to rounding, which
-validates kernel logic (indexing, reductions, Schur, Cholesky, LM control).  precision="fp32" is the product:
-  linearisation (Jacobi-normalised H, W, g)        <= 2e-4   (fp32 Jacobians; residuals, J^T r inputs and costs in fp64)
-  one LM step (relative, max-norm)                 <= 5e-3
-  final state vs the fp64 reference solve at Ceres' own tolerances (BASELINE target)  <= 1e-4
+Tolerances.  precision="fp64" (the default) is the product: every kernel in double, like the reference -- it must reproduce the oracle's
+iterates (final state <= 1e-6 asserted, ~1e-9 measured; the BASELINE contract is 1e-4).  precision="fp32" is the optional
+mixed fast mode (fp32 Jacobians / J^T J / Schur): linearisation <= 2e-4, one LM step <= 5e-3, no 1e-4 contract.
 """
 import os
 import sys
@@ -81,31 +79,59 @@ def test_solve_fp64_reproduces_oracle_iterates(cv, oracle):
         assert cv.rel_state_error(wg, wo)["state"] < 1e-6
 
 
-def mixed_bounds(sm, sm_o, cfg):
-    """(state, cost) tolerances of the mixed fp32/fp64 path (profiles/r01_v5_parity_study.txt).
-    While the device LM takes the oracle's accept / reject decisions: state 2e-4 (configs 1-2; study max 2.1e-4 over 58
-    solves, 9e-5 on the seeds used here) / 1e-3 (rolling-shutter stress config; study max 6.9e-4), cost 2e-6.
-    If one borderline step is accepted by one solver and rejected by the other, the trust-region sequences diverge and the two
-    15th iterates differ by up to 7e-4 (configs 1-2) / 4.5e-3 (config 3), the cost by up to 1e-6 / 2.5e-5: bounded here by
-    2e-3 / 1e-2 and 1e-5 / 1e-4.  Global atomics make the last digits vary from run to run, so a flip can appear in one run and
-    not in the next; the looser branch keeps the test meaningful (and not flaky) in that case."""
-    same = sm["num_successful"] == sm_o.num_successful and sm["num_unsuccessful"] == sm_o.num_unsuccessful
-    if cfg == "config3":
-        return (1e-3, 1e-5) if same else (1e-2, 1e-4)
-    return (2e-4, 2e-6) if same else (2e-3, 1e-5)
+N_SEEDS = 32
 
 
-def mixed_state_bound(sm, sm_o, cfg):
-    return mixed_bounds(sm, sm_o, cfg)[0]
+@pytest.mark.parametrize("cfg", ["config1", "config2", "config3"])
+def test_product_parity_every_window(cv, oracle, cfg):
+    """BASELINE target: final state within 1e-4 (relative) of the fp64 reference solve with identical Ceres settings (15
+    iterations, function tolerance 1e-6, projected line search) on EVERY window -- 32 seeds per config, solved as one batch
+    by the product path (all-fp64 HIP).  The same restated solver runs on both sides, so the device must reproduce the
+    reference's decisions: iteration count, successful / unsuccessful steps and line-search steps are compared exactly; the
+    contract bound is 1e-4, the engineering bound asserted on top of it is 1e-6 (measured ~1e-9)."""
+    ws = [cv.synth.make_window(cfg, seed=1000 + i) for i in range(N_SEEDS)]
+    refs = [w.copy() for w in ws]
+    sms_o = [oracle.OracleWindow(r).solve(15) for r in refs]
+    with cv.Solver() as s:
+        batch = [w.copy() for w in ws]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    worst = 0.0
+    for i, (sm, so) in enumerate(zip(sms, sms_o)):
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), (i, sm)
+        assert (sm["num_line_search_steps"], sm["num_line_search_reduced"]) == (so.num_line_search_steps, so.num_line_search_reduced), (i, sm)
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        err = cv.rel_state_error(batch[i], refs[i])["state"]
+        worst = max(worst, err)
+        assert err < 1e-4, (i, err)          # the contract (BASELINE.json north_star)
+    assert worst < 1e-6, worst               # what the all-fp64 path actually delivers
+    if cfg == "config3":                     # the rolling-shutter stress windows exercise the projected line search
+        assert sum(so.num_line_search_reduced for so in sms_o) > 0
 
 
-@pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config1", 1001), ("config2", 1000), ("config2", 1001), ("config2", 1002)])
-def test_solve_fp32_vs_oracle_at_ceres_tolerances(cv, oracle, cfg, seed):
-    """BASELINE target.  Product precision (fp32 Jacobians / normal equations / Schur, fp64 residuals and costs)
-    against the fp64 reference solve with identical Ceres settings (15 iterations, function tolerance 1e-6):
-    same iteration count, cost to 2e-6, final state within mixed_state_bound: 2e-4 while the accept / reject decisions
-    coincide (measured 1e-5 .. 9e-5 on these seeds, run-to-run spread included: global atomics make the order of additions
-    vary), looser if a borderline decision flips (see the helper and DESIGN.md section 3)."""
+def test_config2_batch_of_64_equals_64_singles(cv):
+    """BASELINE configs[3] shape: 64 independent config-2 windows (seeds 1000..1063) in one batch give, window by window, what
+    64 single-window solves give (same kernels, different launch geometry / tile maps / atomics order)."""
+    ws = [cv.synth.make_window("config2", seed=1000 + i) for i in range(64)]
+    with cv.Solver() as s:
+        batch = [w.copy() for w in ws]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    with cv.Solver() as s1:
+        for i, w in enumerate(ws):
+            w1 = w.copy()
+            s1.set_windows([w1])
+            sm1 = s1.solve(15)[0]
+            assert sms[i]["iterations"] == sm1["iterations"] and sms[i]["num_successful"] == sm1["num_successful"]
+            assert sms[i]["final_cost"] == pytest.approx(sm1["final_cost"], rel=1e-10)
+            assert cv.rel_state_error(batch[i], w1)["state"] < 1e-7, i
+
+
+@pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config2", 1000), ("config2", 1001)])
+def test_mixed_fast_mode_is_approximate_but_sane(cv, oracle, cfg, seed):
+    """precision="fp32" (fp32 Jacobians / J^T J / Schur, fp64 residuals and Cholesky; no line search) is an optional fast
+    mode that does NOT carry the 1e-4 contract (~3 windows in 4 meet it).  Only sanity is asserted:
+    same cost to 1e-5, state within 1e-2 of the reference."""
     w0 = cv.synth.make_window(cfg, seed=seed)
     wo = w0.copy()
     sm_o = oracle.OracleWindow(wo).solve(15)
@@ -114,10 +140,8 @@ def test_solve_fp32_vs_oracle_at_ceres_tolerances(cv, oracle, cfg, seed):
         s.set_windows([wg])
         sm = s.solve(15)[0]
     assert abs(sm["iterations"] - sm_o.iterations) <= 1
-    sb, cb = mixed_bounds(sm, sm_o, cfg)
-    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=cb)
-    err = cv.rel_state_error(wg, wo)
-    assert err["state"] < sb, err
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-5)
+    assert cv.rel_state_error(wg, wo)["state"] < 1e-2
 
 
 @pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config2", 1000), ("config2", 1002)])
@@ -143,34 +167,12 @@ def test_solve_fp32_precision_floor(cv, oracle, cfg, seed):
     assert err["state"] < 5e-4, err
 
 
-def test_pure_fp32_residuals_within_stopping_slop(cv, oracle):
-    """fp64_residuals = 0 (everything in fp32): the residual noise (~5e-5 sigma) perturbs Ceres' accept / terminate
-    decisions, so the result is only guaranteed to lie within the reference solve's own stopping slop (oracle at Ceres
-    tolerances vs oracle converged tightly), which is measured here."""
-    w0 = cv.synth.make_window("config2", seed=1000)
-    wo = w0.copy()
-    sm_o = oracle.OracleWindow(wo).solve(15)
-    oracle.set_tolerances(1e-13, 1e-14, 1e-13)
-    try:
-        wt = w0.copy()
-        oracle.OracleWindow(wt).solve(200)
-    finally:
-        oracle.set_tolerances()
-    slop = cv.rel_state_error(wo, wt)["state"]
-    with cv.Solver(precision="fp32", fp64_residuals=False) as s:
-        wg = w0.copy()
-        s.set_windows([wg])
-        sm = s.solve(15)[0]
-    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=3e-6)
-    assert cv.rel_state_error(wg, wo)["state"] < max(3.0 * slop, 1e-4)
-
-
 def test_golden_converged_state(cv, golden_dir):
     """Committed scipy fixture (tests/golden/config1_seed1000_converged.npz): independent minimiser."""
     d = np.load(os.path.join(golden_dir, "config1_seed1000_converged.npz"))
     w = cv.Window.from_dict(d, "w_")
     wf = cv.Window.from_dict(d, "f_")
-    with cv.Solver(precision="fp32") as s:
+    with cv.Solver() as s:
         s.set_windows([w])
         sm = s.solve(50)[0]
     assert sm["final_cost"] == pytest.approx(float(d["final_cost"]), rel=2e-6)
@@ -196,9 +198,7 @@ def test_config3_rolling_shutter_stress(cv, oracle):
     """BASELINE configs[3]: 300 landmarks, 640-row images, 30 us line delay (every block's two ends evaluate at their own
     per-row times), line delay estimated from 0.  These windows are NOT converged after Ceres' 15 iterations, so the 15th
     iterate is only determined up to the solver's own stopping slop (oracle at 15 iterations vs oracle run to 1e-13):
-      * the all-fp64 device path must reproduce the oracle's iterate itself (same decisions, state to 1e-6);
-      * the mixed fp32/fp64 product path: cost to 1e-4, state within mixed_state_bound (1e-3 with the oracle's accept /
-        reject sequence, 1e-2 after a decision flip -- profiles/r01_v5_parity_study.txt).
+      * the product (all-fp64) path must reproduce the oracle's iterate itself (same decisions, state to 1e-6).
     Then the spline is evaluated at every row time of every frame (11 x 640 = 7040 timestamps) against the oracle."""
     w0 = cv.synth.make_window("config3", seed=1003)
     wo = w0.copy()
@@ -217,16 +217,13 @@ def test_config3_rolling_shutter_stress(cv, oracle):
     assert sm64["iterations"] == sm_o.iterations and sm64["num_successful"] == sm_o.num_successful
     assert sm64["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-9)
     assert cv.rel_state_error(w64, wo)["state"] < 1e-6
-    with cv.Solver(precision="fp32") as s:
+    with cv.Solver() as s:
         wg = w0.copy()
         s.set_windows([wg])
         sm = s.solve(15)[0]
-        assert abs(sm["iterations"] - sm_o.iterations) <= 1
-        assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-4)
-        err = cv.rel_state_error(wg, wo)
-        bound = mixed_state_bound(sm, sm_o, "config3")
-        assert err["state"] < bound, (err, slop)
-        assert abs(wg.ld - wo.ld) < bound * abs(wo.ld) + 1e-9
+        assert sm["iterations"] == sm_o.iterations
+        assert cv.rel_state_error(wg, wo)["state"] < 1e-6
+        assert abs(wg.ld - wo.ld) < 1e-6 * abs(wo.ld) + 1e-12
         frames = np.unique(np.concatenate([wg.v_ti, wg.v_tj]))
         ld_ns = int(wg.ld * 1e9)
         t = (frames[:, None] + np.arange(640, dtype=np.int64)[None, :] * ld_ns).reshape(-1)
@@ -382,7 +379,7 @@ def test_full_size_properties(cv):
     the order of the windows."""
     w2 = cv.synth.make_window("config2", seed=1010)
     w5 = cv.synth.make_window("config5", seed=1011)
-    with cv.Solver(precision="fp32") as s:
+    with cv.Solver() as s:
         a, b = w2.copy(), w5.copy()
         s.set_windows([a, b])
         sm = s.solve(30)
@@ -392,3 +389,92 @@ def test_full_size_properties(cv):
         sm2 = s.solve(30)
         assert all(m["iterations"] <= 2 for m in sm2), sm2
         assert cv.rel_state_error(c, a)["state"] < 1e-5 and cv.rel_state_error(d, b)["state"] < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_imu_only_window_without_landmarks(cv, oracle, prec):
+    """L = 0, V = 0 (IMU-only window, e.g. the predict solve of the reference's InitTrajectory with no features yet): the Schur
+    kernels must not touch a landmark row (k_schur_mfma / k_schur_tile_f64 used to clamp to row L - 1 = -1)."""
+    w = cv.synth.make_window("config1", seed=1004)
+    z = lambda a: a[:0]
+    w.v_lm, w.v_ti, w.v_tj, w.v_rowi, w.v_rowj, w.v_pi, w.v_pj = z(w.v_lm), z(w.v_ti), z(w.v_tj), z(w.v_rowi), z(w.v_rowj), z(w.v_pi), z(w.v_pj)
+    w.rho = w.rho[:0]
+    w.fix_ld = True
+    w.normalize()
+    assert w.L == 0 and w.V == 0
+    wo = w.copy()
+    sm_o = oracle.OracleWindow(wo).solve(15)
+    with cv.Solver(precision=prec) as s:
+        wg = w.copy()
+        s.set_windows([wg])
+        sm = s.solve(15)[0]
+    assert np.isfinite(sm["final_cost"]) and sm["termination"] != "failure"
+    # (the mixed mode has no 1e-4 contract; an IMU-only window has unobservable directions in which its 15th iterate drifts)
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-9 if prec == "fp64" else 1e-3)
+    assert cv.rel_state_error(wg, wo)["state"] < (1e-6 if prec == "fp64" else 5e-2)
+
+
+def test_imu_only_predict_named_entry(cv, oracle):
+    """Solver.predict = the reference's InitTrajectory (trajectory_manager.cpp:288-315): IMU factors only, biases locked, knots
+    up to the fixed index constant, Solve(8) -- on a config-2-sized window, product precision and the mixed mode."""
+    w = cv.synth.make_window("config2", seed=1005, with_prior=False)
+    fixed = w.K - 5                                       # only the newly added control points are optimised
+    wo = cv.Solver.predict_window(w, fixed_upto=fixed)
+    sm_o = oracle.OracleWindow(wo).solve(8)
+    for prec, tol in (("fp64", 1e-6), ("fp32", 1e-3)):
+        with cv.Solver(precision=prec) as s:
+            wg = w.copy()
+            sm = s.predict([wg], fixed_upto=[fixed])[0]
+        assert sm["iterations"] == sm_o.iterations or prec == "fp32"
+        assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-8 if prec == "fp64" else 1e-4)
+        np.testing.assert_array_equal(wg.quat[:fixed + 1], w.quat[:fixed + 1])   # constant blocks untouched
+        np.testing.assert_array_equal(wg.bias, w.bias)
+        np.testing.assert_array_equal(wg.rho, w.rho)
+        assert np.abs(wg.quat - wo.quat).max() < tol and np.abs(wg.pos - wo.pos).max() < tol
+
+
+@pytest.mark.parametrize("name", ["tiny_ld_lo.npz", "tiny_ld_hi.npz", "tiny_rows.npz", "tiny_seed7.npz"])
+@pytest.mark.parametrize("prec,tol", [("fp64", 1e-9), ("fp32", 5e-4)])
+def test_golden_edge_fixtures_through_the_hip_path(cv, oracle, golden_dir, name, prec, tol):
+    """The committed edge fixtures (line delay at both bounds, rows 0 / 1023; made by the independent NumPy restatement) pushed
+    through k_vis_eval / k_imu_linearize and the assembly: cost against the fixture's own value, dense H / g against the oracle
+    (which tests/test_oracle_golden.py pins block by block to the same fixtures)."""
+    d = np.load(os.path.join(golden_dir, name))
+    w = cv.Window.from_dict(d, "w_")
+    H, g, cost = oracle.OracleWindow(w.copy()).build_normal()
+    P = w.P
+    sc = _scaled(H)
+    with cv.Solver(precision=prec) as s:
+        s.set_windows([w.copy()])
+        Hg, Wg, Hllg, gg, costg = s.linearize(0)
+    assert costg == pytest.approx(float(d["cost"]), rel=1e-10 if prec == "fp64" else 1e-6)
+    assert np.abs((Hg - H[:P, :P]) / np.outer(sc[:P], sc[:P])).max() < tol
+    assert np.abs((Wg - H[:P, P:]) / np.outer(sc[:P], sc[P:])).max() < tol
+    assert np.abs(Hllg / np.diag(H)[P:] - 1).max() < tol
+    assert np.abs((gg - g) / sc).max() < tol * max(np.abs(g / sc).max(), 1.0)
+
+
+def test_config5_large_window_vs_oracle(cv, oracle):
+    """BASELINE configs[4]: 30 KF / 1000 landmarks / 6000 IMU (K = 64, P = 571, dense N = 1571): the product path against the
+    oracle's solve, iterate for iterate."""
+    w0 = cv.synth.make_window("config5", seed=1011)
+    wo = w0.copy()
+    sm_o = oracle.OracleWindow(wo).solve(15)
+    with cv.Solver() as s:
+        wg = w0.copy()
+        s.set_windows([wg])
+        sm = s.solve(15)[0]
+    assert (sm["iterations"], sm["num_successful"]) == (sm_o.iterations, sm_o.num_successful)
+    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-9)
+    assert cv.rel_state_error(wg, wo)["state"] < 1e-6
+
+
+def test_rccl_gather_world_size_1(cv):
+    """sharding.gather_records on GPU tensors over the nccl backend (= RCCL on ROCm), world size 1, in a fresh interpreter
+    (tests/rccl_gather_check.py): every window id comes back exactly once, values intact.  (N > 1 is covered with gloo on
+    CPU: tests/test_sharding_gloo.py; bench.py --gpus N runs the same gather on N GPUs.)"""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_gather_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_GATHER_OK 0 1" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
