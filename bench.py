@@ -1,25 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- sliding-window solves/sec on MI355X (BASELINE.json metric, configs[1] workload).
 
-A "step" = one batched solve of `--windows` independent config-2 windows (10 KF / 200 landmarks / 2000 IMU,
-<= 15 LM iterations, Ceres tolerances) per GPU.  Factors and the initial state are resident in HBM before the
-timed region (ctvio_restore_state resets the state on the device between steps; packing + H2D are outside).
-value = windows solved by all ranks / wall-clock of the K timed steps (max over ranks).
+A "step" = `--windows` independent config-2 windows (10 KF / 200 landmarks / 2000 IMU, <= 15 LM iterations, Ceres
+tolerances and projected line search) per GPU, taken END TO END through the C ABI exactly as SURVEY.md section 8d defines one
+solve: ctvio_set_batch (validate + pack on host threads + one H2D copy) -> ctvio_solve (device-resident LM) ->
+ctvio_get_batch_state (one D2H copy).  The windows of a step are split over `--streams` solver handles driven by host
+threads, so batch n+1 is packed and uploaded while batch n solves.  value = windows solved by all ranks / wall-clock of the
+K timed steps (max over ranks).  The device-resident rate (state restored on the device, no packing or PCIe traffic) is
+reported next to it as `device_resident_solves_per_s`.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), windows sharded by seed, no data-path
-collective (independent windows); RCCL only carries the barrier and the max-over-ranks time.
+N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one process per GPU, backend nccl = RCCL);
+windows are sharded by id (w mod N), no data-path collective (independent windows); RCCL carries the
+barrier, the max-over-ranks time and the all-gather of the per-window result records (every id must come back exactly once).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (largest share of a profiled solve, HIP events on the solver's stream):
-                achieved = algorithmic bytes / average launch duration, against 8 TB/s HBM;
-                roofline_mfma: the Schur SYRK against the 157.3 TFLOP/s fp32 MFMA peak.
-  cpu_baseline  the fp64 C oracle (a port of the reference's Ceres path: oracle/ctvo.c) on 1 host core, ~10 s sample.
+  roofline       dominant kernel of a profiled solve (HIP events on the solver's stream): achieved = algorithmic bytes
+                  / average launch duration, against 8 TB/s HBM; roofline_mfma: the Schur SYRK.
+  parity         max relative state error of the timed path against the fp64 CPU oracle on a sample of the windows
+  cpu_baseline   the oracle (a port of the reference's Ceres path: oracle/ctvo.c) on 1 host core, the same sample.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,24 +33,30 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# phase of the solver's event profile -> kernel name in the rocprofv3 tables (profiles/)
-KERNEL_OF_PHASE = {"k_imu_linearize": "k_imu_linearize", "k_vis_eval": "k_vis_eval<float, true, double>",
-                   "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve"}
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}   # v_mfma_f32_32x32x2_f32 (guide) / v_mfma_f64_16x16x4_f64 (AMD MI355X spec sheet: 78.6 TF fp64 matrix)
 
 
-def algorithmic_bytes(w, phase, fp_bytes=4):
-    """Algorithmic HBM bytes of ONE window for one launch of a kernel group."""
+def kernel_of_phase(precision):
+    if precision == "fp64":
+        return {"k_imu_linearize": "k_imu_linearize<double, 32, double>", "k_vis_eval": "k_vis_eval<double, true, double>",
+                "k_assemble_vis": "k_assemble_vis<double>", "k_schur_mfma": "k_schur_f64", "k_cholesky_solve": "k_cholesky_solve<double>"}
+    return {"k_imu_linearize": "k_imu_linearize<float, 64, double>", "k_vis_eval": "k_vis_eval<float, true, double>",
+            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve<float>"}
+
+
+def algorithmic_bytes(w, phase, fp_bytes):
+    """Algorithmic HBM bytes of ONE window for one launch of a kernel group; fp_bytes = size of the
+    linearisation scalar (8 in the product path)."""
     K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
     G = len({(int((t - w.t0_ns) // w.dt_ns), int(b)) for t, b in zip(w.imu_t, w.imu_bias)})
     if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
         return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
-    if phase == "k_vis_eval":        # SURVEY 8d: 284 B in, 408 B out per block (J materialised once)
-        return V * (284 + 408 + 8)
-    if phase == "k_assemble_vis":    # J read once + W/Hll/g rows + packed visual Hessian flushed once (fp64)
+    if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (2 r + 100 J) out + the landmark row (54)
+        return V * (284 + (102 + 54) * fp_bytes)
+    if phase == "k_assemble_vis":    # J~, r~ read once + packed visual Hessian flushed once (fp64)
         K6 = 6 * K
-        return V * (408 + 8 + 51 * fp_bytes) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8
+        return V * (102 * fp_bytes + 8) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8
     if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
         return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
     if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written
@@ -52,58 +64,91 @@ def algorithmic_bytes(w, phase, fp_bytes=4):
     return 0
 
 
+def respawn_under_torchrun(args):
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=1024, help="independent windows per GPU per step")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows generated per GPU (replicated to --windows)")
+    ap.add_argument("--windows", type=int, default=4096, help="independent windows per GPU per step")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic windows per GPU (seeds 1000 + 64 rank + i), replicated to --windows")
     ap.add_argument("--config", default="config2")
     ap.add_argument("--iters", type=int, default=15)
-    ap.add_argument("--precision", default="fp32")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--precision", default="fp64", help="fp64 = the product (all-fp64); fp32 = the mixed fast mode (no 1e-4 contract)")
+    ap.add_argument("--parity-sample", type=int, default=16, help="windows solved by the CPU oracle (state error of the timed path + cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-inclusive", action="store_true", help="also time pack + H2D + solve + D2H of one batch (DESIGN.md section 6; never the headline value)")
-    ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams) per GPU; the windows are split evenly among them")
+    ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams + host threads) per GPU")
+    ap.add_argument("--host-threads", type=int, default=0, help="packing threads per handle (0: cores / streams, at most 16)")
+    ap.add_argument("--device-resident-only", action="store_true", help="time the device-resident solve instead (diagnostics)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
 
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
     cv = importlib.import_module("ctrl-vio_amd")
+    import ctypes as C
 
-    # synthetic windows, seeds 1000 + rank*unique + i; a few distinct ones replicated to fill the batch
-    uniq = [cv.synth.make_window(args.config, seed=1000 + rank * args.unique + i) for i in range(min(args.unique, args.windows))]
-    import threading
-    nstream = max(1, args.streams)
+    # ---- synthetic windows: global window id g = rank + world * j (sharding.shard), content = one of this rank's
+    #      `unique` windows (seeds 1000 + unique * rank + i; configs[3] names seeds 1000..1063)
+    nuniq = max(1, min(args.unique, args.windows))
+    uniq = [cv.synth.make_window(args.config, seed=1000 + rank * nuniq + i) for i in range(nuniq)]
+    nstream = max(1, min(args.streams, args.windows))
     per = [args.windows // nstream + (1 if i < args.windows % nstream else 0) for i in range(nstream)]
-    solvers = []
-    for si_, cnt in enumerate(per):
-        sv = cv.Solver(device=local, precision=args.precision)
-        sv.set_windows([uniq[(i + si_) % len(uniq)].copy() for i in range(cnt)])
-        sv.snapshot_state()
-        solvers.append(sv)
-    solver = solvers[0]
+    first = np.concatenate([[0], np.cumsum(per)])          # local window index range of every handle
+    my_ids = cv.sharding.shard(args.windows * world, rank, world)
+    hthreads = args.host_threads or max(1, min(16, (os.cpu_count() or 8) // nstream))
+    solvers, cbatches, keeps, outs = [], [], [], []
+    for si in range(nstream):
+        sv = cv.Solver(device=local, precision=args.precision, host_threads=hthreads)
+        keep = []
+        arr = (cv.capi.CWindow * per[si])()
+        wl = []
+        for j in range(per[si]):
+            w = uniq[(int(first[si]) + j) % nuniq]
+            arr[j] = cv.capi.to_cwindow(w, keep)
+            wl.append(w)
+        K = sum(w.K for w in wl); F = sum(w.F for w in wl); L = sum(w.L for w in wl)
+        outs.append((np.zeros((K, 4)), np.zeros((K, 3)), np.zeros((F, 6)), np.zeros(max(L, 1)), np.zeros(per[si])))
+        solvers.append(sv); cbatches.append(arr); keeps.append((keep, wl))
+    lib = cv.capi.load_library()
 
-    def solve_all():
-        if nstream == 1:
-            solver.solve_raw(args.iters)
+    def run_handle(si, resident):
+        sv = solvers[si]
+        if resident:
+            sv.restore_state()
+            sv.solve_raw(args.iters)
             return
-        th = [threading.Thread(target=sv.solve_raw, args=(args.iters,)) for sv in solvers]
+        cv.capi.check(lib.ctvio_set_batch(sv._h, per[si], C.cast(cbatches[si], C.c_void_p)))      # validate + pack + H2D
+        cv.capi.check(lib.ctvio_solve(sv._h, args.iters, None))                                     # device-resident LM
+        o = outs[si]
+        cv.capi.check(lib.ctvio_get_batch_state(sv._h, *[cv.capi._p(a) for a in o]))                # D2H
+
+    def step(resident=False):
+        if nstream == 1:
+            run_handle(0, resident)
+            return
+        th = [threading.Thread(target=run_handle, args=(si, resident)) for si in range(nstream)]
         for t in th: t.start()
         for t in th: t.join()
-
-    def restore_all():
-        for sv in solvers: sv.restore_state()
 
     def barrier():
         torch.cuda.synchronize()
@@ -111,101 +156,131 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        restore_all()
-        solve_all()
-    t_total = 0.0
-    dev_ms = []
-    for _ in range(args.steps):
-        restore_all()
+    def timed(nsteps, resident):
         barrier()
         t0 = time.perf_counter()
-        solve_all()                           # returns after every stream is drained (summaries copied back)
+        for _ in range(nsteps):
+            step(resident)                    # returns after every handle has drained its stream (results on the host)
         torch.cuda.synchronize()
-        t_total += time.perf_counter() - t0
-        dev_ms.append(solver.last_timing()[0][7])
-    barrier()
-    if dist is not None:
-        tt = torch.tensor([t_total], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_total = float(tt.item())
+        t = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+
+    def prepare_resident():
+        """upload every handle's batch and keep a device-side copy of the initial state (ctvio_snapshot_state)"""
+        for si in range(nstream):
+            cv.capi.check(lib.ctvio_set_batch(solvers[si]._h, per[si], C.cast(cbatches[si], C.c_void_p)))
+            solvers[si].snapshot_state()
+
+    resident_headline = args.device_resident_only
+    if resident_headline:
+        prepare_resident()
+    for _ in range(args.warmup):
+        step(resident_headline)
+    t_total = timed(args.steps, resident_headline)
     n_solved = args.windows * world * args.steps
+    fp_bytes = 8 if args.precision == "fp64" else 4
     out = {
         "metric": "sliding-window solves/sec (10 KF, 200 lm, 2000 IMU)", "value": n_solved / t_total, "unit": "solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_total / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: 10 KF / 200 landmarks / 2000 IMU sliding window, <= {args.iters} LM iterations",
-                   "windows_per_gpu": args.windows, "streams_per_gpu": nstream, "sharding": f"independent windows, {world} rank(s), no data-path collective"},
-        "device_ms_per_step": float(np.mean(dev_ms)),
+        "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: 10 KF / 200 landmarks / 2000 IMU sliding window, <= {args.iters} LM iterations "
+                               f"(Ceres 1.14 trust region + projected line search)",
+                   "timed_region": "device-resident solve only" if resident_headline else
+                                   "end to end per batch: validate + pack (host threads) + H2D + LM solve + D2H of every state",
+                   "windows_per_gpu_per_step": args.windows, "distinct_windows_per_gpu": nuniq, "streams_per_gpu": nstream,
+                   "pack_threads_per_stream": hthreads,
+                   "sharding": f"independent windows, window id mod {world} rank(s), no data-path collective"},
     }
+    # ---- device-resident rate next to it (no packing, no PCIe: ctvio_restore_state on the device between solves)
+    if not resident_headline:
+        prepare_resident()
+        step(True)
+        nres = max(2, min(args.steps, 4))
+        t_res = timed(nres, True)
+        out["device_resident_solves_per_s"] = args.windows * world * nres / t_res
+        out["end_to_end_over_device_resident"] = out["value"] / out["device_resident_solves_per_s"]
+    # ---- RCCL: all-gather of the per-window result records of one batch, every id exactly once
+    sms_all = []
+    for si in range(nstream):
+        solvers[si].restore_state()
+        sm = (cv.capi.Summary * per[si])()
+        cv.capi.check(lib.ctvio_solve(solvers[si]._h, args.iters, C.cast(sm, C.c_void_p)))
+        sms_all += [s.as_dict() for s in sm]
+    rec_local = cv.sharding.make_records(my_ids, sms_all)
+    rec = cv.sharding.gather_records(rec_local, args.windows * world, device=torch.device("cuda", local)) if dist is not None else None
+    if rec is not None:
+        ids = rec[:, 0]
+        assert not np.isnan(ids).any() and sorted(ids.astype(int).tolist()) == list(range(args.windows * world)), "RCCL gather lost a window"
     if rank == 0:
-        # ---- quality of what was timed: the solved batch against the fp64 oracle on the distinct windows
-        solver.restore_state()
-        sms = solver.solve(args.iters, writeback=False)
-        out["solve_summary"] = {"iterations_mean": float(np.mean([m["iterations"] for m in sms])),
-                                "terminations": sorted({m["termination"] for m in sms})}
-        # ---- roofline: one more step of the same workload (all streams running, as in the timed region) with HIP events
-        #      around every launch group of stream 0 -- the launches of that stream carry per[0] windows each
-        restore_all()
+        src = rec if rec is not None else rec_local
+        out["solve_summary"] = {"windows": int(src.shape[0]), "iterations_mean": float(np.mean(src[:, 1])),
+                                "terminations": sorted({cv.capi.TERMINATION.get(int(t), "?") for t in src[:, 2]}),
+                                "line_search_reduced_steps": int(sum(s["num_line_search_reduced"] for s in sms_all)),
+                                "gathered_with": "RCCL all_gather (GPU tensors)" if rec is not None else "single rank"}
+        # ---- roofline: one more device-resident step with HIP events around every launch group of handle 0 (all handles running)
+        solver = solvers[0]
         solver.set_profiling(True)
-        solve_all()
+        step(True)
         solver.set_profiling(False)
         torch.cuda.synchronize()
         ms, n = solver.last_timing()
         names = cv.Solver.PHASES
-        shares = {names[i]: float(ms[i]) for i in range(7)}
+        kmap = kernel_of_phase(args.precision)
         dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
-        w_ref = uniq[0]
-        nbytes = sum(algorithmic_bytes(uniq[i % len(uniq)], names[dom]) for i in range(per[0]))
+        wl0 = keeps[0][1]
+        nbytes = sum(algorithmic_bytes(w, names[dom], fp_bytes) for w in wl0)
         avg_s = 1e-3 * ms[dom] / max(int(n[dom]), 1)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                key = KERNEL_OF_PHASE.get(names[dom], names[dom])
-                traffic = json.load(open(tfile)).get(key, {}).get(str(per[0]), {}).get("traffic_bytes")
+                traffic = json.load(open(tfile)).get(kmap.get(names[dom], names[dom]), {}).get(str(per[0]), {}).get("traffic_bytes")
             except Exception:
                 traffic = None
         ach = nbytes / avg_s / 1e9
-        out["roofline"] = {"kernel": KERNEL_OF_PHASE.get(names[dom], names[dom]).split("<")[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"kernel": kmap.get(names[dom], names[dom]), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "avg_launch_us": 1e6 * avg_s, "launches": int(n[dom]), "windows_per_launch": per[0],
                            "algorithmic_bytes_per_launch": nbytes,
                            "share_of_profiled_solve": float(ms[dom] / max(sum(ms[:7]), 1e-12))}
-        P, L = w_ref.P, w_ref.L
-        fl = P * (P + 1) * L * per[0]                        # SYRK count
+        w_ref = uniq[0]
+        fl = w_ref.P * (w_ref.P + 1) * w_ref.L * per[0]      # SYRK count (SURVEY 8d)
         avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
-        out["roofline_mfma"] = {"kernel": "k_schur_window", "bound": "mfma", "achieved": fl / avg_schur / 1e12,
-                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
-        out["phase_ms_profiled_solve"] = shares               # stream 0 only
-        if args.host_inclusive:
-            # the C ABI takes host buffers: pack (host, 1 thread) + H2D + solve + D2H of the states, one solver, one batch
-            wl = [uniq[i % len(uniq)].copy() for i in range(args.windows)]
-            with cv.Solver(device=local, precision=args.precision) as hs:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                hs.set_windows(wl)                          # ctvio_add_window x N + ctvio_upload
-                t1 = time.perf_counter()
-                hs.solve(args.iters, writeback=True)        # ctvio_solve + ctvio_get_state x N
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-            out["host_inclusive"] = {"windows": args.windows, "pack_upload_s": t1 - t0, "solve_readback_s": t2 - t1,
-                                     "solves_per_s": args.windows / (t2 - t0)}
-        # ---- CPU baseline: the oracle (a port, not the reference binary: Ceres/Eigen are not installable here)
+        pk = MFMA_PEAK_TFLOPS["fp64" if args.precision == "fp64" else "fp32"]
+        out["roofline_mfma"] = {"kernel": kmap["k_schur_mfma"], "bound": "mfma", "achieved": fl / avg_schur / 1e12, "peak": pk,
+                                "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / pk, "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
+        out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}   # handle 0 only
+        # ---- parity of what was timed + CPU baseline: the oracle solves a sample of the same windows on one host core
+        out["parity"] = None
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the scaling runs must not wait on a CPU loop
             import pyctvo
-            t0 = time.perf_counter(); k = 0
-            while time.perf_counter() - t0 < args.cpu_seconds:
-                ww = uniq[k % len(uniq)].copy()
-                pyctvo.OracleWindow(ww).solve(args.iters)
-                k += 1
+            nsamp = max(1, min(args.parity_sample, nuniq))
+            ref = [uniq[i].copy() for i in range(nsamp)]
+            t0 = time.perf_counter()
+            for r in ref:
+                pyctvo.OracleWindow(r).solve(args.iters)
             dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": k / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-                                   "sample": f"{k} solves of {args.config} windows (seeds 1000..), fp64 C oracle (oracle/ctvo.c, gcc -O2), "
-                                             f"1 thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
+            out["cpu_baseline"] = {"value": nsamp / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+                                   "sample": f"{nsamp} solves of {args.config} windows (seeds 1000..{1000 + nsamp - 1}), fp64 C oracle "
+                                             f"(oracle/ctvo.c, gcc -O2), 1 thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
+            # the same windows as they came out of the timed path (handle 0 holds local windows 0.. = uniq[0..]): end-to-end solve
+            run_handle(0, False)
+            q, p, b, r, ld = outs[0]
+            errs, k0, f0, l0 = [], 0, 0, 0
+            for j in range(min(nsamp, per[0])):
+                w = uniq[j].copy()
+                w.quat[:] = q[k0:k0 + w.K]; w.pos[:] = p[k0:k0 + w.K]; w.bias[:] = b[f0:f0 + w.F]; w.rho[:] = r[l0:l0 + w.L]; w.ld = float(ld[j])
+                errs.append(cv.rel_state_error(w, ref[j])["state"])
+                k0 += w.K; f0 += w.F; l0 += w.L
+            out["parity"] = {"max_rel_state_err": float(max(errs)), "median_rel_state_err": float(np.median(errs)), "windows": len(errs),
+                             "tolerance": 1e-4, "reference": "fp64 C oracle, same Ceres settings", "pass": bool(max(errs) <= 1e-4)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
