@@ -105,7 +105,8 @@ struct SolverBase {
 
 template <class T> class SolverImpl : public SolverBase {
  public:
-  static constexpr int VCH = 16;   // visual blocks per work item (k_assemble_vis): with the fp64 LDS accumulators 16 leaves room for 8 staging areas
+  // visual blocks per work item (k_assemble_vis*): eight per-wave staging areas [102][VCH + 2] must fit beside the fp64 LDS Hessian
+  static constexpr int VCH = sizeof(T) == 8 ? 8 : 16;
   static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
   explicit SolverImpl(const ctvio_options &o) : opt_(o), mixed_(sizeof(T) == 4 && o.fp64_residuals != 0) {}
   ~SolverImpl() override {
@@ -124,7 +125,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (sizeof(T) == 4) HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
@@ -470,10 +471,7 @@ template <class T> class SolverImpl : public SolverBase {
     hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, 2);
     ph_begin(PH_IMU_LIN);
     const size_t imu_lds = (sizeof(T) == 4 ? (size_t)3 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 0;
-    if (d.Gtot) {
-      if (mixed_) hipLaunchKernelGGL((k_imu_linearize<T, CH, double>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
-      else hipLaunchKernelGGL((k_imu_linearize<T, CH, T>), dim3(d.Gtot), dim3(64), imu_lds, stream_, d);
-    }
+    if (d.Gtot) launch_imu_linearize(imu_lds);
     ph_end();
     ph_begin(PH_VIS_LIN);
     if (d.Vtot) {
@@ -521,6 +519,7 @@ template <class T> class SolverImpl : public SolverBase {
     ph_end();
   }
   void launch_schur();
+  void launch_imu_linearize(size_t vals_lds);
   void launch_assemble_vis_lds(int parts);
   bool schur_makes_rhs() const { return sizeof(T) == 4 && opt_.use_mfma != 0; }
   void launch_cost(bool candidate, int force) {
@@ -875,6 +874,17 @@ template <class T> class SolverImpl : public SolverBase {
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
 };
 
+template <> void SolverImpl<float>::launch_imu_linearize(size_t lds) {
+  const Dev<float> &d = dev_;
+  if (mixed_) hipLaunchKernelGGL((k_imu_linearize<float, 64, double>), dim3(d.Gtot), dim3(64), lds, stream_, d);
+  else hipLaunchKernelGGL((k_imu_linearize<float, 64, float>), dim3(d.Gtot), dim3(64), lds, stream_, d);
+}
+template <> void SolverImpl<double>::launch_imu_linearize(size_t lds) {
+  const Dev<double> &d = dev_;
+  // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
+  if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d);
+  else hipLaunchKernelGGL((k_imu_linearize<double, 32, double>), dim3(d.Gtot), dim3(64), lds, stream_, d);
+}
 template <> void SolverImpl<float>::launch_schur() {
   const Dev<float> &d = dev_;
   const int nt = (d.maxP + 1 + 31) / 32;
@@ -892,12 +902,13 @@ template <> void SolverImpl<float>::launch_schur() {
 }
 template <> void SolverImpl<float>::launch_assemble_vis_lds(int parts) {
   const Dev<float> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<float, VCH>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
   else hipLaunchKernelGGL((k_assemble_vis<float, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
 }
 template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
   const Dev<double> &d = dev_;
-  hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
 }
 template <> void SolverImpl<double>::launch_schur() {
   const Dev<double> &d = dev_;

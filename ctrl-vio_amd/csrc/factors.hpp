@@ -23,7 +23,25 @@ template <class T> struct Knots4 {
 template <class T> struct SegConst {
   V3<T> d[3];      // d_i = log(R_i^-1 R_{i+1})
   M3<T> JrI[3];    // Jr^-1(d_i)
+  CTV_DI M3<T> jri(int i) const { return JrI[i]; }
 };
+// The same with Jr^-1(d_i) left in the per-window table (k_knot_prep) and fetched where it is used: the 27 values per knot
+// group are not held in registers across the whole block evaluation (fp64: 54 VGPRs per spline end).
+template <class T, class TJ> struct SegConstLazy {
+  V3<T> d[3];
+  const TJ *tab;   // [3][9]
+  CTV_DI M3<T> jri(int i) const {
+    M3<T> J;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) J.m[e] = (T)tab[9 * i + e];
+    return J;
+  }
+};
+template <class T, class TJ> CTV_DI void seg_const_lazy(const double *kd, const TJ *kjri, SegConstLazy<T, TJ> &sc) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sc.d[i] = mk<T>((T)kd[3 * i], (T)kd[3 * i + 1], (T)kd[3 * i + 2]);
+  sc.tab = kjri;
+}
 template <class T> CTV_DI void seg_const(const Knots4<T> &k, SegConst<T> &sc, bool want_jac) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -65,10 +83,19 @@ template <class T, class TJ> CTV_DI void seg_const_load(const double *kd, const 
 // q'_k = q_ref^-1 q_k, p'_k = R_ref^T (p_k - p_ref), and gravity as R_ref^T g.  Residuals are invariant under this
 // change of gauge and right-perturbation rotation Jacobians are unchanged; only the position Jacobians need
 // J_p = J_p' R_ref^T (RrefT).  Rotations near identity keep ~10x more significant digits in fp32.
-template <class T, class Sink>
-CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T> gravity, const T bias[6],
-                     const T gyro[3], const T acc[3], const T w[6], const M3<T> &RrefT, T r[6], bool want_jac, Sink &sink) {
-  T lamA[4], lamR[4], lamW[4];
+// Jacobian of one IMU block in factored form: the 6 x 30 matrix is w .* [Jw | 0 | I3 | 0 ; Ja | lamA (x) Rinv_g | 0 | I3]
+// (trajectory_value_factor.h:198-245).  Consumers read it column by column (imu_emit_cols) or row by row (imu_row_*).
+template <class T> struct ImuJac {
+  M3<T> Jw[4], Ja[4];   // d(gyro) / d(rot knot k), d(accel) / d(rot knot k)
+  M3<T> Rinv_g;         // R(t)^T in the global frame: d(accel) / d(pos knot k) = lamA[k] * Rinv_g
+  T lamA[4];
+};
+
+template <class T, class SC>
+CTV_DI void imu_eval_core(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity, const T bias[6],
+                          const T gyro[3], const T acc[3], const T w[6], const M3<T> &RrefT, T r[6], bool want_jac, ImuJac<T> &J) {
+  T lamR[4], lamW[4];
+  T (&lamA)[4] = J.lamA;
   basis<T, false, 2>(u, idt * idt, lamA);
   basis<T, true, 0>(u, T(1), lamR);
   basis<T, true, 1>(u, idt, lamW);
@@ -104,7 +131,8 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
   if (!want_jac) return;
 
   // gyro rows: d(omega)/d(d_j), split_spline_view.h:157-181
-  M3<T> Jw[4], Ja[4];
+  M3<T> (&Jw)[4] = J.Jw;
+  M3<T> (&Ja)[4] = J.Ja;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { Jw[i] = m3_zero<T>(); Ja[i] = m3_zero<T>(); }
   {
@@ -112,13 +140,14 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (i > 0) dod = add(scale(mul(mul_hat(Apost[i], om[i]), JrK[i]), lamR[i + 1]), scale(Apost[i + 1], lamW[i + 1]));
-      Jw[i] = sub(Jw[i], mulT(dod, sc.JrI[i]));
-      Jw[i + 1] = add(Jw[i + 1], mul(dod, sc.JrI[i]));
+      const M3<T> JrIi = sc.jri(i);
+      Jw[i] = sub(Jw[i], mulT(dod, JrIi));
+      Jw[i + 1] = add(Jw[i + 1], mul(dod, JrIi));
     }
   }
   // accel rows, split_spline_view.h:183-211 (three R_accum entries: the reference's 2-entry array is a bug)
   const M3<T> Rinv = q2R(Rinv_q);
-  const M3<T> Rinv_g = mul(Rinv, RrefT);  // R(t)^T in the global frame, for the position-knot columns
+  J.Rinv_g = mul(Rinv, RrefT);  // R(t)^T in the global frame, for the position-knot columns
   {
     const M3<T> lhs = mul_hat(Rinv, ag);
     M3<T> Racc = q2R(k.q[0]);
@@ -127,11 +156,15 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
     for (int i = 0; i < 3; ++i) {
       if (i > 0) Racc = mulT(Racc, q2R(Ainv[i - 1]));
       const M3<T> dad = scale(mul(mul(lhs, Racc), JrK[i]), lamR[i + 1]);
-      Ja[i] = sub(Ja[i], mulT(dad, sc.JrI[i]));
-      Ja[i + 1] = add(Ja[i + 1], mul(dad, sc.JrI[i]));
+      const M3<T> JrIi = sc.jri(i);
+      Ja[i] = sub(Ja[i], mulT(dad, JrIi));
+      Ja[i + 1] = add(Ja[i + 1], mul(dad, JrIi));
     }
   }
-  // trajectory_value_factor.h:198-245, column by column
+}
+
+// trajectory_value_factor.h:198-245, column by column
+template <class T, class Sink> CTV_DI void imu_emit_cols(const ImuJac<T> &J, const T w[6], Sink &sink) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -139,10 +172,10 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
       T c6[6], p6[6];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        c6[a] = w[a] * Jw[kk].m[3 * a + b];
-        c6[3 + a] = w[3 + a] * Ja[kk].m[3 * a + b];
+        c6[a] = w[a] * J.Jw[kk].m[3 * a + b];
+        c6[3 + a] = w[3 + a] * J.Ja[kk].m[3 * a + b];
         p6[a] = T(0);
-        p6[3 + a] = w[3 + a] * lamA[kk] * Rinv_g.m[3 * a + b];
+        p6[3 + a] = w[3 + a] * J.lamA[kk] * J.Rinv_g.m[3 * a + b];
       }
       sink.put_col(3 * kk + b, c6);
       sink.put_col(12 + 3 * kk + b, p6);
@@ -156,11 +189,44 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SegConst<T> &sc, T u, T idt, V3<T
     sink.put_col(27 + a, h6);
   }
 }
+// The same entries row by row (same expressions, hence bit-identical values):
+//   accelerometer row a: 32 columns [rot 0..11 | pos 12..23 | bg 24..26 = 0 | ba 27..29 | residual 30 | 0]
+//   gyroscope row a    : its 16 non-zero columns [rot 0..11 | bg (columns 24..26) | residual (column 30)]
+template <class T> CTV_DI void imu_row_accel(const ImuJac<T> &J, const T w[6], const T r[6], int a, T out[32]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      out[3 * kk + b] = w[3 + a] * J.Ja[kk].m[3 * a + b];
+      out[12 + 3 * kk + b] = w[3 + a] * J.lamA[kk] * J.Rinv_g.m[3 * a + b];
+    }
+#pragma unroll
+  for (int c = 24; c < 32; ++c) out[c] = T(0);
+  out[27 + a] = w[3 + a];
+  out[30] = r[3 + a];
+}
+template <class T> CTV_DI void imu_row_gyro(const ImuJac<T> &J, const T w[6], const T r[6], int a, T out[16]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) out[3 * kk + b] = w[a] * J.Jw[kk].m[3 * a + b];
+  out[12] = out[13] = out[14] = T(0);
+  out[12 + a] = w[a];
+  out[15] = r[a];
+}
+
+template <class T, class Sink, class SC>
+CTV_DI void imu_eval(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity, const T bias[6],
+                     const T gyro[3], const T acc[3], const T w[6], const M3<T> &RrefT, T r[6], bool want_jac, Sink &sink) {
+  ImuJac<T> J;
+  imu_eval_core<T, SC>(k, sc, u, idt, gravity, bias, gyro, acc, w, RrefT, r, want_jac, J);
+  if (want_jac) imu_emit_cols<T>(J, w, sink);
+}
 
 // ------------------------------------------------------------------------------------------------
 // SO(3) spline views on 4 knots.
 // EvaluateRp (so3_spline_view.h:136-198): returns R(t); J[k] = per-knot 3x3 "partial" Jacobians.
-template <class T> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SegConst<T> &sc, T u, M3<T> J[4], bool want_jac) {
+template <class T, class SC> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> accq = qmk<T>(0, 0, 0, 1);
@@ -178,14 +244,14 @@ template <class T> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SegConst<T> &sc,
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const M3<T> Jh = scale(mul(Apost[i + 1], JrK[i]), c[i + 1]);
-      J[i] = sub(J[i], mulT(Jh, sc.JrI[i]));
-      J[i + 1] = mul(Jh, sc.JrI[i]);
+      J[i] = sub(J[i], mulT(Jh, sc.jri(i)));
+      J[i + 1] = mul(Jh, sc.jri(i));
     }
   }
   return res;
 }
 // EvaluateRTp (so3_spline_view.h:208-276): returns R(t)^T.
-template <class T> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SegConst<T> &sc, T u, M3<T> J[4], bool want_jac) {
+template <class T, class SC> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> S[4];
@@ -202,14 +268,14 @@ template <class T> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SegConst<T> &sc
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const M3<T> Jh = scale(mul(q2R(S[i]), JrK[i]), c[i + 1]);
-      J[i] = sub(J[i], mulT(Jh, sc.JrI[i]));
-      J[i + 1] = mul(Jh, sc.JrI[i]);
+      J[i] = sub(J[i], mulT(Jh, sc.jri(i)));
+      J[i + 1] = mul(Jh, sc.jri(i));
     }
   }
   return qconj(S[3]);
 }
 // VelocityBody value (so3_spline_view.h:356-411)
-template <class T> CTV_DI V3<T> eval_omega(const SegConst<T> &sc, T u, T idt) {
+template <class T, class SC> CTV_DI V3<T> eval_omega(const SC &sc, T u, T idt) {
   T c[4], dc[4];
   basis<T, true, 0>(u, T(1), c);
   basis<T, true, 1>(u, idt, dc);
@@ -219,13 +285,54 @@ template <class T> CTV_DI V3<T> eval_omega(const SegConst<T> &sc, T u, T idt) {
   return rv;
 }
 // R(t) only (So3Spline::evaluate, so3_spline.h:240-289)
-template <class T> CTV_DI Q4<T> eval_R(const Q4<T> q[4], const SegConst<T> &sc, T u) {
+template <class T, class SC> CTV_DI Q4<T> eval_R(const Q4<T> q[4], const SC &sc, T u) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> res = q[0];
 #pragma unroll
   for (int i = 0; i < 3; ++i) res = qmul(res, so3_exp(c[i + 1] * sc.d[i]));
   return res;
+}
+
+// Streaming forms of the two views: the per-knot partial Jacobians are handed to `f(knot, J)` one at a time, as soon as they
+// are final, instead of being returned as four 3 x 3 matrices -- the same operations in the same order (bit-identical
+// values), but only ~5 matrices are live at any time (the array forms keep 11, i.e. ~200 fp64 registers for both ends).
+//   EvaluateRp : J_3 = H_2 JrI_2 ; J_i = H_{i-1} JrI_{i-1} - H_i JrI_i^T ; J_0 = Apost_0 - H_0 JrI_0^T, H_i = c_{i+1} Apost_{i+1} Jr(c_{i+1} d_i):
+//                Apost is built from the last knot backwards, so the knots come out 3, 2, 1, 0.
+//   EvaluateRTp: H_i = c_{i+1} R(S_i) Jr(-c_{i+1} d_i), S built forwards: knots come out 0, 1, 2, 3.
+template <class T, class SC, class F> CTV_DI void eval_Rp_jac_stream(const SC &sc, T u, F &&f) {
+  T c[4];
+  basis<T, true, 0>(u, T(1), c);
+  Q4<T> accq = qmk<T>(0, 0, 0, 1);
+  M3<T> Ap = m3_id<T>(), pending = m3_zero<T>();
+#pragma unroll
+  for (int i = 2; i >= 0; --i) {
+    const V3<T> kd = c[i + 1] * sc.d[i];
+    const M3<T> Jh = scale(mul(Ap, so3_Jr(kd)), c[i + 1]);
+    const M3<T> JrIi = sc.jri(i);
+    const M3<T> Jn = mul(Jh, JrIi);
+    f(i + 1, i == 2 ? Jn : add(Jn, pending));
+    pending = scale(mulT(Jh, JrIi), T(-1));
+    accq = qmul(accq, so3_exp(neg(kd)));
+    Ap = q2R(accq);
+  }
+  f(0, add(Ap, pending));
+}
+template <class T, class SC, class F> CTV_DI void eval_RTp_jac_stream(const Q4<T> q[4], const SC &sc, T u, F &&f) {
+  T c[4];
+  basis<T, true, 0>(u, T(1), c);
+  Q4<T> S = q[0];
+  M3<T> pending = q2R(S);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const V3<T> kd = c[i + 1] * sc.d[i];
+    const M3<T> Jh = scale(mul(q2R(S), so3_Jr(neg(kd))), c[i + 1]);
+    const M3<T> JrIi = sc.jri(i);
+    f(i, sub(pending, mulT(Jh, JrIi)));
+    pending = mul(Jh, JrIi);
+    S = qmul(S, so3_exp(kd));
+  }
+  f(3, pending);
 }
 
 template <class T> struct Calib {
@@ -238,23 +345,30 @@ template <class T> struct Calib {
 // Visual block.  Local column order of J (2 x 50): rot_i (12) | pos_i (12) | rot_j (12) | pos_j (12) | rho | ld.
 // Outputs are already robust-corrected (r~ = sqrt(rho') r, J~ = sqrt(rho')(J - alpha/s r r^T J)); returns
 // the block's cost contribution rho(s)/2.  Emit::put(col, j0, j1) receives column `col` of J~ (both rows).
-template <class T, class Emit>
-CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SegConst<T> &sci, const SegConst<T> &scj, T ui, T uj, T idt,
+template <class T, class Emit, class SC>
+CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, const SC &scj, T ui, T uj, T idt,
                      const Calib<T> &cal, const M3<T> &RrefT, T pix, T piy, T pjx, T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac,
                      Emit &emit) {
   const T inv_d = T(1) / d_inv;
   const V3<T> x_ci = mk<T>(pix * inv_d, piy * inv_d, inv_d);
   const V3<T> p_Ii = qrot(cal.q_CI, x_ci) + cal.p_CI;
 
-  M3<T> JR0[4], JR1[4];
-  const Q4<T> S_IitoG = eval_Rp(ki.q, sci, ui, JR0, want_jac);
-  const Q4<T> S_GtoIj = eval_RTp(kj.q, scj, uj, JR1, want_jac);
+  const Q4<T> S_IitoG = eval_Rp<T, SC>(ki.q, sci, ui, (M3<T> *)nullptr, false);     // values only; the Jacobians are streamed below
+  const Q4<T> S_GtoIj = eval_RTp<T, SC>(kj.q, scj, uj, (M3<T> *)nullptr, false);
   T cp0[4], cp1[4];
   basis<T, false, 0>(ui, T(1), cp0);
   basis<T, false, 0>(uj, T(1), cp1);
   V3<T> p_IiinG = mk<T>(0, 0, 0), p_IjinG = mk<T>(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { p_IiinG = p_IiinG + cp0[i] * ki.p[i]; p_IjinG = p_IjinG + cp1[i] * kj.p[i]; }
+  V3<T> v_i = mk<T>(0, 0, 0), v_j = mk<T>(0, 0, 0);   // spline velocities of both ends (line-delay column): taken here, so the
+  if (want_jac) {                                       // knot positions are dead after this point
+    T dcp0[4], dcp1[4];
+    basis<T, false, 1>(ui, idt, dcp0);
+    basis<T, false, 1>(uj, idt, dcp1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v_i = v_i + dcp0[i] * ki.p[i]; v_j = v_j + dcp1[i] * kj.p[i]; }
+  }
 
   const V3<T> p_G = qrot(S_IitoG, p_Ii) + p_IiinG;
   const Q4<T> S_ItoC = qconj(cal.q_CI);
@@ -330,27 +444,25 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SegConst<T>
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        T a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          a0 += lhsR0[c] * JR0[kk].m[3 * c + b]; a1 += lhsR0[3 + c] * JR0[kk].m[3 * c + b];
-          b0 += lhsR1[c] * JR1[kk].m[3 * c + b]; b1 += lhsR1[3 + c] * JR1[kk].m[3 * c + b];
-        }
-        out(3 * kk + b, sw * a0, sw * a1);
-        out(24 + 3 * kk + b, sw * b0, sw * b1);
         out(12 + 3 * kk + b, sw * cp0[kk] * lhsP0[b], sw * cp0[kk] * lhsP0[3 + b]);
         out(36 + 3 * kk + b, -sw * cp1[kk] * lhsP0[b], -sw * cp1[kk] * lhsP0[3 + b]);
       }
+    // rotation columns, knot by knot as the per-knot partial Jacobians become final (image_feature_factor.h:199-216)
+    auto rot_cols = [&](int col0, const T lhs[6], const M3<T> &Jk) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        T a0 = 0, a1 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a0 += lhs[c] * Jk.m[3 * c + b]; a1 += lhs[3 + c] * Jk.m[3 * c + b]; }
+        out(col0 + b, sw * a0, sw * a1);
+      }
+    };
+    eval_Rp_jac_stream<T, SC>(sci, ui, [&](int kk, const M3<T> &Jk) { rot_cols(3 * kk, lhsR0, Jk); });
+    eval_RTp_jac_stream<T, SC>(kj.q, scj, uj, [&](int kk, const M3<T> &Jk) { rot_cols(24 + 3 * kk, lhsR1, Jk); });
   }
   // line delay (image_feature_factor.h:251-264)
   {
-    T dcp0[4], dcp1[4];
-    basis<T, false, 1>(ui, idt, dcp0);
-    basis<T, false, 1>(uj, idt, dcp1);
-    V3<T> v_i = mk<T>(0, 0, 0), v_j = mk<T>(0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v_i = v_i + dcp0[i] * ki.p[i]; v_j = v_j + dcp1[i] * kj.p[i]; }
-    const V3<T> Om_i = eval_omega(sci, ui, idt), Om_j = eval_omega(scj, uj, idt);
+    const V3<T> Om_i = eval_omega<T, SC>(sci, ui, idt), Om_j = eval_omega<T, SC>(scj, uj, idt);
     const M3<T> RGIj = q2R(S_GtoIj);
     const V3<T> a1 = qrot(S_GtoIj, rowi * v_i - rowj * v_j);
     const V3<T> a2 = (-rowj) * cross(Om_j, mul(RGIj, dpg));

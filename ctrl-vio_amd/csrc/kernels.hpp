@@ -537,6 +537,109 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
   }
 }
 
+// All-fp64 product path: one wave per IMU group, 64 samples per pass (one per lane), A^T A on the fp64 matrix cores.
+// The 6 x 30 Jacobian of a sample stays in REGISTERS in factored form (ImuJac); its six rows are streamed through LDS one
+// row index at a time -- phase a: row a of all 64 samples ([64][33] doubles = 16.9 KB, so 8 waves fit a CU and every lane
+// evaluates a sample), then 16 K-steps of v_mfma_f64_16x16x4_f64 per output tile.  Accelerometer rows feed the three lower
+// 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
+// tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
+// B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
+  double *A = reinterpret_cast<double *>(smraw);   // [64][33]
+  const ImuGroup grp = d.groups[blockIdx.x];
+  const int w = grp.win;
+  if (!lin_needed(d.lm[w])) return;
+  const WinMeta &m = d.wins[w];
+  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
+  const bool at_cand = lin_at_candidate(d.lm[w]);
+  const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
+  Knots4<double> k;
+  LocalFrame<double> lf;
+  lf.init(s_quat, s_pos, m.knot0 + grp.s);
+  lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
+  const M3<double> RrefT = lf.RrefT();
+  SegConstLazy<double, double> sc;   // Jr^-1 of the three knot pairs: fetched from the table where it is used
+  seg_const_lazy(d.lkd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc);
+  double bias[6], wgt[6];
+  const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { bias[i] = bp[i]; wgt[i] = m.imu_w[i]; }
+  const V3<double> grav = lf.rotate(m.gravity);
+  const double idt = m.inv_dt;
+  f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
+  const size_t Mt = (size_t)d.Mtot;
+  for (int c0 = 0; c0 < grp.count; c0 += 64) {
+    const int nval = min(64, grp.count - c0);
+    const bool live = lane < nval;
+    const int idx = m.imu0 + grp.start + min(c0 + lane, grp.count - 1);   // clamped: every lane evaluates (uniform control flow around the MFMAs)
+    double gy[3], ac[3], r[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+    ImuJac<double> J;
+    imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, J);
+    const int kmax = (nval + 3) & ~3;
+    // ---- accelerometer rows: 32 columns, tiles (0,0), (1,0), (1,1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
+      double row[32];
+      imu_row_accel<double>(J, wgt, r, a, row);
+      __builtin_amdgcn_wave_barrier();   // the previous phase's operand reads are complete (consumed by its MFMAs)
+#pragma unroll
+      for (int c = 0; c < 32; ++c) A[lane * 33 + c] = live ? row[c] : 0.0;
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the rows are in LDS
+      __builtin_amdgcn_wave_barrier();
+      for (int k0 = 0; k0 < kmax; k0 += 4) {
+        const double lo = A[(k0 + q4) * 33 + l15], hi = A[(k0 + q4) * 33 + 16 + l15];
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, acc11, 0, 0, 0);
+      }
+    }
+    // ---- gyro rows: 16 compacted columns, one tile
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
+      double row[16];
+      imu_row_gyro<double>(J, wgt, r, a, row);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 16; ++c) A[lane * 17 + c] = live ? row[c] : 0.0;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      for (int k0 = 0; k0 < kmax; k0 += 4) {
+        const double v = A[(k0 + q4) * 17 + l15];
+        gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gacc, 0, 0, 0);
+      }
+    }
+  }
+  // ---- combine in LDS into the full symmetric 32 x 32 tile, then one coalesced store
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = q4 + 4 * r, col = l15;
+    A[row * 32 + col] = acc00[r];
+    A[(16 + row) * 32 + 16 + col] = acc11[r];
+    A[(16 + row) * 32 + col] = acc10[r];
+    A[col * 32 + 16 + row] = acc10[r];     // mirror of the off-diagonal tile
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int tc = l15 < 12 ? l15 : (l15 < 15 ? l15 + 12 : 30);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int grow = q4 + 4 * r;
+      const int tr = grow < 12 ? grow : (grow < 15 ? grow + 12 : 30);
+      A[tr * 32 + tc] += gacc[r];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  double *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
+}
+
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
 template <class T> __global__ void k_assemble_imu(Dev<T> d) {
   const ImuGroup grp = d.groups[blockIdx.x];
@@ -680,7 +783,7 @@ __device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, in
 }
 
 template <class T, bool LIN, class RT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ T wcs[LIN ? 64 * 55 : 1];   // per-lane W contributions (row of WC_STRIDE entries), written out coalesced at the end
   __shared__ int wcs_on[LIN ? 64 : 1];   // destination row (slot in landmark order, see Dev::Wc) or -1
@@ -724,9 +827,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
         VisGlobalSink<T> sink{d.Jv, V, wcs + 55 * threadIdx.x, T(0), T(0), (unsigned)v};
         wcs_on[threadIdx.x] = d.v_slot[v];
         if (sizeof(RT) != sizeof(T)) cal.sq_override = d.vis_rc[2 * V + v];   // robust scale of the fp64 residual pass
-        SegConst<T> sci, scj;
-        seg_const_load(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci, true);
-        seg_const_load(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj, true);
+        SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+        seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
+        seg_const_lazy(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
         c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
         if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state
@@ -957,7 +1060,16 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 //   * the staging area of a wave is private, so there is no workgroup barrier inside the item loop, and the next item's
 //     J~ (51 values per lane) is requested before the current item is processed: its latency hides under the products.
 // C/D layout of the 16x16x4 fp32 MFMA: register r of lane l = D[4 (l / 16) + r][l % 16].
-template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<float> d) {
+// T = double (product path): the same kernel on v_mfma_f64_16x16x4_f64 (D register r of lane l = D[(l / 16) + 4 r][l % 16]), items of
+// <= 8 blocks so that eight fp64 staging areas fit beside the packed Hessian.
+template <class T> struct MfmaAcc;
+template <> struct MfmaAcc<float> { typedef f32x4 type; };
+template <> struct MfmaAcc<double> { typedef f64x4 type; };
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d) {
+  constexpr bool F64 = sizeof(T) == 8;
+  typedef typename MfmaAcc<T>::type acc_t;
   constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;
   const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
@@ -973,12 +1085,12 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
   const int nHh = tri + K6 + 1;                // packed Hessian entries: knot x knot lower triangle, line-delay row
   const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay)
   double *gs = Hs + nHh;
-  float *stage = reinterpret_cast<float *>(Hs + ((nH + 3) & ~3));     // [NW][102][CHP]
+  T *stage = reinterpret_cast<T *>(Hs + ((nH + 3) & ~3));     // [NW][102][CHP]
   int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < nH; i += 512) Hs[i] = 0.0;
   __syncthreads();
-  float *Js = stage + wave * 102 * CHP;
+  T *Js = stage + wave * 102 * CHP;
   int *ks = keys + wave * 2 * CH;
   const size_t V = (size_t)d.Vtot;
   const int per_round = NW * nparts;
@@ -999,7 +1111,7 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
 #pragma unroll
   for (int I = 0; I < 3; ++I) orow[I] = (2 * (16 * I + l15) + rr) * CHP;
   const int ldrow = (98 + rr) * CHP, rrow = (100 + rr) * CHP;
-  float tmp[NPASS];
+  T tmp[NPASS];
   int n = 0, v0 = 0, key_i = 0, key_j = 0;
   // the (start, count) of this wave's items: lane r holds item r, read once -- a per-item load of the descriptor would put a
   // full memory round trip in front of every item's J~ request
@@ -1024,11 +1136,18 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
     const int c = sc < icount ? sc : 0;
     // address = uniform row base (SGPR pair) + one 32-bit lane offset shared by all passes: pass i covers staged rows
     // RPP i .. RPP i + RPP - 1, the lane's row inside the pass is srr  (64-bit per-lane addresses would cost 2 VGPRs per load)
-    static_assert(100 % RPP == 0, "a pass must not straddle the J / residual boundary");
     const unsigned loff = (unsigned)srr * (unsigned)V + (unsigned)(v0 + c);
     const unsigned loff_r = (unsigned)min(srr, 1) * (unsigned)V + (unsigned)(v0 + c);   // the residual has 2 rows only
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) tmp[i] = (i * RPP < 100) ? (d.Jv + (size_t)(i * RPP) * V)[loff] : d.rv[loff_r];
+    for (int i = 0; i < NPASS; ++i) {
+      if (i * RPP + RPP <= 100) tmp[i] = (d.Jv + (size_t)(i * RPP) * V)[loff];          // whole pass inside J~
+      else if (i * RPP >= 100) tmp[i] = d.rv[loff_r];                                     // whole pass inside r~
+      else {                                                                               // the pass straddles the boundary
+        const int row = i * RPP + srr;
+        const T *src = row < 100 ? d.Jv + (size_t)row * V : d.rv + (size_t)min(row - 100, 1) * V;
+        tmp[i] = src[v0 + c];
+      }
+    }
     const int kc = lane < icount ? lane : 0;
     key_i = d.vs[v0 + kc];
     key_j = d.vs[V + v0 + kc];
@@ -1040,7 +1159,7 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int row = i * RPP + srr;
-      if (row < 102) Js[row * CHP + sc] = (sc < ncur) ? tmp[i] : 0.0f;
+      if (row < 102) Js[row * CHP + sc] = (sc < ncur) ? tmp[i] : T(0);
     }
     if (lane < CH) { ks[lane] = key_i; ks[CH + lane] = key_j; }
     __builtin_amdgcn_wave_barrier();
@@ -1051,13 +1170,13 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
       const bool diff = (lane > start && lane < ncur) && (ks[lane] != si || ks[CH + lane] != sj);
       const unsigned long long mask = __ballot(diff);
       const int end = mask ? (__ffsll((long long)mask) - 1) : ncur;
-      f32x4 acc[6];
+      acc_t acc[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      float pl[3] = {0.0f, 0.0f, 0.0f}, pr[3] = {0.0f, 0.0f, 0.0f}, pll = 0.0f, prl = 0.0f;
+      for (int q = 0; q < 6; ++q) acc[q] = acc_t{T(0), T(0), T(0), T(0)};
+      T pl[3] = {T(0), T(0), T(0)}, pr[3] = {T(0), T(0), T(0)}, pll = T(0), prl = T(0);
       // 4 K-steps (8 blocks) per trip: the operand reads first, then the products -- one LDS latency per trip
       for (int v8 = start; v8 < end; v8 += 8) {
-        float a[4][3], ldv[4], rv[4];
+        T a[4][3], ldv[4], rv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int blk = v8 + 2 * s + bsel;
@@ -1068,9 +1187,9 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
           ldv[s] = Js[ldrow + bc];
           rv[s] = Js[rrow + bc];
 #pragma unroll
-          for (int I = 0; I < 3; ++I) a[s][I] = in ? a[s][I] : 0.0f;
-          ldv[s] = in ? ldv[s] : 0.0f;
-          rv[s] = in ? rv[s] : 0.0f;
+          for (int I = 0; I < 3; ++I) a[s][I] = in ? a[s][I] : T(0);
+          ldv[s] = in ? ldv[s] : T(0);
+          rv[s] = in ? rv[s] : T(0);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1079,7 +1198,7 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
 #pragma unroll
           for (int I = 0; I < 3; ++I)
 #pragma unroll
-            for (int J = 0; J <= I; ++J, ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][I], a[s][J], acc[q], 0, 0, 0);
+            for (int J = 0; J <= I; ++J, ++q) acc[q] = mfma16(a[s][I], a[s][J], acc[q]);
 #pragma unroll
           for (int I = 0; I < 3; ++I) { pl[I] += a[s][I] * ldv[s]; pr[I] += a[s][I] * rv[s]; }
           pll += ldv[s] * ldv[s];
@@ -1103,7 +1222,7 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
         tcol[J] = gcol[J] * (gcol[J] + 1) / 2;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          grow[J][rg] = vis_col(16 * J + 4 * q4 + rg, si, sj, P);
+          grow[J][rg] = vis_col(16 * J + (F64 ? q4 + 4 * rg : 4 * q4 + rg), si, sj, P);
           trow[J][rg] = grow[J][rg] * (grow[J][rg] + 1) / 2;
         }
       }
@@ -1115,11 +1234,11 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
           for (int J = 0; J <= I; ++J, ++q) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-              const int ca = 16 * I + 4 * q4 + rg, cb = 16 * J + l15;
+              const int ca = 16 * I + (F64 ? q4 + 4 * rg : 4 * q4 + rg), cb = 16 * J + l15;
               if (I == J && ca < cb) continue;
               const int gA = grow[I][rg], gB = gcol[J];
-              float hv = acc[q][rg];
-              if (gA == gB && ca != cb) hv *= 2.0f;
+              T hv = acc[q][rg];
+              if (gA == gB && ca != cb) hv *= T(2);
               const bool ge = gA >= gB;
               atomicAdd(&Hs[(ge ? trow[I][rg] : tcol[J]) + (ge ? gB : gA)], (double)hv);
             }
@@ -1142,8 +1261,8 @@ template <int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev
   // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments)
   for (int gi = part * NW + wave; gi < ngrp; gi += per_round) {
     const ImuGroup grp = d.groups[grp0 + gi];
-    const float *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
-    float tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
+    const T *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
+    T tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
 #pragma unroll
     for (int u = 0; u < 9; ++u) { const int e = lane + 64 * u; tv[u] = tile[(e / 24) * 32 + e % 24]; }
 #pragma unroll

@@ -183,8 +183,14 @@ CTV_DI V3<float> so3_log(Q4<float> q) {
 
 // ---- Jr: I - a*hat + b*hat^2,  a = (1-cos t)/t^2, b = (t - sin t)/t^3   (sophus_utils.hpp:166-199)
 CTV_DI void jr_coeffs(double n2, double &a, double &b) {
-  if (n2 > 1e-10) { const double n = sqrt(n2); a = (1 - cos(n)) / n2; b = (n - sin(n)) / (n2 * n); }
-  else { a = 0.5; b = 1.0 / 6.0; }
+  if (n2 < 0.25) {
+    // |t| < 0.5 (lambda * d between neighbouring knots): alternating Taylor series, truncation < 1e-17 relative -- the same
+    // function as the reference's closed form (which itself loses ~1e-16 / t^2 to cancellation), without sqrt / sin / cos
+    a = 0.5 + n2 * (-1.0 / 24.0 + n2 * (1.0 / 720.0 + n2 * (-1.0 / 40320.0 + n2 * (1.0 / 3628800.0 + n2 * (-1.0 / 479001600.0 +
+        n2 * (1.0 / 87178291200.0 + n2 * (-1.0 / 20922789888000.0)))))));
+    b = 1.0 / 6.0 + n2 * (-1.0 / 120.0 + n2 * (1.0 / 5040.0 + n2 * (-1.0 / 362880.0 + n2 * (1.0 / 39916800.0 + n2 * (-1.0 / 6227020800.0 +
+        n2 * (1.0 / 1307674368000.0 + n2 * (-1.0 / 355687428096000.0)))))));
+  } else { const double n = sqrt(n2); a = (1 - cos(n)) / n2; b = (n - sin(n)) / (n2 * n); }
 }
 CTV_DI void jr_coeffs(float n2, float &a, float &b) {
   if (n2 < 1.0f) {
@@ -208,8 +214,11 @@ template <class T> CTV_DI M3<T> so3_Jr(V3<T> phi) {
 }
 // ---- Jr^-1: I + hat/2 + c*hat^2, c = 1/t^2 - (1+cos t)/(2 t sin t)   (sophus_utils.hpp:210-242)
 CTV_DI double jrinv_coeff(double n2) {
-  if (n2 > 1e-10) { const double n = sqrt(n2); return 1.0 / n2 - (1 + cos(n)) / (2 * n * sin(n)); }
-  return 1.0 / 12.0;
+  if (n2 < 0.25)   // (1 - (t/2) cot(t/2)) / t^2 = sum |B_2k| t^(2k-2) / (2k)!, truncation < 1e-17
+    return 1.0 / 12.0 + n2 * (1.0 / 720.0 + n2 * (1.0 / 30240.0 + n2 * (1.0 / 1209600.0 + n2 * (1.0 / 47900160.0 +
+           n2 * (691.0 / 1307674368000.0 + n2 * (1.0 / 74724249600.0 + n2 * (3617.0 / 10670622842880000.0)))))));
+  const double n = sqrt(n2);
+  return 1.0 / n2 - (1 + cos(n)) / (2 * n * sin(n));
 }
 CTV_DI float jrinv_coeff(float n2) {
   if (n2 < 1.0f)  // 1/12 + t^2/720 + t^4/30240 + t^6/1209600 + t^8/47900160
