@@ -126,6 +126,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (sizeof(T) == 8) HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
@@ -521,7 +522,8 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_schur();
   void launch_imu_linearize(size_t vals_lds);
   void launch_assemble_vis_lds(int parts);
-  bool schur_makes_rhs() const { return sizeof(T) == 4 && opt_.use_mfma != 0; }
+  bool schur_makes_rhs() const { return (sizeof(T) == 4 && opt_.use_mfma != 0) || schur_rhs_done_; }
+  bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
   void launch_cost(bool candidate, int force) {
     const Dev<T> &d = dev_;
     const double *q = candidate ? d.cquat : d.quat, *p = candidate ? d.cpos : d.pos, *b = candidate ? d.cbias : d.bias;
@@ -912,9 +914,20 @@ template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
 }
 template <> void SolverImpl<double>::launch_schur() {
   const Dev<double> &d = dev_;
-  if (opt_.use_mfma) {   // fp64 matrix cores, one wave per 16 x 16 tile; k_rhs forms the reduced right-hand side
-    const int nt = (d.maxP + 15) / 16, ntile = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile);
+  schur_rhs_done_ = false;
+  if (opt_.use_mfma) {   // fp64 matrix cores
+    const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
+    const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32) * sizeof(double);
+    // large batches: one workgroup per window, W staged through LDS once, reduced rhs produced on the way; small batches: one
+    // wave per 16 x 16 tile (shorter latency, W re-read per tile), k_rhs forms the reduced right-hand side
+    const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
+    if (!small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024) {
+      hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+      schur_rhs_done_ = true;
+    } else {
+      const int nt2 = (d.maxP + 15) / 16, ntile2 = nt2 * (nt2 + 1) / 2;
+      hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile2);
+    }
   } else {
     hipLaunchKernelGGL((k_schur_generic<double>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
   }

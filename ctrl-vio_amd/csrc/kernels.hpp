@@ -544,7 +544,7 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
 // 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
 // tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
 // B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d) {
+__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   double *A = reinterpret_cast<double *>(smraw);   // [64][33]
   const ImuGroup grp = d.groups[blockIdx.x];
@@ -639,6 +639,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
   for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
 }
+
+// One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
+// (Two waves per SIMD with the overflow spilled to scratch was measured 3x slower: 1690 vs 540 us per 1024 windows.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d) { imu_linearize_f64_body(d); }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
 template <class T> __global__ void k_assemble_imu(Dev<T> d) {
@@ -1709,6 +1713,117 @@ template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_wave
         S[(long long)ii * ldh + jj] = val;
       } else if (ii == P && jj < P) {
         rhs[jj] = act_j ? (double)acc[q][r] - g_j : 0.0;
+      }
+    }
+  }
+}
+
+// fp64 product path, large batches: the window kernel on the fp64 matrix cores.  One workgroup (8 waves) per window; W is read
+// from HBM once, staged through LDS in double-buffered chunks of 16 landmarks (masked by the active flags, g_rho appended as
+// column P so that the tile row holding index P also produces the reduced right-hand side: no k_rhs pass).  Output tiles are
+// 16 x 16 (v_mfma_f64_16x16x4_f64, K = 4 landmarks per instruction); tile t of the lower triangle belongs to wave t % 8, which
+// keeps its <= NTQ accumulators in registers over the whole landmark loop; tiles over bias-only columns skip the products.
+// NPRE = chunk elements per thread (16 ldw / 512); NTQ = ceil(ntile / 8).
+template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_window_f64(Dev<double> d) {
+  const int w = blockIdx.x;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int nt = ldw >> 4, ntile = nt * (nt + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double smd64[];
+  double *Wb = smd64;                    // [2][16][ldw]
+  double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)
+  double *dch = acts + ldw;              // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
+  const double *Wp = d.W + m.W0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
+  for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0 : 0.0;
+  int bi[NTQ], bj[NTQ];
+  bool run[NTQ];
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) {
+    const int t = wave + 8 * q;
+    tile_decode(min(t, ntile - 1), bi[q], bj[q]);
+    // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P)
+    const bool nz_i = (16 * bi[q] < K6) || (P >= 16 * bi[q] && P - 1 < 16 * bi[q] + 16);
+    const bool nz_j = (16 * bj[q] < K6) || (P - 1 >= 16 * bj[q] && P - 1 < 16 * bj[q] + 16);
+    run[q] = t < ntile && nz_i && nz_j;
+  }
+  f64x4 acc[NTQ];
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int nchunk = (L + 15) >> 4, nel = 16 * ldw;
+  double pre[NPRE];
+  double pre_d = 0.0;
+  auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = min(tid + 512 * k, nel - 1), l = min(16 * ch + e / ldw, L - 1), c = e % ldw;
+      pre[k] = (c == P) ? gl[l] : Wp[(long long)l * ldw + c];
+    }
+    if (tid < 16) pre_d = dinv[min(16 * ch + tid, L - 1)];
+  };
+  auto stash = [&](int ch, int buf) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = min(tid + 512 * k, nel - 1);
+      const int lr = e / ldw, c = e % ldw;
+      const bool lv = 16 * ch + lr < L;
+      Wb[buf * nel + e] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0;
+    }
+    if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
+  };
+  __syncthreads();   // acts
+  if (nchunk > 0) { fetch(0); stash(0, 0); }
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) fetch(ch + 1);
+    const double *B = Wb + buf * nel;
+    double dl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
+#pragma unroll
+    for (int q = 0; q < NTQ; ++q) {
+      if (!run[q]) continue;   // wave-uniform
+      double a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int l = 4 * s + q4;
+        a[s] = B[l * ldw + 16 * bi[q] + l15];
+        b[s] = B[l * ldw + 16 * bj[q] + l15];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
+    }
+    if (ch + 1 < nchunk) stash(ch + 1, buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
+  const double *H = d.Hpp + m.H0;
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) {
+    if (wave + 8 * q >= ntile) continue;
+    const int jj = 16 * bj[q] + l15, jc = min(jj, P - 1);
+    const bool act_j = d.active[u0 + jc] != 0;
+    const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
+    double hv[4];
+    unsigned char act_i[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ic = min(16 * bi[q] + q4 + 4 * r, P - 1);
+      act_i[r] = d.active[u0 + ic];
+      hv[r] = H[(long long)ic * ldh + min(jc, ic)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = 16 * bi[q] + q4 + 4 * r;
+      if (ii < P && jj <= ii) {
+        const bool on = act_i[r] && act_j;
+        S[(long long)ii * ldh + jj] = on ? hv[r] - acc[q][r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+      } else if (ii == P && jj < P) {
+        rhs[jj] = act_j ? acc[q][r] - g_j : 0.0;
       }
     }
   }

@@ -127,6 +127,26 @@ def test_config2_batch_of_64_equals_64_singles(cv):
             assert cv.rel_state_error(batch[i], w1)["state"] < 1e-7, i
 
 
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_large_batch_kernels_match_small_batch_kernels(cv, prec):
+    """From 192 windows per launch on, the per-window kernels take over (k_schur_window_f64 / k_schur_window, single-part
+    visual assembly): 208 windows (8 distinct config-1 windows, 26 copies each) against the same 8 solved in a small batch
+    (per-tile kernels).  Both are the same arithmetic in a different order."""
+    base = [cv.synth.make_window("config1", seed=1100 + i) for i in range(8)]
+    with cv.Solver(precision=prec) as s:
+        small = [w.copy() for w in base]
+        s.set_windows(small)
+        sm_small = s.solve(15)
+        big = [base[i % 8].copy() for i in range(208)]
+        s.set_windows(big)
+        sm_big = s.solve(15)
+    tol = 1e-7 if prec == "fp64" else 1e-3
+    for i in range(208):
+        assert sm_big[i]["iterations"] == sm_small[i % 8]["iterations"] or prec == "fp32"
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 8]["final_cost"], rel=1e-10 if prec == "fp64" else 1e-5)
+        assert cv.rel_state_error(big[i], small[i % 8])["state"] < tol, i
+
+
 @pytest.mark.parametrize("cfg,seed", [("config1", 1000), ("config2", 1000), ("config2", 1001)])
 def test_mixed_fast_mode_is_approximate_but_sane(cv, oracle, cfg, seed):
     """precision="fp32" (fp32 Jacobians / J^T J / Schur, fp64 residuals and Cholesky; no line search) is an optional fast

@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2c; mkdir -p $O; export TMPDIR=/tmp; cd $R
-python -m pytest tests -m gpu -q -x -k "linearize or lm_step or product_parity or ragged or edge or golden" 2>&1 | tail -5
+python -m pytest tests -m gpu -q -x -k "linearize or lm_step or product_parity or ragged or edge or golden or large_batch" 2>&1 | tail -5
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --streams 1 --windows 1024 --steps 2 --warmup 1 --device-resident-only > $O/bench_1s.json 2> $O/kt.err
 python $R/tests/prof_summary.py stats $(find $O/kt -name "*.db") > $O/kstats.txt; find $O/kt -name "*.db" -delete
