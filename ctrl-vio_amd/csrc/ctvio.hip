@@ -96,6 +96,7 @@ struct SolverBase {
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
   virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
   virtual int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
+  virtual int residual_summary(int id, double *sums, int32_t *counts4) = 0;
   virtual int bind() = 0;   // make the solver's device current on the calling thread (every ABI entry: callers use threads)
   virtual int snapshot(int restore) = 0;
   virtual int last_timing(double *ms8, int32_t *n8) = 0;
@@ -232,6 +233,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_v_obs_d = dup64 ? seg(8 * 4 * Vt) : o_v_obs;
     const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_lm_blk_off = seg(4 * ((size_t)L0 + 1)), o_lm_blk = seg(4 * Vt);
     const size_t o_bc_win = seg(4 * (size_t)B0), o_bc_i = seg(4 * (size_t)B0), o_bc_j = seg(4 * (size_t)B0), o_bc_w = seg(8 * 6 * (size_t)B0);
+    const size_t o_pJ0 = seg(8 * (size_t)pH0), o_pr0 = seg(8 * (size_t)pv0);
     const size_t o_pH = seg(8 * (size_t)pH0), o_pb0 = seg(8 * (size_t)pv0), o_pc0 = seg(8 * (size_t)nw), o_p_x0 = seg(8 * 4 * (size_t)pb);
     const size_t o_pcol = seg(4 * (size_t)pv0), o_p_kind = seg(4 * (size_t)pb), o_p_index = seg(4 * (size_t)pb), o_p_off = seg(4 * (size_t)pb);
     const size_t o_active = seg((size_t)U0);
@@ -256,6 +258,7 @@ template <class T> class SolverImpl : public SolverBase {
     VisItem *h_vitems = CTV_H(VisItem, o_vitems);
     int32_t *h_lm_blk_off = CTV_H(int32_t, o_lm_blk_off), *h_lm_blk = CTV_H(int32_t, o_lm_blk);
     int32_t *h_bc_win = CTV_H(int32_t, o_bc_win), *h_bc_i = CTV_H(int32_t, o_bc_i), *h_bc_j = CTV_H(int32_t, o_bc_j);
+    double *h_pJ0 = CTV_H(double, o_pJ0), *h_pr0 = CTV_H(double, o_pr0);
     double *h_bc_w = CTV_H(double, o_bc_w), *h_pH = CTV_H(double, o_pH), *h_pb0 = CTV_H(double, o_pb0), *h_pc0 = CTV_H(double, o_pc0),
            *h_p_x0 = CTV_H(double, o_p_x0);
     int32_t *h_pcol = CTV_H(int32_t, o_pcol), *h_p_kind = CTV_H(int32_t, o_p_kind), *h_p_index = CTV_H(int32_t, o_p_index), *h_p_off = CTV_H(int32_t, o_p_off);
@@ -338,6 +341,8 @@ template <class T> class SolverImpl : public SolverBase {
           for (int k = 0; k < prior_block_size(kind); ++k) col[w.p_off[b] + k] = u0 + k;
         }
         double *pH = h_pH + m.pH0, *pb0 = h_pb0 + m.pv0;
+        std::memcpy(h_pJ0 + m.pH0, w.pJ0, sizeof(double) * (size_t)n * n);
+        std::memcpy(h_pr0 + m.pv0, w.pr0, sizeof(double) * (size_t)n);
         for (int i = 0; i < n; ++i) {
           const double *Ji = w.pJ0 + (size_t)i * n;
           double bi = 0;
@@ -372,6 +377,7 @@ template <class T> class SolverImpl : public SolverBase {
     d.v_slot = CTV_D(int32_t, o_v_slot); d.v_ti = CTV_D(int64_t, o_v_ti); d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
     d.vitems = CTV_D(VisItem, o_vitems); d.lm_blk_off = CTV_D(int32_t, o_lm_blk_off); d.lm_blk = CTV_D(int32_t, o_lm_blk);
     d.bc_win = CTV_D(int32_t, o_bc_win); d.bc_i = CTV_D(int32_t, o_bc_i); d.bc_j = CTV_D(int32_t, o_bc_j); d.bc_w = CTV_D(double, o_bc_w);
+    d.pJ0 = CTV_D(double, o_pJ0); d.pr0 = CTV_D(double, o_pr0);
     d.pH = CTV_D(double, o_pH); d.pb0 = CTV_D(double, o_pb0); d.pc0 = CTV_D(double, o_pc0); d.p_x0 = CTV_D(double, o_p_x0);
     d.pcol = CTV_D(int32_t, o_pcol); d.p_kind = CTV_D(int32_t, o_p_kind); d.p_index = CTV_D(int32_t, o_p_index); d.p_off = CTV_D(int32_t, o_p_off);
     d.active = CTV_D(uint8_t, o_active);
@@ -800,6 +806,21 @@ template <class T> class SolverImpl : public SolverBase {
     std::copy(rv.begin(), rv.end(), r0);
     return CTVIO_OK;
   }
+  // ResidualSummary (reference trajectory_estimator.h:37-59): per-type sums of |r_i| at the current state
+  int residual_summary(int id, double *sums, int32_t *counts4) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    if (id < 0 || id >= dev_.nwin || !sums) return fail(CTVIO_ERR_INVALID, "bad arguments");
+    const WinMeta &m = meta_[id];
+    const int n = 14 + m.pn;
+    DBuf<double> out;
+    HIPCHK(out.alloc(n));
+    hipLaunchKernelGGL((k_residual_summary<T>), dim3(1), dim3(256), (size_t)(14 + 2 * m.pn) * sizeof(double), stream_, dev_, id, out.p);
+    HIPCHK(hipMemcpyAsync(sums, out.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    if (counts4) { counts4[0] = m.M; counts4[1] = m.NB; counts4[2] = m.V; counts4[3] = m.pn > 0 ? 1 : 0; }
+    return CTVIO_OK;
+  }
   int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (n < 0 || (n && (!ids || !knot || !q0 || !t0))) return fail(CTVIO_ERR_INVALID, "bad arguments");
@@ -1010,6 +1031,7 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_marginalize(ctvio_solver *s, int32_t id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) {
   CHK_S; return s->impl->marginalize(id, role, eps, n_keep, kept, J0, r0);
 }
+int32_t ctvio_residual_summary(ctvio_solver *s, int32_t id, double *sums, int32_t *counts4) { CHK_S; return s->impl->residual_summary(id, sums, counts4); }
 int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) {
   CHK_S; return s->impl->gauge_restore(n, ids, knot, q0, t0);
 }

@@ -103,6 +103,7 @@ template <class T> struct Dev {
   const double *bc_w;    // [NBtot][6]
   // prior (J0^T J0, J0^T r0, r0^T r0 precomputed on the host in fp64)
   const double *pH, *pb0, *pc0;
+  const double *pJ0, *pr0;   // the prior as given: J0 (column-major n x n at pH0) and r0 (at pv0) -- residual summary only
   const int32_t *pcol;   // [sum pn] unknown index of each prior dimension
   const int32_t *p_kind, *p_index, *p_off;
   const double *p_x0;

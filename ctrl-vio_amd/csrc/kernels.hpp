@@ -2429,6 +2429,102 @@ template <class T> __global__ void k_gauge_restore(Dev<T> d, int n, const int32_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ residual summary
+// ResidualSummary::AddResidualInfo (reference trajectory_estimator.cpp:36-67): per factor type, the sum of |r_i| of every
+// residual component over all blocks (the cost functions' raw whitened residuals: no robust loss) and the block count.
+// Diagnostic entry (fp64 evaluation, one workgroup per call): out = [imu 6 | bias 6 | image 2 | prior pn].
+template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev<T> d, int w, double *out) {
+  const WinMeta &m = d.wins[w];
+  extern __shared__ __attribute__((aligned(16))) double smr[];   // [14 + pn] sums, then [pn] dx
+  const int tid = threadIdx.x, n = m.pn;
+  double *sums = smr, *dx = smr + 14 + n;
+  for (int i = tid; i < 14 + 2 * n; i += 256) smr[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < m.M; i += 256) {
+    const int idx = m.imu0 + i;
+    const ImuGroup grp = d.groups[d.imu_grp[idx]];
+    Knots4<double> k;
+    LocalFrame<double> lf;
+    lf.init(d.quat, d.pos, m.knot0 + grp.s);
+    lf.load(d.quat, d.pos, m.knot0 + grp.s, k);
+    SegConst<double> sc;
+    seg_const(k, sc, false);
+    double b[6], wgt[6], gy[3], ac[3], r[6];
+    const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
+    for (int c = 0; c < 6; ++c) { b[c] = bp[c]; wgt[c] = m.imu_w[c]; }
+    for (int c = 0; c < 3; ++c) { gy[c] = (double)d.imu_meas_d[(size_t)c * d.Mtot + idx]; ac[c] = (double)d.imu_meas_d[(size_t)(3 + c) * d.Mtot + idx]; }
+    ImuJac<double> J;
+    imu_eval_core<double>(k, sc, (double)d.imu_ud[idx], m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, J);
+    for (int c = 0; c < 6; ++c) atomicAdd(&sums[c], fabs(r[c]));
+  }
+  for (int e = tid; e < m.NB * 6; e += 256) {
+    const int b = e / 6, k = e % 6;
+    const int bi = d.bc_i[m.bc0 + b], bj = d.bc_j[m.bc0 + b];
+    const double r = d.bc_w[(size_t)(m.bc0 + b) * 6 + k] * (d.bias[6 * (m.bias0 + bj) + k] - d.bias[6 * (m.bias0 + bi) + k]);
+    atomicAdd(&sums[6 + k], fabs(r));
+  }
+  for (int i = tid; i < m.V; i += 256) {
+    const int v = m.vis0 + i;
+    int si, sj;
+    double ui, uj;
+    const double ld = d.ld[w];
+    const int rowi = d.v_rowi[v], rowj = d.v_rowj[v];
+    vis_times(m, d.v_ti[v], rowi, ld, si, ui);
+    vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
+    si = max(0, min(si, m.K - 4)); sj = max(0, min(sj, m.K - 4));
+    Knots4<double> ki, kj;
+    LocalFrame<double> lf;
+    lf.init(d.quat, d.pos, m.knot0 + si);
+    lf.load(d.quat, d.pos, m.knot0 + si, ki);
+    lf.load(d.quat, d.pos, m.knot0 + sj, kj);
+    SegConst<double> sci, scj;
+    {
+      Knots4<double> gi, gj;   // pair constants straight from the (global-frame) knots: independent of the tables
+      const double z3[3] = {0, 0, 0};
+      load_knots<double>(d.quat, d.pos, m.knot0 + si, z3, gi);
+      load_knots<double>(d.quat, d.pos, m.knot0 + sj, z3, gj);
+      seg_const(gi, sci, false);
+      seg_const(gj, scj, false);
+    }
+    Calib<double> cal;
+    cal.q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
+    cal.p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+    cal.img_w = m.img_w;
+    cal.cauchy_a = -1.0;   // raw residual
+    const size_t V = (size_t)d.Vtot;
+    double r[2];
+    VisNullSink<double> sink;
+    visual_eval<double>(ki, kj, sci, scj, ui, uj, m.inv_dt, cal, lf.RrefT(), (double)d.v_obs_d[v], (double)d.v_obs_d[V + v], (double)d.v_obs_d[2 * V + v],
+                        (double)d.v_obs_d[3 * V + v], (double)rowi, (double)rowj, d.rho[m.lm0 + d.v_lm[v]], r, false, sink);
+    atomicAdd(&sums[12], fabs(r[0]));
+    atomicAdd(&sums[13], fabs(r[1]));
+  }
+  if (n > 0) {   // prior r = r0 + J0 dx (MarginalizationFactor::Evaluate, marginalization_factor.cpp:326-353)
+    for (int b = tid; b < m.pnb; b += 256) {
+      const int kind = d.p_kind[m.pblk0 + b], idx = d.p_index[m.pblk0 + b], off = d.p_off[m.pblk0 + b];
+      const double *x = prior_block_ptr(m, kind, idx, d.quat, d.pos, d.bias, d.ld, w);
+      const double *x0 = d.p_x0 + 4 * (size_t)(m.pblk0 + b);
+      if (kind == 0) {
+        const Q4<double> dq = qmul_raw(qmk<double>(-x0[0], -x0[1], -x0[2], x0[3]), qmk<double>(x[0], x[1], x[2], x[3]));
+        const double sg = (dq.w >= 0) ? 2.0 : -2.0;
+        dx[off] = sg * dq.x; dx[off + 1] = sg * dq.y; dx[off + 2] = sg * dq.z;
+      } else {
+        const int sz = (kind == 4) ? 1 : 3;
+        for (int k = 0; k < sz; ++k) dx[off + k] = x[k] - x0[k];
+      }
+    }
+    __syncthreads();
+    const double *pJ = d.pJ0 + m.pH0, *pr0 = d.pr0 + m.pv0;   // J0 (column-major, as uploaded) and r0
+    for (int i = tid; i < n; i += 256) {
+      double r = pr0[i];
+      for (int j = 0; j < n; ++j) r += pJ[(size_t)j * n + i] * dx[j];
+      sums[14 + i] = fabs(r);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 14 + n; i += 256) out[i] = sums[i];
+}
+
 // ------------------------------------------------------------------------------------------------ trajectory query
 // Se3Spline::poseNs / transVelWorld / rotVelBody / transAccelWorld (se3_spline.h:361-399), fp64, one lane per query.
 template <class T>

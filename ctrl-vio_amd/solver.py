@@ -190,6 +190,14 @@ class Solver:
         capi.check(self._lib.ctvio_lm_step(self._h, wid, float(mu), capi._p(d), C.cast(C.byref(mc), C.c_void_p)))
         return d, float(mc.value)
 
+    def residual_summary(self, wid: int):
+        """ResidualSummary of window wid at its current state: dict type -> (sum |r_i| per component, block count)."""
+        w = self.windows[wid]
+        sums = np.zeros(14 + w.pn); cnt = np.zeros(4, np.int32)
+        capi.check(self._lib.ctvio_residual_summary(self._h, wid, capi._p(sums), capi._p(cnt)))
+        return {"imu": (sums[:6].copy(), int(cnt[0])), "bias": (sums[6:12].copy(), int(cnt[1])), "image": (sums[12:14].copy(), int(cnt[2])),
+                "prior": (sums[14:].copy(), int(cnt[3]))}
+
     def marginalize(self, wid: int, role, eps: float = 1e-8):
         """Prior construction from window `wid` (ctvio_marginalize): role[N] 1 = marginalise, 0 = keep, -1 = not involved.
         Returns (kept indices, J0 (n, n), r0 (n))."""

@@ -160,6 +160,11 @@ int32_t ctvio_restore_state(ctvio_solver *s);
 int32_t ctvio_linearize(ctvio_solver *s, int32_t id, double *Hpp, double *W, double *Hll, double *g, double *cost);
 /* Cost only (residual kernels). */
 int32_t ctvio_cost(ctvio_solver *s, int32_t id, double *cost);
+/* ResidualSummary (trajectory_estimator.h:37-59, AddResidualInfo at trajectory_estimator.cpp:36-67): for window id at its
+ * current state, the sum over all blocks of |r_i| for every residual component of each factor type (the cost functions' own
+ * whitened residuals, before any robust loss) and the block counts.  sums: IMU [6], bias [6], image [2], prior [pn]
+ * (14 + pn doubles); counts4 = {M, NB, V, prior present}; err_ave of PrintSummary = sums / count. */
+int32_t ctvio_residual_summary(ctvio_solver *s, int32_t id, double *sums, int32_t *counts4);
 /* One LM step for radius mu at the current state (Jacobi scaling from this same point): delta (N),
  * model cost change; the state is not modified. */
 int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, double *model_cost_change);

@@ -10,12 +10,16 @@
 // records the factors in flat arrays, and ships one ctvio_window to the GPU.  No Eigen/Sophus/Ceres/glog types:
 // the reference's Eigen::Vector3d arguments become `const double*` (Eigen users pass v.data()).
 //
-// Not provided (reference methods that are declared but never defined, trajectory_estimator.h:87-143, or that
-// belong to prior construction -- SURVEY.md section 8f-1): AddPoseMeasurementAnalytic, AddStartTimePose,
-// AddStaticSegment, AddPreIntegrationAnalytic, AddImageFeatureAnalytic, AddDelayAnalytic, SetKeyScanConstant,
-// PrepareMarginalizationInfo / SaveMarginalizationInfo.
+// Marginalisation side-channel: marg_this_factor flags, PrepareMarginalizationInfo (previous prior + drop set) and
+// SaveMarginalizationInfo (-> ctvio_marginalize) build the next window's prior; GetResidualSummary -> ctvio_residual_summary.
+// Only the knots the factors touch are shipped (the trajectory may be arbitrarily long); one solver handle per thread is
+// kept alive across estimators (SolverCache).
+// Not provided (reference methods that are declared but never defined, trajectory_estimator.h:87-143):
+// AddPoseMeasurementAnalytic, AddStartTimePose, AddStaticSegment, AddPreIntegrationAnalytic, AddImageFeatureAnalytic,
+// AddDelayAnalytic, SetKeyScanConstant; AddCallback (debug hook, never called).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <deque>
@@ -76,11 +80,14 @@ struct IMUData {
   double accel[3];
 };
 
-// reference src/estimator/trajectory_estimator_options.h:34-68 (fields the solve reads)
+// reference src/estimator/trajectory_estimator_options.h:34-68 (fields the solve / the marginalisation read)
 struct TrajectoryEstimatorOptions {
   bool lock_traj = false, lock_ab = false, lock_wb = false;
+  bool is_marg_state = false;                       // :58  the estimator collects a MarginalizationInfo
+  int ctrl_to_be_opt_now = 0, ctrl_to_be_opt_later = 0;   // :60-64  knots with index < ctrl_to_be_opt_later are marginalised
+  bool show_residual_summary = false;               // :66
   double image_weight = 800.0;  // ImageFeatureDelayFactor::sqrt_info (trajectory_manager.cpp:55-61)
-  int precision = CTVIO_FP32;
+  int precision = CTVIO_FP64;   // the product path (all-fp64, like the reference); CTVIO_FP32 = mixed fast mode
   int device = 0;
 };
 
@@ -94,6 +101,25 @@ struct MarginalizationInfo {
   std::vector<std::array<double, 4>> keep_block_data;  // linearisation point of each block
 };
 
+// reference trajectory_estimator.h:37-59: per residual type, sum of |r_i| per component and the number of blocks
+struct ResidualSummary {
+  std::vector<double> imu_sum = std::vector<double>(6, 0.0), bias_sum = std::vector<double>(6, 0.0), image_sum = std::vector<double>(2, 0.0),
+                      prior_sum;
+  int imu_num = 0, bias_num = 0, image_num = 0, prior_num = 0;
+  std::string descri_info;
+  std::string PrintSummary() const {
+    std::string o = "ResidualSummary :" + descri_info + "\n";
+    auto line = [&](const char *name, int num, const std::vector<double> &sum) {
+      if (num <= 0) return;
+      o += std::string("\t- ") + name + ": num = " + std::to_string(num) + "; err_ave = ";
+      for (double v : sum) o += std::to_string(v / num) + ", ";
+      o += "\n";
+    };
+    line("IMU", imu_num, imu_sum); line("Bias", bias_num, bias_sum); line("Image", image_num, image_sum); line("Prior", prior_num, prior_sum);
+    return o;
+  }
+};
+
 struct SolveSummary {
   ctvio_summary s{};
   std::string BriefReport() const {  // the only thing the reference's callers use (trajectory_manager.cpp:314,455)
@@ -104,34 +130,64 @@ struct SolveSummary {
   }
 };
 
+// One solver handle (HIP stream + grow-only device / pinned arenas) per (device, precision) and host thread, kept alive
+// across estimators: the reference builds a fresh TrajectoryEstimator for every solve (trajectory_manager.cpp:350); here
+// that costs no device allocation after the first one.
+class SolverCache {
+ public:
+  static ctvio_solver *get(int device, int precision) {
+    thread_local SolverCache cache;
+    for (auto &e : cache.items_) if (e.device == device && e.precision == precision) return e.s;
+    ctvio_options o;
+    ctvio_default_options(&o);
+    o.precision = precision; o.device = device; o.host_threads = 1;   // a single window: no packing threads
+    ctvio_solver *s = nullptr;
+    const int rc = ctvio_create(&o, &s);
+    if (rc) throw std::runtime_error(std::string(ctvio_status_string(rc)) + ": " + ctvio_last_error());
+    cache.items_.push_back({device, precision, s});
+    return s;
+  }
+  ~SolverCache() { for (auto &e : items_) ctvio_destroy(e.s); }
+ private:
+  struct Item { int device, precision; ctvio_solver *s; };
+  std::vector<Item> items_;
+};
+
 class TrajectoryEstimator {
  public:
   // TrajectoryEstimator(Trajectory::Ptr, TrajectoryEstimatorOptions&)  trajectory_estimator.h:76-77
   TrajectoryEstimator(Trajectory *trajectory, const TrajectoryEstimatorOptions &option) : traj_(trajectory), opt_(option) {
-    for (size_t k = 0; k < traj_->numKnots(); ++k) knot_of_[traj_->so3_[k].data()] = (int)k;
+    for (size_t k = 0; k < traj_->numKnots(); ++k) { knot_of_[traj_->so3_[k].data()] = (int)k; knot_of_[traj_->pos_[k].data()] = (int)k; }
+    const int64_t ld_ns = (int64_t)((traj_->fix_ld ? traj_->line_delay : std::max(traj_->line_delay, traj_->ld_upper)) * 1e9);
+    (void)ld_ns;
   }
-  // void SetFixedIndex(int idx)  trajectory_estimator.h:90
-  void SetFixedIndex(int idx) { fixed_upto_ = idx; }
+  // void SetFixedIndex(int idx)  trajectory_estimator.h:90.  As in the reference, constancy is decided when a factor adds its
+  // knots (AddControlPoints, trajectory_estimator.cpp:134-138): only knots touched by factors added AFTER this call are fixed.
+  void SetFixedIndex(int idx) { fixed_idx_ = idx; }
 
   // trajectory_estimator.h:102-106 / .cpp:219-263.  gyro_bias / accel_bias: pointers to 3 doubles; identical pointers
   // denote the same bias state (one per keyframe interval, trajectory_manager.cpp:332-342).
   void AddIMUMeasurementAnalytic(const IMUData &imu, const double gravity[3], double *gyro_bias, double *accel_bias,
-                                 const double info_vec[6], bool /*marg_this_factor*/ = false) {
+                                 const double info_vec[6], bool marg_this_factor = false) {
     imu_t_.push_back(imu.timestamp);
     for (int c = 0; c < 3; ++c) { imu_gyro_.push_back(imu.gyro[c]); imu_acc_.push_back(imu.accel[c]); gravity_[c] = gravity[c]; }
     for (int c = 0; c < 6; ++c) imu_w_[c] = info_vec[c];
     imu_bias_.push_back(bias_index(gyro_bias, accel_bias));
+    imu_marg_.push_back(opt_.is_marg_state && marg_this_factor);
+    const int s = (int)traj_->computeTIndexNs(imu.timestamp).second;     // CaculateSplineMeta({{t, t}}): 4 knots
+    touch(s, s + 3);
   }
   // trajectory_estimator.h:109-112 / .cpp:265-291
-  void AddBiasFactor(double *bg_i, double *bg_j, double *ba_i, double *ba_j, double dt, const double info_vec[6], bool /*marg*/ = false) {
+  void AddBiasFactor(double *bg_i, double *bg_j, double *ba_i, double *ba_j, double dt, const double info_vec[6], bool marg_this_factor = false) {
     bc_i_.push_back(bias_index(bg_i, ba_i));
     bc_j_.push_back(bias_index(bg_j, ba_j));
     const double s = 1.0 / std::sqrt(dt);  // BiasFactor: sqrt_info / sqrt(dt), trajectory_value_factor.h:39-44
     for (int c = 0; c < 6; ++c) bc_w_.push_back(info_vec[c] * s);
+    bc_marg_.push_back(opt_.is_marg_state && marg_this_factor);
   }
   // trajectory_estimator.h:128-131 / .cpp:293-332.  pi / pj: normalised image points (x, y, 1).
   void AddImageFeatureDelayAnalytic(int64_t ti, int rowi, const double pi[3], int64_t tj, int rowj, const double pj[3],
-                                    double *inv_depth, double *line_delay, bool /*fixed_depth*/ = false, bool /*marg*/ = false) {
+                                    double *inv_depth, double *line_delay, bool /*fixed_depth*/ = false, bool marg_this_feature = false) {
     if (line_delay != &traj_->line_delay) throw std::invalid_argument("line_delay must be &trajectory->line_delay");
     auto it = lm_of_.find(inv_depth);
     int l;
@@ -140,81 +196,173 @@ class TrajectoryEstimator {
     v_lm_.push_back(l); v_ti_.push_back(ti); v_tj_.push_back(tj); v_rowi_.push_back(rowi); v_rowj_.push_back(rowj);
     v_pi_.push_back(pi[0] / pi[2]); v_pi_.push_back(pi[1] / pi[2]);
     v_pj_.push_back(pj[0] / pj[2]); v_pj_.push_back(pj[1] / pj[2]);
+    v_marg_.push_back(opt_.is_marg_state && marg_this_feature);
+    const int64_t pad = (int64_t)(0.039 * 1e9);   // spans [t, t + 0.039 s] (trajectory_estimator.cpp:299)
+    for (int64_t t : {ti, tj}) touch((int)traj_->computeTIndexNs(t).second, (int)traj_->computeTIndexNs(t + pad).second + 3);
   }
   // trajectory_estimator.h:146-148 / .cpp:334-348: the kept parameter blocks are identified by address.
   void AddMarginalizationFactor(const MarginalizationInfo *info, const std::vector<double *> &parameter_blocks) {
     prior_ = info;
     prior_blocks_ = parameter_blocks;
+    touch_prior(parameter_blocks, info);
+  }
+  // trajectory_estimator.h:158-162 (the RType_Prior overload used by TrajectoryManager::UpdateVIOPrior,
+  // trajectory_manager.cpp:161-200): the previous prior enters the marginalisation with `drop_set` = indices into
+  // parameter_blocks of the blocks to marginalise.
+  void PrepareMarginalizationInfo(const MarginalizationInfo *last_info, const std::vector<double *> &parameter_blocks,
+                                  const std::vector<int> &drop_set) {
+    marg_prior_ = last_info;
+    marg_prior_blocks_ = parameter_blocks;
+    marg_prior_drop_ = drop_set;
+    touch_prior(parameter_blocks, last_info);
   }
 
   // ceres::Solver::Summary Solve(int max_iterations = 50, ...)  trajectory_estimator.h:154-155 / .cpp:367-408
   SolveSummary Solve(int max_iterations = 50, bool /*progress*/ = false, int /*num_threads*/ = -1) {
-    const int K = (int)traj_->numKnots(), F = (int)bias_ptr_.size(), L = (int)lm_ptr_.size();
-    std::vector<double> quat(4 * (size_t)K), pos(3 * (size_t)K), bias(6 * (size_t)F), rho(L);
-    for (int k = 0; k < K; ++k) {
-      for (int c = 0; c < 4; ++c) quat[4 * k + c] = traj_->so3_[k][c];
-      for (int c = 0; c < 3; ++c) pos[3 * k + c] = traj_->pos_[k][c];
-    }
-    for (int f = 0; f < F; ++f)
-      for (int c = 0; c < 3; ++c) { bias[6 * f + c] = bias_ptr_[f].first[c]; bias[6 * f + 3 + c] = bias_ptr_[f].second[c]; }
-    for (int l = 0; l < L; ++l) rho[l] = *lm_ptr_[l];
-    ctvio_window w{};
-    w.K = K; w.F = F; w.L = L; w.M = (int)imu_t_.size(); w.NB = (int)bc_i_.size(); w.V = (int)v_lm_.size();
-    w.t0_ns = traj_->minTimeNs(); w.dt_ns = traj_->getDtNs();
-    w.quat = quat.data(); w.pos = pos.data(); w.bias = bias.data(); w.rho = rho.data();
-    w.ld = traj_->line_delay; w.ld_lo = traj_->ld_lower; w.ld_hi = traj_->ld_upper; w.fix_ld = traj_->fix_ld;
-    w.lock_bg = opt_.lock_wb; w.lock_ba = opt_.lock_ab; w.fixed_upto = opt_.lock_traj ? K - 1 : fixed_upto_;
-    for (int c = 0; c < 4; ++c) w.q_CI[c] = traj_->q_CI[c];
-    for (int c = 0; c < 3; ++c) { w.p_CI[c] = traj_->p_CI[c]; w.gravity[c] = gravity_[c]; }
-    for (int c = 0; c < 6; ++c) w.imu_w[c] = imu_w_[c];
-    w.img_w = opt_.image_weight; w.cauchy_a = 2.0;  // CauchyLoss(2), trajectory_estimator.cpp:321-322
-    w.imu_t = imu_t_.data(); w.imu_gyro = imu_gyro_.data(); w.imu_acc = imu_acc_.data(); w.imu_bias = imu_bias_.data();
-    w.bc_i = bc_i_.data(); w.bc_j = bc_j_.data(); w.bc_w = bc_w_.data();
-    w.v_lm = v_lm_.data(); w.v_ti = v_ti_.data(); w.v_tj = v_tj_.data(); w.v_rowi = v_rowi_.data(); w.v_rowj = v_rowj_.data();
-    w.v_pi = v_pi_.data(); w.v_pj = v_pj_.data();
-    std::vector<int32_t> p_kind, p_index, p_off;
-    std::vector<double> p_x0;
-    if (prior_ && prior_->n > 0) {
-      for (size_t b = 0; b < prior_blocks_.size(); ++b) {
-        int kind, index;
-        classify(prior_blocks_[b], prior_->keep_block_size[b], kind, index);
-        p_kind.push_back(kind); p_index.push_back(index); p_off.push_back(prior_->keep_block_idx[b]);
-        for (int c = 0; c < 4; ++c) p_x0.push_back(prior_->keep_block_data[b][c]);
-      }
-      w.pn = prior_->n; w.pnb = (int)p_kind.size();
-      w.pJ0 = prior_->linearized_jacobians.data(); w.pr0 = prior_->linearized_residuals.data();
-      w.p_kind = p_kind.data(); w.p_index = p_index.data(); w.p_off = p_off.data(); w.p_x0 = p_x0.data();
-    }
-    ctvio_options o;
-    ctvio_default_options(&o);
-    o.precision = opt_.precision; o.device = opt_.device;
-    ctvio_solver *s = nullptr;
-    check(ctvio_create(&o, &s));
+    Packed pk;
+    pack(pk, /*marg_only=*/false);
+    ctvio_solver *s = SolverCache::get(opt_.device, opt_.precision);
+    check(ctvio_set_batch(s, 1, &pk.w));
     SolveSummary sum;
-    int32_t id = 0;
-    int rc = ctvio_add_window(s, &w, &id);
-    if (!rc) rc = ctvio_upload(s);
-    if (!rc) rc = ctvio_solve(s, max_iterations, &sum.s);
+    check(ctvio_solve(s, max_iterations, &sum.s));
     double ld = traj_->line_delay;
-    if (!rc) rc = ctvio_get_state(s, id, quat.data(), pos.data(), bias.data(), rho.data(), &ld);
-    const std::string err = rc ? std::string(ctvio_last_error()) : std::string();
-    ctvio_destroy(s);
-    if (rc) throw std::runtime_error(std::string(ctvio_status_string(rc)) + ": " + err);
+    check(ctvio_get_state(s, 0, pk.quat.data(), pk.pos.data(), pk.bias.data(), pk.rho.data(), &ld));
     // results back in place, like Ceres writing through the double* (trajectory_manager.cpp:457-463)
-    for (int k = 0; k < K; ++k) {
-      for (int c = 0; c < 4; ++c) traj_->so3_[k][c] = quat[4 * k + c];
-      for (int c = 0; c < 3; ++c) traj_->pos_[k][c] = pos[3 * k + c];
+    for (int k = 0; k < pk.w.K; ++k) {
+      for (int c = 0; c < 4; ++c) traj_->so3_[pk.kmin + k][c] = pk.quat[4 * k + c];
+      for (int c = 0; c < 3; ++c) traj_->pos_[pk.kmin + k][c] = pk.pos[3 * k + c];
     }
-    for (int f = 0; f < F; ++f)
-      for (int c = 0; c < 3; ++c) { bias_ptr_[f].first[c] = bias[6 * f + c]; bias_ptr_[f].second[c] = bias[6 * f + 3 + c]; }
-    for (int l = 0; l < L; ++l) *lm_ptr_[l] = rho[l];
+    for (int f = 0; f < pk.w.F; ++f)
+      for (int c = 0; c < 3; ++c) { bias_ptr_[f].first[c] = pk.bias[6 * f + c]; bias_ptr_[f].second[c] = pk.bias[6 * f + 3 + c]; }
+    for (int l = 0; l < pk.w.L; ++l) *lm_ptr_[l] = pk.rho[l];
     traj_->line_delay = ld;
     return sum;
   }
 
+  // trajectory_estimator.h:165-166 / .cpp:178-204: preMarginalize + marginalize of the factors added with
+  // marg_this_factor (and the prior given to PrepareMarginalizationInfo).  Dropped: knots below ctrl_to_be_opt_later
+  // (PrepareMarginalizationInfo, .cpp:153-176), the bias blocks of the marginalised IMU factors and the first pair of the
+  // marginalised bias factors (.cpp:248-257, 281-285), the inverse depths of the marginalised features (.cpp:325-331), the
+  // drop_set of the previous prior.  Returns false (marg_info_out untouched, blocks cleared) when nothing is kept.
+  bool SaveMarginalizationInfo(MarginalizationInfo &marg_info_out, std::vector<double *> &marg_param_blocks_out) {
+    Packed pk;
+    pack(pk, /*marg_only=*/true);
+    const int K = pk.w.K, F = pk.w.F, L = pk.w.L, P = 6 * K + 6 * F + 1, N = P + L;
+    // involved = every parameter block of the collected residual blocks (constant or not); role 1 = drop, 0 = keep
+    std::vector<int8_t> role((size_t)N, -1);
+    auto involve = [&](int u, int n) { for (int c = 0; c < n; ++c) if (role[u + c] < 0) role[u + c] = 0; };
+    auto drop = [&](int u, int n) { for (int c = 0; c < n; ++c) role[u + c] = 1; };
+    const int64_t pad = (int64_t)(0.039 * 1e9);
+    for (size_t m = 0; m < imu_t_.size(); ++m) {
+      if (!imu_marg_[m]) continue;
+      const int s0 = (int)traj_->computeTIndexNs(imu_t_[m]).second - pk.kmin;
+      involve(6 * s0, 24);
+      drop(6 * K + 6 * pk.bias_map[imu_bias_[m]], 6);
+    }
+    for (size_t b = 0; b < bc_i_.size(); ++b) {
+      if (!bc_marg_[b]) continue;
+      drop(6 * K + 6 * pk.bias_map[bc_i_[b]], 6);
+      involve(6 * K + 6 * pk.bias_map[bc_j_[b]], 6);
+    }
+    for (size_t v = 0; v < v_lm_.size(); ++v) {
+      if (!v_marg_[v]) continue;
+      for (int64_t t : {v_ti_[v], v_tj_[v]}) {
+        const int s0 = (int)traj_->computeTIndexNs(t).second - pk.kmin, s1 = (int)traj_->computeTIndexNs(t + pad).second - pk.kmin;
+        involve(6 * s0, 6 * (s1 + 4 - s0));
+      }
+      drop(P + pk.lm_map[v_lm_[v]], 1);
+      involve(P - 1, 1);
+    }
+    if (marg_prior_) {
+      for (size_t b = 0; b < marg_prior_blocks_.size(); ++b) {
+        int kind, index;
+        classify(marg_prior_blocks_[b], marg_prior_->keep_block_size[b], kind, index);
+        const int u = unknown_of(kind, index, pk), n = kind == CTVIO_PK_LD ? 1 : 3;
+        const bool dropped = std::find(marg_prior_drop_.begin(), marg_prior_drop_.end(), (int)b) != marg_prior_drop_.end();
+        if (dropped) drop(u, n); else involve(u, n);
+      }
+    }
+    if (opt_.ctrl_to_be_opt_later > opt_.ctrl_to_be_opt_now)
+      for (int k = 0; k < K && pk.kmin + k < opt_.ctrl_to_be_opt_later; ++k)
+        for (int c = 0; c < 6; ++c) if (role[6 * k + c] >= 0) role[6 * k + c] = 1;
+    ctvio_solver *s = SolverCache::get(opt_.device, opt_.precision);
+    check(ctvio_set_batch(s, 1, &pk.w));
+    std::vector<int32_t> kept((size_t)N);
+    std::vector<double> J0((size_t)N * N), r0((size_t)N);
+    int32_t n = 0;
+    check(ctvio_marginalize(s, 0, role.data(), 1e-8, &n, kept.data(), J0.data(), r0.data()));
+    marg_param_blocks_out.clear();
+    if (n <= 0) return false;
+    MarginalizationInfo out;
+    out.n = n;
+    out.linearized_jacobians.resize((size_t)n * n);
+    out.linearized_residuals.assign(r0.begin(), r0.begin() + n);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) out.linearized_jacobians[(size_t)j * n + i] = J0[(size_t)i * n + j];   // column-major (Eigen)
+    // group the kept unknowns into parameter blocks; the linearisation point is the current value (marginalization_factor.cpp:292-311)
+    for (int j = 0; j < n;) {
+      const int u = kept[j];
+      double *ptr; int size; std::array<double, 4> x0{0, 0, 0, 0};
+      if (u == P - 1) { ptr = &traj_->line_delay; size = 1; x0[0] = traj_->line_delay; }
+      else if (u < 6 * K) {
+        const int k = u / 6 + pk.kmin;
+        if (u % 6 == 0) { ptr = traj_->so3_[k].data(); size = 4; for (int c = 0; c < 4; ++c) x0[c] = traj_->so3_[k][c]; }
+        else { ptr = traj_->pos_[k].data(); size = 3; for (int c = 0; c < 3; ++c) x0[c] = traj_->pos_[k][c]; }
+      } else {
+        const int f = pk.bias_unmap[(u - 6 * K) / 6];
+        const bool gyro = (u - 6 * K) % 6 == 0;
+        ptr = gyro ? bias_ptr_[f].first : bias_ptr_[f].second; size = 3;
+        for (int c = 0; c < 3; ++c) x0[c] = ptr[c];
+      }
+      out.keep_block_size.push_back(size);
+      out.keep_block_idx.push_back(j);
+      out.keep_block_data.push_back(x0);
+      marg_param_blocks_out.push_back(ptr);
+      j += (size == 1) ? 1 : 3;
+    }
+    marg_info_out = std::move(out);
+    return true;
+  }
+
+  // trajectory_estimator.h:168-171: residuals of ALL added factors at the current parameter values
+  ResidualSummary GetResidualSummary(const std::string &descri = "") {
+    Packed pk;
+    pack(pk, false, /*all_factors=*/true);
+    ctvio_solver *s = SolverCache::get(opt_.device, opt_.precision);
+    check(ctvio_set_batch(s, 1, &pk.w));
+    std::vector<double> sums((size_t)14 + pk.w.pn);
+    int32_t cnt[4];
+    check(ctvio_residual_summary(s, 0, sums.data(), cnt));
+    ResidualSummary r;
+    r.descri_info = descri;
+    r.imu_sum.assign(sums.begin(), sums.begin() + 6); r.bias_sum.assign(sums.begin() + 6, sums.begin() + 12);
+    r.image_sum.assign(sums.begin() + 12, sums.begin() + 14); r.prior_sum.assign(sums.begin() + 14, sums.end());
+    r.imu_num = cnt[0]; r.bias_num = cnt[1]; r.image_num = cnt[2]; r.prior_num = cnt[3];
+    return r;
+  }
+
  private:
+  // One packed window: only the knots the factors touch (the reference registers exactly those with Ceres,
+  // trajectory_estimator.cpp:114-141; the trajectory itself keeps growing), biases / landmarks that are referenced.
+  struct Packed {
+    ctvio_window w{};
+    int kmin = 0;
+    std::vector<double> quat, pos, bias, rho, imu_gyro, imu_acc, bc_w, v_pi, v_pj, p_x0;
+    std::vector<int64_t> imu_t, v_ti, v_tj;
+    std::vector<int32_t> imu_bias, bc_i, bc_j, v_lm, v_rowi, v_rowj, p_kind, p_index, p_off;
+    std::vector<int> bias_map, bias_unmap, lm_map;   // adaptor bias / landmark index -> index in this window (-1: absent), and back
+  };
   static void check(int rc) {
     if (rc) throw std::runtime_error(std::string(ctvio_status_string(rc)) + ": " + ctvio_last_error());
+  }
+  void touch(int k0, int k1) {
+    kmin_ = std::min(kmin_, k0); kmax_ = std::max(kmax_, k1);
+    if (fixed_idx_ >= 0) fixed_touched_ = std::max(fixed_touched_, std::min(k1, fixed_idx_));   // knots <= fixed_idx_ added while it was set
+    else unfixed_low_ = std::min(unfixed_low_, k0);
+  }
+  void touch_prior(const std::vector<double *> &blocks, const MarginalizationInfo *info) {
+    for (size_t b = 0; b < blocks.size(); ++b)
+      if (info->keep_block_size[b] == 4 || knot_of_.count(blocks[b])) { const int k = knot_of_.at(blocks[b]); touch(k, k); }
   }
   int bias_index(double *bg, double *ba) {
     auto it = bias_of_.find(bg);
@@ -227,17 +375,114 @@ class TrajectoryEstimator {
   void classify(double *p, int size, int &kind, int &index) {
     if (size == 4) { kind = CTVIO_PK_ROT; index = knot_of_.at(p); return; }
     if (size == 1) { kind = CTVIO_PK_LD; index = 0; return; }
-    for (size_t k = 0; k < traj_->numKnots(); ++k)
-      if (traj_->pos_[k].data() == p) { kind = CTVIO_PK_POS; index = (int)k; return; }
+    auto kt = knot_of_.find(p);
+    if (kt != knot_of_.end()) { kind = CTVIO_PK_POS; index = kt->second; return; }
     auto it = bias_of_.find(p);
     if (it == bias_of_.end()) throw std::invalid_argument("prior parameter block is not a knot / bias of this window");
     index = it->second;
     kind = (bias_ptr_[index].first == p) ? CTVIO_PK_BG : CTVIO_PK_BA;
   }
+  static int unknown_of(int kind, int index, const Packed &pk) {   // index: global knot / adaptor bias index
+    const int K = pk.w.K, F = pk.w.F;
+    switch (kind) {
+      case CTVIO_PK_ROT: return 6 * (index - pk.kmin);
+      case CTVIO_PK_POS: return 6 * (index - pk.kmin) + 3;
+      case CTVIO_PK_BG: return 6 * K + 6 * pk.bias_map[index];
+      case CTVIO_PK_BA: return 6 * K + 6 * pk.bias_map[index] + 3;
+      default: return 6 * K + 6 * F;
+    }
+  }
+  // marg_only: the factors flagged marg_this_factor + the prior of PrepareMarginalizationInfo, CauchyLoss(1)
+  // (trajectory_estimator.cpp:320-322); otherwise every factor + the prior of AddMarginalizationFactor, CauchyLoss(2).
+  void pack(Packed &pk, bool marg_only, bool all_factors = false) {
+    if (kmin_ > kmax_) throw std::logic_error("no factor touches the trajectory");
+    const int kmin = std::max(0, kmin_), kmax = std::min((int)traj_->numKnots() - 1, std::max(kmax_, kmin + 3));
+    const int K = kmax - kmin + 1;
+    pk.kmin = kmin;
+    auto want = [&](bool flag) { return all_factors || (marg_only ? flag : true); };
+    // bias states and landmarks referenced by the selected factors
+    pk.bias_map.assign(bias_ptr_.size(), -1);
+    pk.lm_map.assign(lm_ptr_.size(), -1);
+    auto use_bias = [&](int f) { if (pk.bias_map[f] < 0) { pk.bias_map[f] = (int)pk.bias_unmap.size(); pk.bias_unmap.push_back(f); } };
+    const MarginalizationInfo *prior = marg_only ? marg_prior_ : prior_;
+    const std::vector<double *> &pblocks = marg_only ? marg_prior_blocks_ : prior_blocks_;
+    if (!marg_only) for (size_t f = 0; f < bias_ptr_.size(); ++f) use_bias((int)f);   // frame order = registration order
+    for (size_t b = 0; b < bc_i_.size(); ++b) if (want(bc_marg_[b])) { use_bias(bc_i_[b]); use_bias(bc_j_[b]); }
+    for (size_t m = 0; m < imu_t_.size(); ++m) if (want(imu_marg_[m])) use_bias(imu_bias_[m]);
+    if (prior)
+      for (size_t b = 0; b < pblocks.size(); ++b) {
+        int kind, index; classify(pblocks[b], prior->keep_block_size[b], kind, index);
+        if (kind == CTVIO_PK_BG || kind == CTVIO_PK_BA) use_bias(index);
+      }
+    if (pk.bias_unmap.empty()) use_bias(0 < (int)bias_ptr_.size() ? 0 : throw std::logic_error("no bias state registered"));
+    for (size_t v = 0; v < v_lm_.size(); ++v)
+      if (want(v_marg_[v]) && pk.lm_map[v_lm_[v]] < 0) { pk.lm_map[v_lm_[v]] = (int)pk.rho.size(); pk.rho.push_back(*lm_ptr_[v_lm_[v]]); }
+    const int F = (int)pk.bias_unmap.size(), L = (int)pk.rho.size();
+    pk.quat.resize(4 * (size_t)K); pk.pos.resize(3 * (size_t)K); pk.bias.resize(6 * (size_t)F);
+    for (int k = 0; k < K; ++k) {
+      for (int c = 0; c < 4; ++c) pk.quat[4 * k + c] = traj_->so3_[kmin + k][c];
+      for (int c = 0; c < 3; ++c) pk.pos[3 * k + c] = traj_->pos_[kmin + k][c];
+    }
+    for (int f = 0; f < F; ++f)
+      for (int c = 0; c < 3; ++c) { pk.bias[6 * f + c] = bias_ptr_[pk.bias_unmap[f]].first[c]; pk.bias[6 * f + 3 + c] = bias_ptr_[pk.bias_unmap[f]].second[c]; }
+    for (size_t m = 0; m < imu_t_.size(); ++m) {
+      if (!want(imu_marg_[m])) continue;
+      pk.imu_t.push_back(imu_t_[m]); pk.imu_bias.push_back(pk.bias_map[imu_bias_[m]]);
+      for (int c = 0; c < 3; ++c) { pk.imu_gyro.push_back(imu_gyro_[3 * m + c]); pk.imu_acc.push_back(imu_acc_[3 * m + c]); }
+    }
+    for (size_t b = 0; b < bc_i_.size(); ++b) {
+      if (!want(bc_marg_[b])) continue;
+      pk.bc_i.push_back(pk.bias_map[bc_i_[b]]); pk.bc_j.push_back(pk.bias_map[bc_j_[b]]);
+      for (int c = 0; c < 6; ++c) pk.bc_w.push_back(bc_w_[6 * b + c]);
+    }
+    for (size_t v = 0; v < v_lm_.size(); ++v) {
+      if (!want(v_marg_[v])) continue;
+      pk.v_lm.push_back(pk.lm_map[v_lm_[v]]); pk.v_ti.push_back(v_ti_[v]); pk.v_tj.push_back(v_tj_[v]);
+      pk.v_rowi.push_back(v_rowi_[v]); pk.v_rowj.push_back(v_rowj_[v]);
+      for (int c = 0; c < 2; ++c) { pk.v_pi.push_back(v_pi_[2 * v + c]); pk.v_pj.push_back(v_pj_[2 * v + c]); }
+    }
+    ctvio_window &w = pk.w;
+    w.K = K; w.F = F; w.L = L; w.M = (int)pk.imu_t.size(); w.NB = (int)pk.bc_i.size(); w.V = (int)pk.v_lm.size();
+    w.t0_ns = traj_->minTimeNs() + (int64_t)kmin * traj_->getDtNs(); w.dt_ns = traj_->getDtNs();
+    w.quat = pk.quat.data(); w.pos = pk.pos.data(); w.bias = pk.bias.data(); w.rho = pk.rho.data();
+    w.ld = traj_->line_delay; w.ld_lo = traj_->ld_lower; w.ld_hi = traj_->ld_upper; w.fix_ld = traj_->fix_ld;
+    w.lock_bg = opt_.lock_wb; w.lock_ba = opt_.lock_ab;
+    // constant knots: the library takes a prefix [0, fixed_upto]; what AddControlPoints produces is a prefix too as long as
+    // SetFixedIndex was called before the factors (or after all of them: nothing fixed, the reference's InitTrajectory)
+    if (opt_.lock_traj) w.fixed_upto = K - 1;
+    else if (fixed_touched_ < 0) w.fixed_upto = -1;
+    else {
+      if (unfixed_low_ <= fixed_touched_) throw std::logic_error("SetFixedIndex between Add* calls: the constant knots are not a prefix");
+      w.fixed_upto = fixed_touched_ - kmin;
+    }
+    for (int c = 0; c < 4; ++c) w.q_CI[c] = traj_->q_CI[c];
+    for (int c = 0; c < 3; ++c) { w.p_CI[c] = traj_->p_CI[c]; w.gravity[c] = gravity_[c]; }
+    for (int c = 0; c < 6; ++c) w.imu_w[c] = imu_w_[c];
+    w.img_w = opt_.image_weight;
+    w.cauchy_a = marg_only ? 1.0 : 2.0;  // CauchyLoss(marg_this_feature ? 1 : 2), trajectory_estimator.cpp:320-322
+    w.imu_t = pk.imu_t.data(); w.imu_gyro = pk.imu_gyro.data(); w.imu_acc = pk.imu_acc.data(); w.imu_bias = pk.imu_bias.data();
+    w.bc_i = pk.bc_i.data(); w.bc_j = pk.bc_j.data(); w.bc_w = pk.bc_w.data();
+    w.v_lm = pk.v_lm.data(); w.v_ti = pk.v_ti.data(); w.v_tj = pk.v_tj.data(); w.v_rowi = pk.v_rowi.data(); w.v_rowj = pk.v_rowj.data();
+    w.v_pi = pk.v_pi.data(); w.v_pj = pk.v_pj.data();
+    if (prior && prior->n > 0) {
+      for (size_t b = 0; b < pblocks.size(); ++b) {
+        int kind, index;
+        classify(pblocks[b], prior->keep_block_size[b], kind, index);
+        pk.p_kind.push_back(kind);
+        pk.p_index.push_back(kind <= CTVIO_PK_POS ? index - kmin : (kind <= CTVIO_PK_BA ? pk.bias_map[index] : 0));
+        pk.p_off.push_back(prior->keep_block_idx[b]);
+        for (int c = 0; c < 4; ++c) pk.p_x0.push_back(prior->keep_block_data[b][c]);
+      }
+      w.pn = prior->n; w.pnb = (int)pk.p_kind.size();
+      w.pJ0 = prior->linearized_jacobians.data(); w.pr0 = prior->linearized_residuals.data();
+      w.p_kind = pk.p_kind.data(); w.p_index = pk.p_index.data(); w.p_off = pk.p_off.data(); w.p_x0 = pk.p_x0.data();
+    }
+  }
 
   Trajectory *traj_;
   TrajectoryEstimatorOptions opt_;
-  int fixed_upto_ = -1;
+  int fixed_idx_ = -1, fixed_touched_ = -1, unfixed_low_ = 1 << 30;
+  int kmin_ = 1 << 30, kmax_ = -1;
   std::unordered_map<const double *, int> knot_of_, bias_of_, lm_of_;
   std::vector<std::pair<double *, double *>> bias_ptr_;
   std::vector<double *> lm_ptr_;
@@ -245,8 +490,10 @@ class TrajectoryEstimator {
   std::vector<int64_t> imu_t_, v_ti_, v_tj_;
   std::vector<double> imu_gyro_, imu_acc_, bc_w_, v_pi_, v_pj_;
   std::vector<int32_t> imu_bias_, bc_i_, bc_j_, v_lm_, v_rowi_, v_rowj_;
-  const MarginalizationInfo *prior_ = nullptr;
-  std::vector<double *> prior_blocks_;
+  std::vector<char> imu_marg_, bc_marg_, v_marg_;
+  const MarginalizationInfo *prior_ = nullptr, *marg_prior_ = nullptr;
+  std::vector<double *> prior_blocks_, marg_prior_blocks_;
+  std::vector<int> marg_prior_drop_;
 };
 
 }  // namespace ctvio

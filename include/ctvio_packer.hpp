@@ -94,4 +94,55 @@ inline void depths_from_solution(const std::vector<double> &rho, std::vector<dou
   for (size_t l = 0; l < rho.size(); ++l) { depth[l] = 1.0 / rho[l]; ok[l] = depth[l] < 0 ? 0 : 1; }
 }
 
+// 4-DoF gauge restore after a solve, on the host (TrajectoryManager::double2vector, trajectory_manager.cpp:485-516, with
+// Utility::R2ypr, visual_odometry/utility.h:74-93): one rigid transform puts the yaw (the whole rotation within 1 degree of the
+// Euler singularity) and the position of knot `knot` back to the pre-solve pose (q0 = x,y,z,w; t0); it is applied to knots
+// knot..last.  Same arithmetic as the batched device entry ctvio_gauge_restore.  Traj: getKnotSO3(i) / getKnotPos(i) -> arrays.
+template <class Traj> inline void gauge_restore_4dof(Traj &traj, int knot, int last, const double q0[4], const double t0[3]) {
+  auto q2R = [](const double *q, double *R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+  };
+  const double pi = 3.14159265358979323846;
+  auto yaw_pitch = [&](const double *R, double &y, double &p) {   // degrees
+    y = std::atan2(R[3], R[0]);
+    p = std::atan2(-R[6], R[0] * std::cos(y) + R[3] * std::sin(y)) / pi * 180.0;
+    y = y / pi * 180.0;
+  };
+  double R0[9], R00[9], y0, p0, y00, p00, Rd[9], td[3], qd[4];
+  q2R(q0, R0);
+  q2R(traj.getKnotSO3(knot).data(), R00);
+  yaw_pitch(R0, y0, p0);
+  yaw_pitch(R00, y00, p00);
+  if (std::fabs(std::fabs(p0) - 90.0) < 1.0 || std::fabs(std::fabs(p00) - 90.0) < 1.0) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Rd[3 * i + j] = R0[3 * i] * R00[3 * j] + R0[3 * i + 1] * R00[3 * j + 1] + R0[3 * i + 2] * R00[3 * j + 2];
+  } else {
+    const double y = (y0 - y00) / 180.0 * pi;
+    Rd[0] = std::cos(y); Rd[1] = -std::sin(y); Rd[2] = 0; Rd[3] = std::sin(y); Rd[4] = std::cos(y); Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1;
+  }
+  const auto &p00v = traj.getKnotPos(knot);
+  for (int i = 0; i < 3; ++i) td[i] = t0[i] - (Rd[3 * i] * p00v[0] + Rd[3 * i + 1] * p00v[1] + Rd[3 * i + 2] * p00v[2]);
+  const double tr = Rd[0] + Rd[4] + Rd[8];   // rotation matrix -> unit quaternion (trace / largest-diagonal branches)
+  if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; qd[3] = 0.25 * s; qd[0] = (Rd[7] - Rd[5]) / s; qd[1] = (Rd[2] - Rd[6]) / s; qd[2] = (Rd[3] - Rd[1]) / s; }
+  else if (Rd[0] > Rd[4] && Rd[0] > Rd[8]) { const double s = std::sqrt(1.0 + Rd[0] - Rd[4] - Rd[8]) * 2; qd[3] = (Rd[7] - Rd[5]) / s; qd[0] = 0.25 * s; qd[1] = (Rd[1] + Rd[3]) / s; qd[2] = (Rd[2] + Rd[6]) / s; }
+  else if (Rd[4] > Rd[8]) { const double s = std::sqrt(1.0 + Rd[4] - Rd[0] - Rd[8]) * 2; qd[3] = (Rd[2] - Rd[6]) / s; qd[0] = (Rd[1] + Rd[3]) / s; qd[1] = 0.25 * s; qd[2] = (Rd[5] + Rd[7]) / s; }
+  else { const double s = std::sqrt(1.0 + Rd[8] - Rd[0] - Rd[4]) * 2; qd[3] = (Rd[3] - Rd[1]) / s; qd[0] = (Rd[2] + Rd[6]) / s; qd[1] = (Rd[5] + Rd[7]) / s; qd[2] = 0.25 * s; }
+  for (int k = knot; k <= last; ++k) {
+    auto &qk = traj.getKnotSO3(k);
+    auto &pk = traj.getKnotPos(k);
+    double q[4], pn[3];
+    q[0] = qd[3] * qk[0] + qd[0] * qk[3] + qd[1] * qk[2] - qd[2] * qk[1];
+    q[1] = qd[3] * qk[1] - qd[0] * qk[2] + qd[1] * qk[3] + qd[2] * qk[0];
+    q[2] = qd[3] * qk[2] + qd[0] * qk[1] - qd[1] * qk[0] + qd[2] * qk[3];
+    q[3] = qd[3] * qk[3] - qd[0] * qk[0] - qd[1] * qk[1] - qd[2] * qk[2];
+    const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 3; ++i) pn[i] = Rd[3 * i] * pk[0] + Rd[3 * i + 1] * pk[1] + Rd[3 * i + 2] * pk[2] + td[i];
+    for (int i = 0; i < 4; ++i) qk[i] = q[i] / nq;
+    for (int i = 0; i < 3; ++i) pk[i] = pn[i];
+  }
+}
+
 }  // namespace ctvio

@@ -1,0 +1,78 @@
+"""GPU: three consecutive sliding windows -- solve -> 4-DoF gauge restore -> marginalise the oldest frame -> next solve with
+the new prior (tests/slide_helpers.py; reference trajectory_manager.cpp:122-286, 317-516) -- through the C ABI and through the
+reference-shaped C++ adaptor (PrepareMarginalizationInfo / SaveMarginalizationInfo / AddMarginalizationFactor), against the
+CPU oracle running the same protocol."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+
+
+@pytest.fixture(scope="module")
+def slide_reference(oracle):
+    import slide_helpers as sh
+    world = sh.make_world()
+    st, rec = sh.run_slide(world, sh.OracleBackend())
+    return sh, world, st, rec
+
+
+def test_three_windows_through_the_c_abi(cv, slide_reference):
+    sh, world, st_o, rec_o = slide_reference
+    st_g, rec_g = sh.run_slide(world, sh.DeviceBackend("fp64"))
+    for a, b in zip(rec_g, rec_o):
+        assert a["iterations"] == b["iterations"] and a.get("n_keep") == b.get("n_keep"), (a, b)
+        # (the prior's constant r0^T r0 depends on which noise-level eigenvalues of the rank-deficient A' fall on which side of
+        #  eps = 1e-8 -- one of them differs between the two eigen-solvers here, as it would against Eigen's; the quadratic
+        #  form, hence the minimiser, is unaffected: the states below agree to 1e-6)
+        assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-3)
+    err = sh.state_error(st_g, st_o)
+    assert max(err.values()) < 1e-6, err          # asked for: 1e-6 (fp64) -- and the product path IS the fp64 path (contract 1e-4)
+
+
+def test_three_windows_through_the_cpp_adaptor(cv, slide_reference, tmp_path):
+    sh, world, st_o, rec_o = slide_reference
+    from test_gpu_adaptor import _dump
+    exe = str(tmp_path / "slide_demo")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "slide_demo.cpp"),
+                           "-L", os.path.join(ROOT, "ctrl-vio_amd"), "-lctvio", "-Wl,-rpath," + os.path.join(ROOT, "ctrl-vio_amd"), "-o", exe])
+    _dump(world, str(tmp_path / "world.txt"))
+    out = subprocess.check_output([exe, str(tmp_path / "world.txt"), str(tmp_path / "out.txt")], text=True)
+    assert out.count("ctvio: iterations") == 3 and "ResidualSummary" in out and "- Image: num =" in out, out
+    for k, r in enumerate(rec_o[:-1]):
+        assert f"prior {k}: n = {r['n_keep']}," in out, out
+    arr = np.array(open(tmp_path / "out.txt").read().split(), float)
+    K, F, L = world.K, world.F, world.L
+    kn = arr[:7 * K].reshape(K, 7)
+    st = sh.State(world)
+    st.quat, st.pos = kn[:, :4].copy(), kn[:, 4:].copy()
+    st.bias = arr[7 * K:7 * K + 6 * F].reshape(F, 6).copy()
+    st.rho = arr[7 * K + 6 * F:7 * K + 6 * F + L].copy()
+    st.ld = float(arr[7 * K + 6 * F + L])
+    err = sh.state_error(st, st_o)
+    assert max(err.values()) < 1e-6, err
+
+
+def test_residual_summary_matches_oracle(cv, oracle):
+    """ctvio_residual_summary (reference ResidualSummary, trajectory_estimator.cpp:36-67): sums of |r_i| per factor type."""
+    w = cv.synth.make_window("config1", seed=1003)
+    o = oracle.OracleWindow(w.copy())
+    r_imu = np.abs(np.array([o.imu_block(m, jac=False)[0] for m in range(w.M)])).sum(0)
+    r_vis = np.abs(np.array([o.visual_block(v, jac=False)[0] for v in range(w.V)])).sum(0)
+    r_bias = np.abs(np.array([o.bias_block(b)[0] for b in range(w.NB)])).sum(0)
+    r_prior = np.abs(o.prior_residual()[0])
+    for prec in ("fp64", "fp32"):
+        with cv.Solver(precision=prec) as s:
+            s.set_windows([w.copy()])
+            rs = s.residual_summary(0)
+        assert rs["imu"][1] == w.M and rs["bias"][1] == w.NB and rs["image"][1] == w.V and rs["prior"][1] == 1
+        np.testing.assert_allclose(rs["imu"][0], r_imu, rtol=1e-9)
+        np.testing.assert_allclose(rs["bias"][0], r_bias, rtol=1e-9)
+        np.testing.assert_allclose(rs["image"][0], r_vis, rtol=1e-9)
+        np.testing.assert_allclose(rs["prior"][0], r_prior, rtol=1e-9, atol=1e-9)
