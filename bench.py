@@ -39,10 +39,10 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}   # v_mfma_f32_32x32x2_f32 (gui
 
 def kernel_of_phase(precision):
     if precision == "fp64":
-        return {"k_imu_linearize": "k_imu_linearize<double, 32, double>", "k_vis_eval": "k_vis_eval<double, true, double>",
-                "k_assemble_vis": "k_assemble_vis<double>", "k_schur_mfma": "k_schur_f64", "k_cholesky_solve": "k_cholesky_solve<double>"}
-    return {"k_imu_linearize": "k_imu_linearize<float, 64, double>", "k_vis_eval": "k_vis_eval<float, true, double>",
-            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve<float>"}
+        return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_eval<double, true, double>",
+                "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve"}
+    return {"k_imu_linearize": "k_imu_linearize", "k_vis_eval": "k_vis_eval<float, true, double>",
+            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve"}
 
 
 def algorithmic_bytes(w, phase, fp_bytes):
@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--precision", default="fp64", help="fp64 = the product (all-fp64); fp32 = the mixed fast mode (no 1e-4 contract)")
     ap.add_argument("--parity-sample", type=int, default=16, help="windows solved by the CPU oracle (state error of the timed path + cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams + host threads) per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="solver handles (HIP streams + host threads) per GPU")
     ap.add_argument("--host-threads", type=int, default=0, help="packing threads per handle (0: cores / streams, at most 16)")
     ap.add_argument("--device-resident-only", action="store_true", help="time the device-resident solve instead (diagnostics)")
     args = ap.parse_args()
@@ -115,7 +115,7 @@ def main():
     per = [args.windows // nstream + (1 if i < args.windows % nstream else 0) for i in range(nstream)]
     first = np.concatenate([[0], np.cumsum(per)])          # local window index range of every handle
     my_ids = cv.sharding.shard(args.windows * world, rank, world)
-    hthreads = args.host_threads or max(1, min(16, (os.cpu_count() or 8) // nstream))
+    hthreads = args.host_threads or max(1, min(16, (os.cpu_count() or 8) // (nstream * max(world, 1))))
     solvers, cbatches, keeps, outs = [], [], [], []
     for si in range(nstream):
         sv = cv.Solver(device=local, precision=args.precision, host_threads=hthreads)

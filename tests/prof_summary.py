@@ -54,8 +54,27 @@ def pmc(wpl, out, paths):
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
+def counters(out, paths):
+    """Average per launch of every counter found, per kernel -> table + JSON (MFMA busy cycles, ops, wave cycles ...)."""
+    acc = defaultdict(lambda: defaultdict(list))
+    for p in paths:
+        with open(p, newline="") as f:
+            for row in csv.DictReader(f):
+                acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    names = sorted({c for k in acc.values() for c in k})
+    res = {}
+    print(f"{'kernel':52s} " + " ".join(f"{n[-26:]:>26s}" for n in names))
+    for k, c in sorted(acc.items()):
+        res[k] = {n: (sum(v) / len(v)) for n, v in c.items()}
+        res[k]["launches"] = max(len(v) for v in c.values())
+        print(f"{k[:52]:52s} " + " ".join(f"{res[k].get(n, float('nan')):26.4g}" for n in names))
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2:])
     elif sys.argv[1] == "pmc":
         pmc(int(sys.argv[2]), sys.argv[3], sys.argv[4:])

@@ -62,8 +62,9 @@ def test_adaptor_header_compiles_standalone():
     compiler alone -- no HIP, no torch headers in the drop-in boundary."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "tests", "estimator_demo.cpp")])
+    for demo in ("estimator_demo.cpp", "slide_demo.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                               os.path.join(root, "tests", demo)])
     src = open(os.path.join(root, "include", "ctvio.h")).read()
     includes = re.findall(r"#\s*include\s*[<\"]([^>\"]+)[>\"]", src)
     assert all(not inc.startswith(("hip", "torch", "ATen", "c10")) for inc in includes), includes
