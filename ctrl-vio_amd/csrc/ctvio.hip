@@ -21,6 +21,7 @@
 #include "../../include/ctvio.h"
 #include "kernels.hpp"
 #include "marginalize.hpp"
+#include "marg_device.hpp"
 #include "host_pack.hpp"
 
 namespace ctv {
@@ -96,6 +97,7 @@ struct SolverBase {
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
   virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
   virtual int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
+  virtual int marginalize_batch(const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
   virtual int residual_summary(int id, double *sums, int32_t *counts4) = 0;
   virtual int bind() = 0;   // make the solver's device current on the calling thread (every ABI entry: callers use threads)
   virtual int snapshot(int restore) = 0;
@@ -779,8 +781,86 @@ template <class T> class SolverImpl : public SolverBase {
     if (mc) *mc = lm.step_valid ? lm.model_change : -1.0;
     return CTVIO_OK;
   }
-  // Prior construction: A, b of the window's factors on the device (the linearise kernels), elimination of
-  // the marginalised unknowns and the factorisation into (J0, r0) on the host (csrc/marginalize.hpp).
+  // Prior construction, all on the device: A, b of every window's factors by the linearise kernels, then one
+  // workgroup per window eliminates the marginalised unknowns and factors the rest (csrc/marg_device.hpp: parallel Jacobi
+  // in LDS).  role: concatenated per window (sum N entries, window i at its unknown offset); `only` >= 0 restricts the work
+  // to that window.  Outputs: n_keep[nwin]; kept at the window's unknown offset; J0 / r0 packed tightly in window order.
+  int marg_device(const int8_t *role_all, int only, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0, bool *too_large) {
+    Dev<T> &d = dev_;
+    const int nw = d.nwin, wb = nblk(nw, 64);
+    *too_large = false;
+    std::vector<MargMeta> metas((size_t)nw);
+    std::vector<int32_t> iscr;
+    size_t scr = 0, outd = 0;
+    for (int w = 0; w < nw; ++w) {
+      const WinMeta &m = meta_[w];
+      MargMeta &mm = metas[w];
+      std::memset(&mm, 0, sizeof mm);
+      mm.N = m.N; mm.P = m.P;
+      if (only >= 0 && w != only) { n_keep[w] = 0; continue; }
+      const int8_t *role = role_all + m.u0;
+      mm.idx0 = (int32_t)iscr.size();
+      for (int i = 0; i < m.N; ++i) if (role[i] == 1) { iscr.push_back(i); mm.m++; }
+      for (int i = 0; i < m.N; ++i) if (role[i] == 0) { iscr.push_back(i); kept[m.u0 + mm.n] = i; mm.n++; }
+      n_keep[w] = mm.n;
+      if (mm.m > MARG_MAXD || mm.n > MARG_MAXD) { *too_large = true; return CTVIO_OK; }
+      const int np = std::max(mm.m, mm.n) + (std::max(mm.m, mm.n) & 1);
+      mm.A0 = (int64_t)scr; scr += (size_t)m.N * m.N;
+      mm.V0 = (int64_t)scr; scr += (size_t)mm.m * mm.m;
+      mm.X0 = (int64_t)scr; scr += (size_t)mm.m * (mm.n + 1);
+      mm.Y0 = (int64_t)scr; scr += (size_t)mm.m * (mm.n + 1);
+      mm.rot0 = (int64_t)scr; scr += (size_t)MARG_MAX_SWEEPS * std::max(np - 1, 1) * (np / 2) * 2;
+      mm.b0 = (int64_t)scr; scr += (size_t)mm.n;
+      mm.J0 = (int64_t)outd; outd += (size_t)mm.n * mm.n;
+      mm.r0 = (int64_t)outd; outd += (size_t)mm.n;
+    }
+    // normal equations of every window at its current state
+    set_params(1);
+    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 0);
+    launch_cost(false, 1);
+    hipLaunchKernelGGL((k_set_initial_cost<T>), dim3(wb), dim3(64), 0, stream_, d);
+    launch_linearize();
+    launch_assemble();
+    HIPCHK(mg_meta_.upload(metas, stream_));
+    if (iscr.empty()) iscr.push_back(0);
+    HIPCHK(mg_idx_.upload(iscr, stream_));
+    HIPCHK(mg_scr_.alloc(scr));
+    HIPCHK(mg_out_.alloc(outd));
+    constexpr size_t lds = ((size_t)MARG_MAXD * (MARG_MAXD + 1) / 2 + 4 * MARG_MAXD + 512) * sizeof(double) + 2 * MARG_MAXD * sizeof(int);
+    if (!marg_attr_set_) { HIPCHK(hipFuncSetAttribute((const void *)k_marginalize<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); marg_attr_set_ = true; }
+    hipLaunchKernelGGL((k_marginalize<T>), dim3(nw), dim3(256), lds, stream_, d, mg_meta_.p, mg_idx_.p, mg_scr_.p, mg_out_.p, eps);
+    std::vector<double> outh(std::max<size_t>(outd, 1));
+    HIPCHK(hipMemcpyAsync(outh.data(), mg_out_.p, sizeof(double) * std::max<size_t>(outd, 1), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(metas.data(), mg_meta_.p, sizeof(MargMeta) * nw, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    size_t oj = 0, orr = 0;
+    for (int w = 0; w < nw; ++w) {
+      const MargMeta &mm = metas[w];
+      if (mm.n <= 0) continue;
+      if (std::getenv("CTVIO_MARG_DEBUG") && w == (only >= 0 ? only : 0)) {
+        std::fprintf(stderr, "[ctvio] marg window %d: m %d n %d sweeps %d / %d; off/dia per sweep (A'):", w, mm.m, mm.n, mm.sweeps_m, mm.sweeps_n);
+        for (int i = 0; i < 26 && i <= std::max(mm.sweeps_n, 0) + 1; ++i) std::fprintf(stderr, " %.2e", mm.trace[26 + i]);
+        std::fprintf(stderr, "\n");
+      }
+      if (mm.status) return fail(CTVIO_ERR_HIP, "device eigen-solver did not converge (window " + std::to_string(w) + ")");
+      std::memcpy(J0 + oj, outh.data() + mm.J0, sizeof(double) * (size_t)mm.n * mm.n);
+      std::memcpy(r0 + orr, outh.data() + mm.r0, sizeof(double) * (size_t)mm.n);
+      oj += (size_t)mm.n * mm.n; orr += (size_t)mm.n;
+    }
+    return CTVIO_OK;
+  }
+  int marginalize_batch(const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    if (!role || !n_keep || !kept || !J0 || !r0 || !(eps >= 0)) return fail(CTVIO_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < dev_.Utot; ++i) if (role[i] < -1 || role[i] > 1) return fail(CTVIO_ERR_INVALID, "role must be -1, 0 or 1");
+    bool too_large = false;
+    const int rc = marg_device(role, -1, eps, n_keep, kept, J0, r0, &too_large);
+    if (rc != CTVIO_OK) return rc;
+    if (too_large) return fail(CTVIO_ERR_INVALID, "a window has more than " + std::to_string(MARG_MAXD) + " marginalised or kept unknowns: use ctvio_marginalize");
+    return CTVIO_OK;
+  }
+  // one window; windows beyond the device eigen-solver's size (m or n > MARG_MAXD) take the host path (csrc/marginalize.hpp)
   int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
@@ -788,6 +868,19 @@ template <class T> class SolverImpl : public SolverBase {
     const WinMeta &m = meta_[id];
     const int N = m.N, P = m.P, L = m.L;
     for (int i = 0; i < N; ++i) if (role[i] < -1 || role[i] > 1) return fail(CTVIO_ERR_INVALID, "role must be -1, 0 or 1");
+    if (!std::getenv("CTVIO_MARG_HOST")) {
+      std::vector<int8_t> role_all((size_t)dev_.Utot, (int8_t)-1);
+      std::copy(role, role + N, role_all.begin() + m.u0);
+      std::vector<int32_t> nk((size_t)dev_.nwin), kv((size_t)dev_.Utot);
+      bool too_large = false;
+      const int rc = marg_device(role_all.data(), id, eps, nk.data(), kv.data(), J0, r0, &too_large);
+      if (rc != CTVIO_OK) return rc;
+      if (!too_large) {
+        *n_keep = nk[id];
+        std::copy(kv.begin() + m.u0, kv.begin() + m.u0 + nk[id], kept);
+        return CTVIO_OK;
+      }
+    }
     std::vector<double> Hpp((size_t)P * P), W((size_t)P * std::max(L, 1)), Hll(std::max(L, 1)), g(N);
     const int rc = linearize(id, Hpp.data(), L ? W.data() : nullptr, L ? Hll.data() : nullptr, g.data(), nullptr);
     if (rc != CTVIO_OK) return rc;
@@ -889,6 +982,10 @@ template <class T> class SolverImpl : public SolverBase {
   int Mtot_ = 0, Vtot_ = 0;
   size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0, in_bytes_ = 0, state_doubles_ = 0;
   Arena in_, work_;          // uploaded inputs (pinned mirror) / device-only work buffers
+  DBuf<MargMeta> mg_meta_;   // device marginalisation: descriptors, index lists, scratch, outputs
+  DBuf<int32_t> mg_idx_;
+  DBuf<double> mg_scr_, mg_out_;
+  bool marg_attr_set_ = false;
   double *snap_ = nullptr;   // state snapshot (inside work_)
   Lm *lm_host_ = nullptr; size_t lm_host_cap_ = 0;
   hipGraphExec_t graph_exec_ = nullptr;   // one LM pass (launch_pass) as a graph, valid while dev_ == graph_dev_
@@ -1032,6 +1129,9 @@ int32_t ctvio_marginalize(ctvio_solver *s, int32_t id, const int8_t *role, doubl
   CHK_S; return s->impl->marginalize(id, role, eps, n_keep, kept, J0, r0);
 }
 int32_t ctvio_residual_summary(ctvio_solver *s, int32_t id, double *sums, int32_t *counts4) { CHK_S; return s->impl->residual_summary(id, sums, counts4); }
+int32_t ctvio_marginalize_batch(ctvio_solver *s, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) {
+  CHK_S; return s->impl->marginalize_batch(role, eps, n_keep, kept, J0, r0);
+}
 int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) {
   CHK_S; return s->impl->gauge_restore(n, ids, knot, q0, t0);
 }

@@ -209,6 +209,22 @@ class Solver:
         n = n.value
         return kept[:n].copy(), J0[: n * n].reshape(n, n).copy(), r0[:n].copy()
 
+    def marginalize_batch(self, roles, eps: float = 1e-8):
+        """ctvio_marginalize_batch: roles = list of per-window role arrays.  Returns a list of (kept, J0, r0) per window."""
+        Ns = [w.N for w in self.windows]
+        role = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int8) for r in roles]), np.int8)
+        assert role.shape[0] == sum(Ns)
+        nk = np.zeros(len(Ns), np.int32); kept = np.zeros(sum(Ns), np.int32)
+        nkeep = [int((np.asarray(r) == 0).sum()) for r in roles]
+        J0 = np.zeros(max(sum(k * k for k in nkeep), 1)); r0 = np.zeros(max(sum(nkeep), 1))
+        capi.check(self._lib.ctvio_marginalize_batch(self._h, capi._p(role), float(eps), capi._p(nk), capi._p(kept), capi._p(J0), capi._p(r0)))
+        out, u, oj, orr = [], 0, 0, 0
+        for N, n in zip(Ns, nk):
+            n = int(n)
+            out.append((kept[u:u + n].copy(), J0[oj:oj + n * n].reshape(n, n).copy(), r0[orr:orr + n].copy()))
+            u += N; oj += n * n; orr += n
+        return out
+
     def gauge_restore(self, wids, knots, q0, t0):
         """4-DoF gauge restore (reference double2vector): windows `wids`, reference knot index per window, its pre-solve
         quaternion (n,4) (x,y,z,w) and position (n,3).  Acts on the device state; read it back with get_state."""

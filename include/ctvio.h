@@ -186,6 +186,13 @@ int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t 
  * the prior has to match an fp64 reference tightly: the elimination amplifies the fp32 noise of the default path. */
 int32_t ctvio_marginalize(ctvio_solver *s, int32_t id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0);
 
+/* The same for EVERY window of the batch in one launch (one workgroup per window: Schur elimination + two parallel-Jacobi
+ * eigendecompositions in LDS).  role: the windows' role arrays concatenated (sum of N_i entries, window order); outputs:
+ * n_keep[n_windows]; kept: window i's kept unknowns at offset sum_{k<i} N_k; J0 / r0 packed tightly in window order
+ * (offsets sum_{k<i} n_keep_k^2 / sum_{k<i} n_keep_k).  Every window needs <= 180 marginalised and <= 180 kept unknowns
+ * (ctvio_marginalize falls back to a host factorisation beyond that). */
+int32_t ctvio_marginalize_batch(ctvio_solver *s, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0);
+
 /* 4-DoF gauge restore after a solve, on the device, for n windows of the batch at once (reference
  * TrajectoryManager::double2vector, src/estimator/trajectory_manager.cpp:485-516, called at :467 right after Solve):
  * for window ids[i], the rigid transform that puts the yaw (full rotation near the Euler singularity) and the position

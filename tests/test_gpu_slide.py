@@ -76,3 +76,31 @@ def test_residual_summary_matches_oracle(cv, oracle):
         np.testing.assert_allclose(rs["bias"][0], r_bias, rtol=1e-9)
         np.testing.assert_allclose(rs["image"][0], r_vis, rtol=1e-9)
         np.testing.assert_allclose(rs["prior"][0], r_prior, rtol=1e-9, atol=1e-9)
+
+
+def test_marginalize_batch_on_device(cv, slide_reference):
+    """ctvio_marginalize_batch: 256 marginalisation windows (the MARGIN_OLD factor set of the first slide step, m = 26 dropped /
+    n = 91 kept unknowns) in one launch -- Schur elimination and both eigendecompositions on the device (parallel Jacobi in
+    LDS, csrc/marg_device.hpp) -- against the oracle, and under 2 ms per window."""
+    import time
+    sh, world, st_o, rec_o = slide_reference
+    st = sh.State(world)
+    w, info = sh.window_of(world, st, 0, sh.initial_prior(world))
+    m, role = sh.marg_window_of(world, st, 0, w, info)
+    import pyctvo
+    ko, Jo, ro = pyctvo.OracleWindow(m.copy()).marginalize(role, 1e-8)
+    Ho, go = Jo.T @ Jo, Jo.T @ ro
+    nb = 256
+    with cv.Solver() as s:
+        s.set_windows([m.copy() for _ in range(nb)])
+        s.marginalize_batch([role] * nb)                     # warm-up (allocations, kernel load)
+        t0 = time.perf_counter()
+        res = s.marginalize_batch([role] * nb)
+        dt = time.perf_counter() - t0
+        one = s.marginalize(3, role)                         # the single-window entry takes the same device path
+    assert dt / nb < 2e-3, dt / nb
+    for kept, J0, r0 in (res[0], res[nb // 2], res[-1], one):
+        assert np.array_equal(kept, ko)
+        assert np.abs(J0.T @ J0 - Ho).max() <= 1e-7 * np.abs(Ho).max()
+        assert np.abs(J0.T @ r0 - go).max() <= 1e-7 * np.abs(go).max()
+    print(f"marginalize_batch: {1e3 * dt / nb:.3f} ms per window ({nb} windows, {1e3 * dt:.1f} ms)")
