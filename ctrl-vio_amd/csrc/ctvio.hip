@@ -119,6 +119,7 @@ template <class T> class SolverImpl : public SolverBase {
     if (lm_host_) (void)hipHostFree(lm_host_);
     if (state_host_) (void)hipHostFree(state_host_);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (call_host_) (void)hipHostFree(call_host_);
   }
   int init() {
     HIPCHK(hipSetDevice(opt_.device));
@@ -923,10 +924,16 @@ template <class T> class SolverImpl : public SolverBase {
       for (int j = 0; j < i; ++j) if (ids[j] == ids[i]) return fail(CTVIO_ERR_INVALID, "window listed twice");
     }
     if (n == 0) return CTVIO_OK;
-    DBuf<int32_t> di, dk; DBuf<double> dq, dt;
-    HIPCHK(di.upload(std::vector<int32_t>(ids, ids + n), stream_)); HIPCHK(dk.upload(std::vector<int32_t>(knot, knot + n), stream_));
-    HIPCHK(dq.upload(std::vector<double>(q0, q0 + 4 * (size_t)n), stream_)); HIPCHK(dt.upload(std::vector<double>(t0, t0 + 3 * (size_t)n), stream_));
-    hipLaunchKernelGGL((k_gauge_restore<T>), dim3(n), dim3(64), 0, stream_, dev_, n, di.p, dk.p, dq.p, dt.p);
+    // one grow-only scratch buffer and one staged copy: [ids | knot] as int32, then [q0 | t0] as doubles
+    const size_t nbytes = (((size_t)2 * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)7 * n * sizeof(double);
+    if (const int rc = call_scratch(nbytes)) return rc;
+    char *hs = call_host_, *ds = call_dev_.p;
+    const size_t ioff = ((size_t)2 * n * sizeof(int32_t) + 15) & ~(size_t)15;
+    std::memcpy(hs, ids, sizeof(int32_t) * n); std::memcpy(hs + sizeof(int32_t) * n, knot, sizeof(int32_t) * n);
+    std::memcpy(hs + ioff, q0, sizeof(double) * 4 * n); std::memcpy(hs + ioff + sizeof(double) * 4 * n, t0, sizeof(double) * 3 * n);
+    HIPCHK(hipMemcpyAsync(ds, hs, nbytes, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL((k_gauge_restore<T>), dim3(n), dim3(64), 0, stream_, dev_, n, reinterpret_cast<const int32_t *>(ds),
+                       reinterpret_cast<const int32_t *>(ds) + n, reinterpret_cast<const double *>(ds + ioff), reinterpret_cast<const double *>(ds + ioff) + 4 * (size_t)n);
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
     return CTVIO_OK;
@@ -935,26 +942,28 @@ template <class T> class SolverImpl : public SolverBase {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin || n < 0 || (n && !t_ns)) return fail(CTVIO_ERR_INVALID, "bad arguments");
     if (n == 0) return CTVIO_OK;
-    std::vector<long long> rel(n);
+    // grow-only scratch (pinned host mirror): [t_rel n x i64 | err | pose 7n | vel 3n | omega 3n | acc 3n]
+    const size_t o_err = sizeof(long long) * (size_t)n, o_out = o_err + 16;
+    const size_t nd = (size_t)n * ((pose7 ? 7 : 0) + (vel3 ? 3 : 0) + (omega3 ? 3 : 0) + (acc3 ? 3 : 0));
+    if (const int rc = call_scratch(o_out + nd * sizeof(double))) return rc;
+    char *hs = call_host_, *ds = call_dev_.p;
+    long long *rel = reinterpret_cast<long long *>(hs);
     for (int i = 0; i < n; ++i) rel[i] = (long long)(t_ns[i] - t0_[id]);
-    DBuf<long long> dt; DBuf<double> dp, dv, dw, da; DBuf<int> derr;
-    HIPCHK(dt.alloc(n)); HIPCHK(derr.alloc(1));
-    HIPCHK(hipMemcpyAsync(dt.p, rel.data(), sizeof(long long) * n, hipMemcpyHostToDevice, stream_));
-    HIPCHK(hipMemsetAsync(derr.p, 0, sizeof(int), stream_));
-    if (pose7) HIPCHK(dp.alloc((size_t)7 * n));
-    if (vel3) HIPCHK(dv.alloc((size_t)3 * n));
-    if (omega3) HIPCHK(dw.alloc((size_t)3 * n));
-    if (acc3) HIPCHK(da.alloc((size_t)3 * n));
-    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, n, dt.p, pose7 ? dp.p : nullptr,
-                       vel3 ? dv.p : nullptr, omega3 ? dw.p : nullptr, acc3 ? da.p : nullptr, derr.p);
-    int err = 0;
-    if (pose7) HIPCHK(hipMemcpyAsync(pose7, dp.p, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, stream_));
-    if (vel3) HIPCHK(hipMemcpyAsync(vel3, dv.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
-    if (omega3) HIPCHK(hipMemcpyAsync(omega3, dw.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
-    if (acc3) HIPCHK(hipMemcpyAsync(acc3, da.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipMemcpyAsync(&err, derr.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    *reinterpret_cast<int *>(hs + o_err) = 0;
+    HIPCHK(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, stream_));
+    double *dp = reinterpret_cast<double *>(ds + o_out), *dv = dp + (pose7 ? (size_t)7 * n : 0), *dw = dv + (vel3 ? (size_t)3 * n : 0),
+           *da = dw + (omega3 ? (size_t)3 * n : 0);
+    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, n, reinterpret_cast<const long long *>(ds),
+                       pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr, reinterpret_cast<int *>(ds + o_err));
+    HIPCHK(hipMemcpyAsync(hs + o_err, ds + o_err, 16 + nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    const int err = *reinterpret_cast<int *>(hs + o_err);
+    const double *ho = reinterpret_cast<const double *>(hs + o_out);
+    if (pose7) { std::memcpy(pose7, ho, sizeof(double) * 7 * n); ho += (size_t)7 * n; }
+    if (vel3) { std::memcpy(vel3, ho, sizeof(double) * 3 * n); ho += (size_t)3 * n; }
+    if (omega3) { std::memcpy(omega3, ho, sizeof(double) * 3 * n); ho += (size_t)3 * n; }
+    if (acc3) std::memcpy(acc3, ho, sizeof(double) * 3 * n);
     if (err) return fail(CTVIO_ERR_INVALID, "query time outside the spline");
     return CTVIO_OK;
   }
@@ -982,6 +991,18 @@ template <class T> class SolverImpl : public SolverBase {
   int Mtot_ = 0, Vtot_ = 0;
   size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0, in_bytes_ = 0, state_doubles_ = 0;
   Arena in_, work_;          // uploaded inputs (pinned mirror) / device-only work buffers
+  // scratch of the small per-call entries (spline query, gauge restore): grow-only device buffer + pinned host mirror
+  DBuf<char> call_dev_;
+  char *call_host_ = nullptr; size_t call_host_cap_ = 0;
+  int call_scratch(size_t bytes) {
+    HIPCHK(call_dev_.alloc(bytes));
+    if (bytes > call_host_cap_) {
+      if (call_host_) (void)hipHostFree(call_host_);
+      call_host_cap_ = bytes + bytes / 4 + 4096;
+      HIPCHK(hipHostMalloc((void **)&call_host_, call_host_cap_, hipHostMallocDefault));
+    }
+    return CTVIO_OK;
+  }
   DBuf<MargMeta> mg_meta_;   // device marginalisation: descriptors, index lists, scratch, outputs
   DBuf<int32_t> mg_idx_;
   DBuf<double> mg_scr_, mg_out_;
