@@ -108,9 +108,9 @@ struct SolverBase {
 
 template <class T> class SolverImpl : public SolverBase {
  public:
-  // visual blocks per work item (k_assemble_vis*): eight per-wave staging areas [102][VCH + 2] must fit beside the fp64 LDS Hessian
+  // visual blocks per work item (k_assemble_vis*): eight per-wave staging areas [116][VCH + 2] must fit beside the fp64 LDS Hessian
   static constexpr int VCH = sizeof(T) == 8 ? 8 : 16;
-  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 102 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
+  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 116 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
   explicit SolverImpl(const ctvio_options &o) : opt_(o), mixed_(sizeof(T) == 4 && o.fp64_residuals != 0) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -395,6 +395,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_kd = seg(8 * 3 * (size_t)K0), o_ckd = seg(8 * 3 * (size_t)K0), o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
     const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
     const size_t o_imu_rc = mixed_ ? seg(sizeof(T) * 6 * Mt) : 0, o_vis_rc = mixed_ ? seg(sizeof(T) * 3 * Vt) : 0;
+    const size_t o_Jp = seg(sizeof(T) * 14 * Vt);
     const size_t o_Jv = seg(sizeof(T) * 100 * Vt), o_rv = seg(sizeof(T) * 2 * Vt), o_vs = seg(4 * 2 * Vt), o_Wc = seg(sizeof(T) * WC_STRIDE * Vt);
     const size_t o_Hpp = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
@@ -413,6 +414,7 @@ template <class T> class SolverImpl : public SolverBase {
     snap_ = CTV_W(double, o_snap);
     d.kd = CTV_W(double, o_kd); d.ckd = CTV_W(double, o_ckd); d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
     if (mixed_) { d.imu_rc = CTV_W(T, o_imu_rc); d.vis_rc = CTV_W(T, o_vis_rc); }
+    d.Jp = CTV_W(T, o_Jp);
     d.Jv = CTV_W(T, o_Jv); d.rv = CTV_W(T, o_rv); d.vs = CTV_W(int32_t, o_vs); d.Wc = CTV_W(T, o_Wc);
     d.Hpp = CTV_W(double, o_Hpp); d.S = CTV_W(double, o_S); d.W = CTV_W(T, o_W); d.Hll = CTV_W(double, o_Hll); d.g = CTV_W(double, o_g);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);

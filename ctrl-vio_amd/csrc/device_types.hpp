@@ -87,7 +87,8 @@ template <class T> struct Dev {
   const int32_t *v_rowi, *v_rowj;
   const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
   const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
-  T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row)
+  T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row); the 48 position rows are never touched:
+  T *Jp;                 // [14][Vtot] their compact form: P~ (2 x 3), cp0[4], cp1[4]  (J~_pos(k, b) = cp0[k] P~[b] / -cp1[k] P~[b])
   T *rv;                 // [2][Vtot]
   T *vis_rc;             // [3][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc) and the block's
                          // sqrt(rho') = exp(-cost / a^2) from that fp64 evaluation (row 2)

@@ -440,13 +440,26 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, co
 #pragma unroll
       for (int i = 0; i < 6; ++i) lhsP0[i] = g6[i];
     }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    // position columns: the 2 x 3 block P~ = corrector(sw * lhsP0) is shared by all eight position knots, column (knot k, axis b)
+    // of the i-end is cp0[k] P~[b], of the j-end -cp1[k] P~[b] (the corrector is linear in J).  Sinks that materialise J~ keep
+    // just P~ and the two sets of blending coefficients (put_pos) instead of the 48 columns.
+    {
+      T Pt[6];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        out(12 + 3 * kk + b, sw * cp0[kk] * lhsP0[b], sw * cp0[kk] * lhsP0[3 + b]);
-        out(36 + 3 * kk + b, -sw * cp1[kk] * lhsP0[b], -sw * cp1[kk] * lhsP0[3 + b]);
+        const T j0 = sw * lhsP0[b], j1 = sw * lhsP0[3 + b], rj = r0 * j0 + r1 * j1;
+        Pt[2 * b] = sq * (j0 - alpha_sq * r0 * rj);
+        Pt[2 * b + 1] = sq * (j1 - alpha_sq * r1 * rj);
       }
+      emit.put_pos(Pt, cp0, cp1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          emit.put(12 + 3 * kk + b, cp0[kk] * Pt[2 * b], cp0[kk] * Pt[2 * b + 1]);
+          emit.put(36 + 3 * kk + b, -cp1[kk] * Pt[2 * b], -cp1[kk] * Pt[2 * b + 1]);
+        }
+    }
     // rotation columns, knot by knot as the per-knot partial Jacobians become final (image_feature_factor.h:199-216)
     auto rot_cols = [&](int col0, const T lhs[6], const M3<T> &Jk) {
 #pragma unroll

@@ -733,21 +733,40 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
 }
 
 // ------------------------------------------------------------------------------------------------ visual
+// is local column c (0..49) one of the 24 position columns (i-end 12..23, j-end 36..47)?  Those are not materialised:
+// J~[c] = cp0[k] P~[b] / -cp1[k] P~[b], rebuilt from the 14 numbers of Jp by the assembly kernels.
+__device__ __forceinline__ constexpr bool vis_pos_col(int c) { return (c >= 12 && c < 24) || (c >= 36 && c < 48); }
 template <class T> struct VisGlobalSink {
-  T *J;        // Jv (uniform): row r of the materialised Jacobian starts at J + r * stride
+  T *J;        // Jv (uniform): row r of the materialised Jacobian starts at J + r * stride (rotation, depth, line-delay columns)
+  T *Jp;       // [14][stride]: P~ (rows 2 b + residual row), cp0[4], cp1[4]
   size_t stride;
   T *wc;       // LDS row of this lane: J_rho^T J_c for the 49 pose columns (slot 48 = line delay), then Hll, g_rho
   T jr0, jr1;
   unsigned v;  // this lane's block: uniform row base + one 32-bit lane offset (no 64-bit address per store)
   __device__ __forceinline__ void put(int col, T j0, T j1) {
-    (J + (size_t)(2 * col) * stride)[v] = j0; (J + (size_t)(2 * col + 1) * stride)[v] = j1;
+    if (!vis_pos_col(col)) { (J + (size_t)(2 * col) * stride)[v] = j0; (J + (size_t)(2 * col + 1) * stride)[v] = j1; }
     if (col == 48) { jr0 = j0; jr1 = j1; }                       // visual_eval emits the inverse-depth column first
     else wc[col < 48 ? col : 48] = jr0 * j0 + jr1 * j1;
+  }
+  __device__ __forceinline__ void put_pos(const T Pt[6], const T cp0[4], const T cp1[4]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) (Jp + (size_t)i * stride)[v] = Pt[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { (Jp + (size_t)(6 + i) * stride)[v] = cp0[i]; (Jp + (size_t)(10 + i) * stride)[v] = cp1[i]; }
   }
 };
 template <class T> struct VisNullSink {
   __device__ __forceinline__ void put(int, T, T) {}
+  __device__ __forceinline__ void put_pos(const T *, const T *, const T *) {}
 };
+// J~ entry (staging row = 2 * column + residual row, < 100) of block v from the compact storage
+template <class T> __device__ __forceinline__ T vis_J_entry(const T *Jv, const T *Jp, size_t V, int row, size_t v) {
+  const int col = row >> 1, rr = row & 1;
+  if (!vis_pos_col(col)) return Jv[(size_t)row * V + v];
+  const int c = col < 24 ? col - 12 : col - 36, kk = c / 3, b = c % 3;
+  const T pt = Jp[(size_t)(2 * b + rr) * V + v];
+  return col < 24 ? Jp[(size_t)(6 + kk) * V + v] * pt : -Jp[(size_t)(10 + kk) * V + v] * pt;
+}
 
 // time -> (first active knot, u) in integer ns (reference spline_segment.h:83-85); the line delay is
 // truncated to integer ns exactly as image_feature_factor.h:72.
@@ -828,7 +847,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisGlobalSink<T> sink{d.Jv, V, wcs + 55 * threadIdx.x, T(0), T(0), (unsigned)v};
+        VisGlobalSink<T> sink{d.Jv, d.Jp, V, wcs + 55 * threadIdx.x, T(0), T(0), (unsigned)v};
         wcs_on[threadIdx.x] = d.v_slot[v];
         if (sizeof(RT) != sizeof(T)) cal.sq_override = d.vis_rc[2 * V + v];   // robust scale of the fp64 residual pass
         SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
@@ -936,7 +955,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       for (int i = 0; i < NPASS; ++i) {
         const int row = i * RPP + rr;
         tmp[i] = T(0);
-        if (row < 102 && c < n) tmp[i] = (row < 100) ? d.Jv[(size_t)row * V + v0 + c] : d.rv[(size_t)(row - 100) * V + v0 + c];
+        if (row < 102 && c < n) tmp[i] = (row < 100) ? vis_J_entry<T>(d.Jv, d.Jp, V, row, (size_t)(v0 + c)) : d.rv[(size_t)(row - 100) * V + v0 + c];
       }
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
@@ -1074,7 +1093,12 @@ __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __
 template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d) {
   constexpr bool F64 = sizeof(T) == 8;
   typedef typename MfmaAcc<T>::type acc_t;
-  constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;
+  constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH;
+  // staged rows per item: 0..95 pose columns (row = 2 * column + residual row), 98/99 line delay, 100/101 residual, 102..115 the
+  // compact position data (P~ 6 rows, cp0 4, cp1 4).  Only 66 of them come from HBM -- the 48 position rows (24..47, 72..95)
+  // are rebuilt in LDS from rows 102..115, the inverse-depth rows 96/97 are not needed here.
+  constexpr int SROWS = 116, NSRC = 66, NPASS = (NSRC + RPP - 1) / RPP, NEXP = 48 / RPP;
+  static_assert(24 % RPP == 0, "source regions must start on a pass boundary");
   const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_needed(d.lm[w])) return;
@@ -1089,12 +1113,12 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
   const int nHh = tri + K6 + 1;                // packed Hessian entries: knot x knot lower triangle, line-delay row
   const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay)
   double *gs = Hs + nHh;
-  T *stage = reinterpret_cast<T *>(Hs + ((nH + 3) & ~3));     // [NW][102][CHP]
-  int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
+  T *stage = reinterpret_cast<T *>(Hs + ((nH + 3) & ~3));     // [NW][SROWS][CHP]
+  int *keys = reinterpret_cast<int *>(stage + NW * SROWS * CHP);        // [NW][2][CH]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < nH; i += 512) Hs[i] = 0.0;
   __syncthreads();
-  T *Js = stage + wave * 102 * CHP;
+  T *Js = stage + wave * SROWS * CHP;
   int *ks = keys + wave * 2 * CH;
   const size_t V = (size_t)d.Vtot;
   const int per_round = NW * nparts;
@@ -1141,14 +1165,15 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
     // address = uniform row base (SGPR pair) + one 32-bit lane offset shared by all passes: pass i covers staged rows
     // RPP i .. RPP i + RPP - 1, the lane's row inside the pass is srr  (64-bit per-lane addresses would cost 2 VGPRs per load)
     const unsigned loff = (unsigned)srr * (unsigned)V + (unsigned)(v0 + c);
-    const unsigned loff_r = (unsigned)min(srr, 1) * (unsigned)V + (unsigned)(v0 + c);   // the residual has 2 rows only
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      if (i * RPP + RPP <= 100) tmp[i] = (d.Jv + (size_t)(i * RPP) * V)[loff];          // whole pass inside J~
-      else if (i * RPP >= 100) tmp[i] = d.rv[loff_r];                                     // whole pass inside r~
-      else {                                                                               // the pass straddles the boundary
-        const int row = i * RPP + srr;
-        const T *src = row < 100 ? d.Jv + (size_t)row * V : d.rv + (size_t)min(row - 100, 1) * V;
+      const int q0 = i * RPP, q1 = q0 + RPP;                                              // source rows of this pass
+      if (q1 <= 24) tmp[i] = (d.Jv + (size_t)q0 * V)[loff];                               // rotation columns, i end
+      else if (q0 >= 24 && q1 <= 48) tmp[i] = (d.Jv + (size_t)(q0 + 24) * V)[loff];       // rotation columns, j end
+      else if (q0 >= 52 && q1 <= NSRC) tmp[i] = (d.Jp + (size_t)(q0 - 52) * V)[loff];     // compact position data
+      else {                                                                               // a pass across two arrays
+        const int q = min(q0 + srr, NSRC - 1);
+        const T *src = q < 50 ? d.Jv + (size_t)(q + 50) * V : q < 52 ? d.rv + (size_t)(q - 50) * V : d.Jp + (size_t)(q - 52) * V;
         tmp[i] = src[v0 + c];
       }
     }
@@ -1162,10 +1187,21 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
     const int ncur = n;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int row = i * RPP + srr;
-      if (row < 102) Js[row * CHP + sc] = (sc < ncur) ? tmp[i] : T(0);
+      const int q = i * RPP + srr;
+      const int row = q + (q < 24 ? 0 : q < 48 ? 24 : 50);
+      if (q < NSRC) Js[row * CHP + sc] = (sc < ncur) ? tmp[i] : T(0);
     }
     if (lane < CH) { ks[lane] = key_i; ks[CH + lane] = key_j; }
+    __builtin_amdgcn_wave_barrier();
+    // position rows: column 12 + 3 k + b (i end) = cp0[k] P~[b], column 36 + 3 k + b (j end) = -cp1[k] P~[b]
+#pragma unroll
+    for (int e = 0; e < NEXP; ++e) {
+      constexpr int HALF = 24 / RPP;
+      const int side = e / HALF, rem = (e % HALF) * RPP + srr;    // rem = 2 * (3 k + b) + residual row
+      const int pc = rem >> 1, kk = pc / 3, b = pc - 3 * kk;
+      const T pv = Js[(102 + 2 * b + (rem & 1)) * CHP + sc], cv = Js[(108 + 4 * side + kk) * CHP + sc];
+      Js[(24 + 48 * side + rem) * CHP + sc] = side ? -(cv * pv) : cv * pv;
+    }
     __builtin_amdgcn_wave_barrier();
     fetch(r + 1);
     int start = 0;

@@ -14,6 +14,7 @@ template <class T> struct ImuSink {
 template <class T> struct VisSink {
   T *J;
   void put(int col, T j0, T j1) { J[col] = j0; J[50 + col] = j1; }
+  void put_pos(const T *, const T *, const T *) {}
 };
 
 // local frame of the reference knot (q_ref, p_ref): the same preparation the kernels do (LocalFrame in kernels.hpp)
