@@ -129,7 +129,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (sizeof(T) == 8) HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
@@ -499,7 +500,7 @@ template <class T> class SolverImpl : public SolverBase {
     {  // few windows: split each window's items over several workgroups to fill the chip
       const int parts = vis_parts();
       if (any_vis_lds_) launch_assemble_vis_lds(parts);
-      if (any_vis_glb_) hipLaunchKernelGGL((k_assemble_vis<T, VCH, false>), dim3(nw, parts), dim3(512), vis_glb_, stream_, d);
+      if (any_vis_glb_) launch_assemble_vis_glb(parts);
     }
     ph_end();
     ph_begin(PH_ASM_REST);
@@ -533,6 +534,7 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_schur();
   void launch_imu_linearize(size_t vals_lds);
   void launch_assemble_vis_lds(int parts);
+  void launch_assemble_vis_glb(int parts);
   bool schur_makes_rhs() const { return (sizeof(T) == 4 && opt_.use_mfma != 0) || schur_rhs_done_; }
   bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
   void launch_cost(bool candidate, int force) {
@@ -1045,13 +1047,25 @@ template <> void SolverImpl<float>::launch_schur() {
 }
 template <> void SolverImpl<float>::launch_assemble_vis_lds(int parts) {
   const Dev<float> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<float, VCH>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<float, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
   else hipLaunchKernelGGL((k_assemble_vis<float, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+}
+// windows whose packed Hessian does not fit in LDS (K > 25): run products on the MFMA units, added to Hpp with global atomics
+template <> void SolverImpl<float>::launch_assemble_vis_glb(int parts) {
+  const Dev<float> &d = dev_;
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<float, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
+  else hipLaunchKernelGGL((k_assemble_vis<float, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
 }
 template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
   const Dev<double> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
   else hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+}
+// windows whose packed Hessian does not fit in LDS (K > 25): run products on the MFMA units, added to Hpp with global atomics
+template <> void SolverImpl<double>::launch_assemble_vis_glb(int parts) {
+  const Dev<double> &d = dev_;
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
+  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
 }
 template <> void SolverImpl<double>::launch_schur() {
   const Dev<double> &d = dev_;

@@ -1090,7 +1090,7 @@ template <> struct MfmaAcc<float> { typedef f32x4 type; };
 template <> struct MfmaAcc<double> { typedef f64x4 type; };
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d) {
+template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d) {
   constexpr bool F64 = sizeof(T) == 8;
   typedef typename MfmaAcc<T>::type acc_t;
   constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH;
@@ -1104,13 +1104,14 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
   if (!lin_needed(d.lm[w])) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0, ldh = m.ldh;
-  if (m.vis_lds == 0) return;   // those windows go through k_assemble_vis<float, CH, false>
+  if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
+  if (!LDSH && m.V == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
   // fp64 accumulators: ds_add_f64 sustains ~8 cycles per wave instruction on gfx950, ds_add_f32 ~190 (measured,
   // tools/lds_atomic_bench.hip) -- and the fp64 sums do not depend on the order of the additions to ~1e-16
   double *Hs = reinterpret_cast<double *>(smv);
   const int K6 = 6 * K, tri = K6 * (K6 + 1) / 2;
-  const int nHh = tri + K6 + 1;                // packed Hessian entries: knot x knot lower triangle, line-delay row
+  const int nHh = LDSH ? tri + K6 + 1 : 0;     // packed Hessian entries: knot x knot lower triangle, line-delay row
   const int nH = nHh + K6 + 1;                 // + gradient of the pose columns (knots, line delay)
   double *gs = Hs + nHh;
   T *stage = reinterpret_cast<T *>(Hs + ((nH + 3) & ~3));     // [NW][SROWS][CHP]
@@ -1122,7 +1123,10 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
   int *ks = keys + wave * 2 * CH;
   const size_t V = (size_t)d.Vtot;
   const int per_round = NW * nparts;
-  const int rounds = (nvitem + per_round - 1) / per_round;
+  // LDSH: items dealt round-robin over the waves of the window.  !LDSH: every wave owns a contiguous range of items, so a
+  // run that continues into the wave's next item keeps its accumulators and is scattered (global atomics) once.
+  const int it0 = LDSH ? 0 : (int)((long long)nvitem * (part * NW + wave) / per_round);
+  const int rounds = LDSH ? (nvitem + per_round - 1) / per_round : (int)((long long)nvitem * (part * NW + wave + 1) / per_round) - it0;
   double *Hg = d.Hpp + m.H0;
   const int q4 = lane >> 4, l15 = lane & 15, bsel = q4 >> 1, rr = q4 & 1;   // MFMA k index = 2 * (block of the pair) + residual row
   const int sc = lane % CH, srr = lane / CH;                               // staging: column (block) and row parity of this lane
@@ -1145,7 +1149,7 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
   // full memory round trip in front of every item's J~ request
   int my_start, my_count;
   {
-    const int it = (lane * nparts + part) * NW + wave;
+    const int it = LDSH ? (lane * nparts + part) * NW + wave : it0 + lane;
     const VisItem I = d.vitems[vitem0 + min(it, max(nvitem - 1, 0))];   // clamped: always a valid descriptor
     my_start = I.start;
     my_count = (lane < rounds && it < nvitem) ? I.count : 0;
@@ -1154,7 +1158,7 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
     int istart, icount;
     if (r < 64) { istart = __shfl(my_start, r); icount = __shfl(my_count, r); }
     else {
-      const int it = (r * nparts + part) * NW + wave;
+      const int it = LDSH ? (r * nparts + part) * NW + wave : it0 + r;
       const VisItem I = d.vitems[vitem0 + min(it, nvitem - 1)];
       istart = I.start; icount = (r < rounds && it < nvitem) ? I.count : 0;
     }
@@ -1182,6 +1186,71 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
     key_j = d.vs[V + v0 + kc];
   };
   if (nvitem > 0) fetch(0);
+  // accumulators of the open run (asi, asj): 3 x 3 lower tiles of the 48 x 48 pose block, line-delay column, residual
+  acc_t acc[6];
+  T pl[3], pr[3], pll, prl;
+  int asi = -1, asj = -1;
+  auto reset_acc = [&]() {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc[q] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int I = 0; I < 3; ++I) { pl[I] = T(0); pr[I] = T(0); }
+    pll = T(0); prl = T(0);
+  };
+  // ---- scatter: local column -> unknown, each unordered local pair once; pairs of different local columns that map
+  //      to the same unknown (ends sharing a knot) count twice on the diagonal
+  auto scatter = [&](int si, int sj) {
+#pragma unroll
+    for (int I = 0; I < 3; ++I) {
+      pl[I] += __shfl_xor(pl[I], 16); pl[I] += __shfl_xor(pl[I], 32);
+      pr[I] += __shfl_xor(pr[I], 16); pr[I] += __shfl_xor(pr[I], 32);
+    }
+    pll += __shfl_xor(pll, 16); pll += __shfl_xor(pll, 32);
+    prl += __shfl_xor(prl, 16); prl += __shfl_xor(prl, 32);
+    // unknown index and triangular row offset g (g + 1) / 2 of this lane's 3 tile columns and 12 tile rows, once per run
+    int gcol[3], tcol[3], grow[3][4], trow[3][4];
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      gcol[J] = vis_col(16 * J + l15, si, sj, P);
+      tcol[J] = gcol[J] * (gcol[J] + 1) / 2;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        grow[J][rg] = vis_col(16 * J + (F64 ? q4 + 4 * rg : 4 * q4 + rg), si, sj, P);
+        trow[J][rg] = grow[J][rg] * (grow[J][rg] + 1) / 2;
+      }
+    }
+    int q = 0;
+#pragma unroll
+    for (int I = 0; I < 3; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J, ++q) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ca = 16 * I + (F64 ? q4 + 4 * rg : 4 * q4 + rg), cb = 16 * J + l15;
+          if (I == J && ca < cb) continue;
+          const int gA = grow[I][rg], gB = gcol[J];
+          T hv = acc[q][rg];
+          if (gA == gB && ca != cb) hv *= T(2);
+          const bool ge = gA >= gB;
+          if (LDSH) atomicAdd(&Hs[(ge ? trow[I][rg] : tcol[J]) + (ge ? gB : gA)], (double)hv);
+          else atomicAdd(&Hg[(long long)(ge ? gA : gB) * ldh + (ge ? gB : gA)], (double)hv);
+        }
+      }
+    // line-delay row of the Hessian and the pose gradient (every k group holds the totals; group q4 = 0 adds them)
+    if (q4 == 0) {
+#pragma unroll
+      for (int J = 0; J < 3; ++J) {
+        if (LDSH) atomicAdd(&Hs[tri + gcol[J]], (double)pl[J]);
+        else atomicAdd(&Hg[(long long)(P - 1) * ldh + gcol[J]], (double)pl[J]);
+        atomicAdd(&gs[gcol[J]], (double)pr[J]);
+      }
+      if (l15 == 0) {   // (ld, ld) and r . J_ld
+        if (LDSH) atomicAdd(&Hs[tri + K6], (double)pll);
+        else atomicAdd(&Hg[(long long)(P - 1) * ldh + (P - 1)], (double)pll);
+        atomicAdd(&gs[K6], (double)prl);
+      }
+    }
+  };
   for (int r = 0; r < rounds && nvitem > 0; ++r) {
     // ---- stage the fetched item (LDS operations of one wave are ordered: no barrier), then request the next one
     const int ncur = n;
@@ -1210,10 +1279,12 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
       const bool diff = (lane > start && lane < ncur) && (ks[lane] != si || ks[CH + lane] != sj);
       const unsigned long long mask = __ballot(diff);
       const int end = mask ? (__ffsll((long long)mask) - 1) : ncur;
-      acc_t acc[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) acc[q] = acc_t{T(0), T(0), T(0), T(0)};
-      T pl[3] = {T(0), T(0), T(0)}, pr[3] = {T(0), T(0), T(0)}, pll = T(0), prl = T(0);
+      if (LDSH) reset_acc();
+      else if (asi != si || asj != sj) {     // a run that continues from the previous item keeps accumulating
+        if (asi >= 0) scatter(asi, asj);
+        reset_acc();
+        asi = si; asj = sj;
+      }
       // 4 K-steps (8 blocks) per trip: the operand reads first, then the products -- one LDS latency per trip
       for (int v8 = start; v8 < end; v8 += 8) {
         T a[4][3], ldv[4], rv[4];
@@ -1245,61 +1316,16 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
           prl += rv[s] * ldv[s];
         }
       }
-#pragma unroll
-      for (int I = 0; I < 3; ++I) {
-        pl[I] += __shfl_xor(pl[I], 16); pl[I] += __shfl_xor(pl[I], 32);
-        pr[I] += __shfl_xor(pr[I], 16); pr[I] += __shfl_xor(pr[I], 32);
-      }
-      pll += __shfl_xor(pll, 16); pll += __shfl_xor(pll, 32);
-      prl += __shfl_xor(prl, 16); prl += __shfl_xor(prl, 32);
-      // ---- scatter: local column -> unknown, each unordered local pair once; pairs of different local columns that map
-      //      to the same unknown (ends sharing a knot) count twice on the diagonal
-      // unknown index and triangular row offset g (g + 1) / 2 of this lane's 3 tile columns and 12 tile rows, once per run
-      int gcol[3], tcol[3], grow[3][4], trow[3][4];
-#pragma unroll
-      for (int J = 0; J < 3; ++J) {
-        gcol[J] = vis_col(16 * J + l15, si, sj, P);
-        tcol[J] = gcol[J] * (gcol[J] + 1) / 2;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          grow[J][rg] = vis_col(16 * J + (F64 ? q4 + 4 * rg : 4 * q4 + rg), si, sj, P);
-          trow[J][rg] = grow[J][rg] * (grow[J][rg] + 1) / 2;
-        }
-      }
-      {
-        int q = 0;
-#pragma unroll
-        for (int I = 0; I < 3; ++I)
-#pragma unroll
-          for (int J = 0; J <= I; ++J, ++q) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int ca = 16 * I + (F64 ? q4 + 4 * rg : 4 * q4 + rg), cb = 16 * J + l15;
-              if (I == J && ca < cb) continue;
-              const int gA = grow[I][rg], gB = gcol[J];
-              T hv = acc[q][rg];
-              if (gA == gB && ca != cb) hv *= T(2);
-              const bool ge = gA >= gB;
-              atomicAdd(&Hs[(ge ? trow[I][rg] : tcol[J]) + (ge ? gB : gA)], (double)hv);
-            }
-          }
-        // line-delay row of the Hessian and the pose gradient (every k group holds the totals; group q4 = 0 adds them)
-        if (q4 == 0) {
-#pragma unroll
-          for (int J = 0; J < 3; ++J) {
-            atomicAdd(&Hs[tri + gcol[J]], (double)pl[J]);
-            atomicAdd(&gs[gcol[J]], (double)pr[J]);
-          }
-          if (l15 == 0) { atomicAdd(&Hs[tri + K6], (double)pll); atomicAdd(&gs[K6], (double)prl); }   // (ld, ld) and r . J_ld
-        }
-      }
+      if (LDSH) scatter(si, sj);
       start = end;
     }
   }
+  if (!LDSH && asi >= 0) scatter(asi, asj);
   __syncthreads();
   CTV_STAMP();
-  // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments)
-  for (int gi = part * NW + wave; gi < ngrp; gi += per_round) {
+  // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments); without the LDS
+  // Hessian k_assemble_imu adds them
+  for (int gi = part * NW + wave; LDSH && gi < ngrp; gi += per_round) {
     const ImuGroup grp = d.groups[grp0 + gi];
     const T *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
     T tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
@@ -1314,7 +1340,7 @@ template <class T, int CH> __global__ __launch_bounds__(512) void k_assemble_vis
   }
   __syncthreads();
   CTV_STAMP();
-  for (int i = tid; i < nHh; i += 512) {
+  for (int i = tid; LDSH && i < nHh; i += 512) {
     const double hv = Hs[i];
     if (nparts > 1 && hv == 0.0) continue;
     int ga, gb;
