@@ -4,9 +4,10 @@
 A "step" = `--windows` independent config-2 windows (10 KF / 200 landmarks / 2000 IMU, <= 15 LM iterations, Ceres
 tolerances and projected line search) per GPU, taken END TO END through the C ABI exactly as SURVEY.md section 8d defines one
 solve: ctvio_set_batch (validate + pack on host threads + one H2D copy) -> ctvio_solve (device-resident LM) ->
-ctvio_get_batch_state (one D2H copy).  The windows of a step are split over `--streams` solver handles driven by host
-threads, so batch n+1 is packed and uploaded while batch n solves.  value = windows solved by all ranks / wall-clock of the
-K timed steps (max over ranks).  The device-resident rate (state restored on the device, no packing or PCIe traffic) is
+ctvio_get_batch_state (one D2H copy).  The windows of a step are split over `--streams` solver handles, each driven by its
+own host thread through the K steps; at most `--gpu-slots` handles are inside ctvio_solve at a time, so the others pack,
+upload and read back while the GPU stays busy.  value = windows solved by all ranks / wall-clock of the K timed steps (max
+over ranks).  The device-resident rate (state restored on the device, no packing or PCIe traffic) is
 reported next to it as `device_resident_solves_per_s`.
 
 N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one process per GPU, backend nccl = RCCL);
@@ -14,8 +15,10 @@ windows are sharded by id (w mod N), no data-path collective (independent window
 barrier, the max-over-ranks time and the all-gather of the per-window result records (every id must come back exactly once).
 
 Extra objects on the JSON line:
-  roofline       dominant kernel of a profiled solve (HIP events on the solver's stream): achieved = algorithmic bytes
-                  / average launch duration, against 8 TB/s HBM; roofline_mfma: the Schur SYRK.
+  roofline       dominant kernel of a profiled solve of one handle (HIP events on the solver's stream, other handles idle):
+                 achieved = algorithmic bytes (or flops, when the kernel's intensity is beyond the ridge) per launch
+                 (DESIGN.md section 4) / average launch duration, against 8 TB/s HBM (78.6 TFLOP/s fp64);
+                 roofline_kernels: the same line for every named kernel; roofline_mfma: the Schur SYRK.
   parity         max relative state error of the timed path against the fp64 CPU oracle on a sample of the windows
   cpu_baseline   the oracle (a port of the reference's Ceres path: oracle/ctvo.c) on 1 host core, the same sample.
 """
@@ -45,22 +48,43 @@ def kernel_of_phase(precision):
             "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve"}
 
 
+def imu_groups(w):
+    return len({(int((t - w.t0_ns) // w.dt_ns), int(b)) for t, b in zip(w.imu_t, w.imu_bias)})
+
+
 def algorithmic_bytes(w, phase, fp_bytes):
     """Algorithmic HBM bytes of ONE window for one launch of a kernel group; fp_bytes = size of the
     linearisation scalar (8 in the product path)."""
     K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
-    G = len({(int((t - w.t0_ns) // w.dt_ns), int(b)) for t, b in zip(w.imu_t, w.imu_bias)})
+    G = imu_groups(w)
     if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
         return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
-    if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (2 r + 100 J) out + the landmark row (54)
-        return V * (284 + (102 + 54) * fp_bytes)
-    if phase == "k_assemble_vis":    # J~, r~ read once + packed visual Hessian flushed once (fp64)
+    # a visual block's J~ is stored compactly: 2 r + 52 J (rotation, inverse depth, line delay) + 14 (P~, blending coefficients)
+    if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (r, compact J~) out + the landmark row (54)
+        return V * (284 + (68 + 54) * fp_bytes)
+    if phase == "k_assemble_vis":    # compact J~ and r~ read once (the depth column is not needed) + keys + packed fp64 Hessian flushed once
         K6 = 6 * K
-        return V * (102 * fp_bytes + 8) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8
+        return V * (66 * fp_bytes + 8) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8
     if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
         return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
     if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written
         return L * P * fp_bytes + (P * (P + 1) // 2) * 16
+    return 0
+
+
+def algorithmic_flops(w, phase):
+    """Algorithmic flops of ONE window for one launch of a kernel group."""
+    K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
+    if phase == "k_imu_linearize":   # per sample: J^T [J r] lower triangle (3 accel rows x 28 columns, 3 gyro rows x 16) + ~4.1 k evaluation
+        return M * (2 * 3 * (28 * 29 // 2) + 2 * 3 * (16 * 17 // 2) + 4100)
+    if phase == "k_vis_eval":        # SURVEY 8d: ~3 k per block for r, J~ (two SO(3) spline poses and their Jacobians)
+        return V * 3000
+    if phase == "k_assemble_vis":    # 48 x 48 lower triangle + line-delay and residual columns, 2 rows per block
+        return V * 2 * 2 * (48 * 49 // 2 + 2 * 49)
+    if phase == "k_cholesky_solve":
+        return P ** 3 // 3 + 2 * P * P
+    if phase == "k_schur_mfma":      # SYRK count (SURVEY 8d)
+        return P * (P + 1) * L
     return 0
 
 
@@ -74,16 +98,17 @@ def respawn_under_torchrun(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=4096, help="independent windows per GPU per step")
+    ap.add_argument("--windows", type=int, default=8192, help="independent windows per GPU per step")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic windows per GPU (seeds 1000 + 64 rank + i), replicated to --windows")
     ap.add_argument("--config", default="config2")
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--precision", default="fp64", help="fp64 = the product (all-fp64); fp32 = the mixed fast mode (no 1e-4 contract)")
     ap.add_argument("--parity-sample", type=int, default=16, help="windows solved by the CPU oracle (state error of the timed path + cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="solver handles (HIP streams + host threads) per GPU")
+    ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams + host threads) per GPU")
+    ap.add_argument("--gpu-slots", type=int, default=0, help="handles allowed inside ctvio_solve at once (0: half of the streams, at least 1)")
     ap.add_argument("--host-threads", type=int, default=0, help="packing threads per handle (0: cores / streams, at most 16)")
     ap.add_argument("--device-resident-only", action="store_true", help="time the device-resident solve instead (diagnostics)")
     args = ap.parse_args()
@@ -131,24 +156,36 @@ def main():
         solvers.append(sv); cbatches.append(arr); keeps.append((keep, wl))
     lib = cv.capi.load_library()
 
-    def run_handle(si, resident):
-        sv = solvers[si]
-        if resident:
-            sv.restore_state()
-            sv.solve_raw(args.iters)
-            return
-        cv.capi.check(lib.ctvio_set_batch(sv._h, per[si], C.cast(cbatches[si], C.c_void_p)))      # validate + pack + H2D
-        cv.capi.check(lib.ctvio_solve(sv._h, args.iters, None))                                     # device-resident LM
-        o = outs[si]
-        cv.capi.check(lib.ctvio_get_batch_state(sv._h, *[cv.capi._p(a) for a in o]))                # D2H
+    # Handles run their own sub-batch of every step without waiting for each other (one host thread per handle); at most
+    # --gpu-slots of them are inside ctvio_solve at a time, so a handle packs / copies while the others keep the GPU busy.
+    nslots = args.gpu_slots if args.gpu_slots > 0 else max(1, nstream // 2)
+    slots = threading.Semaphore(nslots)
 
-    def step(resident=False):
+    def run_handle_steps(si, nsteps, resident):
+        sv = solvers[si]
+        for _ in range(nsteps):
+            if resident:
+                sv.restore_state()
+                with slots:
+                    sv.solve_raw(args.iters)
+                continue
+            cv.capi.check(lib.ctvio_set_batch(sv._h, per[si], C.cast(cbatches[si], C.c_void_p)))      # validate + pack + H2D
+            with slots:
+                cv.capi.check(lib.ctvio_solve(sv._h, args.iters, None))                                 # device-resident LM
+            o = outs[si]
+            cv.capi.check(lib.ctvio_get_batch_state(sv._h, *[cv.capi._p(a) for a in o]))                # D2H
+
+    def steps(nsteps, resident=False):
+        """nsteps passes over the rank's windows; returns after every handle has drained its stream (results on the host)"""
         if nstream == 1:
-            run_handle(0, resident)
+            run_handle_steps(0, nsteps, resident)
             return
-        th = [threading.Thread(target=run_handle, args=(si, resident)) for si in range(nstream)]
+        th = [threading.Thread(target=run_handle_steps, args=(si, nsteps, resident)) for si in range(nstream)]
         for t in th: t.start()
         for t in th: t.join()
+
+    def step(resident=False):
+        steps(1, resident)
 
     def barrier():
         torch.cuda.synchronize()
@@ -159,8 +196,7 @@ def main():
     def timed(nsteps, resident):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(nsteps):
-            step(resident)                    # returns after every handle has drained its stream (results on the host)
+        steps(nsteps, resident)
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         barrier()
@@ -179,8 +215,7 @@ def main():
     resident_headline = args.device_resident_only
     if resident_headline:
         prepare_resident()
-    for _ in range(args.warmup):
-        step(resident_headline)
+    steps(args.warmup, resident_headline)
     t_total = timed(args.steps, resident_headline)
     n_solved = args.windows * world * args.steps
     fp_bytes = 8 if args.precision == "fp64" else 4
@@ -193,7 +228,7 @@ def main():
                                f"(Ceres 1.14 trust region + projected line search)",
                    "timed_region": "device-resident solve only" if resident_headline else
                                    "end to end per batch: validate + pack (host threads) + H2D + LM solve + D2H of every state",
-                   "windows_per_gpu_per_step": args.windows, "distinct_windows_per_gpu": nuniq, "streams_per_gpu": nstream,
+                   "windows_per_gpu_per_step": args.windows, "distinct_windows_per_gpu": nuniq, "streams_per_gpu": nstream, "concurrent_solves_per_gpu": nslots,
                    "pack_threads_per_stream": hthreads,
                    "sharding": f"independent windows, window id mod {world} rank(s), no data-path collective"},
     }
@@ -223,36 +258,48 @@ def main():
                                 "terminations": sorted({cv.capi.TERMINATION.get(int(t), "?") for t in src[:, 2]}),
                                 "line_search_reduced_steps": int(sum(s["num_line_search_reduced"] for s in sms_all)),
                                 "gathered_with": "RCCL all_gather (GPU tensors)" if rec is not None else "single rank"}
-        # ---- roofline: one more device-resident step with HIP events around every launch group of handle 0 (all handles running)
+        # ---- roofline: one more device-resident solve of handle 0 with HIP events around every launch group on its stream;
+        #      the other handles are idle, so a duration is the kernel's own (two streams sharing the chip stretch both)
         solver = solvers[0]
         solver.set_profiling(True)
-        step(True)
+        run_handle_steps(0, 1, True)
         solver.set_profiling(False)
         torch.cuda.synchronize()
         ms, n = solver.last_timing()
         names = cv.Solver.PHASES
         kmap = kernel_of_phase(args.precision)
-        dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
         wl0 = keeps[0][1]
-        nbytes = sum(algorithmic_bytes(w, names[dom], fp_bytes) for w in wl0)
-        avg_s = 1e-3 * ms[dom] / max(int(n[dom]), 1)
-        traffic = None
+        w_ref = uniq[0]
+        pk = MFMA_PEAK_TFLOPS["fp64" if args.precision == "fp64" else "fp32"]
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc = {}
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(kmap.get(names[dom], names[dom]), {}).get(str(per[0]), {}).get("traffic_bytes")
+                pmc = json.load(open(tfile))
             except Exception:
-                traffic = None
-        ach = nbytes / avg_s / 1e9
-        out["roofline"] = {"kernel": kmap.get(names[dom], names[dom]), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "avg_launch_us": 1e6 * avg_s, "launches": int(n[dom]), "windows_per_launch": per[0],
-                           "algorithmic_bytes_per_launch": nbytes,
-                           "share_of_profiled_solve": float(ms[dom] / max(sum(ms[:7]), 1e-12))}
-        w_ref = uniq[0]
+                pmc = {}
+
+        def kernel_line(i):
+            """roofline entry of launch group i: HBM-bound unless its algorithmic intensity is beyond the ridge (peak flops / peak bytes)"""
+            nb = sum(algorithmic_bytes(w, names[i], fp_bytes) for w in wl0)
+            nf = sum(algorithmic_flops(w, names[i]) for w in wl0)
+            avg_s = 1e-3 * ms[i] / max(int(n[i]), 1)
+            kname = kmap.get(names[i], names[i])
+            traffic = pmc.get(kname, {}).get(str(per[0]), {}).get("traffic_bytes")
+            compute = nf / max(nb, 1) > pk * 1e12 / (HBM_PEAK_GBS * 1e9)
+            ach = nf / avg_s / 1e12 if compute else nb / avg_s / 1e9
+            peak = pk if compute else HBM_PEAK_GBS
+            return {"kernel": kname, "bound": "mfma" if compute else "hbm", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s" if compute else "GB/s", "frac": ach / peak, "traffic": traffic, "avg_launch_us": 1e6 * avg_s,
+                    "launches": int(n[i]), "windows_per_launch": per[0], "algorithmic_bytes_per_launch": nb,
+                    "algorithmic_flops_per_launch": nf, "share_of_profiled_solve": float(ms[i] / max(sum(ms[:7]), 1e-12))}
+
+        dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
+        out["roofline"] = kernel_line(dom)
+        out["roofline"]["measured"] = "HIP events on the solver's stream around every launch, other handles idle"
+        out["roofline_kernels"] = [kernel_line(i) for i in sorted(range(6), key=lambda i: -ms[i]) if n[i] > 0 and names[i] in kmap]
         fl = w_ref.P * (w_ref.P + 1) * w_ref.L * per[0]      # SYRK count (SURVEY 8d)
         avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
-        pk = MFMA_PEAK_TFLOPS["fp64" if args.precision == "fp64" else "fp32"]
         out["roofline_mfma"] = {"kernel": kmap["k_schur_mfma"], "bound": "mfma", "achieved": fl / avg_schur / 1e12, "peak": pk,
                                 "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / pk, "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
         out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}   # handle 0 only
@@ -271,7 +318,7 @@ def main():
                                    "sample": f"{nsamp} solves of {args.config} windows (seeds 1000..{1000 + nsamp - 1}), fp64 C oracle "
                                              f"(oracle/ctvo.c, gcc -O2), 1 thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
             # the same windows as they came out of the timed path (handle 0 holds local windows 0.. = uniq[0..]): end-to-end solve
-            run_handle(0, False)
+            run_handle_steps(0, 1, False)
             q, p, b, r, ld = outs[0]
             errs, k0, f0, l0 = [], 0, 0, 0
             for j in range(min(nsamp, per[0])):
