@@ -640,7 +640,7 @@ template <class T> class SolverImpl : public SolverBase {
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n[ctvio] imu_linearize clock64 deltas:");
       for (int i = 33; i < 48; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
-      std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | rounds | imu tiles | H flush | g flush):");
+      std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | per item of rounds 0, 1: staged, run products.., scatter | rounds | imu tiles | H flush | g flush):");
       for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n");
     }

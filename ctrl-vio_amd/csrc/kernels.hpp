@@ -1117,16 +1117,45 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   T *stage = reinterpret_cast<T *>(Hs + ((nH + 3) & ~3));     // [NW][SROWS][CHP]
   int *keys = reinterpret_cast<int *>(stage + NW * SROWS * CHP);        // [NW][2][CH]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < nH; i += 512) Hs[i] = 0.0;
+  const int per_round = NW * nparts;
+  // IMU group tiles (knot x knot part, 24 x 24 per group, overlapping between consecutive segments): the loads of this wave's
+  // first NGI groups are issued before the LDS Hessian is zeroed and added right after -- at the end of the kernel they
+  // were three exposed memory round trips (24 k of 243 k cycles, measured)
+  constexpr int NGI = 3;
+  T tv[NGI][9];
+  int gs_[NGI], gb_[NGI];
+  if (LDSH) {
+#pragma unroll
+    for (int u = 0; u < NGI; ++u) {
+      const int gi = min(part * NW + wave + u * per_round, max(ngrp - 1, 0));
+      const ImuGroup grp = d.groups[grp0 + gi];
+      gs_[u] = grp.s; gb_[u] = grp.bias;
+      const T *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; tv[u][q] = ngrp > 0 ? tile[(e / 24) * 32 + e % 24] : T(0); }
+    }
+  }
+  for (int i = 2 * tid; i < ((nH + 3) & ~3); i += 1024) *reinterpret_cast<double2 *>(Hs + i) = double2{0.0, 0.0};
   __syncthreads();
+  if (LDSH) {
+#pragma unroll
+    for (int u = 0; u < NGI; ++u) {
+      if (part * NW + wave + u * per_round >= ngrp) continue;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int e = lane + 64 * q, a = e / 24, b = e % 24;
+        const int ga = imu_col(a, gs_[u], K, gb_[u]), gb = imu_col(b, gs_[u], K, gb_[u]);
+        if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], (double)tv[u][q]);
+      }
+    }
+  }
   T *Js = stage + wave * SROWS * CHP;
   int *ks = keys + wave * 2 * CH;
   const size_t V = (size_t)d.Vtot;
-  const int per_round = NW * nparts;
-  // LDSH: items dealt round-robin over the waves of the window.  !LDSH: every wave owns a contiguous range of items, so a
-  // run that continues into the wave's next item keeps its accumulators and is scattered (global atomics) once.
-  const int it0 = LDSH ? 0 : (int)((long long)nvitem * (part * NW + wave) / per_round);
-  const int rounds = LDSH ? (nvitem + per_round - 1) / per_round : (int)((long long)nvitem * (part * NW + wave + 1) / per_round) - it0;
+  // every wave owns a contiguous range of items: a run that continues into the wave's next item keeps its accumulators
+  // and is scattered once (the scatter costs as much as the products of an item: ~5 k cycles, measured)
+  const int it0 = (int)((long long)nvitem * (part * NW + wave) / per_round);
+  const int rounds = (int)((long long)nvitem * (part * NW + wave + 1) / per_round) - it0;
   double *Hg = d.Hpp + m.H0;
   const int q4 = lane >> 4, l15 = lane & 15, bsel = q4 >> 1, rr = q4 & 1;   // MFMA k index = 2 * (block of the pair) + residual row
   const int sc = lane % CH, srr = lane / CH;                               // staging: column (block) and row parity of this lane
@@ -1149,7 +1178,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   // full memory round trip in front of every item's J~ request
   int my_start, my_count;
   {
-    const int it = LDSH ? (lane * nparts + part) * NW + wave : it0 + lane;
+    const int it = it0 + lane;
     const VisItem I = d.vitems[vitem0 + min(it, max(nvitem - 1, 0))];   // clamped: always a valid descriptor
     my_start = I.start;
     my_count = (lane < rounds && it < nvitem) ? I.count : 0;
@@ -1158,7 +1187,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
     int istart, icount;
     if (r < 64) { istart = __shfl(my_start, r); icount = __shfl(my_count, r); }
     else {
-      const int it = LDSH ? (r * nparts + part) * NW + wave : it0 + r;
+      const int it = it0 + r;
       const VisItem I = d.vitems[vitem0 + min(it, nvitem - 1)];
       istart = I.start; icount = (r < rounds && it < nvitem) ? I.count : 0;
     }
@@ -1272,6 +1301,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       Js[(24 + 48 * side + rem) * CHP + sc] = side ? -(cv * pv) : cv * pv;
     }
     __builtin_amdgcn_wave_barrier();
+    if (r < 2) CTV_STAMP();
     fetch(r + 1);
     int start = 0;
     while (start < ncur) {
@@ -1279,8 +1309,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       const bool diff = (lane > start && lane < ncur) && (ks[lane] != si || ks[CH + lane] != sj);
       const unsigned long long mask = __ballot(diff);
       const int end = mask ? (__ffsll((long long)mask) - 1) : ncur;
-      if (LDSH) reset_acc();
-      else if (asi != si || asj != sj) {     // a run that continues from the previous item keeps accumulating
+      if (asi != si || asj != sj) {     // a run that continues from the previous item keeps accumulating
         if (asi >= 0) scatter(asi, asj);
         reset_acc();
         asi = si; asj = sj;
@@ -1316,16 +1345,17 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
           prl += rv[s] * ldv[s];
         }
       }
-      if (LDSH) scatter(si, sj);
+      if (r < 2) CTV_STAMP();
       start = end;
     }
+    if (r < 2) CTV_STAMP();
   }
-  if (!LDSH && asi >= 0) scatter(asi, asj);
+  if (asi >= 0) scatter(asi, asj);
   __syncthreads();
   CTV_STAMP();
   // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments); without the LDS
   // Hessian k_assemble_imu adds them
-  for (int gi = part * NW + wave; LDSH && gi < ngrp; gi += per_round) {
+  for (int gi = part * NW + wave + NGI * per_round; LDSH && gi < ngrp; gi += per_round) {   // groups beyond the prefetched ones
     const ImuGroup grp = d.groups[grp0 + gi];
     const T *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
     T tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
@@ -1340,21 +1370,28 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   }
   __syncthreads();
   CTV_STAMP();
-  for (int i = tid; LDSH && i < nHh; i += 512) {
-    const double hv = Hs[i];
-    if (nparts > 1 && hv == 0.0) continue;
-    int ga, gb;
-    if (i < tri) {
-      ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
-      while ((ga + 1) * (ga + 2) / 2 <= i) ++ga;
-      while (ga * (ga + 1) / 2 > i) --ga;
-      gb = i - ga * (ga + 1) / 2;
-    } else {
-      ga = P - 1;
-      gb = (i - tri) < K6 ? (i - tri) : P - 1;
+  for (int i0 = tid; LDSH && i0 < nHh; i0 += 4 * 512) {     // 4 entries per trip: the LDS reads first, then decode + store
+    double hv4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hv4[u] = Hs[min(i0 + 512 * u, nHh - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 512 * u;
+      const double hv = hv4[u];
+      if (i >= nHh || (nparts > 1 && hv == 0.0)) continue;
+      int ga, gb;
+      if (i < tri) {
+        ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
+        ga += ((ga + 1) * (ga + 2) / 2 <= i) ? 1 : 0;      // the float estimate is off by at most one either way
+        ga -= (ga * (ga + 1) / 2 > i) ? 1 : 0;
+        gb = i - ga * (ga + 1) / 2;
+      } else {
+        ga = P - 1;
+        gb = (i - tri) < K6 ? (i - tri) : P - 1;
+      }
+      if (nparts > 1) atomicAdd(&Hg[(long long)ga * ldh + gb], hv);
+      else Hg[(long long)ga * ldh + gb] = hv;  // first writer after k_zero_normal; later kernels add atomically
     }
-    if (nparts > 1) atomicAdd(&Hg[(long long)ga * ldh + gb], hv);
-    else Hg[(long long)ga * ldh + gb] = hv;  // first writer after k_zero_normal; later kernels add atomically
   }
   CTV_STAMP();
   for (int i = tid; i < K6 + 1; i += 512) {
