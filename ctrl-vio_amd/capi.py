@@ -76,7 +76,7 @@ class Summary(C.Structure):
 # every symbol include/ctvio.h declares (tests check the .so exports all of them)
 SYMBOLS = ["ctvio_default_options", "ctvio_status_string", "ctvio_last_error", "ctvio_device_count", "ctvio_create",
            "ctvio_destroy", "ctvio_clear", "ctvio_add_window", "ctvio_upload", "ctvio_set_batch", "ctvio_num_windows", "ctvio_solve",
-           "ctvio_get_state", "ctvio_get_batch_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_gauge_restore", "ctvio_marginalize", "ctvio_marginalize_batch", "ctvio_residual_summary",
+           "ctvio_get_state", "ctvio_get_batch_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_sensor_pose", "ctvio_gauge_restore", "ctvio_marginalize", "ctvio_marginalize_batch", "ctvio_residual_summary",
            "ctvio_last_timing", "ctvio_set_profiling", "ctvio_stream"]
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library():
         lib.ctvio_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.ctvio_lm_step.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
         lib.ctvio_spline_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
+        lib.ctvio_sensor_pose.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
         lib.ctvio_marginalize.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double] + [C.c_void_p] * 4
         lib.ctvio_marginalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
         lib.ctvio_residual_summary.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

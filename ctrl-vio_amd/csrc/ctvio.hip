@@ -94,7 +94,8 @@ struct SolverBase {
   virtual int linearize(int id, double *Hpp, double *W, double *Hll, double *g, double *cost) = 0;
   virtual int cost(int id, double *cost) = 0;
   virtual int lm_step(int id, double mu, double *delta, double *mc) = 0;
-  virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) = 0;
+  virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3,
+                          const double *q_SI = nullptr, const double *p_SI = nullptr) = 0;
   virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
   virtual int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
   virtual int marginalize_batch(const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
@@ -131,7 +132,10 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (sizeof(T) == 8) HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (sizeof(T) == 8) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
@@ -187,7 +191,7 @@ template <class T> class SolverImpl : public SolverBase {
     t0_.resize(nw);
     int64_t H0 = 0, W0 = 0, pH0 = 0;
     int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0;
-    int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0;
+    int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0, maxK = 0;
     size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     for (int wi = 0; wi < nw; ++wi) {
       const ctvio_window &w = *wins[wi];
@@ -216,7 +220,7 @@ template <class T> class SolverImpl : public SolverBase {
       G0 += m.ngrp; I0 += m.nvitem;
       H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)w.pn * w.pn;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, w.pn);
-      maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw);
+      maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw); maxK = std::max(maxK, m.K);
     }
     const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
     if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
@@ -371,7 +375,7 @@ template <class T> class SolverImpl : public SolverBase {
     Dev<T> &d = dev_;
     std::memset(&d, 0, sizeof d);
     d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0;
-    d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw;
+    d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw; maxK_ = maxK;
     d.wins = CTV_D(WinMeta, o_meta);
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
@@ -942,7 +946,16 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipGetLastError());
     return CTVIO_OK;
   }
-  int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) override {
+  int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3, const double *q_SI,
+                  const double *p_SI) override {
+    SensorExt ext{};
+    if (q_SI && p_SI) {
+      const double nq = std::sqrt(q_SI[0] * q_SI[0] + q_SI[1] * q_SI[1] + q_SI[2] * q_SI[2] + q_SI[3] * q_SI[3]);
+      if (!(nq > 0.0) || !std::isfinite(nq)) return fail(CTVIO_ERR_INVALID, "sensor extrinsic: quaternion must be non-zero and finite");
+      for (int i = 0; i < 4; ++i) ext.q[i] = q_SI[i] / nq;
+      for (int i = 0; i < 3; ++i) ext.p[i] = p_SI[i];
+      ext.on = 1;
+    }
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin || n < 0 || (n && !t_ns)) return fail(CTVIO_ERR_INVALID, "bad arguments");
     if (n == 0) return CTVIO_OK;
@@ -958,7 +971,7 @@ template <class T> class SolverImpl : public SolverBase {
     double *dp = reinterpret_cast<double *>(ds + o_out), *dv = dp + (pose7 ? (size_t)7 * n : 0), *dw = dv + (vel3 ? (size_t)3 * n : 0),
            *da = dw + (omega3 ? (size_t)3 * n : 0);
     hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, n, reinterpret_cast<const long long *>(ds),
-                       pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr, reinterpret_cast<int *>(ds + o_err));
+                       pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr, reinterpret_cast<int *>(ds + o_err), ext);
     HIPCHK(hipMemcpyAsync(hs + o_err, ds + o_err, 16 + nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
@@ -1017,6 +1030,7 @@ template <class T> class SolverImpl : public SolverBase {
   Dev<T> graph_dev_;
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
+  int maxK_ = 0;
 };
 
 template <> void SolverImpl<float>::launch_imu_linearize(size_t lds) {
@@ -1076,8 +1090,10 @@ template <> void SolverImpl<double>::launch_schur() {
     // large batches: one workgroup per window, W staged through LDS once, reduced rhs produced on the way; small batches: one
     // wave per 16 x 16 tile (shorter latency, W re-read per tile), k_rhs forms the reduced right-hand side
     const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
-    if (!small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024) {
-      hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
+    if (!small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224) {
+      if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+      else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       schur_rhs_done_ = true;
     } else {
       const int nt2 = (d.maxP + 15) / 16, ntile2 = nt2 * (nt2 + 1) / 2;
@@ -1174,6 +1190,11 @@ int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, cons
 }
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) {
   CHK_S; return s->impl->spline_eval(id, n, t_ns, pose7, vel3, omega3, acc3);
+}
+int32_t ctvio_sensor_pose(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, const double *q_SI, const double *p_SI, double *pose7) {
+  CHK_S;
+  if (!q_SI || !p_SI || (n && !pose7)) return ctv::fail(CTVIO_ERR_INVALID, "ctvio_sensor_pose: null argument");
+  return s->impl->spline_eval(id, n, t_ns, pose7, nullptr, nullptr, nullptr, q_SI, p_SI);
 }
 int32_t ctvio_last_timing(ctvio_solver *s, double *ms8, int32_t *launches8) { CHK_S; return s->impl->last_timing(ms8, launches8); }
 int32_t ctvio_snapshot_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(0); }

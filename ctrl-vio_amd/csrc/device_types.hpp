@@ -35,6 +35,9 @@ struct VisItem { int32_t start, count; };  // start = global visual block index
 struct ImuGroup { int32_t win, s, bias, start, count; };
 
 // Per-window Levenberg-Marquardt state (Ceres 1.14 TrustRegionMinimizer variables).
+// sensor-to-IMU extrinsic applied by k_spline_eval when on != 0 (reference ExtrinsicParam::se3)
+struct SensorExt { double q[4]; double p[3]; int on; };
+
 struct Lm {
   double cost, cand_cost, initial_cost;
   double mu, nu;               // trust-region radius, decrease factor

@@ -1447,8 +1447,12 @@ template <class T> __global__ __launch_bounds__(64) void k_build_W(Dev<T> d) {
   }
   __builtin_amdgcn_wave_barrier();
   if (valid) {
+    // only the knot columns [0, 6K) and the line-delay column P - 1 can be non-zero; the bias and padding columns were
+    // zeroed once at upload and are never written (35% of the row at K = 24)
     T *Wr = d.W + W0 + (long long)l * ldw;
-    for (int i = lane; i < ldw; i += 64) Wr[i] = (T)row[i];
+    const int K6 = 6 * m.K;
+    for (int i = lane; i < K6; i += 64) Wr[i] = (T)row[i];
+    if (lane == 0) Wr[P - 1] = (T)row[P - 1];
     if (lane == 49) d.Hll[lm0 + l] = hll;
     if (lane == 50) d.g[u0 + P + l] = gl;
   }
@@ -1851,13 +1855,23 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   f64x4 acc[NTQ];
 #pragma unroll
   for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const int nchunk = (L + 15) >> 4, nel = 16 * ldw;
+  // Only the knot columns [0, 6K), the line-delay column P - 1 and the appended g_rho column P are fetched and staged (NC
+  // compact columns per landmark); every other column of the two LDS buffers is zeroed once and stays zero.
+  const int nchunk = (L + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
+  for (int e = tid; e < 2 * nel; e += 512) Wb[e] = 0.0;
   double pre[NPRE];
   double pre_d = 0.0;
+  int pre_lr[NPRE], pre_c[NPRE];     // chunk row and window column of this thread's elements (the same for every chunk)
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int e = min(tid + 512 * k, nelc - 1), cc = e % NC;
+    pre_lr[k] = e / NC;
+    pre_c[k] = cc < K6 ? cc : P - 1 + (cc - K6);
+  }
   auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int e = min(tid + 512 * k, nel - 1), l = min(16 * ch + e / ldw, L - 1), c = e % ldw;
+      const int l = min(16 * ch + pre_lr[k], L - 1), c = pre_c[k];
       pre[k] = (c == P) ? gl[l] : Wp[(long long)l * ldw + c];
     }
     if (tid < 16) pre_d = dinv[min(16 * ch + tid, L - 1)];
@@ -1865,14 +1879,13 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   auto stash = [&](int ch, int buf) {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int e = min(tid + 512 * k, nel - 1);
-      const int lr = e / ldw, c = e % ldw;
+      const int lr = pre_lr[k], c = pre_c[k];
       const bool lv = 16 * ch + lr < L;
-      Wb[buf * nel + e] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0;
+      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0;
     }
     if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
   };
-  __syncthreads();   // acts
+  __syncthreads();   // acts, zeroed buffers
   if (nchunk > 0) { fetch(0); stash(0, 0); }
   __syncthreads();
   for (int ch = 0; ch < nchunk; ++ch) {
@@ -2311,21 +2324,25 @@ template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
     const int lrow = min(l0 + (lane >> 3), L - 1);
     const double g_l = g[P + lrow], dinv_l = d.dinv[lm0 + lrow];
     const bool act_l = d.active[u0 + P + lrow] != 0;
-    for (int i0 = 0; i0 < P; i0 += 256) {
+    // W is non-zero in the knot columns [0, 6K) and the line-delay column P - 1 only: NCB compact columns
+    const int K6 = 6 * m.K, NCB = K6 + 1;
+    for (int i0 = 0; i0 < NCB; i0 += 256) {
       T wv[8][4];
+      int col[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int cc = min(i0 + lane + 64 * k, NCB - 1); col[k] = cc < K6 ? cc : P - 1; }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           // clamped, unconditional loads (a predicated load compiles to branch + load + s_waitcnt: one round trip EACH);
           // out-of-range columns are masked through xi below, out-of-range rows are never written
-          const int i = min(i0 + lane + 64 * k, P - 1), l = min(l0 + u, L - 1);
-          wv[u][k] = Wp[(long long)l * ldw + i];
+          const int l = min(l0 + u, L - 1);
+          wv[u][k] = Wp[(long long)l * ldw + col[k]];
         }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = i0 + lane + 64 * k;
-        const double xi = i < P ? xs[i] : 0.0;
+        const double xi = (i0 + lane + 64 * k < NCB) ? xs[col[k]] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc8[u] += (double)wv[u][k] * xi;
       }
@@ -2628,7 +2645,7 @@ template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev
 // Se3Spline::poseNs / transVelWorld / rotVelBody / transAccelWorld (se3_spline.h:361-399), fp64, one lane per query.
 template <class T>
 __global__ void k_spline_eval(Dev<T> d, int w, int n, const long long *t_rel, double *pose7, double *vel3, double *omega3, double *acc3,
-                              int *err) {
+                              int *err, SensorExt ext) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const WinMeta &m = d.wins[w];
@@ -2643,11 +2660,15 @@ __global__ void k_spline_eval(Dev<T> d, int w, int n, const long long *t_rel, do
   seg_const(k, sc, false);
   const double idt = m.inv_dt;
   if (pose7) {
-    const Q4<double> q = eval_R(k.q, sc, u);
     double c[4];
     basis<double, false, 0>(u, 1.0, c);
     V3<double> p = mk<double>(0, 0, 0);
     for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
+    Q4<double> q = eval_R(k.q, sc, u);
+    if (ext.on) {   // Trajectory::GetSensorPose (trajectory.cpp:39-56): pose_S_to_G = pose_I_to_G * T_StoI
+      p = p + qrot(q, mk<double>(ext.p[0], ext.p[1], ext.p[2]));
+      q = qmul(q, qmk<double>(ext.q[0], ext.q[1], ext.q[2], ext.q[3]));
+    }
     double *o = pose7 + 7 * (size_t)i;
     o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
   }

@@ -240,6 +240,15 @@ class Solver:
         capi.check(self._lib.ctvio_spline_eval(self._h, wid, n, capi._p(t), capi._p(pose), capi._p(vel), capi._p(om), capi._p(acc)))
         return pose, vel, om, acc
 
+    def sensor_pose(self, wid: int, t_ns, q_SI, p_SI):
+        """Trajectory::GetSensorPose (reference src/spline/trajectory.cpp:39-56): poseNs(t) * T_StoI, evaluated on the device.
+        q_SI = (x,y,z,w).  Returns (n,7) = (p, q)."""
+        t = np.ascontiguousarray(t_ns, np.int64)
+        q = np.ascontiguousarray(q_SI, np.float64).reshape(4); p = np.ascontiguousarray(p_SI, np.float64).reshape(3)
+        pose = np.zeros((t.shape[0], 7))
+        capi.check(self._lib.ctvio_sensor_pose(self._h, wid, int(t.shape[0]), capi._p(t), capi._p(q), capi._p(p), capi._p(pose)))
+        return pose
+
     PHASES = ("k_imu_linearize", "k_vis_eval", "k_assemble_vis", "assemble_rest", "k_schur_mfma", "k_cholesky_solve", "rest", "solve")
 
     def set_profiling(self, on: bool):

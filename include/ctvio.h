@@ -174,6 +174,11 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3,
                           double *omega3, double *acc3);
 
+/* Sensor pose on the device: Trajectory::GetSensorPose (src/spline/trajectory.cpp:39-56; used for the camera by
+ * visual_odometry.cpp:197-221): pose_S_to_G(t) = poseNs(t) * T_StoI with T_StoI = (q_SI = (x,y,z,w), p_SI).  pose7 as above.
+ * A query outside [minTimeNs, maxTimeNs) is an error (the reference asserts). */
+int32_t ctvio_sensor_pose(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, const double *q_SI, const double *p_SI, double *pose7);
+
 /* Prior construction for the next window (reference MarginalizationInfo::preMarginalize / marginalize,
  * src/estimator/factor/analytic_diff/marginalization_factor.cpp:106-265, driven by TrajectoryEstimator::
  * PrepareMarginalizationInfo / SaveMarginalizationInfo, trajectory_estimator.cpp:143-204).  Window `id` holds the factors

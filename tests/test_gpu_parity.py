@@ -214,6 +214,38 @@ def test_spline_eval(cv, oracle, win_cfg1):
             s.spline_eval(0, np.array([w.max_time_ns()], np.int64))
 
 
+def test_sensor_pose(cv, oracle, win_cfg1):
+    """ctvio_sensor_pose = Trajectory::GetSensorPose (trajectory.cpp:39-56): pose_I_to_G(t) * T_StoI, against the oracle's
+    poseNs composed with the reference's camera extrinsic on the host (numpy, fp64)."""
+    w = win_cfg1.copy()
+    t = np.linspace(w.t0_ns, w.max_time_ns() - 1, 129).astype(np.int64)
+    pose = oracle.OracleWindow(w.copy()).spline_eval(t)[0]
+    q_SI = np.asarray(w.q_CI, float); p_SI = np.asarray(w.p_CI, float)
+
+    def qmul(a, b):
+        ax, ay, az, aw = a.T; bx, by, bz, bw = b.T
+        return np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], -1)
+
+    def qrot(q, v):
+        qv = np.concatenate([np.broadcast_to(v, (q.shape[0], 3)), np.zeros((q.shape[0], 1))], 1)
+        qc = q * np.array([-1.0, -1.0, -1.0, 1.0])
+        return qmul(qmul(q, qv), qc)[:, :3]
+
+    q = pose[:, 3:7]
+    ref = np.concatenate([pose[:, :3] + qrot(q, p_SI), qmul(q, np.broadcast_to(q_SI / np.linalg.norm(q_SI), q.shape))], 1)
+    with cv.Solver() as s:
+        s.set_windows([w])
+        got = s.sensor_pose(0, t, q_SI, p_SI)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-11)
+        ident = s.sensor_pose(0, t, [0, 0, 0, 1], [0, 0, 0])
+        np.testing.assert_allclose(ident, pose, rtol=1e-12, atol=1e-11)
+        with pytest.raises(cv.capi.CtvioError):
+            s.sensor_pose(0, np.array([w.max_time_ns()], np.int64), q_SI, p_SI)
+        with pytest.raises(cv.capi.CtvioError):
+            s.sensor_pose(0, t, [0, 0, 0, 0], p_SI)
+
+
 def test_config3_rolling_shutter_stress(cv, oracle):
     """BASELINE configs[3]: 300 landmarks, 640-row images, 30 us line delay (every block's two ends evaluate at their own
     per-row times), line delay estimated from 0.  These windows are NOT converged after Ceres' 15 iterations, so the 15th
