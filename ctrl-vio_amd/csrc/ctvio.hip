@@ -135,6 +135,7 @@ template <class T> class SolverImpl : public SolverBase {
     if (sizeof(T) == 8) {
       HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return CTVIO_OK;
   }
@@ -191,7 +192,7 @@ template <class T> class SolverImpl : public SolverBase {
     t0_.resize(nw);
     int64_t H0 = 0, W0 = 0, pH0 = 0;
     int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0;
-    int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0, maxK = 0;
+    int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0, maxK = 0, maxSchurTiles = 0;
     size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     for (int wi = 0; wi < nw; ++wi) {
       const ctvio_window &w = *wins[wi];
@@ -221,6 +222,17 @@ template <class T> class SolverImpl : public SolverBase {
       H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)w.pn * w.pn;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, w.pn);
       maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw); maxK = std::max(maxK, m.K);
+      {   // 16 x 16 tiles of the reduced system that receive Schur products (k_schur_window_f64): knot columns, line delay, rhs row
+        const int ntl = m.ldw / 16, K6 = 6 * m.K;
+        int cnt = 0;
+        for (int ti = 0; ti < ntl; ++ti)
+          for (int tj = 0; tj <= ti; ++tj) {
+            const bool nzr = (16 * ti < K6) || (m.P >= 16 * ti && m.P - 1 < 16 * ti + 16);
+            const bool nzc = (16 * tj < K6) || (m.P - 1 >= 16 * tj && m.P - 1 < 16 * tj + 16);
+            cnt += (nzr && nzc) ? 1 : 0;
+          }
+        maxSchurTiles = std::max(maxSchurTiles, cnt);
+      }
     }
     const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
     if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
@@ -375,7 +387,7 @@ template <class T> class SolverImpl : public SolverBase {
     Dev<T> &d = dev_;
     std::memset(&d, 0, sizeof d);
     d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0;
-    d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw; maxK_ = maxK;
+    d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw; maxK_ = maxK; max_schur_tiles_ = maxSchurTiles;
     d.wins = CTV_D(WinMeta, o_meta);
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
@@ -1030,7 +1042,7 @@ template <class T> class SolverImpl : public SolverBase {
   Dev<T> graph_dev_;
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
-  int maxK_ = 0;
+  int maxK_ = 0, max_schur_tiles_ = 0;
 };
 
 template <> void SolverImpl<float>::launch_imu_linearize(size_t lds) {
@@ -1086,13 +1098,14 @@ template <> void SolverImpl<double>::launch_schur() {
   schur_rhs_done_ = false;
   if (opt_.use_mfma) {   // fp64 matrix cores
     const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
-    const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32) * sizeof(double);
+    const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32 + 64) * sizeof(double);   // + the list of tiles with products
     // large batches: one workgroup per window, W staged through LDS once, reduced rhs produced on the way; small batches: one
     // wave per 16 x 16 tile (shorter latency, W re-read per tile), k_rhs forms the reduced right-hand side
     const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
     const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
     if (!small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224) {
-      if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+      if (16 * nc <= 5 * 512 && max_schur_tiles_ <= 56) hipLaunchKernelGGL((k_schur_window_f64<5, 7>), dim3(d.nwin), dim3(512), lds, stream_, d);
+      else if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       schur_rhs_done_ = true;
     } else {

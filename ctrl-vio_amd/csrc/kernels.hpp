@@ -1825,8 +1825,8 @@ template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_wave
 // from HBM once, staged through LDS in double-buffered chunks of 16 landmarks (masked by the active flags, g_rho appended as
 // column P so that the tile row holding index P also produces the reduced right-hand side: no k_rhs pass).  Output tiles are
 // 16 x 16 (v_mfma_f64_16x16x4_f64, K = 4 landmarks per instruction); tile t of the lower triangle belongs to wave t % 8, which
-// keeps its <= NTQ accumulators in registers over the whole landmark loop; tiles over bias-only columns skip the products.
-// NPRE = chunk elements per thread (16 ldw / 512); NTQ = ceil(ntile / 8).
+// keeps its <= NTQ accumulators in registers over the whole landmark loop; tiles over bias-only columns have no products.
+// NPRE = compact chunk elements per thread (16 (6K + 2) / 512 rounded up); NTQ = ceil(tiles with products / 8).
 template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_window_f64(Dev<double> d) {
   const int w = blockIdx.x;
   if (d.lm[w].status || d.lm[w].ls_active) return;
@@ -1837,24 +1837,24 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   double *Wb = smd64;                    // [2][16][ldw]
   double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)
   double *dch = acts + ldw;              // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
+  int *tlist = reinterpret_cast<int *>(dch + 32);   // [8 NTQ] tiles with products (bi << 8 | bj), any order
+  int &tcount = tlist[8 * NTQ];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
   const double *Wp = d.W + m.W0;
   const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
   for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0 : 0.0;
-  int bi[NTQ], bj[NTQ];
-  bool run[NTQ];
-#pragma unroll
-  for (int q = 0; q < NTQ; ++q) {
-    const int t = wave + 8 * q;
-    tile_decode(min(t, ntile - 1), bi[q], bj[q]);
-    // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P)
-    const bool nz_i = (16 * bi[q] < K6) || (P >= 16 * bi[q] && P - 1 < 16 * bi[q] + 16);
-    const bool nz_j = (16 * bj[q] < K6) || (P - 1 >= 16 * bj[q] && P - 1 < 16 * bj[q] + 16);
-    run[q] = t < ntile && nz_i && nz_j;
+  if (tid == 0) tcount = 0;
+  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P - 1 (plus the rhs row P): a tile has products
+  // when its row tile and its column tile both hold such a column.  Those tiles (55 of 105 at K = 24) are listed and dealt to
+  // the waves; the others only need the epilogue (S = Hpp + D).
+  auto nz_row = [&](int b) { return (16 * b < K6) || (P >= 16 * b && P - 1 < 16 * b + 16); };
+  auto nz_col = [&](int b) { return (16 * b < K6) || (P - 1 >= 16 * b && P - 1 < 16 * b + 16); };
+  __syncthreads();   // tcount
+  for (int t = tid; t < ntile; t += 512) {
+    int ti, tj;
+    tile_decode(t, ti, tj);
+    if (nz_row(ti) && nz_col(tj)) { const int pos = atomicAdd(&tcount, 1); if (pos < 8 * NTQ) tlist[pos] = (ti << 8) | tj; }
   }
-  f64x4 acc[NTQ];
-#pragma unroll
-  for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
   // Only the knot columns [0, 6K), the line-delay column P - 1 and the appended g_rho column P are fetched and staged (NC
   // compact columns per landmark); every other column of the two LDS buffers is zeroed once and stays zero.
   const int nchunk = (L + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
@@ -1885,25 +1885,36 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
     }
     if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
   };
-  __syncthreads();   // acts, zeroed buffers
+  __syncthreads();   // acts, zeroed buffers, tile list
+  const int nact = min(tcount, 8 * NTQ);
+  // this wave's tiles: slot q holds list entry wave + 8 q; slots past the end repeat the wave's first tile (products computed,
+  // result dropped) so that the tile loop below has no branches and the operand reads of a tile overlap the previous products
+  int offa[NTQ], offb[NTQ];
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) {
+    const int e = tlist[(wave + 8 * q < nact) ? wave + 8 * q : min(wave, max(nact - 1, 0))];
+    offa[q] = 16 * (e >> 8) + l15;
+    offb[q] = 16 * (e & 255) + l15;
+  }
+  f64x4 acc[NTQ];
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
   if (nchunk > 0) { fetch(0); stash(0, 0); }
   __syncthreads();
-  for (int ch = 0; ch < nchunk; ++ch) {
+  for (int ch = 0; ch < nchunk && nact > 0; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) fetch(ch + 1);
-    const double *B = Wb + buf * nel;
+    const double *B = Wb + buf * nel + q4 * ldw;
     double dl[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
 #pragma unroll
     for (int q = 0; q < NTQ; ++q) {
-      if (!run[q]) continue;   // wave-uniform
       double a[4], b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int l = 4 * s + q4;
-        a[s] = B[l * ldw + 16 * bi[q] + l15];
-        b[s] = B[l * ldw + 16 * bj[q] + l15];
+        a[s] = B[4 * s * ldw + offa[q]];
+        b[s] = B[4 * s * ldw + offb[q]];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
@@ -1914,30 +1925,40 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
   double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
   const double *H = d.Hpp + m.H0;
-#pragma unroll
-  for (int q = 0; q < NTQ; ++q) {
-    if (wave + 8 * q >= ntile) continue;
-    const int jj = 16 * bj[q] + l15, jc = min(jj, P - 1);
+  auto write_tile = [&](int ti, int tj, const f64x4 &av) {
+    const int jj = 16 * tj + l15, jc = min(jj, P - 1);
     const bool act_j = d.active[u0 + jc] != 0;
     const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
     double hv[4];
     unsigned char act_i[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ic = min(16 * bi[q] + q4 + 4 * r, P - 1);
+      const int ic = min(16 * ti + q4 + 4 * r, P - 1);
       act_i[r] = d.active[u0 + ic];
       hv[r] = H[(long long)ic * ldh + min(jc, ic)];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ii = 16 * bi[q] + q4 + 4 * r;
+      const int ii = 16 * ti + q4 + 4 * r;
       if (ii < P && jj <= ii) {
         const bool on = act_i[r] && act_j;
-        S[(long long)ii * ldh + jj] = on ? hv[r] - acc[q][r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+        S[(long long)ii * ldh + jj] = on ? hv[r] - av[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
       } else if (ii == P && jj < P) {
-        rhs[jj] = act_j ? acc[q][r] - g_j : 0.0;
+        rhs[jj] = act_j ? av[r] - g_j : 0.0;
       }
     }
+  };
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) {
+    if (wave + 8 * q >= nact) continue;
+    write_tile((offa[q] - l15) >> 4, (offb[q] - l15) >> 4, acc[q]);
+  }
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  for (int t = wave; t < ntile; t += 8) {     // tiles without products
+    int ti, tj;
+    tile_decode(t, ti, tj);
+    if (nz_row(ti) && nz_col(tj)) continue;
+    write_tile(ti, tj, zero4);
   }
 }
 
