@@ -1827,7 +1827,7 @@ template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_wave
 // 16 x 16 (v_mfma_f64_16x16x4_f64, K = 4 landmarks per instruction); tile t of the lower triangle belongs to wave t % 8, which
 // keeps its <= NTQ accumulators in registers over the whole landmark loop; tiles over bias-only columns have no products.
 // NPRE = compact chunk elements per thread (16 (6K + 2) / 512 rounded up); NTQ = ceil(tiles with products / 8).
-template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_window_f64(Dev<double> d) {
+template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2) void k_schur_window_f64(Dev<double> d) {
   const int w = blockIdx.x;
   if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
@@ -1839,7 +1839,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   double *dch = acts + ldw;              // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
   int *tlist = reinterpret_cast<int *>(dch + 32);   // [8 NTQ] tiles with products (bi << 8 | bj), any order
   int &tcount = tlist[8 * NTQ];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
   const double *Wp = d.W + m.W0;
   const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
   for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0 : 0.0;
@@ -1861,17 +1861,16 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   for (int e = tid; e < 2 * nel; e += 512) Wb[e] = 0.0;
   double pre[NPRE];
   double pre_d = 0.0;
-  int pre_lr[NPRE], pre_c[NPRE];     // chunk row and window column of this thread's elements (the same for every chunk)
+  int pre_lc[NPRE];     // chunk row << 16 | window column of this thread's elements (the same for every chunk)
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) {
     const int e = min(tid + 512 * k, nelc - 1), cc = e % NC;
-    pre_lr[k] = e / NC;
-    pre_c[k] = cc < K6 ? cc : P - 1 + (cc - K6);
+    pre_lc[k] = ((e / NC) << 16) | (cc < K6 ? cc : P - 1 + (cc - K6));
   }
   auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int l = min(16 * ch + pre_lr[k], L - 1), c = pre_c[k];
+      const int l = min(16 * ch + (pre_lc[k] >> 16), L - 1), c = pre_lc[k] & 0xffff;
       pre[k] = (c == P) ? gl[l] : Wp[(long long)l * ldw + c];
     }
     if (tid < 16) pre_d = dinv[min(16 * ch + tid, L - 1)];
@@ -1879,7 +1878,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   auto stash = [&](int ch, int buf) {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int lr = pre_lr[k], c = pre_c[k];
+      const int lr = pre_lc[k] >> 16, c = pre_lc[k] & 0xffff;
       const bool lv = 16 * ch + lr < L;
       if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0;
     }
@@ -1889,13 +1888,9 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   const int nact = min(tcount, 8 * NTQ);
   // this wave's tiles: slot q holds list entry wave + 8 q; slots past the end repeat the wave's first tile (products computed,
   // result dropped) so that the tile loop below has no branches and the operand reads of a tile overlap the previous products
-  int offa[NTQ], offb[NTQ];
+  int tij[NTQ];
 #pragma unroll
-  for (int q = 0; q < NTQ; ++q) {
-    const int e = tlist[(wave + 8 * q < nact) ? wave + 8 * q : min(wave, max(nact - 1, 0))];
-    offa[q] = 16 * (e >> 8) + l15;
-    offb[q] = 16 * (e & 255) + l15;
-  }
+  for (int q = 0; q < NTQ; ++q) tij[q] = __builtin_amdgcn_readfirstlane(tlist[(wave + 8 * q < nact) ? wave + 8 * q : min(wave, max(nact - 1, 0))]);   // SGPRs
   f64x4 acc[NTQ];
 #pragma unroll
   for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -1904,7 +1899,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
   for (int ch = 0; ch < nchunk && nact > 0; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) fetch(ch + 1);
-    const double *B = Wb + buf * nel + q4 * ldw;
+    const double *B = Wb + buf * nel + q4 * ldw + l15;
     double dl[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
@@ -1913,8 +1908,8 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
       double a[4], b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[s] = B[4 * s * ldw + offa[q]];
-        b[s] = B[4 * s * ldw + offb[q]];
+        a[s] = B[4 * s * ldw + 16 * (tij[q] >> 8)];
+        b[s] = B[4 * s * ldw + 16 * (tij[q] & 255)];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
@@ -1951,7 +1946,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512) void k_schur_wind
 #pragma unroll
   for (int q = 0; q < NTQ; ++q) {
     if (wave + 8 * q >= nact) continue;
-    write_tile((offa[q] - l15) >> 4, (offb[q] - l15) >> 4, acc[q]);
+    write_tile(tij[q] >> 8, tij[q] & 255, acc[q]);
   }
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
   for (int t = wave; t < ntile; t += 8) {     // tiles without products
