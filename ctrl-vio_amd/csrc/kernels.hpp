@@ -2083,38 +2083,63 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
 // MFMA register layout (measured, tools/mfma_f64_layout.hip): A operand lane l = A[l%16][l/16], B operand lane l =
 // B[l/16][l%16], D register r of lane l = D[(l/16) + 4r][l%16].
 
-// One elimination step of the fused factorisation / inversion (see k_cholesky_solve): s = a_j of lane C (two
-// v_readlane into a fixed SGPR pair), then a_c -= a_j s and x_c -= x_j s.  Written as one asm block so the broadcast
-// value lives for exactly these instructions (left to the compiler, every broadcast was spilled and reloaded).
-template <int C> __device__ __forceinline__ void chol_bcast_update(double &ac, double &xc, double aj, double xj, int aj_lo, int aj_hi) {
-  asm volatile("v_readlane_b32 s96, %4, %6\n\tv_readlane_b32 s97, %5, %6\n\ts_nop 1\n\t"
-               "v_fma_f64 %0, -%2, s[96:97], %0\n\tv_fma_f64 %1, -%3, s[96:97], %1"
-               : "+v"(ac), "+v"(xc)
-               : "v"(aj), "v"(xj), "v"(aj_lo), "v"(aj_hi), "n"(C)
-               : "s96", "s97");
+// Diagonal block of k_cholesky_solve: factorisation fused with the inversion, on ONE register array.  Lanes 0-31 hold the rows
+// of the block (v[c] = A[lane][c]), lanes 32-63 the columns of X = L11^-1 in the making (v[c] = X[c][lane - 32], identity at the
+// start).  The rank-1 update of pivot J, a_c -= a_J s with s = L[C][J] = v[J] of lane C, is also the substitution step
+// x_c -= x_J s of the inverse: one v_readlane pair and ONE v_fma per (J, C) serve both halves of the wave.
+// One update as an asm block so that the broadcast value lives for exactly these instructions (left to the compiler, every
+// broadcast was spilled and reloaded).
+template <int C> __device__ __forceinline__ void chol_bcast_update(double &vc, double vj, int vj_lo, int vj_hi) {
+  asm("v_readlane_b32 s96, %2, %4\n\tv_readlane_b32 s97, %3, %4\n\ts_nop 1\n\t"
+      "v_fma_f64 %0, -%1, s[96:97], %0"
+      : "+v"(vc)
+      : "v"(vj), "v"(vj_lo), "v"(vj_hi), "n"(C)
+      : "s96", "s97");
 }
-template <int J, int... Cs>
-__device__ __forceinline__ void chol_row_updates(double (&a)[32], double (&xa)[32], double xj, std::integer_sequence<int, Cs...>) {
-  const int lo = __double2loint(a[J]), hi = __double2hiint(a[J]);
-  (chol_bcast_update<J + 1 + Cs>(a[J + 1 + Cs], xa[J + 1 + Cs], a[J], xj, lo, hi), ...);
+// The same for the first column after the pivot, whose result feeds the next pivot's v_readlane straight away: gfx950 needs a
+// wait state between a VALU write of a VGPR and a v_readlane of it (and between the compiler's scaling of v[J] and the first
+// v_readlane here); the hazard recogniser cannot see into an asm block, so the s_nops are spelled out.
+template <int C> __device__ __forceinline__ void chol_bcast_update_first(double &vc, double vj, int vj_lo, int vj_hi) {
+  asm("s_nop 1\n\tv_readlane_b32 s96, %2, %4\n\tv_readlane_b32 s97, %3, %4\n\ts_nop 1\n\t"
+      "v_fma_f64 %0, -%1, s[96:97], %0\n\ts_nop 1"
+      : "+v"(vc)
+      : "v"(vj), "v"(vj_lo), "v"(vj_hi), "n"(C)
+      : "s96", "s97");
 }
-template <int J> __device__ __forceinline__ void chol_diag_step(double (&a)[32], double (&xa)[32], int &bad) {
-  const double pj = readlane_d(a[J], J);
+// 1 / sqrt(p) of the pivot: hardware estimate + two Newton steps (short dependent chain instead of sqrt + divide)
+__device__ __forceinline__ double chol_pivot_rsqrt(double pj, int &bad) {
   const bool ok = (pj > 0.0) && isfinite(pj);
   if (!ok) bad = 1;
-  // 1/sqrt(pj): hardware estimate + two Newton steps (short dependent chain instead of sqrt + divide)
   const double ps = ok ? pj : 1.0;
   double di = __builtin_amdgcn_rsq(ps);
   const double hp = 0.5 * ps;
   di = di * (1.5 - hp * di * di);
   di = di * (1.5 - hp * di * di);
-  a[J] *= di;                     // lane J: sqrt(pj); lanes > J: L[i][J]  (lanes < J hold unused upper-triangle values)
-  const double xj = xa[J] * di;   // X[J][lane], final: every k < J has been eliminated
-  xa[J] = xj;
-  chol_row_updates<J>(a, xa, xj, std::make_integer_sequence<int, 31 - J>{});
+  return di;
 }
-template <int... Js> __device__ __forceinline__ void chol_diag_all(double (&a)[32], double (&xa)[32], int &bad, std::integer_sequence<int, Js...>) {
-  (chol_diag_step<Js>(a, xa, bad), ...);
+template <int J, int... Cs>
+__device__ __forceinline__ void chol_row_updates(double (&v)[32], int lo, int hi, std::integer_sequence<int, Cs...>) {
+  (chol_bcast_update<J + 2 + Cs>(v[J + 2 + Cs], v[J], lo, hi), ...);
+}
+// Pivot J with its 1 / sqrt already known (di): scale column J, update column J + 1 first, start the NEXT pivot's reciprocal
+// square root from it (its dependent chain of ~10 fp64 operations then overlaps the remaining updates), update the rest.
+template <int J> __device__ __forceinline__ double chol_diag_step(double (&v)[32], double di, int &bad) {
+  v[J] *= di;   // lanes < 32: lane J sqrt(p_J), lanes > J L[i][J]; lanes >= 32: X[J][.], final (every k < J has been eliminated)
+  const int lo = __double2loint(v[J]), hi = __double2hiint(v[J]);
+  double di_next = 0.0;
+  if constexpr (J < 31) {
+    chol_bcast_update_first<J + 1>(v[J + 1], v[J], lo, hi);
+    di_next = chol_pivot_rsqrt(readlane_d(v[J + 1], J + 1), bad);
+    if constexpr (J < 30) chol_row_updates<J>(v, lo, hi, std::make_integer_sequence<int, 30 - J>{});
+  }
+  return di_next;
+}
+template <int J> __device__ __forceinline__ void chol_diag_from(double (&v)[32], double di, int &bad) {
+  const double dn = chol_diag_step<J>(v, di, bad);
+  if constexpr (J < 31) chol_diag_from<J + 1>(v, dn, bad);
+}
+__device__ __forceinline__ void chol_diag_all(double (&v)[32], int &bad) {
+  chol_diag_from<0>(v, chol_pivot_rsqrt(readlane_d(v[0], 0), bad), bad);
 }
 template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev<T> d) {
   const int w = blockIdx.x;
@@ -2147,36 +2172,32 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0, ntr = nt + 1;  // ntr: trailing rows incl. the rhs row
     const int RS = (ntr + 15) & ~15, ntile = RS >> 4;
     if (wave == 0) {
-      // ---- diagonal block: lanes >= nb (last, partial block) carry identity rows
-      double a[32];
+      // ---- diagonal block: lanes 0-31 the rows (lanes >= nb of the last, partial block carry identity rows), lanes 32-63 the
+      //      columns of the inverse (identity)
+      double v[32];
       {
         // the block is in LDS: the first one staged below, the later ones left there by the previous trailing update
 #pragma unroll
         for (int c = 0; c < 32; c += 2) {
           const VecN<double, 2> v2 = *reinterpret_cast<const VecN<double, 2> *>(Lb + (lane & 31) * 34 + c);
-          a[c] = v2.v[0]; a[c + 1] = v2.v[1];
+          v[c] = v2.v[0]; v[c + 1] = v2.v[1];
         }
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
           const bool in = lane < nb && c < nb && c <= lane;
-          a[c] = in ? a[c] : ((c == lane && lane < 32) ? 1.0 : 0.0);
+          v[c] = in ? v[c] : ((c == (lane & 31)) ? 1.0 : 0.0);
         }
       }
       int bad = 0;
-      // Right-looking factorisation fused with the inversion X = L11^-1 (lane = column of X, forward substitution):
-      // the multiplier L[c][j] = readlane(a[j], c) of the rank-1 update is also the coefficient of the substitution
-      // x_c -= L[c][j] x_j, so one v_readlane pair feeds two FMAs and no LDS round trip sits on the critical path.
-      double xa[32];
-#pragma unroll
-      for (int i = 0; i < 32; ++i) xa[i] = (i == lane) ? 1.0 : 0.0;
-      chol_diag_all(a, xa, bad, std::make_integer_sequence<int, 32>{});
+      chol_diag_all(v, bad);
       // (L11 itself is not written back: the back-substitution uses the stored inverse, nothing else reads it)
-      if (lane < 32) {
+      if (lane >= 32) {
+        const int col = lane - 32;
         double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;   // kept for the back-substitution
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-          LiT[lane * 34 + i] = xa[i];   // LiT[k = lane][j = i] = Linv[i][lane]
-          gi[i * 32 + lane] = xa[i];    // row-major Linv[i][lane]
+          LiT[col * 34 + i] = v[i];   // LiT[k = col][j = i] = Linv[i][col]
+          gi[i * 32 + col] = v[i];    // row-major Linv[i][col]
         }
       }
       if (lane == 0 && bad) s_fail = 1;
