@@ -63,8 +63,8 @@ def algorithmic_bytes(w, phase, fp_bytes):
     if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (r, compact J~) out + the landmark row (54)
         return V * (284 + (68 + 54) * fp_bytes)
     if phase == "k_assemble_vis":    # compact J~ and r~ read once (the depth column is not needed) + keys + packed fp64 Hessian flushed once
-        K6 = 6 * K
-        return V * (66 * fp_bytes + 8) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8
+        K6 = 6 * K   # + the knot x knot part (24 x 24) of every IMU group tile, added into the same LDS Hessian
+        return V * (66 * fp_bytes + 8) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
     if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
         return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
     if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written
@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--config", default="config2")
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--precision", default="fp64", help="fp64 = the product (all-fp64); fp32 = the mixed fast mode (no 1e-4 contract)")
-    ap.add_argument("--parity-sample", type=int, default=16, help="windows solved by the CPU oracle (state error of the timed path + cpu_baseline)")
+    ap.add_argument("--parity-sample", type=int, default=48, help="windows solved by the CPU oracle (state error of the timed path + cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams + host threads) per GPU")
     ap.add_argument("--gpu-slots", type=int, default=0, help="handles allowed inside ctvio_solve at once (0: half of the streams, at least 1)")
