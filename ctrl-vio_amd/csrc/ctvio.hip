@@ -412,8 +412,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_kd = seg(8 * 3 * (size_t)K0), o_ckd = seg(8 * 3 * (size_t)K0), o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
     const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
     const size_t o_imu_rc = mixed_ ? seg(sizeof(T) * 6 * Mt) : 0, o_vis_rc = mixed_ ? seg(sizeof(T) * 3 * Vt) : 0;
-    const size_t o_Jp = seg(sizeof(T) * 14 * Vt);
-    const size_t o_Jv = seg(sizeof(T) * 100 * Vt), o_rv = seg(sizeof(T) * 2 * Vt), o_vs = seg(4 * 2 * Vt), o_Wc = seg(sizeof(T) * WC_STRIDE * Vt);
+    const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt), o_Wc = seg(sizeof(T) * WC_STRIDE * Vt);
     const size_t o_Hpp = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
     const size_t o_W = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_g = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
@@ -431,8 +430,7 @@ template <class T> class SolverImpl : public SolverBase {
     snap_ = CTV_W(double, o_snap);
     d.kd = CTV_W(double, o_kd); d.ckd = CTV_W(double, o_ckd); d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
     if (mixed_) { d.imu_rc = CTV_W(T, o_imu_rc); d.vis_rc = CTV_W(T, o_vis_rc); }
-    d.Jp = CTV_W(T, o_Jp);
-    d.Jv = CTV_W(T, o_Jv); d.rv = CTV_W(T, o_rv); d.vs = CTV_W(int32_t, o_vs); d.Wc = CTV_W(T, o_Wc);
+    d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs); d.Wc = CTV_W(T, o_Wc);
     d.Hpp = CTV_W(double, o_Hpp); d.S = CTV_W(double, o_S); d.W = CTV_W(T, o_W); d.Hll = CTV_W(double, o_Hll); d.g = CTV_W(double, o_g);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
     d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;

@@ -36,6 +36,7 @@ struct ImuGroup { int32_t win, s, bias, start, count; };
 
 // Per-window Levenberg-Marquardt state (Ceres 1.14 TrustRegionMinimizer variables).
 // sensor-to-IMU extrinsic applied by k_spline_eval when on != 0 (reference ExtrinsicParam::se3)
+constexpr int VT_ROWS = 68;   // rows of a visual tile (Dev::Jt)
 struct SensorExt { double q[4]; double p[3]; int on; };
 
 struct Lm {
@@ -90,9 +91,11 @@ template <class T> struct Dev {
   const int32_t *v_rowi, *v_rowj;
   const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
   const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
-  T *Jv;                 // [100][Vtot] robust-corrected Jacobian, entry (2*col + row); the 48 position rows are never touched:
-  T *Jp;                 // [14][Vtot] their compact form: P~ (2 x 3), cp0[4], cp1[4]  (J~_pos(k, b) = cp0[k] P~[b] / -cp1[k] P~[b])
-  T *rv;                 // [2][Vtot]
+  T *Jt;                 // robust-corrected visual Jacobian + residual, tiles of 64 blocks: [ceil(Vtot / 64)][VT_ROWS][64], so that a
+                         // wave of k_vis_eval writes ONE contiguous 34 KB region (68 row arrays Vtot apart meant 68 DRAM pages per wave).
+                         // Tile rows: 0-23 rotation columns of the i end (2 col + residual row), 24-47 of the j end, 48/49 inverse
+                         // depth, 50/51 line delay, 52/53 residual, 54-67 the position columns in compact form: P~ (2 x 3), cp0[4],
+                         // cp1[4]  (J~_pos(k, b) = cp0[k] P~[b] / -cp1[k] P~[b])
   T *vis_rc;             // [3][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc) and the block's
                          // sqrt(rho') = exp(-cost / a^2) from that fp64 evaluation (row 2)
   T *Wc;                 // [Vtot][WC_STRIDE] per block, rows in LANDMARK order (row v_slot[v]): J~_rho^T J~_c (49 pose columns),

@@ -736,36 +736,39 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
 // is local column c (0..49) one of the 24 position columns (i-end 12..23, j-end 36..47)?  Those are not materialised:
 // J~[c] = cp0[k] P~[b] / -cp1[k] P~[b], rebuilt from the 14 numbers of Jp by the assembly kernels.
 __device__ __forceinline__ constexpr bool vis_pos_col(int c) { return (c >= 12 && c < 24) || (c >= 36 && c < 48); }
+// Tile row of staging row `row` = 2 * column + residual row (< 100) of a materialised (non-position) column, and the offset of
+// block v's entries inside Dev::Jt (+ 64 * tile row)
+__device__ __forceinline__ constexpr int vis_trow(int row) { return row < 24 ? row : (row < 72 ? row - 24 : row - 48); }
+__device__ __forceinline__ unsigned vis_tbase(unsigned v) { return (v >> 6) * (unsigned)(VT_ROWS * 64) + (v & 63u); }
 template <class T> struct VisGlobalSink {
-  T *J;        // Jv (uniform): row r of the materialised Jacobian starts at J + r * stride (rotation, depth, line-delay columns)
-  T *Jp;       // [14][stride]: P~ (rows 2 b + residual row), cp0[4], cp1[4]
-  size_t stride;
+  T *J;        // Dev::Jt + vis_tbase(v): tile row r of this lane's block is J[64 r]
   T *wc;       // LDS row of this lane: J_rho^T J_c for the 49 pose columns (slot 48 = line delay), then Hll, g_rho
   T jr0, jr1;
-  unsigned v;  // this lane's block: uniform row base + one 32-bit lane offset (no 64-bit address per store)
   __device__ __forceinline__ void put(int col, T j0, T j1) {
-    if (!vis_pos_col(col)) { (J + (size_t)(2 * col) * stride)[v] = j0; (J + (size_t)(2 * col + 1) * stride)[v] = j1; }
+    if (!vis_pos_col(col)) { J[64 * vis_trow(2 * col)] = j0; J[64 * (vis_trow(2 * col) + 1)] = j1; }
     if (col == 48) { jr0 = j0; jr1 = j1; }                       // visual_eval emits the inverse-depth column first
     else wc[col < 48 ? col : 48] = jr0 * j0 + jr1 * j1;
   }
   __device__ __forceinline__ void put_pos(const T Pt[6], const T cp0[4], const T cp1[4]) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) (Jp + (size_t)i * stride)[v] = Pt[i];
+    for (int i = 0; i < 6; ++i) J[64 * (54 + i)] = Pt[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { (Jp + (size_t)(6 + i) * stride)[v] = cp0[i]; (Jp + (size_t)(10 + i) * stride)[v] = cp1[i]; }
+    for (int i = 0; i < 4; ++i) { J[64 * (60 + i)] = cp0[i]; J[64 * (64 + i)] = cp1[i]; }
   }
 };
 template <class T> struct VisNullSink {
   __device__ __forceinline__ void put(int, T, T) {}
   __device__ __forceinline__ void put_pos(const T *, const T *, const T *) {}
 };
-// J~ entry (staging row = 2 * column + residual row, < 100) of block v from the compact storage
-template <class T> __device__ __forceinline__ T vis_J_entry(const T *Jv, const T *Jp, size_t V, int row, size_t v) {
+// J~ entry (staging row = 2 * column + residual row, < 100; 100 / 101 = the residual) of block v from the tile storage
+template <class T> __device__ __forceinline__ T vis_J_entry(const T *Jt, int row, unsigned v) {
+  const T *J = Jt + vis_tbase(v);
+  if (row >= 100) return J[64 * (52 + row - 100)];
   const int col = row >> 1, rr = row & 1;
-  if (!vis_pos_col(col)) return Jv[(size_t)row * V + v];
+  if (!vis_pos_col(col)) return J[64 * vis_trow(row)];
   const int c = col < 24 ? col - 12 : col - 36, kk = c / 3, b = c % 3;
-  const T pt = Jp[(size_t)(2 * b + rr) * V + v];
-  return col < 24 ? Jp[(size_t)(6 + kk) * V + v] * pt : -Jp[(size_t)(10 + kk) * V + v] * pt;
+  const T pt = J[64 * (54 + 2 * b + rr)];
+  return col < 24 ? J[64 * (60 + kk)] * pt : -J[64 * (64 + kk)] * pt;
 }
 
 // time -> (first active knot, u) in integer ns (reference spline_segment.h:83-85); the line delay is
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisGlobalSink<T> sink{d.Jv, d.Jp, V, wcs + 55 * threadIdx.x, T(0), T(0), (unsigned)v};
+        VisGlobalSink<T> sink{d.Jt + vis_tbase((unsigned)v), wcs + 55 * threadIdx.x, T(0), T(0)};
         wcs_on[threadIdx.x] = d.v_slot[v];
         if (sizeof(RT) != sizeof(T)) cal.sq_override = d.vis_rc[2 * V + v];   // robust scale of the fp64 residual pass
         SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
         sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
         sink.wc[50] = sink.jr0 * r[0] + sink.jr1 * r[1];
         sink.wc[51] = (T)si; sink.wc[52] = (T)sj;   // knot segments travel with the row (exact in fp32)
-        d.rv[v] = r[0]; d.rv[V + v] = r[1];
+        sink.J[64 * 52] = r[0]; sink.J[64 * 53] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
       } else {
         RT rd[2];
@@ -877,9 +880,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
   }
   if (LIN) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * WC_STRIDE; i += 64) {
-      const int bl = i / WC_STRIDE, cc = i % WC_STRIDE, slot = wcs_on[bl];
-      if (slot >= 0 && cc < 53) d.Wc[(size_t)WC_STRIDE * slot + cc] = wcs[55 * bl + cc];
+    // rows of WC_STRIDE entries, 6 entries per lane and trip (the LDS reads first, then the stores)
+    for (int i0 = threadIdx.x; i0 < 64 * WC_STRIDE; i0 += 6 * 64) {
+      T tv[6];
+      int dsti[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = min(i0 + 64 * u, 64 * WC_STRIDE - 1), bl = i / WC_STRIDE, cc = i % WC_STRIDE, slot = wcs_on[bl];
+        tv[u] = wcs[55 * bl + cc];
+        dsti[u] = (slot >= 0 && cc < 53 && i0 + 64 * u < 64 * WC_STRIDE) ? WC_STRIDE * slot + cc : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u)
+        if (dsti[u] >= 0) d.Wc[(size_t)dsti[u]] = tv[u];
     }
   } else {
     const int w0 = __shfl(w, 0);
@@ -955,7 +968,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       for (int i = 0; i < NPASS; ++i) {
         const int row = i * RPP + rr;
         tmp[i] = T(0);
-        if (row < 102 && c < n) tmp[i] = (row < 100) ? vis_J_entry<T>(d.Jv, d.Jp, V, row, (size_t)(v0 + c)) : d.rv[(size_t)(row - 100) * V + v0 + c];
+        if (row < 102 && c < n) tmp[i] = vis_J_entry<T>(d.Jt, row, (unsigned)(v0 + c));
       }
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
@@ -1197,18 +1210,15 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
     const int c = sc < icount ? sc : 0;
     // address = uniform row base (SGPR pair) + one 32-bit lane offset shared by all passes: pass i covers staged rows
     // RPP i .. RPP i + RPP - 1, the lane's row inside the pass is srr  (64-bit per-lane addresses would cost 2 VGPRs per load)
-    const unsigned loff = (unsigned)srr * (unsigned)V + (unsigned)(v0 + c);
+    // source row q of this lane in pass i = RPP i + srr: rotation rows (q < 48) sit at tile row q, line delay / residual /
+    // compact position data (48 <= q < 66) at tile row q + 2 (the inverse-depth rows 48, 49 are skipped); 24 and 48 are
+    // multiples of RPP, so the shift is the same for a whole pass.  One 32-bit lane offset, the pass offset is a constant.
+    const unsigned loff = vis_tbase((unsigned)(v0 + c)) + 64u * (unsigned)srr;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int q0 = i * RPP, q1 = q0 + RPP;                                              // source rows of this pass
-      if (q1 <= 24) tmp[i] = (d.Jv + (size_t)q0 * V)[loff];                               // rotation columns, i end
-      else if (q0 >= 24 && q1 <= 48) tmp[i] = (d.Jv + (size_t)(q0 + 24) * V)[loff];       // rotation columns, j end
-      else if (q0 >= 52 && q1 <= NSRC) tmp[i] = (d.Jp + (size_t)(q0 - 52) * V)[loff];     // compact position data
-      else {                                                                               // a pass across two arrays
-        const int q = min(q0 + srr, NSRC - 1);
-        const T *src = q < 50 ? d.Jv + (size_t)(q + 50) * V : q < 52 ? d.rv + (size_t)(q - 50) * V : d.Jp + (size_t)(q - 52) * V;
-        tmp[i] = src[v0 + c];
-      }
+      const int q0 = i * RPP;
+      if (q0 + RPP <= NSRC) tmp[i] = d.Jt[loff + 64u * (unsigned)(q0 + (q0 >= 48 ? 2 : 0))];
+      else tmp[i] = d.Jt[vis_tbase((unsigned)(v0 + c)) + 64u * (unsigned)(min(q0 + srr, NSRC - 1) + 2)];   // last, partial pass
     }
     const int kc = lane < icount ? lane : 0;
     key_i = d.vs[v0 + kc];
