@@ -2156,13 +2156,14 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
   Lm &lm = d.lm[w];
   if (lm.status || lm.ls_active) return;
   const WinMeta &m = d.wins[w];
-  const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) double smc[];
   double *Lb = smc;                 // [32][34] NEXT diagonal block (row-major), deposited by the trailing update of the current panel
   double *LiT = Lb + 32 * 34;       // [32][34] L11^-1 transposed: LiT[k][j] = Linv[j][k]
   double *dinvs = LiT + 32 * 34;    // [32] 1 / L_jj
   double *yb = dinvs + 32;          // [32]
   int &s_fail = *reinterpret_cast<int *>(yb + 32);
+  int &s_trip = reinterpret_cast<int *>(yb + 32)[1];   // next unclaimed tile of the trailing update
   double *LpT = yb + 34;            // [32][RS] panel (+ rhs row) k-major: LpT[k][r]
   double *S = d.S + m.H0;
   double *y = d.rhs + m.p0;         // augmented row; becomes L^-1 rhs
@@ -2178,42 +2179,45 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
 #define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
   CTV_STAMP();
   const int q4 = lane >> 4, l15 = lane & 15;
+  // ---- diagonal block at column jb (one wave): lanes 0-31 the rows (lanes >= nb of the last, partial block carry identity
+  //      rows), lanes 32-63 the columns of the inverse (identity).  The block is in LDS (Lb): the first one staged above, the
+  //      later ones left there by the trailing update.  Result: LiT (LDS) and chol_inv (HBM, for the back-substitution); L11
+  //      itself is not written back, nothing reads it.
+  auto diag_block = [&](int jb) {
+    const int nb = min(32, P - jb);
+    double v[32];
+#pragma unroll
+    for (int c = 0; c < 32; c += 2) {
+      const VecN<double, 2> v2 = *reinterpret_cast<const VecN<double, 2> *>(Lb + (lane & 31) * 34 + c);
+      v[c] = v2.v[0]; v[c + 1] = v2.v[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const bool in = lane < nb && c < nb && c <= lane;
+      v[c] = in ? v[c] : ((c == (lane & 31)) ? 1.0 : 0.0);
+    }
+    int bad = 0;
+    chol_diag_all(v, bad);
+    if (lane >= 32) {
+      const int col = lane - 32;
+      double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        LiT[col * 34 + i] = v[i];   // LiT[k = col][j = i] = Linv[i][col]
+        gi[i * 32 + col] = v[i];    // row-major Linv[i][col]
+      }
+    }
+    if (lane == 0 && bad) s_fail = 1;
+  };
   for (int jb = 0; jb < P; jb += 32) {
     const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0, ntr = nt + 1;  // ntr: trailing rows incl. the rhs row
     const int RS = (ntr + 15) & ~15, ntile = RS >> 4;
-    if (wave == 0) {
-      // ---- diagonal block: lanes 0-31 the rows (lanes >= nb of the last, partial block carry identity rows), lanes 32-63 the
-      //      columns of the inverse (identity)
-      double v[32];
-      {
-        // the block is in LDS: the first one staged below, the later ones left there by the previous trailing update
-#pragma unroll
-        for (int c = 0; c < 32; c += 2) {
-          const VecN<double, 2> v2 = *reinterpret_cast<const VecN<double, 2> *>(Lb + (lane & 31) * 34 + c);
-          v[c] = v2.v[0]; v[c + 1] = v2.v[1];
-        }
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          const bool in = lane < nb && c < nb && c <= lane;
-          v[c] = in ? v[c] : ((c == (lane & 31)) ? 1.0 : 0.0);
-        }
-      }
-      int bad = 0;
-      chol_diag_all(v, bad);
-      // (L11 itself is not written back: the back-substitution uses the stored inverse, nothing else reads it)
-      if (lane >= 32) {
-        const int col = lane - 32;
-        double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;   // kept for the back-substitution
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          LiT[col * 34 + i] = v[i];   // LiT[k = col][j = i] = Linv[i][col]
-          gi[i * 32 + col] = v[i];    // row-major Linv[i][col]
-        }
-      }
-      if (lane == 0 && bad) s_fail = 1;
-    } else {
-      // ---- waves 1-3: panel rows (and the rhs row) into the LDS panel, LpT[k][r]
-      for (int r = tid - 64; r < RS; r += 192) {
+    // ---- panel rows (and the rhs row) into the LDS panel, LpT[k][r].  First panel: wave 0 factors the diagonal block
+    //      meanwhile; the later diagonal blocks were factored during the previous trailing update (look-ahead, below).
+    {
+      const int first = jb == 0 ? 64 : 0, nthr = 256 - first;
+      if (jb == 0 && wave == 0) diag_block(0);
+      for (int r = tid - first; r >= 0 && r < RS; r += nthr) {
         const double *src = (r < nt) ? S + (long long)(r0 + r) * ldh + jb : y + jb;
         double tmp[32];
 #pragma unroll
@@ -2223,6 +2227,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
         for (int k = 0; k < 32; ++k) LpT[k * RS + r] = (live && k < nb) ? tmp[k] : 0.0;
       }
     }
+    if (tid == 0) s_trip = 4;   // wave 0 starts with tiles 0-3 (they hold the next diagonal block)
     // LDS-only barrier: what the next phase reads (LiT, LpT) is in LDS; wave 0's global stores of the block inverse may
     // stay in flight (a full __syncthreads would wait for them; they are read after later full barriers only)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
@@ -2253,15 +2258,23 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     }
     __syncthreads();
     CTV_STAMP();
-    // ---- trailing update A22 -= L21 L21^T on the lower triangle (16 x 16 tiles) and the rhs row
+    // ---- trailing update A22 -= L21 L21^T on the lower triangle (16 x 16 tiles) and the rhs row.  Trips of 4 consecutive
+    //      tiles are claimed from an LDS counter.  Wave 0 takes tiles 0-3 first -- (0,0), (1,0), (1,1) are the next diagonal
+    //      block, left in Lb -- then factors that block (LOOK-AHEAD: 21 k cycles on one wave that used to sit between the
+    //      panels with three waves idle) while the other waves work through the rest, then joins them.
     const int ntt = nt > 0 ? ntile * (ntile + 1) / 2 : 0;   // last panel: nothing left to update
-    // (requesting the next trip's S values before the current products was tried: register spills made it slower)
-    for (int tb = wave; tb < ntt; tb += 16) {   // 4 tiles per wave and trip: 16 loads in flight, 32 MFMAs, 16 stores
+    // (requesting the next trip's S values before the current products was tried: no gain, it is bandwidth not latency)
+    bool first_trip = wave == 0;
+    while (true) {   // 4 tiles per trip: 16 loads in flight, 32 MFMAs, 16 stores
+      int tb;
+      if (first_trip) tb = 0;
+      else tb = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(&s_trip, 4) : 0);
+      if (tb >= ntt) break;
       double sv[4][4];
       int ti4[4], tj4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        tile_decode(min(tb + 4 * u, ntt - 1), ti4[u], tj4[u]);
+        tile_decode(min(tb + u, ntt - 1), ti4[u], tj4[u]);
         const int col = 16 * tj4[u] + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2283,13 +2296,18 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ti4[u] + q4 + 4 * r;
-          if (tb + 4 * u < ntt && col < nt && ((row < nt && col <= row) || row == nt)) {
+          if (tb + u < ntt && col < nt && ((row < nt && col <= row) || row == nt)) {
             double *dst = (row < nt) ? S + (long long)(r0 + row) * ldh + r0 : y + r0;
             const double nv = sv[u][r] - c[r];
             dst[col] = nv;
             if (row < 32 && row < nt) Lb[row * 34 + col] = nv;   // tiles (0,0), (1,0), (1,1): the next diagonal block
           }
         }
+      }
+      if (first_trip) {
+        first_trip = false;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's Lb writes
+        diag_block(r0);
       }
     }
     __syncthreads();
