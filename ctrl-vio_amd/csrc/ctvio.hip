@@ -127,7 +127,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipStreamCreate(&stream_));
     for (auto &e : ev_) HIPCHK(hipEventCreate(&e));
     // kernels that need more than 64 KiB of dynamic LDS
-    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -539,7 +540,9 @@ template <class T> class SolverImpl : public SolverBase {
       ph_end();
     }
     ph_begin(PH_CHOL);
-    hipLaunchKernelGGL((k_cholesky_solve<T>), dim3(nw), dim3(256), chol_lds_, stream_, d);
+    // fewer windows than CUs: 8 waves per window (latency); otherwise 4, two windows per CU (throughput)
+    if (nw <= 192) hipLaunchKernelGGL((k_cholesky_solve<T, 8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
+    else hipLaunchKernelGGL((k_cholesky_solve<T, 4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
     hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);

@@ -2151,7 +2151,10 @@ template <int J> __device__ __forceinline__ void chol_diag_from(double (&v)[32],
 __device__ __forceinline__ void chol_diag_all(double (&v)[32], int &bad) {
   chol_diag_from<0>(v, chol_pivot_rsqrt(readlane_d(v[0], 0), bad), bad);
 }
-template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev<T> d) {
+// NW waves per window: 4 for large batches (two windows share a CU), 8 when there are fewer windows than CUs (the parallel
+// phases -- L21, trailing update, staging -- go twice as fast; the diagonal blocks hide behind the trailing updates).
+template <class T, int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev<T> d) {
+  constexpr int NT = 64 * NW;
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
   if (lm.status || lm.ls_active) return;
@@ -2169,7 +2172,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
   double *y = d.rhs + m.p0;         // augmented row; becomes L^-1 rhs
   double *x = d.delta + m.u0;
   if (tid == 0) s_fail = 0;
-  for (int e = tid; e < 32 * 32; e += 256) {   // first diagonal block -> LDS (rows / columns clamped; masked when read)
+  for (int e = tid; e < 32 * 32; e += NT) {   // first diagonal block -> LDS (rows / columns clamped; masked when read)
     const int r = e >> 5, c = e & 31;
     Lb[r * 34 + c] = S[(long long)min(r, P - 1) * ldh + min(c, P - 1)];
   }
@@ -2215,7 +2218,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     // ---- panel rows (and the rhs row) into the LDS panel, LpT[k][r].  First panel: wave 0 factors the diagonal block
     //      meanwhile; the later diagonal blocks were factored during the previous trailing update (look-ahead, below).
     {
-      const int first = jb == 0 ? 64 : 0, nthr = 256 - first;
+      const int first = jb == 0 ? 64 : 0, nthr = NT - first;
       if (jb == 0 && wave == 0) diag_block(0);
       for (int r = tid - first; r >= 0 && r < RS; r += nthr) {
         const double *src = (r < nt) ? S + (long long)(r0 + r) * ldh + jb : y + jb;
@@ -2234,7 +2237,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
     __builtin_amdgcn_s_barrier();
     CTV_STAMP();
     // ---- L21 = A21 L11^-T, in place: Linv is lower triangular, so output columns 0..15 need k < 16 only
-    for (int tr = wave; tr < ntile; tr += 4) {
+    for (int tr = wave; tr < ntile; tr += NW) {
       f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
       const double *pa = LpT + 16 * tr + l15;
 #pragma unroll
@@ -2317,7 +2320,7 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
   //      for the rows above.  x lives in LDS; per block the loads of Linv_b (wave 0) and of the panel rows (everyone) do
   //      not depend on x and are issued together, before the block solve.
   double *xs = LpT;   // the panel is no longer needed
-  for (int i = tid; i < P; i += 256) xs[i] = y[i];
+  for (int i = tid; i < P; i += NT) xs[i] = y[i];
   __syncthreads();
   const int nblk = (P + 31) / 32;
   for (int b = nblk - 1; b >= 0; --b) {
@@ -2348,14 +2351,14 @@ template <class T> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves
       for (int ii = 0; ii < 32; ++ii) sacc += lv[ii] * ((ii < nb) ? yb[ii] : 0.0);
       xs[tid] -= sacc;
     }
-    for (int j = tid + 256; j < jb; j += 256) {   // P > 256 + 32: remaining rows
+    for (int j = tid + NT; j < jb; j += NT) {   // P > NT + 32: remaining rows
       double sacc = 0.0;
       for (int ii = 0; ii < nb; ++ii) sacc += S[(long long)(jb + ii) * ldh + j] * yb[ii];
       xs[j] -= sacc;
     }
     __syncthreads();
   }
-  for (int i = tid; i < P; i += 256) x[i] = xs[i];
+  for (int i = tid; i < P; i += NT) x[i] = xs[i];
   CTV_STAMP();
   if (tid == 0) lm.chol_fail = s_fail;
 #undef CTV_STAMP
