@@ -576,17 +576,22 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
     double gy[3], ac[3], r[6];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+    // lanes past the end of the group evaluate a clamped sample with ZERO weights: every row of w .* [J | r] is then exactly
+    // zero (one select per weight instead of one per stored entry: 288 v_cndmask per pass)
+    double wl[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
     ImuJac<double> J;
-    imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, J);
+    imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, true, J);
     const int kmax = (nval + 3) & ~3;
     // ---- accelerometer rows: 32 columns, tiles (0,0), (1,0), (1,1)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
       double row[32];
-      imu_row_accel<double>(J, wgt, r, a, row);
+      imu_row_accel<double>(J, wl, r, a, row);
       __builtin_amdgcn_wave_barrier();   // the previous phase's operand reads are complete (consumed by its MFMAs)
 #pragma unroll
-      for (int c = 0; c < 32; ++c) A[lane * 33 + c] = live ? row[c] : 0.0;
+      for (int c = 0; c < 32; ++c) A[lane * 33 + c] = row[c];
       __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the rows are in LDS
       __builtin_amdgcn_wave_barrier();
       for (int k0 = 0; k0 < kmax; k0 += 4) {
@@ -600,10 +605,10 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
       double row[16];
-      imu_row_gyro<double>(J, wgt, r, a, row);
+      imu_row_gyro<double>(J, wl, r, a, row);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int c = 0; c < 16; ++c) A[lane * 17 + c] = live ? row[c] : 0.0;
+      for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       for (int k0 = 0; k0 < kmax; k0 += 4) {
