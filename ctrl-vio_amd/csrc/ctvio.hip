@@ -186,6 +186,10 @@ template <class T> class SolverImpl : public SolverBase {
         return;
       }
       plan_window(wins[wi], VCH, tmp[wi]);
+      if (!tmp[wi].err.empty()) {
+        int cur = first_bad.load();
+        while (wi < cur && !first_bad.compare_exchange_weak(cur, wi)) {}
+      }
     });
     if (first_bad.load() < nw) return fail(CTVIO_ERR_INVALID, "window " + std::to_string(first_bad.load()) + ": " + tmp[first_bad.load()].err);
     // ---- offsets (serial prefix sums)
@@ -202,7 +206,7 @@ template <class T> class SolverImpl : public SolverBase {
       m.K = w.K; m.F = w.F; m.L = w.L; m.M = w.M; m.NB = w.NB; m.V = w.V;
       m.P = 6 * w.K + 6 * w.F + 1; m.N = m.P + w.L; m.pn = w.pn; m.pnb = w.pnb;
       m.knot0 = K0; m.bias0 = F0; m.lm0 = L0; m.imu0 = M0; m.vis0 = V0; m.bc0 = B0; m.u0 = U0; m.p0 = Pp0;
-      m.grp0 = G0; m.ngrp = tmp[wi].ngrp; m.vitem0 = I0; m.nvitem = tmp[wi].nvitem;
+      m.grp0 = G0; m.ngrp = tmp[wi].ngrp; m.vitem0 = I0; m.nvitem = tmp[wi].nvitem; m.Vp = tmp[wi].Vp;
       m.ldw = (m.P + 1 + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
       m.pv0 = pv0; m.pblk0 = pb; m.fix_ld = w.fix_ld; m.lock_bg = w.lock_bg; m.lock_ba = w.lock_ba; m.fixed_upto = w.fixed_upto;
       m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.ldh = (m.P + 15) / 16 * 16; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
@@ -218,7 +222,7 @@ template <class T> class SolverImpl : public SolverBase {
         vis_lds_bytes = std::max(vis_lds_bytes, m.vis_lds ? need : need_glb);
         vis_glb_bytes = std::max(vis_glb_bytes, need_glb);
       }
-      K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += w.V; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += w.pn; pb += w.pnb;
+      K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += m.Vp; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += w.pn; pb += w.pnb;
       G0 += m.ngrp; I0 += m.nvitem;
       H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)w.pn * w.pn;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, w.pn);
@@ -249,10 +253,10 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_imu_u = seg(sizeof(T) * Mt), o_imu_meas = seg(sizeof(T) * 6 * Mt);
     const bool dup64 = sizeof(T) == 4;   // the mixed mode keeps an fp64 copy of the measurements for its residual pass
     const size_t o_imu_ud = dup64 ? seg(8 * Mt) : o_imu_u, o_imu_meas_d = dup64 ? seg(8 * 6 * Mt) : o_imu_meas;
-    const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_rowi = seg(4 * Vt), o_v_rowj = seg(4 * Vt), o_v_slot = seg(4 * Vt);
+    const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_rowi = seg(4 * Vt), o_v_rowj = seg(4 * Vt);
     const size_t o_v_ti = seg(8 * Vt), o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(T) * 4 * Vt);
     const size_t o_v_obs_d = dup64 ? seg(8 * 4 * Vt) : o_v_obs;
-    const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_lm_blk_off = seg(4 * ((size_t)L0 + 1)), o_lm_blk = seg(4 * Vt);
+    const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_vblk = seg(4 * Vt);
     const size_t o_bc_win = seg(4 * (size_t)B0), o_bc_i = seg(4 * (size_t)B0), o_bc_j = seg(4 * (size_t)B0), o_bc_w = seg(8 * 6 * (size_t)B0);
     const size_t o_pJ0 = seg(8 * (size_t)pH0), o_pr0 = seg(8 * (size_t)pv0);
     const size_t o_pH = seg(8 * (size_t)pH0), o_pb0 = seg(8 * (size_t)pv0), o_pc0 = seg(8 * (size_t)nw), o_p_x0 = seg(8 * 4 * (size_t)pb);
@@ -273,18 +277,16 @@ template <class T> class SolverImpl : public SolverBase {
     int32_t *h_imu_grp = CTV_H(int32_t, o_imu_grp);
     T *h_imu_u = CTV_H(T, o_imu_u), *h_imu_meas = CTV_H(T, o_imu_meas), *h_v_obs = CTV_H(T, o_v_obs);
     double *h_imu_ud = CTV_H(double, o_imu_ud), *h_imu_meas_d = CTV_H(double, o_imu_meas_d), *h_v_obs_d = CTV_H(double, o_v_obs_d);
-    int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_rowi = CTV_H(int32_t, o_v_rowi), *h_v_rowj = CTV_H(int32_t, o_v_rowj),
-            *h_v_slot = CTV_H(int32_t, o_v_slot);
+    int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_rowi = CTV_H(int32_t, o_v_rowi), *h_v_rowj = CTV_H(int32_t, o_v_rowj);
     int64_t *h_v_ti = CTV_H(int64_t, o_v_ti), *h_v_tj = CTV_H(int64_t, o_v_tj);
     VisItem *h_vitems = CTV_H(VisItem, o_vitems);
-    int32_t *h_lm_blk_off = CTV_H(int32_t, o_lm_blk_off), *h_lm_blk = CTV_H(int32_t, o_lm_blk);
+    int32_t *h_vblk = CTV_H(int32_t, o_vblk);
     int32_t *h_bc_win = CTV_H(int32_t, o_bc_win), *h_bc_i = CTV_H(int32_t, o_bc_i), *h_bc_j = CTV_H(int32_t, o_bc_j);
     double *h_pJ0 = CTV_H(double, o_pJ0), *h_pr0 = CTV_H(double, o_pr0);
     double *h_bc_w = CTV_H(double, o_bc_w), *h_pH = CTV_H(double, o_pH), *h_pb0 = CTV_H(double, o_pb0), *h_pc0 = CTV_H(double, o_pc0),
            *h_p_x0 = CTV_H(double, o_p_x0);
     int32_t *h_pcol = CTV_H(int32_t, o_pcol), *h_p_kind = CTV_H(int32_t, o_p_kind), *h_p_index = CTV_H(int32_t, o_p_index), *h_p_off = CTV_H(int32_t, o_p_off);
     uint8_t *h_active = CTV_H(uint8_t, o_active);
-    h_lm_blk_off[L0] = V0;
     // ---- second pass: every window fills its own slices
     parallel_for(nw, nth, [&](int wi) {
       const ctvio_window &w = *wins[wi];
@@ -317,31 +319,31 @@ template <class T> class SolverImpl : public SolverBase {
           if (dup64) { h_imu_meas_d[(size_t)c * Mt + e] = w.imu_gyro[3 * src + c]; h_imu_meas_d[(size_t)(3 + c) * Mt + e] = w.imu_acc[3 * src + c]; }
         }
       }
-      // visual blocks in frame-pair order, items of <= VCH blocks
-      int it = m.vitem0 - 1;
-      for (int i = 0; i < w.V; ++i) {
-        const int v = t.vord[i];
-        const bool fresh = (i == 0) || w.v_ti[v] != w.v_ti[t.vord[i - 1]] || w.v_tj[v] != w.v_tj[t.vord[i - 1]] || h_vitems[it].count >= VCH;
-        if (fresh) h_vitems[++it] = VisItem{m.vis0 + i, 0};
-        h_vitems[it].count++;
+      // visual blocks: evaluation slots in landmark-major order (padding slots: window -1, harmless values)
+      for (int i = 0; i < m.Vp; ++i) {
+        const int v = t.lord[i];
         const size_t e = (size_t)m.vis0 + i;
+        if (v < 0) {
+          h_v_win[e] = -1; h_v_lm[e] = 0; h_v_ti[e] = 0; h_v_tj[e] = 0; h_v_rowi[e] = 0; h_v_rowj[e] = 0;
+          for (int c = 0; c < 4; ++c) { h_v_obs[(size_t)c * Vt + e] = T(0); if (dup64) h_v_obs_d[(size_t)c * Vt + e] = 0.0; }
+          continue;
+        }
         h_v_win[e] = wi; h_v_lm[e] = w.v_lm[v];
         h_v_ti[e] = w.v_ti[v] - w.t0_ns; h_v_tj[e] = w.v_tj[v] - w.t0_ns;
         h_v_rowi[e] = w.v_rowi[v]; h_v_rowj[e] = w.v_rowj[v];
         const double o4[4] = {w.v_pi[2 * v], w.v_pi[2 * v + 1], w.v_pj[2 * v], w.v_pj[2 * v + 1]};
         for (int c = 0; c < 4; ++c) { h_v_obs[(size_t)c * Vt + e] = (T)o4[c]; if (dup64) h_v_obs_d[(size_t)c * Vt + e] = o4[c]; }
       }
-      {  // CSR landmark -> blocks (positions in the sorted order); v_slot = position of a block in the CSR list
-        std::vector<int32_t> cnt((size_t)w.L + 1, 0);
-        for (int i = 0; i < w.V; ++i) cnt[w.v_lm[t.vord[i]] + 1]++;
-        for (int l = 0; l < w.L; ++l) { cnt[l + 1] += cnt[l]; h_lm_blk_off[m.lm0 + l] = m.vis0 + cnt[l]; }
-        for (int i = 0; i < w.V; ++i) {
-          const int l = w.v_lm[t.vord[i]];
-          const int p = m.vis0 + cnt[l]++;
-          h_lm_blk[p] = m.vis0 + i;
-          h_v_slot[m.vis0 + i] = p;
-        }
+      // the assembly's items: <= VCH blocks of one frame pair, frame-pair order, as lists of slots (vblk)
+      int it = m.vitem0 - 1;
+      for (int i = 0; i < w.V; ++i) {
+        const int v = t.vord[i];
+        const bool fresh = (i == 0) || w.v_ti[v] != w.v_ti[t.vord[i - 1]] || w.v_tj[v] != w.v_tj[t.vord[i - 1]] || h_vitems[it].count >= VCH;
+        if (fresh) h_vitems[++it] = VisItem{m.vis0 + i, 0};
+        h_vitems[it].count++;
+        h_vblk[(size_t)m.vis0 + i] = m.vis0 + t.vpos[v];
       }
+      for (int i = w.V; i < m.Vp; ++i) h_vblk[(size_t)m.vis0 + i] = m.vis0;   // (unused tail of the window's list)
       for (int b = 0; b < w.NB; ++b) { h_bc_win[m.bc0 + b] = wi; h_bc_i[m.bc0 + b] = w.bc_i[b]; h_bc_j[m.bc0 + b] = w.bc_j[b]; }
       if (w.NB) std::memcpy(h_bc_w + (size_t)6 * m.bc0, w.bc_w, sizeof(double) * 6 * w.NB);
       // prior: J0^T J0 (row-major n*n), J0^T r0, r0^T r0 in fp64; J0 is column-major (Eigen)
@@ -395,8 +397,8 @@ template <class T> class SolverImpl : public SolverBase {
     d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(T, o_imu_u); d.imu_meas = CTV_D(T, o_imu_meas);
     d.imu_ud = CTV_D(double, o_imu_ud); d.imu_meas_d = CTV_D(double, o_imu_meas_d); d.v_obs_d = CTV_D(double, o_v_obs_d);
     d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_rowi = CTV_D(int32_t, o_v_rowi); d.v_rowj = CTV_D(int32_t, o_v_rowj);
-    d.v_slot = CTV_D(int32_t, o_v_slot); d.v_ti = CTV_D(int64_t, o_v_ti); d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
-    d.vitems = CTV_D(VisItem, o_vitems); d.lm_blk_off = CTV_D(int32_t, o_lm_blk_off); d.lm_blk = CTV_D(int32_t, o_lm_blk);
+    d.v_ti = CTV_D(int64_t, o_v_ti); d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
+    d.vitems = CTV_D(VisItem, o_vitems); d.vblk = CTV_D(int32_t, o_vblk);
     d.bc_win = CTV_D(int32_t, o_bc_win); d.bc_i = CTV_D(int32_t, o_bc_i); d.bc_j = CTV_D(int32_t, o_bc_j); d.bc_w = CTV_D(double, o_bc_w);
     d.pJ0 = CTV_D(double, o_pJ0); d.pr0 = CTV_D(double, o_pr0);
     d.pH = CTV_D(double, o_pH); d.pb0 = CTV_D(double, o_pb0); d.pc0 = CTV_D(double, o_pc0); d.p_x0 = CTV_D(double, o_p_x0);
@@ -413,7 +415,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_kd = seg(8 * 3 * (size_t)K0), o_ckd = seg(8 * 3 * (size_t)K0), o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
     const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
     const size_t o_imu_rc = mixed_ ? seg(sizeof(T) * 6 * Mt) : 0, o_vis_rc = mixed_ ? seg(sizeof(T) * 3 * Vt) : 0;
-    const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt), o_Wc = seg(sizeof(T) * WC_STRIDE * Vt);
+    const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt);
     const size_t o_Hpp = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
     const size_t o_W = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_g = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
@@ -431,7 +433,7 @@ template <class T> class SolverImpl : public SolverBase {
     snap_ = CTV_W(double, o_snap);
     d.kd = CTV_W(double, o_kd); d.ckd = CTV_W(double, o_ckd); d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
     if (mixed_) { d.imu_rc = CTV_W(T, o_imu_rc); d.vis_rc = CTV_W(T, o_vis_rc); }
-    d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs); d.Wc = CTV_W(T, o_Wc);
+    d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs);
     d.Hpp = CTV_W(double, o_Hpp); d.S = CTV_W(double, o_S); d.W = CTV_W(T, o_W); d.Hll = CTV_W(double, o_Hll); d.g = CTV_W(double, o_g);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
     d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;
@@ -519,7 +521,6 @@ template <class T> class SolverImpl : public SolverBase {
     }
     ph_end();
     ph_begin(PH_ASM_REST);
-    if (d.maxL) hipLaunchKernelGGL((k_build_W<T>), dim3(d.maxL, nw), dim3(64), (size_t)d.maxLdw * sizeof(double), stream_, d);
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d);
     hipLaunchKernelGGL((k_misc<T, true>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, d.quat, d.pos, d.bias, d.ld, 0);
     hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
@@ -655,8 +656,9 @@ template <class T> class SolverImpl : public SolverBase {
       HIPCHK(hipMemcpy(st, d.dbg, sizeof st, hipMemcpyDeviceToHost));
       std::fprintf(stderr, "[ctvio] cholesky clock64 deltas:");
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
-      std::fprintf(stderr, "\n[ctvio] imu_linearize clock64 deltas:");
-      for (int i = 33; i < 48; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> end phase of wave 1000, clock64 deltas (J~ copy-out | landmark contributions | per sweep: scatter, rows out):");
+      for (int i = 33; i < 40; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, " | landmarks %lld, rows per sweep %lld", st[42] / 1000000, st[43] / 1000);
       std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | per item of rounds 0, 1: staged, run products.., scatter | rounds | imu tiles | H flush | g flush):");
       for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n");

@@ -13,9 +13,10 @@ struct WinMeta {
   int32_t pn, pnb;
   int32_t knot0, bias0, lm0;   // offsets into state arrays (knots, bias states, landmarks)
   int32_t imu0, grp0, ngrp;    // IMU samples (sorted by group) / groups
-  int32_t vis0, bc0;           // visual blocks (sorted by frame pair) / bias-chain links
-  int32_t vitem0, nvitem;      // visual work items (<= CH consecutive blocks of one frame pair)
-  int32_t vis_lds, pad0;       // 1: the packed visual Hessian fits in LDS (k_assemble_vis)
+  int32_t vis0, bc0;           // visual blocks (LANDMARK-major, padded: see Vp) / bias-chain links
+  int32_t vitem0, nvitem;      // visual work items (<= CH blocks of one frame pair, listed in Dev::vblk)
+  int32_t vis_lds, Vp;         // 1: the packed visual Hessian fits in LDS (k_assemble_vis); Vp: block slots of the window incl. padding
+                               // (a multiple of 64; a landmark's blocks are consecutive and never straddle a group of 64)
   int32_t u0, p0;              // offsets into per-unknown (sum N) and per-pose-unknown (sum P) arrays
   int32_t ldw, Lpad;           // W is [Lpad][ldw] (landmark-major, zero padded; ldw % 32 == 0, Lpad % 2 == 0)
   int32_t pv0, pblk0;          // prior vectors (sum pn) / prior blocks
@@ -29,7 +30,7 @@ struct WinMeta {
   double q_CI[4], p_CI[3], gravity[3], imu_w[6], img_w, cauchy_a, ld_lo, ld_hi;
 };
 
-struct VisItem { int32_t start, count; };  // start = global visual block index
+struct VisItem { int32_t start, count; };  // blocks Dev::vblk[start .. start + count): one frame pair, frame-pair order
 
 // A run of IMU samples sharing the same 4 active knots (segment s) and the same bias state.
 struct ImuGroup { int32_t win, s, bias, start, count; };
@@ -91,19 +92,17 @@ template <class T> struct Dev {
   const int32_t *v_rowi, *v_rowj;
   const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
   const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
-  T *Jt;                 // robust-corrected visual Jacobian + residual, tiles of 64 blocks: [ceil(Vtot / 64)][VT_ROWS][64], so that a
-                         // wave of k_vis_eval writes ONE contiguous 34 KB region (68 row arrays Vtot apart meant 68 DRAM pages per wave).
-                         // Tile rows: 0-23 rotation columns of the i end (2 col + residual row), 24-47 of the j end, 48/49 inverse
+  T *Jt;                 // robust-corrected visual Jacobian + residual, block-major [Vtot][VT_ROWS]: the assembly gathers the blocks of
+                         // an item (frame-pair order) from the landmark-major block order, 528 contiguous bytes each; a wave of
+                         // k_vis_eval writes the 64 x VT_ROWS entries of its blocks as ONE contiguous 34 KB region (from LDS).
+                         // Row entries: 0-23 rotation columns of the i end (2 col + residual row), 24-47 of the j end, 48/49 inverse
                          // depth, 50/51 line delay, 52/53 residual, 54-67 the position columns in compact form: P~ (2 x 3), cp0[4],
                          // cp1[4]  (J~_pos(k, b) = cp0[k] P~[b] / -cp1[k] P~[b])
   T *vis_rc;             // [3][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc) and the block's
                          // sqrt(rho') = exp(-cost / a^2) from that fp64 evaluation (row 2)
-  T *Wc;                 // [Vtot][WC_STRIDE] per block, rows in LANDMARK order (row v_slot[v]): J~_rho^T J~_c (49 pose columns),
-                         // J~_rho^T J~_rho, J~_rho^T r~, then the block's knot segments si, sj
-  const int32_t *v_slot; // [Vtot] row of block v in Wc
   int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
   const VisItem *vitems;
-  const int32_t *lm_blk_off, *lm_blk;   // CSR landmark -> its visual blocks (global indices), [Ltot+1], [Vtot]
+  const int32_t *vblk;   // [Vtot] block slots in frame-pair order, window by window (VisItem::start indexes it)
   int32_t maxL, maxLdw;
   // bias chain
   const int32_t *bc_win, *bc_i, *bc_j;

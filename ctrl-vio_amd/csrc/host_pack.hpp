@@ -74,8 +74,9 @@ static inline int prior_block_size(int kind) { return kind == CTVIO_PK_LD ? 1 : 
 // Per-window results of the first pass.
 struct PackTmp {
   std::vector<int32_t> iorder, iseg;    // IMU: sample order by (segment, bias state); segment of every sample (input order)
-  std::vector<int32_t> vord;            // visual blocks: order by (ti, tj, rowi, rowj)
-  int32_t ngrp = 0, nvitem = 0;
+  std::vector<int32_t> vord;            // visual blocks: order by (ti, tj, rowi, rowj)  (frame-pair order: the assembly's items)
+  std::vector<int32_t> lord, vpos;      // landmark-major slots: lord[slot] = block or -1 (padding), vpos[block] = slot
+  int32_t ngrp = 0, nvitem = 0, Vp = 0; // Vp: slots incl. padding, a multiple of 64
   std::string err;
 };
 
@@ -161,6 +162,28 @@ inline void plan_window(const ctvio_window *w, int vch, PackTmp &t) {
     const bool fresh = (i == 0) || w->v_ti[v] != w->v_ti[t.vord[i - 1]] || w->v_tj[v] != w->v_tj[t.vord[i - 1]] || cnt >= vch;
     if (fresh) { t.nvitem++; cnt = 0; }
     cnt++;
+  }
+  // Evaluation order: landmark-major (frame-pair order inside a landmark), so that the wave of k_vis_eval that evaluates a
+  // landmark's blocks also forms its row of W.  A landmark never straddles a group of 64 slots (padding slots in front of it);
+  // the window's slot count is a multiple of 64 (windows start on a wave boundary).
+  std::vector<int32_t> lcount((size_t)w->L + 1, 0), lstart((size_t)w->L + 1, 0);
+  for (int v = 0; v < V; ++v) lcount[w->v_lm[v]]++;
+  int pos = 0;
+  for (int l = 0; l < w->L; ++l) {
+    const int c = lcount[l];
+    if (c > 64) { t.err = "more than 64 observations of one landmark"; return; }
+    if ((pos & 63) + c > 64) pos = (pos + 63) & ~63;
+    lstart[l] = pos;
+    pos += c;
+  }
+  t.Vp = (pos + 63) & ~63;
+  t.lord.assign((size_t)t.Vp, -1);
+  t.vpos.resize(V);
+  for (int i = 0; i < V; ++i) {     // frame-pair order inside a landmark
+    const int v = t.vord[i];
+    const int slot = lstart[w->v_lm[v]]++;
+    t.lord[slot] = v;
+    t.vpos[v] = slot;
   }
 }
 

@@ -3,7 +3,7 @@
 //   per state : k_knot_prep (d = log(R_k^-1 R_k+1) and Jr^-1(d) of every knot pair, shared by all blocks)
 //   linearise : k_imu_linearize (LDS-staged J, per-group A^T A on MFMA fp32), k_vis_eval<LIN> (J~ materialised SoA, W rows)
 //   assemble  : k_zero_normal, k_assemble_vis_mfma (MFMA fp32 + fp64 LDS Hessian; k_assemble_vis = generic / fp64 variant),
-//               k_build_W, k_assemble_imu, k_misc<LIN> (bias chain + prior), k_post_linearize
+//               k_assemble_imu, k_misc<LIN> (bias chain + prior), k_post_linearize
 //   solve     : k_damping, k_schur_window (large batches) / k_schur_mfma (per tile) / k_schur_generic + k_rhs (fp64 path),
 //               k_cholesky_solve (fp64 MFMA), k_backsub
 //   update    : k_update<false|true>, k_imu_cost, k_vis_eval<cost>, k_misc<cost>
@@ -313,7 +313,7 @@ template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part) {
   const long long first = (m.vis_lds && single_part) ? (long long)6 * m.K * m.ldh : 0;
   for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) d.g[m.u0 + i] = 0.0;
-  // W, Hll and g[P..N) are written (not accumulated) by k_build_W
+  // W, Hll and g[P..N) are written (not accumulated) by k_vis_eval<LIN>
   if (blockIdx.x == 0 && threadIdx.x == 0 && !lin_at_candidate(d.lm[w])) d.lm[w].gmax_bits = 0ull;
 }
 
@@ -741,39 +741,36 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
 // is local column c (0..49) one of the 24 position columns (i-end 12..23, j-end 36..47)?  Those are not materialised:
 // J~[c] = cp0[k] P~[b] / -cp1[k] P~[b], rebuilt from the 14 numbers of Jp by the assembly kernels.
 __device__ __forceinline__ constexpr bool vis_pos_col(int c) { return (c >= 12 && c < 24) || (c >= 36 && c < 48); }
-// Tile row of staging row `row` = 2 * column + residual row (< 100) of a materialised (non-position) column, and the offset of
-// block v's entries inside Dev::Jt (+ 64 * tile row)
+// Entry index (0 .. VT_ROWS) of staging row `row` = 2 * column + residual row (< 100) of a materialised (non-position) column
 __device__ __forceinline__ constexpr int vis_trow(int row) { return row < 24 ? row : (row < 72 ? row - 24 : row - 48); }
-__device__ __forceinline__ unsigned vis_tbase(unsigned v) { return (v >> 6) * (unsigned)(VT_ROWS * 64) + (v & 63u); }
-template <class T> struct VisGlobalSink {
-  T *J;        // Dev::Jt + vis_tbase(v): tile row r of this lane's block is J[64 r]
-  T *wc;       // LDS row of this lane: J_rho^T J_c for the 49 pose columns (slot 48 = line delay), then Hll, g_rho
-  T jr0, jr1;
+// k_vis_eval<LIN> stages the J~ of its 64 blocks in LDS ([VT_ROWS][65]: this lane's block = column J[0], entry r at J[65 r]; the
+// odd stride makes the block-major copy-out conflict-free) and forms the landmark rows from it after the evaluation.
+constexpr int VT_LD = 65;
+template <class T> struct VisTileSink {
+  T *J;
   __device__ __forceinline__ void put(int col, T j0, T j1) {
-    if (!vis_pos_col(col)) { J[64 * vis_trow(2 * col)] = j0; J[64 * (vis_trow(2 * col) + 1)] = j1; }
-    if (col == 48) { jr0 = j0; jr1 = j1; }                       // visual_eval emits the inverse-depth column first
-    else wc[col < 48 ? col : 48] = jr0 * j0 + jr1 * j1;
+    if (!vis_pos_col(col)) { J[VT_LD * vis_trow(2 * col)] = j0; J[VT_LD * (vis_trow(2 * col) + 1)] = j1; }
   }
   __device__ __forceinline__ void put_pos(const T Pt[6], const T cp0[4], const T cp1[4]) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) J[64 * (54 + i)] = Pt[i];
+    for (int i = 0; i < 6; ++i) J[VT_LD * (54 + i)] = Pt[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { J[64 * (60 + i)] = cp0[i]; J[64 * (64 + i)] = cp1[i]; }
+    for (int i = 0; i < 4; ++i) { J[VT_LD * (60 + i)] = cp0[i]; J[VT_LD * (64 + i)] = cp1[i]; }
   }
 };
 template <class T> struct VisNullSink {
   __device__ __forceinline__ void put(int, T, T) {}
   __device__ __forceinline__ void put_pos(const T *, const T *, const T *) {}
 };
-// J~ entry (staging row = 2 * column + residual row, < 100; 100 / 101 = the residual) of block v from the tile storage
+// J~ entry (staging row = 2 * column + residual row, < 100; 100 / 101 = the residual) of block v from the block-major storage
 template <class T> __device__ __forceinline__ T vis_J_entry(const T *Jt, int row, unsigned v) {
-  const T *J = Jt + vis_tbase(v);
-  if (row >= 100) return J[64 * (52 + row - 100)];
+  const T *J = Jt + (size_t)v * VT_ROWS;
+  if (row >= 100) return J[52 + row - 100];
   const int col = row >> 1, rr = row & 1;
-  if (!vis_pos_col(col)) return J[64 * vis_trow(row)];
+  if (!vis_pos_col(col)) return J[vis_trow(row)];
   const int c = col < 24 ? col - 12 : col - 36, kk = c / 3, b = c % 3;
-  const T pt = J[64 * (54 + 2 * b + rr)];
-  return col < 24 ? J[64 * (60 + kk)] * pt : -J[64 * (64 + kk)] * pt;
+  const T pt = J[54 + 2 * b + rr];
+  return col < 24 ? J[60 + kk] * pt : -J[64 + kk] * pt;
 }
 
 // time -> (first active knot, u) in integer ns (reference spline_segment.h:83-85); the line delay is
@@ -816,15 +813,20 @@ __device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, in
 template <class T, bool LIN, class RT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ T wcs[LIN ? 64 * 55 : 1];   // per-lane W contributions (row of WC_STRIDE entries), written out coalesced at the end
-  __shared__ int wcs_on[LIN ? 64 : 1];   // destination row (slot in landmark order, see Dev::Wc) or -1
-  if (LIN) wcs_on[threadIdx.x] = -1;
+  // LIN: the J~ of the wave's 64 blocks ([VT_ROWS][VT_LD]), afterwards reused for the per-block landmark contributions
+  // ([64][55]) and one fp64 row of W
+  constexpr int LDS_BYTES = LIN ? (VT_ROWS * VT_LD * (int)sizeof(T) > 64 * 55 * (int)sizeof(T) + 640 * 8 ? VT_ROWS * VT_LD * (int)sizeof(T)
+                                                                                                       : 64 * 55 * (int)sizeof(T) + 640 * 8) : 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smt[LDS_BYTES];
+  T *wcs = reinterpret_cast<T *>(smt);
   double c = 0.0;
-  int w = -1;
+  int w = -1, ksi = 0, ksj = 0, my_lm = -1;
+  int mP = 0, mldw = 0, mK6 = 0, mlm0 = 0, mu0 = 0, mW0lo = 0, mW0hi = 0;   // LIN: the lane's window, for the landmark rows
+  bool on = false;
   if (v < d.Vtot) {
     w = d.v_win[v];
-    const Lm &lm = d.lm[w];
-    const bool run = LIN ? lin_needed(lm) : (lm.status == 0 && (lm.step_valid || force));
+    const Lm &lm = d.lm[max(w, 0)];
+    const bool run = w >= 0 && (LIN ? lin_needed(lm) : (lm.status == 0 && (lm.step_valid || force)));
     if (run) {
       const WinMeta &m = d.wins[w];
       if (LIN) {   // the state this window is linearised at (its candidate while it is in the line search)
@@ -855,8 +857,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisGlobalSink<T> sink{d.Jt + vis_tbase((unsigned)v), wcs + 55 * threadIdx.x, T(0), T(0)};
-        wcs_on[threadIdx.x] = d.v_slot[v];
+        VisTileSink<T> sink{wcs + threadIdx.x};
+        on = true;
+        my_lm = d.v_lm[v];
+        mP = m.P; mldw = m.ldw; mK6 = 6 * m.K; mlm0 = m.lm0; mu0 = m.u0; mW0lo = (int)(m.W0 & 0xffffffffll); mW0hi = (int)(m.W0 >> 32);
         if (sizeof(RT) != sizeof(T)) cal.sq_override = d.vis_rc[2 * V + v];   // robust scale of the fp64 residual pass
         SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
         seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
@@ -866,11 +870,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
         if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state
           r[0] = d.vis_rc[v]; r[1] = d.vis_rc[V + v];
         }
-        sink.wc[49] = sink.jr0 * sink.jr0 + sink.jr1 * sink.jr1;
-        sink.wc[50] = sink.jr0 * r[0] + sink.jr1 * r[1];
-        sink.wc[51] = (T)si; sink.wc[52] = (T)sj;   // knot segments travel with the row (exact in fp32)
-        sink.J[64 * 52] = r[0]; sink.J[64 * 53] = r[1];
+        sink.J[VT_LD * 52] = r[0]; sink.J[VT_LD * 53] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
+        ksi = si; ksj = sj;
       } else {
         RT rd[2];
         c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
@@ -884,24 +886,134 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
     }
   }
   if (LIN) {
-    __syncthreads();
-    // rows of WC_STRIDE entries, 6 entries per lane and trip (the LDS reads first, then the stores)
-    for (int i0 = threadIdx.x; i0 < 64 * WC_STRIDE; i0 += 6 * 64) {
-      T tv[6];
-      int dsti[6];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int i = min(i0 + 64 * u, 64 * WC_STRIDE - 1), bl = i / WC_STRIDE, cc = i % WC_STRIDE, slot = wcs_on[bl];
-        tv[u] = wcs[55 * bl + cc];
-        dsti[u] = (slot >= 0 && cc < 53 && i0 + 64 * u < 64 * WC_STRIDE) ? WC_STRIDE * slot + cc : -1;
+    const int lane = threadIdx.x;
+    const unsigned long long on_mask = __ballot(on);
+    if (on_mask == 0) return;                  // (wave-uniform)
+    // One wave per workgroup: LDS hand-overs only need the wave's own LDS operations to have completed.  (__syncthreads() also
+    // waits for vmcnt(0), i.e. for the J~ and W stores in flight to be acknowledged -- ~5 us per barrier here, measured.)
+#define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
+    long long *dbg = (d.dbg && blockIdx.x == 1000) ? d.dbg + 32 : nullptr;
+    if (dbg && lane == 0) dbg[0] = clock64() + (long long)(c * 0);
+    LDS_SYNC();
+    // ---- J~ goes out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs of
+    //      entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
+    {
+      T *dst = d.Jt + (size_t)(blockIdx.x * 64) * VT_ROWS;
+      constexpr int HP = VT_ROWS / 2;            // pairs per block
+#pragma unroll 4
+      for (int k = 0; k < HP; ++k) {             // 64 * HP pairs, 64 per store
+        const int i = k * 64 + lane, bl = i / HP, r = 2 * (i - bl * HP);
+        VecN<T, 2> pr;
+        pr.v[0] = wcs[VT_LD * r + bl];
+        pr.v[1] = wcs[VT_LD * (r + 1) + bl];
+        if ((on_mask >> bl) & 1ull) *reinterpret_cast<VecN<T, 2> *>(dst + (size_t)bl * VT_ROWS + r) = pr;
       }
-#pragma unroll
-      for (int u = 0; u < 6; ++u)
-        if (dsti[u] >= 0) d.Wc[(size_t)dsti[u]] = tv[u];
     }
+    if (dbg && lane == 0) dbg[1] = clock64();
+    // ---- this lane's contributions to its landmark's row of W: J_rho^T J_c for the 49 pose columns (slot 48 = line delay),
+    //      Hll, g_rho
+    T wr[51];
+    {
+      const T *Jl = wcs + lane;
+      const T jr0 = Jl[VT_LD * 48], jr1 = Jl[VT_LD * 49];
+#pragma unroll
+      for (int cc = 0; cc < 12; ++cc) {
+        wr[cc] = jr0 * Jl[VT_LD * (2 * cc)] + jr1 * Jl[VT_LD * (2 * cc + 1)];
+        wr[24 + cc] = jr0 * Jl[VT_LD * (24 + 2 * cc)] + jr1 * Jl[VT_LD * (25 + 2 * cc)];
+      }
+      T qb[3], cp0[4], cp1[4];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) qb[b] = jr0 * Jl[VT_LD * (54 + 2 * b)] + jr1 * Jl[VT_LD * (55 + 2 * b)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { cp0[k] = Jl[VT_LD * (60 + k)]; cp1[k] = Jl[VT_LD * (64 + k)]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { wr[12 + 3 * k + b] = cp0[k] * qb[b]; wr[36 + 3 * k + b] = -(cp1[k] * qb[b]); }
+      wr[48] = jr0 * Jl[VT_LD * 50] + jr1 * Jl[VT_LD * 51];
+      wr[49] = jr0 * jr0 + jr1 * jr1;
+      wr[50] = jr0 * Jl[VT_LD * 52] + jr1 * Jl[VT_LD * 53];
+    }
+    // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave).  The buffer becomes
+    //      NR fp64 rows (+ Hll, g_rho per row); every lane adds its 51 values into the row of its landmark (LDS atomics: blocks
+    //      of a landmark share the anchor end's knots, the two ends of a block may share knots), NR landmarks per sweep; then the
+    //      knot and line-delay columns of every row, Hll and g_rho are written: W is complete when this kernel ends.
+    if (dbg && lane == 0) dbg[2] = clock64() + (long long)(wr[3] * 0);
+    const int prev_lm = __shfl_up(my_lm, 1), prev_w = __shfl_up(w, 1);
+    const bool head = on && (lane == 0 || prev_lm != my_lm || prev_w != w);
+    const unsigned long long heads = __ballot(head);
+    const int ord = __popcll(heads & ((2ull << lane) - 1ull)) - 1;     // ordinal of this lane's landmark in the wave
+    const int nlm = __popcll(heads);
+    int ldmax = mldw;                                                  // (a wave may hold the tail of one window and the head of the next)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ldmax = max(ldmax, __shfl_xor(ldmax, off));
+    ldmax = __builtin_amdgcn_readfirstlane(ldmax) | 1;   // odd row stride: ldw is a multiple of 32 doubles, which would put column g of EVERY row in the same LDS bank
+    double *rows = reinterpret_cast<double *>(smt);
+    const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / (ldmax + 2)));
+    double *hg = rows + (size_t)NR * ldmax;                            // [NR][2] Hll, g_rho
+    __shared__ int4 rmeta[64];                                         // per landmark of the wave: K6, P, W row offset
+    __shared__ int2 rhg[64];                                           //                           where Hll and g_rho go
+    int KC = mK6;                                                      // compact columns per row: knots + line delay
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) KC = max(KC, __shfl_xor(KC, off));
+    KC = __builtin_amdgcn_readfirstlane(KC) + 1;
+    if (head) {
+      const long long wo = (((long long)mW0hi << 32) | (unsigned int)mW0lo) + (long long)my_lm * mldw;
+      rmeta[ord] = int4{mK6, mP, (int)(wo & 0xffffffffll), (int)(wo >> 32)};
+      rhg[ord] = int2{mlm0 + my_lm, mu0 + mP + my_lm};
+    }
+    LDS_SYNC();   // every lane has read its column of J~
+    for (int c0 = 0; c0 < nlm; c0 += NR) {
+      const int nr = min(NR, nlm - c0);
+      for (int i = lane; i < nr * ldmax + 2 * nr; i += 64) (i < nr * ldmax ? rows[i] : hg[i - nr * ldmax]) = 0.0;
+      LDS_SYNC();
+      if (on && ord >= c0 && ord < c0 + nr) {
+        double *row = rows + (size_t)(ord - c0) * ldmax;
+#pragma unroll
+        for (int cc = 0; cc < 48; ++cc) atomicAdd(&row[vis_col(cc, ksi, ksj, mP)], (double)wr[cc]);
+        atomicAdd(&row[mP - 1], (double)wr[48]);
+        atomicAdd(&hg[2 * (ord - c0)], (double)wr[49]);
+        atomicAdd(&hg[2 * (ord - c0) + 1], (double)wr[50]);
+      }
+      LDS_SYNC();
+      if (dbg && lane == 0) dbg[3 + 2 * (c0 / NR)] = clock64();
+      // write-out, row by row (uniform loop: the row's window comes from LDS with broadcast reads), lane = compact column
+      const int4 mymt = rmeta[min(c0 + lane, 63)];           // lane q holds row q's window: x: K6, y: P, z/w: W row offset (elements)
+#pragma unroll 4
+      for (int q = 0; q < nr; ++q) {
+        int4 mt;
+        mt.x = __builtin_amdgcn_readlane(mymt.x, q); mt.y = __builtin_amdgcn_readlane(mymt.y, q);
+        mt.z = __builtin_amdgcn_readlane(mymt.z, q); mt.w = __builtin_amdgcn_readlane(mymt.w, q);
+        T *Wr = d.W + (((long long)mt.w << 32) | (unsigned int)mt.z);
+        const double *row = rows + (size_t)q * ldmax;
+        // pairs of columns (K6 is even, the row starts on a 256-byte boundary): two stores cover K <= 42
+        VecN<T, 2> rv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c2 = min(2 * (lane + 64 * u), mt.x - 2);
+          rv[u].v[0] = (T)row[c2]; rv[u].v[1] = (T)row[c2 + 1];
+        }
+        const double rl = row[mt.y - 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (2 * (lane + 64 * u) < mt.x) *reinterpret_cast<VecN<T, 2> *>(Wr + 2 * (lane + 64 * u)) = rv[u];
+        for (int i = lane + 256; i < mt.x; i += 64) Wr[i] = (T)row[i];     // K > 42
+        if (lane == 0) Wr[mt.y - 1] = (T)rl;
+      }
+      if (lane < nr) {
+        const int2 hgi = rhg[c0 + lane];                     // x: index into Hll, y: index into g
+        d.Hll[hgi.x] = hg[2 * lane];
+        d.g[hgi.y] = hg[2 * lane + 1];
+      }
+      LDS_SYNC();
+      if (dbg && lane == 0) { dbg[4 + 2 * (c0 / NR)] = clock64(); dbg[10] = nlm * 1000000ll + (long long)(LDS_BYTES / 8); dbg[11] = NR * 1000 + ldmax; }
+    }
+#undef LDS_SYNC
   } else {
-    const int w0 = __shfl(w, 0);
-    if (__all(w == w0)) {
+    // (padding slots and blocks of windows that are not evaluated carry w = -1 and c = 0)
+    const unsigned long long live = __ballot(w >= 0);
+    const int w0 = live ? __shfl(w, __ffsll((long long)live) - 1) : -1;
+    if (__all(w == w0 || w < 0)) {
       for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
       if ((threadIdx.x & 63) == 0 && w0 >= 0) atomicAdd(&d.lm[w0].cand_cost, c);
     } else if (w >= 0) {
@@ -968,12 +1080,13 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
     if (it < nvitem) { const VisItem I = d.vitems[vitem0 + it]; n = I.count; v0 = I.start; }
     {
       const int c = lane % CH, rr = lane / CH;
+      const unsigned blk = (unsigned)d.vblk[v0 + (c < n ? c : 0)];   // slot of the item's block c (landmark-major evaluation order)
       T tmp[NPASS];
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         const int row = i * RPP + rr;
         tmp[i] = T(0);
-        if (row < 102 && c < n) tmp[i] = vis_J_entry<T>(d.Jt, row, (unsigned)(v0 + c));
+        if (row < 102 && c < n) tmp[i] = vis_J_entry<T>(d.Jt, row, blk);
       }
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
@@ -981,7 +1094,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
         if (row < 102) Js[row * CHP + c] = tmp[i];
       }
     }
-    if (lane < n) { ks[lane] = d.vs[v0 + lane]; ks[CH + lane] = d.vs[V + v0 + lane]; }
+    if (lane < n) { const int blk = d.vblk[v0 + lane]; ks[lane] = d.vs[blk]; ks[CH + lane] = d.vs[V + blk]; }
     __syncthreads();
     
     int start = 0;
@@ -1201,8 +1314,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
     my_start = I.start;
     my_count = (lane < rounds && it < nvitem) ? I.count : 0;
   }
-  auto fetch = [&](int r) {   // request item r of this wave: unconditional loads on clamped addresses, masked when staged
-    int istart, icount;
+  auto item_desc = [&](int r, int &istart, int &icount) {
     if (r < 64) { istart = __shfl(my_start, r); icount = __shfl(my_count, r); }
     else {
       const int it = it0 + r;
@@ -1210,25 +1322,38 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       istart = I.start; icount = (r < rounds && it < nvitem) ? I.count : 0;
     }
     if (r >= rounds) icount = 0;
+  };
+  // The blocks of an item are slots of the landmark-major evaluation order, listed in Dev::vblk: the slot of this lane's block
+  // (c = sc) and of the block whose keys it reads (lane) are requested one item ahead, so that the J~ loads of an item do not
+  // wait for its slot list.
+  int idn = 0, idkn = 0;
+  auto load_ids = [&](int r) {
+    int istart, icount;
+    item_desc(r, istart, icount);
+    idn = d.vblk[istart + (sc < icount ? sc : 0)];
+    idkn = d.vblk[istart + (lane < icount ? lane : 0)];
+  };
+  auto fetch = [&](int r) {   // request item r of this wave: unconditional loads on clamped addresses, masked when staged
+    int istart, icount;
+    item_desc(r, istart, icount);
     n = icount;
     v0 = istart;
-    const int c = sc < icount ? sc : 0;
-    // address = uniform row base (SGPR pair) + one 32-bit lane offset shared by all passes: pass i covers staged rows
-    // RPP i .. RPP i + RPP - 1, the lane's row inside the pass is srr  (64-bit per-lane addresses would cost 2 VGPRs per load)
-    // source row q of this lane in pass i = RPP i + srr: rotation rows (q < 48) sit at tile row q, line delay / residual /
-    // compact position data (48 <= q < 66) at tile row q + 2 (the inverse-depth rows 48, 49 are skipped); 24 and 48 are
-    // multiples of RPP, so the shift is the same for a whole pass.  One 32-bit lane offset, the pass offset is a constant.
-    const unsigned loff = vis_tbase((unsigned)(v0 + c)) + 64u * (unsigned)srr;
+    // J~ is block-major ([slot][VT_ROWS]): source row q of this lane in pass i = RPP i + srr: rotation entries (q < 48) sit at
+    // entry q, line delay / residual / compact position data (48 <= q < 66) at entry q + 2 (the inverse-depth entries 48, 49
+    // are skipped); 24 and 48 are multiples of RPP, so the shift is the same for a whole pass.  One 32-bit lane offset, the
+    // pass offset is a constant; the RPP lanes of a block read RPP consecutive entries.
+    const unsigned loff = (unsigned)idn * (unsigned)VT_ROWS + (unsigned)srr;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int q0 = i * RPP;
-      if (q0 + RPP <= NSRC) tmp[i] = d.Jt[loff + 64u * (unsigned)(q0 + (q0 >= 48 ? 2 : 0))];
-      else tmp[i] = d.Jt[vis_tbase((unsigned)(v0 + c)) + 64u * (unsigned)(min(q0 + srr, NSRC - 1) + 2)];   // last, partial pass
+      if (q0 + RPP <= NSRC) tmp[i] = d.Jt[loff + (unsigned)(q0 + (q0 >= 48 ? 2 : 0))];
+      else tmp[i] = d.Jt[(unsigned)idn * (unsigned)VT_ROWS + (unsigned)(min(q0 + srr, NSRC - 1) + 2)];   // last, partial pass
     }
-    const int kc = lane < icount ? lane : 0;
-    key_i = d.vs[v0 + kc];
-    key_j = d.vs[V + v0 + kc];
+    key_i = d.vs[idkn];
+    key_j = d.vs[V + idkn];
+    load_ids(r + 1);
   };
+  if (nvitem > 0) load_ids(0);
   if (nvitem > 0) fetch(0);
   // accumulators of the open run (asi, asj): 3 x 3 lower tiles of the 48 x 48 pose block, line-delay column, residual
   acc_t acc[6];
@@ -1415,62 +1540,6 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   }
   CTV_STAMP();
 #undef CTV_STAMP
-}
-
-// W row, Hll and g_rho of every landmark, gathered (no atomics, no zero pass): one wave per landmark walks the
-// landmark's visual blocks (CSR built at upload) and accumulates J~_rho^T J~_pose into a row buffer in LDS.
-template <class T> __global__ __launch_bounds__(64) void k_build_W(Dev<T> d) {
-  const int w = blockIdx.y;
-  const WinMeta &m = d.wins[w];
-  const int P = m.P, L = m.L, ldw = m.ldw, lm0 = m.lm0, u0 = m.u0;   // registers: not re-read after the LDS atomics
-  const long long W0 = m.W0;
-  if (!lin_needed(d.lm[w])) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
-  const int lane = threadIdx.x;
-  double *row = reinterpret_cast<double *>(smw);   // fp64: ds_add_f32 is ~20x slower than ds_add_f64 on gfx950
-  const int l = blockIdx.x;          // one wave per landmark: no workgroup barriers (LDS operations of a wave are ordered)
-  const bool valid = l < L;
-  if (!valid) return;
-  for (int i = lane; i < ldw; i += 64) row[i] = 0.0;
-  __builtin_amdgcn_wave_barrier();
-  double hll = 0.0, gl = 0.0;
-  {
-    const size_t V = (size_t)d.Vtot;
-    (void)V;
-    const int b0 = d.lm_blk_off[lm0 + l], b1 = d.lm_blk_off[lm0 + l + 1];
-    const int lc = min(lane, 50);
-    for (int bb = b0; bb < b1; bb += 8) {
-      // the landmark's rows are consecutive in Wc (k_vis_eval stored them in landmark order); 8 rows per pass, all
-      // loads unconditional on clamped rows -- a predicated load would cost a branch and a full wait each
-      int si[8], sj[8];
-      T wv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const T *rowp = d.Wc + (size_t)WC_STRIDE * min(bb + u, b1 - 1);
-        wv[u] = rowp[lc];
-        si[u] = (int)rowp[51];
-        sj[u] = (int)rowp[52];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (bb + u >= b1) continue;
-        if (lane < 49) atomicAdd(&row[vis_col(lane < 48 ? lane : 49, si[u], sj[u], P)], (double)wv[u]);  // ends may share knots
-        else if (lane == 49) hll += (double)wv[u];
-        else if (lane == 50) gl += (double)wv[u];
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (valid) {
-    // only the knot columns [0, 6K) and the line-delay column P - 1 can be non-zero; the bias and padding columns were
-    // zeroed once at upload and are never written (35% of the row at K = 24)
-    T *Wr = d.W + W0 + (long long)l * ldw;
-    const int K6 = 6 * m.K;
-    for (int i = lane; i < K6; i += 64) Wr[i] = (T)row[i];
-    if (lane == 0) Wr[P - 1] = (T)row[P - 1];
-    if (lane == 49) d.Hll[lm0 + l] = hll;
-    if (lane == 50) d.g[u0 + P + l] = gl;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ bias chain + prior
@@ -2672,8 +2741,9 @@ template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev
     const double r = d.bc_w[(size_t)(m.bc0 + b) * 6 + k] * (d.bias[6 * (m.bias0 + bj) + k] - d.bias[6 * (m.bias0 + bi) + k]);
     atomicAdd(&sums[6 + k], fabs(r));
   }
-  for (int i = tid; i < m.V; i += 256) {
+  for (int i = tid; i < m.Vp; i += 256) {
     const int v = m.vis0 + i;
+    if (d.v_win[v] < 0) continue;   // padding slot
     int si, sj;
     double ui, uj;
     const double ld = d.ld[w];
