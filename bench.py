@@ -60,11 +60,11 @@ def algorithmic_bytes(w, phase, fp_bytes):
     if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
         return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
     # a visual block's J~ is stored compactly: 2 r + 52 J (rotation, inverse depth, line delay) + 14 (P~, blending coefficients)
-    if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (r, compact J~) out + the landmark row (54)
-        return V * (284 + (68 + 54) * fp_bytes)
-    if phase == "k_assemble_vis":    # compact J~ and r~ read once (the depth column is not needed) + keys + packed fp64 Hessian flushed once
+    if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (r, compact J~) out; the rows of W (knot + line-delay columns), Hll, g_rho
+        return V * (284 + 68 * fp_bytes) + L * ((6 * K + 1) * fp_bytes + 16)
+    if phase == "k_assemble_vis":    # compact J~ and r~ read once (the depth column is not needed) + keys + slot list + packed fp64 Hessian flushed once
         K6 = 6 * K   # + the knot x knot part (24 x 24) of every IMU group tile, added into the same LDS Hessian
-        return V * (66 * fp_bytes + 8) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
+        return V * (66 * fp_bytes + 12) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
     if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
         return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
     if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written

@@ -64,7 +64,6 @@ struct LmParams {
 };
 
 // Device pointers of one batch.  T = scalar of the linearisation kernels (float product / double debug).
-constexpr int WC_STRIDE = 54;
 template <class T> struct Dev {
   int32_t nwin, Ktot, Ftot, Ltot, Mtot, Gtot, Vtot, NBtot, Utot, maxN, maxP, maxPn;
   const WinMeta *wins;

@@ -1,11 +1,12 @@
 // kernels.hpp -- gfx950 kernels of the sliding-window solve.  One launch covers a whole batch of windows.
 //
 //   per state : k_knot_prep (d = log(R_k^-1 R_k+1) and Jr^-1(d) of every knot pair, shared by all blocks)
-//   linearise : k_imu_linearize (LDS-staged J, per-group A^T A on MFMA fp32), k_vis_eval<LIN> (J~ materialised SoA, W rows)
-//   assemble  : k_zero_normal, k_assemble_vis_mfma (MFMA fp32 + fp64 LDS Hessian; k_assemble_vis = generic / fp64 variant),
-//               k_assemble_imu, k_misc<LIN> (bias chain + prior), k_post_linearize
-//   solve     : k_damping, k_schur_window (large batches) / k_schur_mfma (per tile) / k_schur_generic + k_rhs (fp64 path),
-//               k_cholesky_solve (fp64 MFMA), k_backsub
+//   linearise : k_imu_linearize_f64 (rows through LDS, per-group A^T A on the fp64 matrix cores; k_imu_linearize = fp32 mixed mode),
+//               k_vis_eval<LIN> (landmark-major: J~ block-major via LDS, the rows of W, Hll, g_rho formed in the same kernel)
+//   assemble  : k_zero_normal, k_assemble_vis_mfma (MFMA + fp64 LDS Hessian, or global atomics for K > 25; k_assemble_vis =
+//               register-tile variant), k_assemble_imu, k_misc<LIN> (bias chain + prior), k_post_linearize
+//   solve     : k_damping, k_schur_window_f64 (large batches) / k_schur_tile_f64 + k_rhs (small; k_schur_window / k_schur_mfma /
+//               k_schur_generic: fp32 mixed mode and vector fallback), k_cholesky_solve (fp64 MFMA), k_backsub
 //   update    : k_update<false|true>, k_imu_cost, k_vis_eval<cost>, k_misc<cost>
 //   control   : k_lm_init, k_set_initial_cost, k_begin_iter, k_lm_control   (Ceres 1.14 trust-region semantics)
 //   after     : k_gauge_restore (double2vector), k_spline_eval (trajectory query)
