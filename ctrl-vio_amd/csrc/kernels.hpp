@@ -744,19 +744,19 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
 __device__ __forceinline__ constexpr bool vis_pos_col(int c) { return (c >= 12 && c < 24) || (c >= 36 && c < 48); }
 // Entry index (0 .. VT_ROWS) of staging row `row` = 2 * column + residual row (< 100) of a materialised (non-position) column
 __device__ __forceinline__ constexpr int vis_trow(int row) { return row < 24 ? row : (row < 72 ? row - 24 : row - 48); }
-// k_vis_eval<LIN> stages the J~ of its 64 blocks in LDS ([VT_ROWS][65]: this lane's block = column J[0], entry r at J[65 r]; the
-// odd stride makes the block-major copy-out conflict-free) and forms the landmark rows from it after the evaluation.
-constexpr int VT_LD = 65;
+// k_vis_eval<LIN> stages the J~ of its 64 blocks in LDS, block-major like the copy in HBM ([64][VT_LD]: this lane's block starts
+// at J[0]; the odd stride spreads the lanes over the banks) and forms the landmark rows from it after the evaluation.
+constexpr int VT_LD = VT_ROWS + 1;
 template <class T> struct VisTileSink {
   T *J;
   __device__ __forceinline__ void put(int col, T j0, T j1) {
-    if (!vis_pos_col(col)) { J[VT_LD * vis_trow(2 * col)] = j0; J[VT_LD * (vis_trow(2 * col) + 1)] = j1; }
+    if (!vis_pos_col(col)) { J[vis_trow(2 * col)] = j0; J[vis_trow(2 * col) + 1] = j1; }
   }
   __device__ __forceinline__ void put_pos(const T Pt[6], const T cp0[4], const T cp1[4]) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) J[VT_LD * (54 + i)] = Pt[i];
+    for (int i = 0; i < 6; ++i) J[54 + i] = Pt[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { J[VT_LD * (60 + i)] = cp0[i]; J[VT_LD * (64 + i)] = cp1[i]; }
+    for (int i = 0; i < 4; ++i) { J[60 + i] = cp0[i]; J[64 + i] = cp1[i]; }
   }
 };
 template <class T> struct VisNullSink {
@@ -814,10 +814,8 @@ __device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, in
 template <class T, bool LIN, class RT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  // LIN: the J~ of the wave's 64 blocks ([VT_ROWS][VT_LD]), afterwards reused for the per-block landmark contributions
-  // ([64][55]) and one fp64 row of W
-  constexpr int LDS_BYTES = LIN ? (VT_ROWS * VT_LD * (int)sizeof(T) > 64 * 55 * (int)sizeof(T) + 640 * 8 ? VT_ROWS * VT_LD * (int)sizeof(T)
-                                                                                                       : 64 * 55 * (int)sizeof(T) + 640 * 8) : 16;
+  // LIN: the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
+  constexpr int LDS_BYTES = LIN ? 64 * VT_LD * (int)sizeof(T) : 16;   // (>= one fp64 row of the largest window: 642 doubles)
   __shared__ __attribute__((aligned(16))) unsigned char smt[LDS_BYTES];
   T *wcs = reinterpret_cast<T *>(smt);
   double c = 0.0;
@@ -858,7 +856,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
       if (LIN) {
-        VisTileSink<T> sink{wcs + threadIdx.x};
+        VisTileSink<T> sink{wcs + VT_LD * threadIdx.x};
         on = true;
         my_lm = d.v_lm[v];
         mP = m.P; mldw = m.ldw; mK6 = 6 * m.K; mlm0 = m.lm0; mu0 = m.u0; mW0lo = (int)(m.W0 & 0xffffffffll); mW0hi = (int)(m.W0 >> 32);
@@ -871,7 +869,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
         if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state
           r[0] = d.vis_rc[v]; r[1] = d.vis_rc[V + v];
         }
-        sink.J[VT_LD * 52] = r[0]; sink.J[VT_LD * 53] = r[1];
+        sink.J[52] = r[0]; sink.J[53] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
         ksi = si; ksj = sj;
       } else {
@@ -905,8 +903,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       for (int k = 0; k < HP; ++k) {             // 64 * HP pairs, 64 per store
         const int i = k * 64 + lane, bl = i / HP, r = 2 * (i - bl * HP);
         VecN<T, 2> pr;
-        pr.v[0] = wcs[VT_LD * r + bl];
-        pr.v[1] = wcs[VT_LD * (r + 1) + bl];
+        pr.v[0] = wcs[VT_LD * bl + r];
+        pr.v[1] = wcs[VT_LD * bl + r + 1];
         if ((on_mask >> bl) & 1ull) *reinterpret_cast<VecN<T, 2> *>(dst + (size_t)bl * VT_ROWS + r) = pr;
       }
     }
@@ -915,25 +913,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
     //      Hll, g_rho
     T wr[51];
     {
-      const T *Jl = wcs + lane;
-      const T jr0 = Jl[VT_LD * 48], jr1 = Jl[VT_LD * 49];
+      const T *Jl = wcs + VT_LD * lane;
+      const T jr0 = Jl[48], jr1 = Jl[49];
 #pragma unroll
       for (int cc = 0; cc < 12; ++cc) {
-        wr[cc] = jr0 * Jl[VT_LD * (2 * cc)] + jr1 * Jl[VT_LD * (2 * cc + 1)];
-        wr[24 + cc] = jr0 * Jl[VT_LD * (24 + 2 * cc)] + jr1 * Jl[VT_LD * (25 + 2 * cc)];
+        wr[cc] = jr0 * Jl[2 * cc] + jr1 * Jl[2 * cc + 1];
+        wr[24 + cc] = jr0 * Jl[24 + 2 * cc] + jr1 * Jl[25 + 2 * cc];
       }
       T qb[3], cp0[4], cp1[4];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) qb[b] = jr0 * Jl[VT_LD * (54 + 2 * b)] + jr1 * Jl[VT_LD * (55 + 2 * b)];
+      for (int b = 0; b < 3; ++b) qb[b] = jr0 * Jl[54 + 2 * b] + jr1 * Jl[55 + 2 * b];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { cp0[k] = Jl[VT_LD * (60 + k)]; cp1[k] = Jl[VT_LD * (64 + k)]; }
+      for (int k = 0; k < 4; ++k) { cp0[k] = Jl[60 + k]; cp1[k] = Jl[64 + k]; }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int b = 0; b < 3; ++b) { wr[12 + 3 * k + b] = cp0[k] * qb[b]; wr[36 + 3 * k + b] = -(cp1[k] * qb[b]); }
-      wr[48] = jr0 * Jl[VT_LD * 50] + jr1 * Jl[VT_LD * 51];
+      wr[48] = jr0 * Jl[50] + jr1 * Jl[51];
       wr[49] = jr0 * jr0 + jr1 * jr1;
-      wr[50] = jr0 * Jl[VT_LD * 52] + jr1 * Jl[VT_LD * 53];
+      wr[50] = jr0 * Jl[52] + jr1 * Jl[53];
     }
     // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave).  The buffer becomes
     //      NR fp64 rows (+ Hll, g_rho per row); every lane adds its 51 values into the row of its landmark (LDS atomics: blocks
