@@ -127,7 +127,8 @@ void ctvio_destroy(ctvio_solver *s);
 int32_t ctvio_clear(ctvio_solver *s);
 /* The Add*Factor calls of one UpdateTrajectory, recorded as one window; returns the window id in *id. */
 int32_t ctvio_add_window(ctvio_solver *s, const ctvio_window *w, int32_t *id);
-/* Pack (sort IMU samples into (segment,bias) groups, prior J0^T J0, ...) and copy to HBM. */
+/* Pack (sort IMU samples into (segment,bias) groups, visual blocks landmark by landmark, prior J0^T J0, ...) and copy to HBM.
+ * Limits checked here: P = 6K + 6F + 1 <= ~600, at most 64 visual blocks per landmark (CTVIO_ERR_INVALID otherwise). */
 int32_t ctvio_upload(ctvio_solver *s);
 /* ctvio_clear + n x ctvio_add_window + ctvio_upload in one call, without the intermediate host copy: the n windows are
  * validated and packed straight from the caller's buffers (read during this call only) by opt.host_threads threads into a

@@ -450,6 +450,16 @@ def test_invalid_inputs(cv):
         s.add_window(w)
         with pytest.raises(cv.capi.CtvioError):
             s.solve(5)            # not uploaded
+    # more than 64 observations of one landmark: the landmark's blocks must fit in one wave of k_vis_eval (rejected at upload)
+    big = w.copy()
+    rep = 70
+    for name in ("v_lm", "v_ti", "v_tj", "v_rowi", "v_rowj"):
+        a = np.asarray(getattr(big, name)); setattr(big, name, np.concatenate([a, np.repeat(a[:1], rep)]))
+    for name in ("v_pi", "v_pj"):
+        a = np.asarray(getattr(big, name)).reshape(-1, 2); setattr(big, name, np.concatenate([a, np.repeat(a[:1], rep, axis=0)]))
+    with cv.Solver() as s:
+        with pytest.raises(cv.capi.CtvioError, match="64 observations"):
+            s.set_windows([big])
 
 
 def test_full_size_properties(cv):
