@@ -12,6 +12,7 @@
 //   after     : k_gauge_restore (double2vector), k_spline_eval (trajectory query)
 #pragma once
 #include <utility>
+
 #include "device_types.hpp"
 #include "factors.hpp"
 
@@ -947,6 +948,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ldmax = max(ldmax, __shfl_xor(ldmax, off));
     ldmax = __builtin_amdgcn_readfirstlane(ldmax) | 1;   // odd row stride: ldw is a multiple of 32 doubles, which would put column g of EVERY row in the same LDS bank
+    // Segmented sums over the lanes of a landmark -- valid when all its blocks share the anchor end (the reference's factors do:
+    // ti and rowi are those of the feature's first observation): same knots, same addresses.  Otherwise every lane adds its own.
+    const int hl = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));       // head lane of this lane's landmark
+    const int hsi = __shfl(ksi, on ? hl : lane);
+    const bool presum = !__any(on && ksi != hsi);                           // (uniform)
+    double wsum[27];
+#pragma unroll
+    for (int cc = 0; cc < 24; ++cc) wsum[cc] = (double)wr[cc];
+    wsum[24] = (double)wr[48]; wsum[25] = (double)wr[49]; wsum[26] = (double)wr[50];
+    int maxlen = on ? lane - hl + 1 : 0;                                               // longest landmark of the wave (uniform)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    for (int off = 1; presum && off < maxlen; off <<= 1) {
+      const int oo = __shfl_down(on ? ord : -1, off);
+      const bool take = on && (lane + off < 64) && oo == ord;
+#pragma unroll
+      for (int cc = 0; cc < 27; ++cc) { const double o = __shfl_down(wsum[cc], off); wsum[cc] += take ? o : 0.0; }
+    }
     double *rows = reinterpret_cast<double *>(smt);
     const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / (ldmax + 2)));
     double *hg = rows + (size_t)NR * ldmax;                            // [NR][2] Hll, g_rho
@@ -964,15 +984,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
     LDS_SYNC();   // every lane has read its column of J~
     for (int c0 = 0; c0 < nlm; c0 += NR) {
       const int nr = min(NR, nlm - c0);
-      for (int i = lane; i < nr * ldmax + 2 * nr; i += 64) (i < nr * ldmax ? rows[i] : hg[i - nr * ldmax]) = 0.0;
+      for (int i = lane; i < NR * (ldmax + 2); i += 64) rows[i] = 0.0;     // (hg follows the rows)
       LDS_SYNC();
       if (on && ord >= c0 && ord < c0 + nr) {
         double *row = rows + (size_t)(ord - c0) * ldmax;
+        // anchor end, line delay, Hll, g_rho: summed over the landmark's lanes beforehand (wsum), added by the head lane alone --
+        // an LDS atomic of several lanes on ONE address costs ~64 cycles per lane (4-8 lanes per landmark: 2/3 of this phase)
+        if (head || !presum) {
 #pragma unroll
-        for (int cc = 0; cc < 48; ++cc) atomicAdd(&row[vis_col(cc, ksi, ksj, mP)], (double)wr[cc]);
-        atomicAdd(&row[mP - 1], (double)wr[48]);
-        atomicAdd(&hg[2 * (ord - c0)], (double)wr[49]);
-        atomicAdd(&hg[2 * (ord - c0) + 1], (double)wr[50]);
+          for (int cc = 0; cc < 24; ++cc) atomicAdd(&row[vis_col(cc, ksi, ksj, mP)], wsum[cc]);
+          atomicAdd(&row[mP - 1], wsum[24]);
+          atomicAdd(&hg[2 * (ord - c0)], wsum[25]);
+          atomicAdd(&hg[2 * (ord - c0) + 1], wsum[26]);
+        }
+#pragma unroll
+        for (int cc = 24; cc < 48; ++cc) atomicAdd(&row[vis_col(cc, ksi, ksj, mP)], (double)wr[cc]);
       }
       LDS_SYNC();
       if (dbg && lane == 0) dbg[3 + 2 * (c0 / NR)] = clock64();
