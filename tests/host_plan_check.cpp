@@ -1,0 +1,25 @@
+// Test shim (CPU): the host-side planning of a window's visual blocks (ctrl-vio_amd/csrc/host_pack.hpp: plan_window) compiled
+// with g++ against the HIP headers (no device code, nothing is launched).  Exposes the slot layout so that
+// tests/test_host_plan.py can check its invariants.
+#define __HIP_PLATFORM_AMD__ 1
+#include "../ctrl-vio_amd/csrc/host_pack.hpp"
+
+extern "C" {
+// in: V blocks (landmark, ti, tj, rowi, rowj), L landmarks, items of <= vch blocks.  out: Vp, lord[Vp_cap], vpos[V], vord[V], nvitem.
+// returns 0, or 1 when the plan is rejected (err_out gets the message).
+int hp_plan(int V, int L, const int32_t *v_lm, const int64_t *v_ti, const int64_t *v_tj, const int32_t *v_rowi, const int32_t *v_rowj, int vch,
+            int Vp_cap, int32_t *Vp, int32_t *lord, int32_t *vpos, int32_t *vord, int32_t *nvitem, char *err_out, int err_cap) {
+  ctvio_window w{};
+  w.V = V; w.L = L; w.M = 0;
+  w.v_lm = v_lm; w.v_ti = v_ti; w.v_tj = v_tj; w.v_rowi = v_rowi; w.v_rowj = v_rowj;
+  w.dt_ns = 1; w.t0_ns = 0;
+  ctv::PackTmp t;
+  ctv::plan_window(&w, vch, t);
+  if (!t.err.empty()) { std::snprintf(err_out, (size_t)err_cap, "%s", t.err.c_str()); return 1; }
+  *Vp = t.Vp; *nvitem = t.nvitem;
+  if (t.Vp > Vp_cap) return 2;
+  for (int i = 0; i < t.Vp; ++i) lord[i] = t.lord[i];
+  for (int i = 0; i < V; ++i) { vpos[i] = t.vpos[i]; vord[i] = t.vord[i]; }
+  return 0;
+}
+}
