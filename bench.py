@@ -41,11 +41,8 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}   # v_mfma_f32_32x32x2_f32 (gui
 
 
 def kernel_of_phase(precision):
-    if precision == "fp64":
-        return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_eval<double, true, double>",
-                "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve"}
-    return {"k_imu_linearize": "k_imu_linearize", "k_vis_eval": "k_vis_eval<float, true, double>",
-            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window", "k_cholesky_solve": "k_cholesky_solve"}
+    return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_eval<double, true>",
+            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve"}
 
 
 def imu_groups(w):
@@ -104,10 +101,10 @@ def main():
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic windows per GPU (seeds 1000 + 64 rank + i), replicated to --windows")
     ap.add_argument("--config", default="config2")
     ap.add_argument("--iters", type=int, default=15)
-    ap.add_argument("--precision", default="fp64", help="fp64 = the product (all-fp64); fp32 = the mixed fast mode (no 1e-4 contract)")
+    ap.add_argument("--precision", default="fp64", help="fp64 (the only arithmetic: all-fp64, like the reference)")
     ap.add_argument("--parity-sample", type=int, default=48, help="windows solved by the CPU oracle (state error of the timed path + cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra fp32 fast-mode measurement")
+    ap.add_argument("--no-fast-mode", action="store_true", help="(ignored: the mixed fp32 mode was removed)")
     ap.add_argument("--streams", type=int, default=4, help="solver handles (HIP streams + host threads) per GPU")
     ap.add_argument("--gpu-slots", type=int, default=0, help="handles allowed inside ctvio_solve at once (0: half of the streams, at least 1)")
     ap.add_argument("--host-threads", type=int, default=0, help="packing threads per handle (0: cores / streams, at most 16)")
@@ -305,23 +302,6 @@ def main():
                                 "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / pk, "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
         out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}   # handle 0 only
         # ---- parity of what was timed + CPU baseline: the oracle solves a sample of the same windows on one host core
-        # ---- the other arithmetic: the mixed fp32 / fp64 "fast" mode on the same windows, device-resident, one handle (it has no
-        #      1e-4 contract -- about one window in four ends a decision flip away from the reference)
-        out["fast_mode_fp32"] = None
-        if args.precision == "fp64" and not args.no_fast_mode and world == 1:
-            fs = cv.Solver(device=local, precision="fp32", host_threads=hthreads)
-            cv.capi.check(lib.ctvio_set_batch(fs._h, per[0], C.cast(cbatches[0], C.c_void_p)))
-            fs.snapshot_state()
-            fs.solve_raw(args.iters)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                fs.restore_state()
-                fs.solve_raw(args.iters)
-            torch.cuda.synchronize()
-            out["fast_mode_fp32"] = {"device_resident_solves_per_s": 3 * per[0] / (time.perf_counter() - t0), "windows": per[0], "handles": 1,
-                                     "note": "fp32 Jacobians / normal equations with fp64 residuals; no line search; not the product path"}
-            fs.close()
         out["parity"] = None
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the scaling runs must not wait on a CPU loop

@@ -13,10 +13,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libctvio.so")
-SRC = [os.path.join(_HERE, "csrc", f) for f in ("ctvio.hip", "kernels.hpp", "factors.hpp", "so3.hpp", "device_types.hpp", "marginalize.hpp", "host_pack.hpp")]
+import glob
+SRC = [os.path.join(_HERE, "csrc", "ctvio.hip")] + sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")))   # every header is a dependency
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctvio.h")
 
-FP32, FP64 = 0, 1
+FP64 = 1   # the only precision (ctvio.h: the mixed fp32 mode was removed)
 TERMINATION = {0: "max-iterations", 1: "gradient-tolerance", 2: "parameter-tolerance", 3: "function-tolerance", 4: "min-radius", 5: "failure"}
 
 
@@ -38,7 +39,7 @@ class Options(C.Structure):
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("max_consecutive_invalid_steps", C.c_int32), ("fp64_residuals", C.c_int32), ("host_threads", C.c_int32),
+                ("max_consecutive_invalid_steps", C.c_int32), ("deterministic", C.c_int32), ("host_threads", C.c_int32),
                 ("use_graph", C.c_int32), ("line_search", C.c_int32)]
 
 
@@ -57,7 +58,7 @@ class CWindow(C.Structure):
         ("v_lm", C.c_void_p), ("v_ti", C.c_void_p), ("v_tj", C.c_void_p), ("v_rowi", C.c_void_p), ("v_rowj", C.c_void_p),
         ("v_pi", C.c_void_p), ("v_pj", C.c_void_p),
         ("pJ0", C.c_void_p), ("pr0", C.c_void_p), ("p_kind", C.c_void_p), ("p_index", C.c_void_p), ("p_off", C.c_void_p),
-        ("p_x0", C.c_void_p),
+        ("p_x0", C.c_void_p), ("v_cauchy", C.c_void_p), ("knot_const", C.c_void_p),
     ]
 
 
@@ -142,6 +143,8 @@ def to_cwindow(w, keep):
     c.v_rowi, c.v_rowj, c.v_pi, c.v_pj = _p(w.v_rowi), _p(w.v_rowj), _p(w.v_pi), _p(w.v_pj)
     c.pJ0 = pJ0_cm.ctypes.data_as(C.c_void_p) if w.pn else None
     c.pr0, c.p_kind, c.p_index, c.p_off, c.p_x0 = _p(w.pr0), _p(w.p_kind), _p(w.p_index), _p(w.p_off), _p(w.p_x0)
+    c.v_cauchy = _p(w.v_cauchy) if w.v_cauchy is not None else None
+    c.knot_const = _p(w.knot_const) if w.knot_const is not None else None
     return c
 
 

@@ -56,7 +56,8 @@ template <class U> struct DBuf {
 // Owning host copy of one window (ctvio_add_window: the caller's buffers are only read inside that call).
 struct HostWindow {
   ctvio_window w;  // scalars + pointers into the vectors below
-  std::vector<double> quat, pos, bias, rho, imu_gyro, imu_acc, bc_w, v_pi, v_pj, pJ0, pr0, p_x0;
+  std::vector<double> quat, pos, bias, rho, imu_gyro, imu_acc, bc_w, v_pi, v_pj, pJ0, pr0, p_x0, v_cauchy;
+  std::vector<uint8_t> knot_const;
   std::vector<int64_t> imu_t, v_ti, v_tj;
   std::vector<int32_t> imu_bias, bc_i, bc_j, v_lm, v_rowi, v_rowj, p_kind, p_index, p_off;
   template <class U> static const U *own(std::vector<U> &dst, const U *src, size_t n) {
@@ -75,6 +76,8 @@ struct HostWindow {
     w.pJ0 = own(pJ0, c.pJ0, (size_t)c.pn * c.pn); w.pr0 = own(pr0, c.pr0, (size_t)c.pn);
     w.p_kind = own(p_kind, c.p_kind, (size_t)c.pnb); w.p_index = own(p_index, c.p_index, (size_t)c.pnb);
     w.p_off = own(p_off, c.p_off, (size_t)c.pnb); w.p_x0 = own(p_x0, c.p_x0, (size_t)4 * c.pnb);
+    if (c.v_cauchy) w.v_cauchy = own(v_cauchy, c.v_cauchy, (size_t)c.V);
+    if (c.knot_const) w.knot_const = own(knot_const, c.knot_const, (size_t)c.K);
   }
   HostWindow(const HostWindow &) = delete;
   HostWindow &operator=(const HostWindow &) = delete;
@@ -110,9 +113,9 @@ struct SolverBase {
 template <class T> class SolverImpl : public SolverBase {
  public:
   // visual blocks per work item (k_assemble_vis*): eight per-wave staging areas [116][VCH + 2] must fit beside the fp64 LDS Hessian
-  static constexpr int VCH = sizeof(T) == 8 ? 8 : 16;
+  static constexpr int VCH = 8;
   static constexpr size_t vis_stage_bytes() { return (size_t)8 * 116 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
-  explicit SolverImpl(const ctvio_options &o) : opt_(o), mixed_(sizeof(T) == 4 && o.fp64_residuals != 0) {}
+  explicit SolverImpl(const ctvio_options &o) : opt_(o) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
@@ -133,11 +136,9 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (sizeof(T) == 8) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
@@ -251,11 +252,9 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_knot_win = seg(4 * (size_t)K0), o_bias_win = seg(4 * (size_t)F0), o_lm_win = seg(4 * (size_t)L0);
     const size_t o_groups = seg(sizeof(ImuGroup) * (size_t)G0), o_imu_grp = seg(4 * Mt);
     const size_t o_imu_u = seg(sizeof(T) * Mt), o_imu_meas = seg(sizeof(T) * 6 * Mt);
-    const bool dup64 = sizeof(T) == 4;   // the mixed mode keeps an fp64 copy of the measurements for its residual pass
-    const size_t o_imu_ud = dup64 ? seg(8 * Mt) : o_imu_u, o_imu_meas_d = dup64 ? seg(8 * 6 * Mt) : o_imu_meas;
     const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_rowi = seg(4 * Vt), o_v_rowj = seg(4 * Vt);
     const size_t o_v_ti = seg(8 * Vt), o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(T) * 4 * Vt);
-    const size_t o_v_obs_d = dup64 ? seg(8 * 4 * Vt) : o_v_obs;
+    const size_t o_v_cauchy = seg(8 * Vt);
     const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_vblk = seg(4 * Vt);
     const size_t o_bc_win = seg(4 * (size_t)B0), o_bc_i = seg(4 * (size_t)B0), o_bc_j = seg(4 * (size_t)B0), o_bc_w = seg(8 * 6 * (size_t)B0);
     const size_t o_pJ0 = seg(8 * (size_t)pH0), o_pr0 = seg(8 * (size_t)pv0);
@@ -276,7 +275,7 @@ template <class T> class SolverImpl : public SolverBase {
     ImuGroup *h_groups = CTV_H(ImuGroup, o_groups);
     int32_t *h_imu_grp = CTV_H(int32_t, o_imu_grp);
     T *h_imu_u = CTV_H(T, o_imu_u), *h_imu_meas = CTV_H(T, o_imu_meas), *h_v_obs = CTV_H(T, o_v_obs);
-    double *h_imu_ud = CTV_H(double, o_imu_ud), *h_imu_meas_d = CTV_H(double, o_imu_meas_d), *h_v_obs_d = CTV_H(double, o_v_obs_d);
+    double *h_v_cauchy = CTV_H(double, o_v_cauchy);
     int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_rowi = CTV_H(int32_t, o_v_rowi), *h_v_rowj = CTV_H(int32_t, o_v_rowj);
     int64_t *h_v_ti = CTV_H(int64_t, o_v_ti), *h_v_tj = CTV_H(int64_t, o_v_tj);
     VisItem *h_vitems = CTV_H(VisItem, o_vitems);
@@ -312,11 +311,9 @@ template <class T> class SolverImpl : public SolverBase {
         const int64_t st = w.imu_t[src] - w.t0_ns;
         const double uu = (double)(st % w.dt_ns) / (double)w.dt_ns;
         h_imu_u[e] = (T)uu;
-        if (dup64) h_imu_ud[e] = uu;
         for (int c = 0; c < 3; ++c) {
           h_imu_meas[(size_t)c * Mt + e] = (T)w.imu_gyro[3 * src + c];
           h_imu_meas[(size_t)(3 + c) * Mt + e] = (T)w.imu_acc[3 * src + c];
-          if (dup64) { h_imu_meas_d[(size_t)c * Mt + e] = w.imu_gyro[3 * src + c]; h_imu_meas_d[(size_t)(3 + c) * Mt + e] = w.imu_acc[3 * src + c]; }
         }
       }
       // visual blocks: evaluation slots in landmark-major order (padding slots: window -1, harmless values)
@@ -324,15 +321,16 @@ template <class T> class SolverImpl : public SolverBase {
         const int v = t.lord[i];
         const size_t e = (size_t)m.vis0 + i;
         if (v < 0) {
-          h_v_win[e] = -1; h_v_lm[e] = 0; h_v_ti[e] = 0; h_v_tj[e] = 0; h_v_rowi[e] = 0; h_v_rowj[e] = 0;
-          for (int c = 0; c < 4; ++c) { h_v_obs[(size_t)c * Vt + e] = T(0); if (dup64) h_v_obs_d[(size_t)c * Vt + e] = 0.0; }
+          h_v_win[e] = -1; h_v_lm[e] = 0; h_v_ti[e] = 0; h_v_tj[e] = 0; h_v_rowi[e] = 0; h_v_rowj[e] = 0; h_v_cauchy[e] = 0.0;
+          for (int c = 0; c < 4; ++c) h_v_obs[(size_t)c * Vt + e] = T(0);
           continue;
         }
         h_v_win[e] = wi; h_v_lm[e] = w.v_lm[v];
         h_v_ti[e] = w.v_ti[v] - w.t0_ns; h_v_tj[e] = w.v_tj[v] - w.t0_ns;
         h_v_rowi[e] = w.v_rowi[v]; h_v_rowj[e] = w.v_rowj[v];
         const double o4[4] = {w.v_pi[2 * v], w.v_pi[2 * v + 1], w.v_pj[2 * v], w.v_pj[2 * v + 1]};
-        for (int c = 0; c < 4; ++c) { h_v_obs[(size_t)c * Vt + e] = (T)o4[c]; if (dup64) h_v_obs_d[(size_t)c * Vt + e] = o4[c]; }
+        for (int c = 0; c < 4; ++c) h_v_obs[(size_t)c * Vt + e] = (T)o4[c];
+        h_v_cauchy[e] = w.v_cauchy ? w.v_cauchy[v] : w.cauchy_a;
       }
       // the assembly's items: <= VCH blocks of one frame pair, frame-pair order, as lists of slots (vblk)
       int it = m.vitem0 - 1;
@@ -395,7 +393,7 @@ template <class T> class SolverImpl : public SolverBase {
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
     d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(T, o_imu_u); d.imu_meas = CTV_D(T, o_imu_meas);
-    d.imu_ud = CTV_D(double, o_imu_ud); d.imu_meas_d = CTV_D(double, o_imu_meas_d); d.v_obs_d = CTV_D(double, o_v_obs_d);
+    d.v_cauchy = CTV_D(double, o_v_cauchy);
     d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_rowi = CTV_D(int32_t, o_v_rowi); d.v_rowj = CTV_D(int32_t, o_v_rowj);
     d.v_ti = CTV_D(int64_t, o_v_ti); d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
     d.vitems = CTV_D(VisItem, o_vitems); d.vblk = CTV_D(int32_t, o_vblk);
@@ -414,7 +412,6 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_cstate = seg(8 * state_doubles_), o_snap = seg(8 * state_doubles_);
     const size_t o_kd = seg(8 * 3 * (size_t)K0), o_ckd = seg(8 * 3 * (size_t)K0), o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
     const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
-    const size_t o_imu_rc = mixed_ ? seg(sizeof(T) * 6 * Mt) : 0, o_vis_rc = mixed_ ? seg(sizeof(T) * 3 * Vt) : 0;
     const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt);
     const size_t o_Hpp = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
@@ -423,7 +420,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_zero1 = off;   // ---- ... to here
     const size_t o_rhs = seg(8 * (size_t)Pp0), o_dd = seg(8 * (size_t)U0), o_dinv = seg(8 * (size_t)L0);
     d.chol_nblk = (maxP + 31) / 32;
-    d.line_search = (sizeof(T) == 8 && opt_.line_search) ? 1 : 0;   // the mixed mode reuses cost-pass residuals: no trial-point linearisations
+    d.line_search = opt_.line_search ? 1 : 0;
     const size_t o_chol_inv = seg(8 * (size_t)nw * d.chol_nblk * 1024);
     HIPCHK(work_.reserve(off, false, &grew));
     if (grew) HIPCHK(hipMemsetAsync(work_.dev, 0, work_.cap, stream_));   // fresh memory may hold NaN patterns (0 * NaN in masked products)
@@ -432,7 +429,6 @@ template <class T> class SolverImpl : public SolverBase {
     d.cquat = CTV_W(double, o_cstate); d.cpos = d.cquat + (size_t)4 * K0; d.cbias = d.cpos + (size_t)3 * K0; d.crho = d.cbias + (size_t)6 * F0; d.cld = d.crho + L0;
     snap_ = CTV_W(double, o_snap);
     d.kd = CTV_W(double, o_kd); d.ckd = CTV_W(double, o_ckd); d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
-    if (mixed_) { d.imu_rc = CTV_W(T, o_imu_rc); d.vis_rc = CTV_W(T, o_vis_rc); }
     d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs);
     d.Hpp = CTV_W(double, o_Hpp); d.S = CTV_W(double, o_S); d.W = CTV_W(T, o_W); d.Hll = CTV_W(double, o_Hll); d.g = CTV_W(double, o_g);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
@@ -494,19 +490,18 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_linearize() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
-    constexpr int CH = sizeof(T) == 4 ? 64 : 32;
+    constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
     hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0);
     ph_end();
     hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, 2);
     ph_begin(PH_IMU_LIN);
-    const size_t imu_lds = (sizeof(T) == 4 ? (size_t)3 * CH * 33 * sizeof(T) : (size_t)32 * (6 * CH + 4) * sizeof(T)) + 0;
+    const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
     if (d.Gtot) launch_imu_linearize(imu_lds);
     ph_end();
     ph_begin(PH_VIS_LIN);
     if (d.Vtot) {
-      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, true, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, d.kd, 0);
-      else hipLaunchKernelGGL((k_vis_eval<T, true, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, d.kd, 0);
+      hipLaunchKernelGGL((k_vis_eval<T, true>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, d.kd, 0);
     }
     ph_end();
   }
@@ -553,7 +548,7 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_imu_linearize(size_t vals_lds);
   void launch_assemble_vis_lds(int parts);
   void launch_assemble_vis_glb(int parts);
-  bool schur_makes_rhs() const { return (sizeof(T) == 4 && opt_.use_mfma != 0) || schur_rhs_done_; }
+  bool schur_makes_rhs() const { return schur_rhs_done_; }
   bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
   void launch_cost(bool candidate, int force) {
     const Dev<T> &d = dev_;
@@ -562,12 +557,10 @@ template <class T> class SolverImpl : public SolverBase {
     const double *kd = candidate ? d.ckd : d.kd;
     hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, candidate ? 1 : 0);
     if (d.Mtot) {
-      if (mixed_) hipLaunchKernelGGL((k_imu_cost<T, double>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
-      else hipLaunchKernelGGL((k_imu_cost<T, T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
+      hipLaunchKernelGGL((k_imu_cost<T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
     }
     if (d.Vtot) {
-      if (mixed_) hipLaunchKernelGGL((k_vis_eval<T, false, double>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, kd, force);
-      else hipLaunchKernelGGL((k_vis_eval<T, false, T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, kd, force);
+      hipLaunchKernelGGL((k_vis_eval<T, false>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, kd, force);
     }
     hipLaunchKernelGGL((k_misc<T, false>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, q, p, b, l, force);
   }
@@ -595,8 +588,15 @@ template <class T> class SolverImpl : public SolverBase {
   }
   // The pass as a hipGraph (captured once per batch shape: the kernel arguments are the Dev struct, so equal shapes in the
   // grow-only arenas give identical graphs), replayed instead of ~25 launches.
+  // Everything the launch list depends on besides the Dev struct: dynamic LDS sizes, kernel choices (template arguments, which
+  // assembly variants run).  Two batches with identical totals can differ in these (e.g. the same sum K split differently).
+  std::vector<long long> launch_signature() const {
+    return {(long long)vis_lds_, (long long)vis_glb_, (long long)any_vis_lds_, (long long)any_vis_glb_, (long long)maxK_, (long long)max_schur_tiles_,
+            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_};
+  }
   int ensure_graph() {
-    if (graph_exec_ && std::memcmp(&graph_dev_, &dev_, sizeof dev_) == 0) return CTVIO_OK;
+    const std::vector<long long> sig = launch_signature();
+    if (graph_exec_ && std::memcmp(&graph_dev_, &dev_, sizeof dev_) == 0 && sig == graph_sig_) return CTVIO_OK;
     if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -606,6 +606,7 @@ template <class T> class SolverImpl : public SolverBase {
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) { graph_exec_ = nullptr; return fail(CTVIO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     graph_dev_ = dev_;
+    graph_sig_ = sig;
     return CTVIO_OK;
   }
 
@@ -790,7 +791,7 @@ template <class T> class SolverImpl : public SolverBase {
     const int wb = nblk(d.nwin, 64);
     set_params(1);
     hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, mu, 0);
-    launch_cost(false, 1);   // mixed mode: the linearisation reuses the residuals of a cost pass at the same state
+    launch_cost(false, 1);
     launch_linearize();
     launch_assemble();
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
@@ -809,7 +810,9 @@ template <class T> class SolverImpl : public SolverBase {
   // workgroup per window eliminates the marginalised unknowns and factors the rest (csrc/marg_device.hpp: parallel Jacobi
   // in LDS).  role: concatenated per window (sum N entries, window i at its unknown offset); `only` >= 0 restricts the work
   // to that window.  Outputs: n_keep[nwin]; kept at the window's unknown offset; J0 / r0 packed tightly in window order.
-  int marg_device(const int8_t *role_all, int only, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0, bool *too_large) {
+  int marg_device(const int8_t *role_all, int only, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0, bool *too_large,
+                  int *stalled = nullptr) {
+    if (stalled) *stalled = -1;
     Dev<T> &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     *too_large = false;
@@ -867,7 +870,7 @@ template <class T> class SolverImpl : public SolverBase {
         for (int i = 0; i < 26 && i <= std::max(mm.sweeps_n, 0) + 1; ++i) std::fprintf(stderr, " %.2e", mm.trace[26 + i]);
         std::fprintf(stderr, "\n");
       }
-      if (mm.status) return fail(CTVIO_ERR_HIP, "device eigen-solver did not converge (window " + std::to_string(w) + ")");
+      if (mm.status) { if (stalled) *stalled = w; return fail(CTVIO_ERR_HIP, "device eigen-solver did not converge (window " + std::to_string(w) + ")"); }
       std::memcpy(J0 + oj, outh.data() + mm.J0, sizeof(double) * (size_t)mm.n * mm.n);
       std::memcpy(r0 + orr, outh.data() + mm.r0, sizeof(double) * (size_t)mm.n);
       oj += (size_t)mm.n * mm.n; orr += (size_t)mm.n;
@@ -879,7 +882,10 @@ template <class T> class SolverImpl : public SolverBase {
     if (!role || !n_keep || !kept || !J0 || !r0 || !(eps >= 0)) return fail(CTVIO_ERR_INVALID, "bad arguments");
     for (int i = 0; i < dev_.Utot; ++i) if (role[i] < -1 || role[i] > 1) return fail(CTVIO_ERR_INVALID, "role must be -1, 0 or 1");
     bool too_large = false;
-    const int rc = marg_device(role, -1, eps, n_keep, kept, J0, r0, &too_large);
+    int stalled = -1;
+    const int rc = marg_device(role, -1, eps, n_keep, kept, J0, r0, &too_large, &stalled);
+    if (rc != CTVIO_OK && stalled >= 0)
+      return fail(CTVIO_ERR_HIP, "device eigen-solver did not converge for window " + std::to_string(stalled) + ": call ctvio_marginalize for it (host factorisation)");
     if (rc != CTVIO_OK) return rc;
     if (too_large) return fail(CTVIO_ERR_INVALID, "a window has more than " + std::to_string(MARG_MAXD) + " marginalised or kept unknowns: use ctvio_marginalize");
     return CTVIO_OK;
@@ -897,9 +903,11 @@ template <class T> class SolverImpl : public SolverBase {
       std::copy(role, role + N, role_all.begin() + m.u0);
       std::vector<int32_t> nk((size_t)dev_.nwin), kv((size_t)dev_.Utot);
       bool too_large = false;
-      const int rc = marg_device(role_all.data(), id, eps, nk.data(), kv.data(), J0, r0, &too_large);
-      if (rc != CTVIO_OK) return rc;
-      if (!too_large) {
+      int stalled = -1;
+      const int rc = marg_device(role_all.data(), id, eps, nk.data(), kv.data(), J0, r0, &too_large, &stalled);
+      if (rc != CTVIO_OK && stalled < 0) return rc;
+      // the in-LDS Jacobi sweep stalled above its (tight) off-diagonal bound: the host Householder / QL path below takes over
+      if (rc == CTVIO_OK && !too_large) {
         *n_keep = nk[id];
         std::copy(kv.begin() + m.u0, kv.begin() + m.u0 + nk[id], kept);
         return CTVIO_OK;
@@ -1010,7 +1018,7 @@ template <class T> class SolverImpl : public SolverBase {
   ctvio_options opt_;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool uploaded_ = false, profiling_ = false, profiling_requested_ = false, mixed_ = false;
+  bool uploaded_ = false, profiling_ = false, profiling_requested_ = false;
   double timing_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int32_t ph_n_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_iters_ = 0;
   std::vector<hipEvent_t> pev_;
@@ -1043,47 +1051,18 @@ template <class T> class SolverImpl : public SolverBase {
   Lm *lm_host_ = nullptr; size_t lm_host_cap_ = 0;
   hipGraphExec_t graph_exec_ = nullptr;   // one LM pass (launch_pass) as a graph, valid while dev_ == graph_dev_
   Dev<T> graph_dev_;
+  std::vector<long long> graph_sig_;
+  bool deterministic_ = false;   // order-fixed accumulation for this batch (ctvio_options.deterministic)
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
   int maxK_ = 0, max_schur_tiles_ = 0;
 };
 
-template <> void SolverImpl<float>::launch_imu_linearize(size_t lds) {
-  const Dev<float> &d = dev_;
-  if (mixed_) hipLaunchKernelGGL((k_imu_linearize<float, 64, double>), dim3(d.Gtot), dim3(64), lds, stream_, d);
-  else hipLaunchKernelGGL((k_imu_linearize<float, 64, float>), dim3(d.Gtot), dim3(64), lds, stream_, d);
-}
 template <> void SolverImpl<double>::launch_imu_linearize(size_t lds) {
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
   if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d);
-  else hipLaunchKernelGGL((k_imu_linearize<double, 32, double>), dim3(d.Gtot), dim3(64), lds, stream_, d);
-}
-template <> void SolverImpl<float>::launch_schur() {
-  const Dev<float> &d = dev_;
-  const int nt = (d.maxP + 1 + 31) / 32;
-  if (opt_.use_mfma) {
-    const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32) * sizeof(float);
-    // few windows: one workgroup per window leaves the chip idle and serialises 13 chunk round trips -- the per-tile
-    // kernel (28 independent waves per window, W re-read per tile) has the shorter latency there
-    const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");   // measured crossover ~256 windows per launch
-    if (small) hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
-    else if (d.maxLdw <= 224 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<7>), dim3(d.nwin), dim3(512), lds, stream_, d);
-    else if (d.maxLdw <= 448 && nt * (nt + 1) / 2 <= 32) hipLaunchKernelGGL((k_schur_window<14>), dim3(d.nwin), dim3(512), lds, stream_, d);
-    else hipLaunchKernelGGL(k_schur_mfma, dim3(nt * (nt + 1) / 2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nt * (nt + 1) / 2);
-  }
-  else hipLaunchKernelGGL((k_schur_generic<float>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
-}
-template <> void SolverImpl<float>::launch_assemble_vis_lds(int parts) {
-  const Dev<float> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<float, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
-  else hipLaunchKernelGGL((k_assemble_vis<float, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
-}
-// windows whose packed Hessian does not fit in LDS (K > 25): run products on the MFMA units, added to Hpp with global atomics
-template <> void SolverImpl<float>::launch_assemble_vis_glb(int parts) {
-  const Dev<float> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<float, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
-  else hipLaunchKernelGGL((k_assemble_vis<float, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
+  else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d);
 }
 template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
   const Dev<double> &d = dev_;
@@ -1134,7 +1113,7 @@ void ctvio_default_options(ctvio_options *o) {
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32; o->min_relative_decrease = 1e-3;
   o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->max_consecutive_invalid_steps = 5;
-  o->fp64_residuals = 1; o->host_threads = 0; o->use_graph = 1; o->line_search = 1;
+  o->deterministic = -1; o->host_threads = 0; o->use_graph = 1; o->line_search = 1;
 }
 const char *ctvio_status_string(int32_t s) {
   switch (s) {
@@ -1162,8 +1141,8 @@ int32_t ctvio_create(const ctvio_options *opt, ctvio_solver **out) {
   if (o.device < 0 || o.device >= n) return ctv::fail(CTVIO_ERR_INVALID, "device ordinal out of range");
   std::unique_ptr<ctvio_solver> s(new ctvio_solver);
   int rc;
-  if (o.precision == CTVIO_FP64) { auto *p = new ctv::SolverImpl<double>(o); s->impl.reset(p); rc = p->init(); }
-  else { auto *p = new ctv::SolverImpl<float>(o); s->impl.reset(p); rc = p->init(); }
+  if (o.precision != CTVIO_FP64) return ctv::fail(CTVIO_ERR_INVALID, "precision: only CTVIO_FP64 exists (the mixed fp32 mode was removed: it missed the 1e-4 contract)");
+  { auto *p = new ctv::SolverImpl<double>(o); s->impl.reset(p); rc = p->init(); }
   if (rc != CTVIO_OK) return rc;
   *out = s.release();
   return CTVIO_OK;

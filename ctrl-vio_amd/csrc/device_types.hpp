@@ -63,7 +63,7 @@ struct LmParams {
   int32_t max_invalid, max_iters;
 };
 
-// Device pointers of one batch.  T = scalar of the linearisation kernels (float product / double debug).
+// Device pointers of one batch.  T = scalar of the linearisation kernels: double (the reference's arithmetic) is the only instantiation.
 template <class T> struct Dev {
   int32_t nwin, Ktot, Ftot, Ltot, Mtot, Gtot, Vtot, NBtot, Utot, maxN, maxP, maxPn;
   const WinMeta *wins;
@@ -81,24 +81,20 @@ template <class T> struct Dev {
   const int32_t *imu_grp;
   const T *imu_u;        // [Mtot] normalised time in the segment
   const T *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
-  const double *imu_ud, *imu_meas_d;   // the same in fp64, read by the residual path of the mixed mode
-  T *imu_rc;             // [6][Mtot] mixed mode: whitened residuals of the last cost pass (fp64 evaluation, rounded once);
-                         // the linearisation always follows a cost pass at the same state and reuses them
   T *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
   // visual factors
   const int32_t *v_win, *v_lm;
   const int64_t *v_ti, *v_tj;   // relative to the window's t0
   const int32_t *v_rowi, *v_rowj;
   const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
-  const double *v_obs_d; // fp64 copy for the residual path of the mixed mode
+  const double *v_cauchy; // [Vtot] width a of the block's ceres::CauchyLoss(a) (<= 0: no loss): the reference picks it per residual
+                         // block (trajectory_estimator.cpp:320-323: 1 when the feature is being marginalised, else 2)
   T *Jt;                 // robust-corrected visual Jacobian + residual, block-major [Vtot][VT_ROWS]: the assembly gathers the blocks of
                          // an item (frame-pair order) from the landmark-major block order, 528 contiguous bytes each; a wave of
                          // k_vis_eval writes the 64 x VT_ROWS entries of its blocks as ONE contiguous 34 KB region (from LDS).
                          // Row entries: 0-23 rotation columns of the i end (2 col + residual row), 24-47 of the j end, 48/49 inverse
                          // depth, 50/51 line delay, 52/53 residual, 54-67 the position columns in compact form: P~ (2 x 3), cp0[4],
                          // cp1[4]  (J~_pos(k, b) = cp0[k] P~[b] / -cp1[k] P~[b])
-  T *vis_rc;             // [3][Vtot] mixed mode: robust-corrected residuals of the last cost pass (see imu_rc) and the block's
-                         // sqrt(rho') = exp(-cost / a^2) from that fp64 evaluation (row 2)
   int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
   const VisItem *vitems;
   const int32_t *vblk;   // [Vtot] block slots in frame-pair order, window by window (VisItem::start indexes it)

@@ -339,7 +339,6 @@ template <class T> struct Calib {
   Q4<T> q_CI;
   V3<T> p_CI;
   T img_w, cauchy_a;
-  T sq_override = T(-1);   // > 0: sqrt(rho') of this block from a more precise residual evaluation (mixed mode), see visual_eval
 };
 
 // Visual block.  Local column order of J (2 x 50): rot_i (12) | pos_i (12) | rot_j (12) | pos_j (12) | rho | ld.
@@ -393,10 +392,6 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, co
   } else {
     cost = T(0.5) * s;
   }
-  // Mixed mode: the fp32 residual carries ~1e-5 relative noise (x/z - obs cancels), which would scale this block's J~ by a
-  // slightly different sqrt(rho') than the fp64 residual pass used for r~ -- a systematic 1e-5 inconsistency in J~^T r~.
-  // The caller passes the fp64 value (Cauchy: rho'' < 0, so alpha = 0 and rs = sq).
-  if (cal.sq_override > T(0)) { sq = cal.sq_override; rs = sq; alpha_sq = T(0); }
   r[0] = rs * r0;
   r[1] = rs * r1;
   if (!want_jac) return cost;

@@ -209,6 +209,8 @@ inline void active_mask(const ctvio_window *w, const PackTmp &t, int P, const in
   for (int b = 0; b < w->NB; ++b) { std::memset(act + 6 * K + 6 * w->bc_i[b], 1, 6); std::memset(act + 6 * K + 6 * w->bc_j[b], 1, 6); }
   for (int i = 0; i < w->pn; ++i) act[pcol[i]] = 1;
   for (int k = 0; k <= w->fixed_upto && k < K; ++k) std::memset(act + 6 * k, 0, 6);
+  if (w->knot_const)
+    for (int k = 0; k < K; ++k) if (w->knot_const[k]) std::memset(act + 6 * k, 0, 6);
   for (int f = 0; f < w->F; ++f) {
     if (w->lock_bg) std::memset(act + 6 * K + 6 * f, 0, 3);
     if (w->lock_ba) std::memset(act + 6 * K + 6 * f + 3, 0, 3);

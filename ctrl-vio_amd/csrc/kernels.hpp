@@ -335,60 +335,26 @@ template <class T> __global__ void k_knot_prep(Dev<T> d, int mode) {
 // ------------------------------------------------------------------------------------------------ IMU
 template <class T, int N> struct alignas(N * sizeof(T)) VecN { T v[N]; };
 
-// LDS layouts of the staged IMU rows (row k = 6 * lane + r of A = [J | r], 32 columns):
-//   MFMA path (float): row-major A[k][33]  -- v_mfma_f32_32x32x2_f32 reads 2 rows x 32 columns per instruction
-//   VALU path        : column-major A^T[32][KS] -- 4 consecutive k per ds_read for the register-tile reduction
-template <class T, bool ROWMAJOR> struct ImuLdsSink {
+// VALU cross-check of k_imu_linearize_f64 (use_mfma = 0): the rows of A = [J | r] (row k = 6 * lane + r, 32 columns) staged
+// column-major in LDS, A^T[32][KS], 4 consecutive k per ds_read; 4 x 4 register tile per lane (rows {ti+8a}, cols {tj+8b}).
+template <class T> struct ImuLdsSink {
   T *A;
   int lane, stride;
   __device__ __forceinline__ void put_col(int col, const T v[6]) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      if (ROWMAJOR) A[(6 * lane + r) * stride + col] = v[r];
-      else A[col * stride + 6 * lane + r] = v[r];
-    }
+    for (int r = 0; r < 6; ++r) A[col * stride + 6 * lane + r] = v[r];
   }
 };
 template <class T> struct NullSink {
   __device__ __forceinline__ void put_col(int, const T *) {}
 };
 
-// MFMA path: the accelerometer rows (3 per sample, all 32 columns) go to LDS as they are produced; the gyro rows are
-// non-zero only in 16 columns (12 rotation, 3 gyro bias, residual) and wait in registers until the accelerometer
-// product is done, then reuse the same LDS.  Halves the LDS per wave (occupancy) and cuts the MFMA work by 40%.
-template <class T> struct ImuSplitSink {
-  T *A;
-  int lane;
-  T g[16][3];
-  __device__ __forceinline__ void put_col(int col, const T v[6]) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) A[(3 * lane + a) * 33 + col] = v[3 + a];
-    const int gc = col < 12 ? col : ((col >= 24 && col < 27) ? col - 12 : (col == 30 ? 15 : -1));
-    if (gc >= 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) g[gc][a] = v[a];
-    }
-  }
-};
-
-// One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane
-// evaluates one sample and its 6 Jacobian rows + residual; then the wave forms the group's 31x31 block
-// A^T A = [J^T J, J^T r; r^T J, r^T r]:
-//   float : on the matrix cores -- accelerometer rows with v_mfma_f32_32x32x2_f32 (row-major A[k][33] in LDS, A and B
-//           operand the same LDS value), gyro rows with v_mfma_f32_16x16x4_f32 on their 16 non-zero columns;
-//   double: rows staged column-major A^T[32][KS], 4x4 register tile per lane (rows {ti+8a}, cols {tj+8b}).
-// The tile is stored, not accumulated -- no atomics, deterministic.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-// RT = scalar of the RESIDUAL (and of the cost kernels).  RT = double with T = float is the mixed mode: Jacobians,
-// J^T J and the Schur complement stay in fp32, but r (hence the gradient J^T r and every cost) is evaluated in fp64
-// from fp64 inputs, which removes the fp32 residual noise (~5e-5 sigma) from the LM decisions and the fixed point.
-template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_imu_linearize(Dev<T> d) {
-  constexpr bool MFMA = sizeof(T) == 4;
-  constexpr bool MIXED = sizeof(RT) != sizeof(T);
+// One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane evaluates one sample and
+// its 6 Jacobian rows + residual; then the wave forms the group's 31 x 31 block A^T A = [J^T J, J^T r; r^T J, r^T r].
+// The tile is stored, not accumulated -- no atomics, deterministic.
+template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_imu_linearize(Dev<T> d) {
   constexpr int KCH = 6 * CHUNK, KS = KCH + 4;
-  constexpr size_t ABYTES = MFMA ? (size_t)3 * CHUNK * 33 * sizeof(T) : (size_t)32 * KS * sizeof(T);
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   T *A = reinterpret_cast<T *>(smraw);
   const ImuGroup grp = d.groups[blockIdx.x];
@@ -411,26 +377,12 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
   for (int i = 0; i < 6; ++i) { bias[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
   const V3<T> grav = lf.rotate(m.gravity);
   const T idt = (T)m.inv_dt;
-  const int ti = lane >> 3, tj = lane & 7, half = lane >> 5, l31 = lane & 31;
+  const int ti = lane >> 3, tj = lane & 7;
   T acc[4][4];
-  f32x16 macc;
-  f32x4 gacc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) macc[r] = 0.0f;
-  long long *dbg = (d.dbg && blockIdx.x == 0) ? d.dbg + 32 : nullptr;
-  int dbi = 0;
-#define CTV_STAMP() do { if (dbg && lane == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
-  CTV_STAMP();
-  // mixed mode: the whitened residual of this sample was evaluated in fp64 by the cost pass at this very state
-  // (k_imu_cost) and rounded once; the fp32 evaluation below only supplies the Jacobian
-  auto residual_rt = [&](int idx, T r[6]) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r[i] = d.imu_rc[(size_t)i * d.Mtot + idx];
-  };
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   for (int c0 = 0; c0 < grp.count; c0 += CHUNK) {
     const int nval = min(CHUNK, grp.count - c0);
@@ -440,103 +392,38 @@ template <class T, int CHUNK, class RT> __global__ __launch_bounds__(64) __attri
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
     }
-    if constexpr (MFMA) {
-      const int kmaxA = (3 * nval + 1) & ~1, kmaxG = (3 * nval + 3) & ~3;   // rows padded to the MFMA's K step
-      ImuSplitSink<T> sink;
-      sink.A = A; sink.lane = lane;
+    const int kmax = (6 * nval + 3) & ~3;
+    ImuLdsSink<T> sink{A, lane, KS};
+    if (lane < nval) {
+      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
+      sink.put_col(30, r);
+      sink.put_col(31, zero6);
+    } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
 #pragma unroll
-      for (int c = 0; c < 16; ++c) sink.g[c][0] = sink.g[c][1] = sink.g[c][2] = T(0);
-      if (lane < nval) {
-        imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
-        if (MIXED) residual_rt(idx, r);
-        sink.put_col(30, r);
-        sink.put_col(31, zero6);
-      } else if (lane == nval) {  // the pad rows (at most 3) must read as zero
-#pragma unroll
-        for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
-      }
-      __syncthreads();
-      CTV_STAMP();
-#pragma unroll 8
-      for (int k0 = 0; k0 < kmaxA; k0 += 2) {
-        const float v = A[(k0 + half) * 33 + l31];
-        macc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, macc, 0, 0, 0);
-      }
-      __syncthreads();
-      CTV_STAMP();
-      if (lane <= nval) {   // gyro rows: [3 * CHUNK][17] in the same LDS
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-          for (int a = 0; a < 3; ++a) A[(3 * lane + a) * 17 + c] = sink.g[c][a];
-      }
-      __syncthreads();
-      {
-        const int q4 = lane >> 4, l15 = lane & 15;
-#pragma unroll 8
-        for (int k0 = 0; k0 < kmaxG; k0 += 4) {
-          const float v = A[(k0 + q4) * 17 + l15];
-          gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, gacc, 0, 0, 0);
-        }
-      }
-      __syncthreads();
-      CTV_STAMP();
-    } else {
-      const int kmax = (6 * nval + 3) & ~3;
-      ImuLdsSink<T, false> sink{A, lane, KS};
-      if (lane < nval) {
-        imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
-        sink.put_col(30, r);
-        sink.put_col(31, zero6);
-      } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
-#pragma unroll
-        for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
-      }
-      __syncthreads();
-      for (int k0 = 0; k0 < kmax; k0 += 4) {
-        VecN<T, 4> av[4], bv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          av[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (ti + 8 * a) * KS + k0);
-          bv[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (tj + 8 * a) * KS + k0);
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
-      }
-      __syncthreads();
+      for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
     }
+    __syncthreads();
+    for (int k0 = 0; k0 < kmax; k0 += 4) {
+      VecN<T, 4> av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        av[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (ti + 8 * a) * KS + k0);
+        bv[a] = *reinterpret_cast<const VecN<T, 4> *>(A + (tj + 8 * a) * KS + k0);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
+    }
+    __syncthreads();
   }
-#undef CTV_STAMP
   T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
-  if constexpr (MFMA) {
-    // combine in LDS: the accelerometer product, plus the gyro product scattered to its 16 rows/columns
-    // (C/D layouts: 32x32 -> row (r&3) + 8(r>>2) + 4(lane>>5), col lane&31;  16x16 -> row 4(lane>>4) + r, col lane&15)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) A[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = macc[r];
-    __syncthreads();
-    {
-      const int gcol = lane & 15;
-      const int tc = gcol < 12 ? gcol : (gcol < 15 ? gcol + 12 : 30);
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int grow = 4 * (lane >> 4) + r;
-        const int tr = grow < 12 ? grow : (grow < 15 ? grow + 12 : 30);
-        A[tr * 32 + tc] += gacc[r];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
-  } else {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
-  }
+    for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
 }
 
 // All-fp64 product path: one wave per IMU group, 64 samples per pass (one per lane), A^T A on the fp64 matrix cores.
@@ -690,7 +577,7 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
 }
 
 // Residual-only pass: one lane per IMU sample, cost accumulated in fp64.
-template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, const double *kd, int force) {
+template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, const double *kd, int force) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   double c = 0.0;
   int w = -1;
@@ -699,32 +586,24 @@ template <class T, class RT> __global__ __launch_bounds__(256) void k_imu_cost(D
     w = grp.win;
     if (d.lm[w].status == 0 && (d.lm[w].step_valid || force)) {
       const WinMeta &m = d.wins[w];
-      Knots4<RT> k;
-      LocalFrame<RT> lf;
+      Knots4<T> k;
+      LocalFrame<T> lf;
       lf.init(quat, pos, m.knot0 + grp.s);
       lf.load(quat, pos, m.knot0 + grp.s, k);
-      SegConst<RT> sc;
+      SegConst<T> sc;
       seg_const_load(kd + 3 * (m.knot0 + grp.s), (const T *)nullptr, sc, false);
-      RT b[6], wgt[6], gy[3], ac[3], r[6];
+      T b[6], wgt[6], gy[3], ac[3], r[6];
       const double *bp = bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { b[i] = (RT)bp[i]; wgt[i] = (RT)m.imu_w[i]; }
-      constexpr bool RD = sizeof(RT) == 8;
+      for (int i = 0; i < 6; ++i) { b[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        gy[i] = RD ? (RT)d.imu_meas_d[(size_t)i * d.Mtot + idx] : (RT)d.imu_meas[(size_t)i * d.Mtot + idx];
-        ac[i] = RD ? (RT)d.imu_meas_d[(size_t)(3 + i) * d.Mtot + idx] : (RT)d.imu_meas[(size_t)(3 + i) * d.Mtot + idx];
-      }
-      NullSink<RT> ns;
-      imu_eval<RT>(k, sc, RD ? (RT)d.imu_ud[idx] : (RT)d.imu_u[idx], (RT)m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, ns);
-      RT s = 0;
+      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
+      NullSink<T> ns;
+      imu_eval<T>(k, sc, d.imu_u[idx], (T)m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, ns);
+      T s = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) s += r[i] * r[i];
       c = 0.5 * (double)s;
-      if (sizeof(RT) != sizeof(T)) {   // mixed mode: the next linearisation (same state, if this step is accepted) reuses them
-#pragma unroll
-        for (int i = 0; i < 6; ++i) d.imu_rc[(size_t)i * d.Mtot + idx] = (T)r[i];
-      }
     } else {
       w = -1;
     }
@@ -775,6 +654,9 @@ template <class T> __device__ __forceinline__ T vis_J_entry(const T *Jt, int row
   return col < 24 ? J[60 + kk] * pt : -J[64 + kk] * pt;
 }
 
+// width of block v's Cauchy loss (per residual block, like the reference: trajectory_estimator.cpp:320-323)
+template <class T> __device__ __forceinline__ double vis_cauchy(const Dev<T> &d, const WinMeta &, int v) { return d.v_cauchy[v]; }
+
 // time -> (first active knot, u) in integer ns (reference spline_segment.h:83-85); the line delay is
 // truncated to integer ns exactly as image_feature_factor.h:72.
 __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int row, double ld, int &s, double &u) {
@@ -786,33 +668,32 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 
 // One lane per visual block.  LIN: evaluate r~, J~ (robust-corrected) and materialise them (SoA, coalesced);
 // otherwise residual only.  Cost contributions are reduced per wave and added in fp64.
-template <class RT, class TD>
-__device__ __forceinline__ double vis_residual(const TD &d, const WinMeta &m, int v, int si, int sj, double ui, double uj, int rowi, int rowj,
-                                               const double *quat, const double *pos, const double *kd, double rho_l, RT r[2]) {
-  Knots4<RT> ki, kj;
-  SegConst<RT> sci, scj;
-  seg_const_load(kd + 3 * (m.knot0 + si), (const RT *)nullptr, sci, false);
-  seg_const_load(kd + 3 * (m.knot0 + sj), (const RT *)nullptr, scj, false);
-  LocalFrame<RT> lf;
+template <class T>
+__device__ __forceinline__ double vis_residual(const Dev<T> &d, const WinMeta &m, int v, int si, int sj, double ui, double uj, int rowi, int rowj,
+                                               const double *quat, const double *pos, const double *kd, double rho_l, T r[2]) {
+  Knots4<T> ki, kj;
+  SegConst<T> sci, scj;
+  seg_const_load(kd + 3 * (m.knot0 + si), (const T *)nullptr, sci, false);
+  seg_const_load(kd + 3 * (m.knot0 + sj), (const T *)nullptr, scj, false);
+  LocalFrame<T> lf;
   lf.init(quat, pos, m.knot0 + si);
   lf.load(quat, pos, m.knot0 + si, ki);
   lf.load(quat, pos, m.knot0 + sj, kj);
-  Calib<RT> cal;
-  cal.q_CI = qmk<RT>((RT)m.q_CI[0], (RT)m.q_CI[1], (RT)m.q_CI[2], (RT)m.q_CI[3]);
-  cal.p_CI = mk<RT>((RT)m.p_CI[0], (RT)m.p_CI[1], (RT)m.p_CI[2]);
-  cal.img_w = (RT)m.img_w;
-  cal.cauchy_a = (RT)m.cauchy_a;
+  Calib<T> cal;
+  cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
+  cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
+  cal.img_w = (T)m.img_w;
+  cal.cauchy_a = (T)vis_cauchy(d, m, v);
   const size_t V = (size_t)d.Vtot;
-  constexpr bool RD = sizeof(RT) == 8;
-  RT o[4];
+  T o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = RD ? (RT)d.v_obs_d[(size_t)i * V + v] : (RT)d.v_obs[(size_t)i * V + v];
-  VisNullSink<RT> sink;
-  return (double)visual_eval<RT>(ki, kj, sci, scj, (RT)ui, (RT)uj, (RT)m.inv_dt, cal, lf.RrefT(), o[0], o[1], o[2], o[3], (RT)rowi, (RT)rowj, (RT)rho_l, r,
+  for (int i = 0; i < 4; ++i) o[i] = d.v_obs[(size_t)i * V + v];
+  VisNullSink<T> sink;
+  return (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, lf.RrefT(), o[0], o[1], o[2], o[3], (T)rowi, (T)rowj, (T)rho_l, r,
                                  false, sink);
 }
 
-template <class T, bool LIN, class RT>
+template <class T, bool LIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   // LIN: the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
@@ -852,7 +733,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
       cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
       cal.img_w = (T)m.img_w;
-      cal.cauchy_a = (T)m.cauchy_a;
+      cal.cauchy_a = (T)vis_cauchy(d, m, v);
       const size_t V = (size_t)d.Vtot;
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
@@ -861,25 +742,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
         on = true;
         my_lm = d.v_lm[v];
         mP = m.P; mldw = m.ldw; mK6 = 6 * m.K; mlm0 = m.lm0; mu0 = m.u0; mW0lo = (int)(m.W0 & 0xffffffffll); mW0hi = (int)(m.W0 >> 32);
-        if (sizeof(RT) != sizeof(T)) cal.sq_override = d.vis_rc[2 * V + v];   // robust scale of the fp64 residual pass
         SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
         seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
         seg_const_lazy(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
         c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
-        if (sizeof(RT) != sizeof(T)) {  // mixed mode: the fp64 residual of the cost pass at this state
-          r[0] = d.vis_rc[v]; r[1] = d.vis_rc[V + v];
-        }
         sink.J[52] = r[0]; sink.J[53] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
         ksi = si; ksj = sj;
       } else {
-        RT rd[2];
-        c = vis_residual<RT>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
-        if (sizeof(RT) != sizeof(T)) {   // mixed mode: reused by the next linearisation (same state, if the step is accepted)
-          d.vis_rc[v] = (T)rd[0]; d.vis_rc[(size_t)d.Vtot + v] = (T)rd[1];
-          d.vis_rc[(size_t)2 * d.Vtot + v] = m.cauchy_a > 0.0 ? (T)exp(-c / (m.cauchy_a * m.cauchy_a)) : T(1);   // cost = b/2 log(1 + s/b)
-        }
+        T rd[2];
+        c = vis_residual<T>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
       }
     } else {
       w = -1;
@@ -1242,9 +1115,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 // T = double (product path): the same kernel on v_mfma_f64_16x16x4_f64 (D register r of lane l = D[(l / 16) + 4 r][l % 16]), items of
 // <= 8 blocks so that eight fp64 staging areas fit beside the packed Hessian.
 template <class T> struct MfmaAcc;
-template <> struct MfmaAcc<float> { typedef f32x4 type; };
 template <> struct MfmaAcc<double> { typedef f64x4 type; };
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d) {
   constexpr bool F64 = sizeof(T) == 8;
@@ -1728,208 +1599,6 @@ __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> 
   bj = t - bi * (bi + 1) / 2;
 }
 
-// S = Hpp + D^2 - W^T diag(dinv) W (lower triangle) on the matrix cores: one wave per 32x32 tile,
-// v_mfma_f32_32x32x2_f32 over the landmark dimension (2 landmarks per instruction), operands read
-// straight from the landmark-major W (32 consecutive floats per half-wave: coalesced).
-// The right-hand side rides along: index P (< ldw, a padding column of W) is fed with g_l on the A side, so the tiles
-// of the last tile row also produce W^T diag(dinv) g_l, i.e. rhs_p = -g_p + W^T dinv g_l, at no extra cost.
-__global__ __launch_bounds__(64) void k_schur_mfma(Dev<float> d, int ntile_max) {
-  // XCD-aware tile -> workgroup map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the
-  // tiles of one window are given ids that are congruent mod 8: they all run on one XCD and the window's W (re-read by
-  // every tile) comes out of that L2 instead of being fetched 8 times over the fabric.
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
-  if (w >= d.nwin) return;
-  if (d.lm[w].status || d.lm[w].ls_active) return;
-  const WinMeta &m = d.wins[w];
-  const int nt = (m.P + 1 + 31) / 32;  // index P (the rhs row) included
-  if (tile >= nt * (nt + 1) / 2) return;
-  int bi, bj;
-  tile_decode(tile, bi, bj);
-  const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
-  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, Lpad = m.Lpad, ldh = m.ldh;
-  const int i = 32 * bi + l31, j = 32 * bj + l31;        // < ldw by construction (ldw = 32 nt)
-  // every load below is unconditional on a clamped address (a predicated load costs a branch and a full wait each)
-  const float ai = (i < P && d.active[u0 + min(i, P - 1)]) ? 1.0f : 0.0f;
-  const float aj = (j < P && d.active[u0 + min(j, P - 1)]) ? 1.0f : 0.0f;
-  const bool rhs_lane = (i == P);
-  const float *Wp = d.W + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P):
-  // tiles over bias columns skip the loop
-  const bool nz_i = (32 * bi < K6) || (P >= 32 * bi && P - 1 < 32 * bi + 32);
-  const bool nz_j = (32 * bj < K6) || (P - 1 >= 32 * bj && P - 1 < 32 * bj + 32);
-  const int lend = (nz_i && nz_j && L > 0) ? Lpad : 0;   // L == 0 (IMU-only window): nothing to eliminate, no row to clamp to
-  for (int l0 = 0; l0 < lend; l0 += 16) {   // 8 MFMA steps (2 landmarks each) per trip: 32 loads in flight, then the products
-    float wa[8], wb[8];
-    double dv[8], gv[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int lc = min(l0 + 2 * s + half, L - 1);
-      wa[s] = Wp[(long long)lc * ldw + i];
-      wb[s] = Wp[(long long)lc * ldw + j];
-      dv[s] = dinv[lc];
-      gv[s] = gl[lc];
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bool lv = l0 + 2 * s + half < L;
-      const float di = lv ? (float)dv[s] : 0.0f;
-      const float a = rhs_lane ? (float)gv[s] : wa[s] * ai;
-      const float b = wb[s] * aj * di;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-  }
-  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
-  const double *H = d.Hpp + m.H0;
-  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
-  // All inputs are fetched first (clamped addresses), then the 16 rows are written.
-  const int jj = 32 * bj + l31, jc = min(jj, P - 1);
-  const bool act_j = d.active[u0 + jc] != 0;
-  const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
-  double hv[16];
-  unsigned char act_i[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ii = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, ic = min(ii, P - 1);
-    act_i[r] = d.active[u0 + ic];
-    hv[r] = H[(long long)ic * ldh + min(jc, ic)];
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ii = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (ii < P && jj <= ii) {
-      const bool on = act_i[r] && act_j;
-      double val;
-      if (on) val = hv[r] - (double)acc[r] + (ii == jj ? dd_j : 0.0);
-      else val = (ii == jj) ? 1.0 : 0.0;
-      S[(long long)ii * ldh + jj] = val;
-    } else if (ii == P && jj < P) {
-      rhs[jj] = act_j ? (double)acc[r] - g_j : 0.0;
-    }
-  }
-}
-
-// Schur complement, one workgroup (8 waves) per window: W is read from HBM exactly ONCE per window.  The landmark rows
-// are staged through LDS in chunks of 16 (double buffered; the next chunk's loads are in flight while the current one is
-// multiplied), masked by the active flags, with the rhs row g_rho appended as column P; every wave owns up to 4 of the
-// 32 x 32 output tiles of the lower triangle and keeps their accumulators in registers across the whole landmark loop.
-// (The per-tile kernel above re-reads the two 32-column panels of W for every tile: 1.2 MB per window instead of 0.18.)
-// NPRE = elements of a chunk per thread (16 ldw / 512), so ldw <= 32 NPRE.
-template <int NPRE> __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_schur_window(Dev<float> d) {
-  const int w = blockIdx.x;
-  if (d.lm[w].status || d.lm[w].ls_active) return;
-  const WinMeta &m = d.wins[w];
-  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
-  const int nt = ldw >> 5, ntile = nt * (nt + 1) / 2;
-  extern __shared__ __attribute__((aligned(16))) float sms[];
-  float *Wb = sms;                       // [2][16][ldw]
-  float *acts = Wb + 2 * 16 * ldw;       // [ldw] 1 / 0 (0 beyond P)
-  float *dch = acts + ldw;               // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const float *Wp = d.W + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
-  for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0f : 0.0f;
-  int bi[4], bj[4];
-  bool run[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int t = wave + 8 * q;
-    tile_decode(min(t, ntile - 1), bi[q], bj[q]);
-    // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1 (plus the rhs row P): tiles over
-    // bias columns skip the products
-    const bool nz_i = (32 * bi[q] < K6) || (P >= 32 * bi[q] && P - 1 < 32 * bi[q] + 32);
-    const bool nz_j = (32 * bj[q] < K6) || (P - 1 >= 32 * bj[q] && P - 1 < 32 * bj[q] + 32);
-    run[q] = t < ntile && nz_i && nz_j;
-  }
-  f32x16 acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
-  const int nchunk = (L + 15) >> 4, nel = 16 * ldw;
-  float pre[NPRE];
-  float pre_d = 0.0f;
-  auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      const int e = min(tid + 512 * k, nel - 1), l = min(16 * ch + e / ldw, L - 1), c = e % ldw;
-      pre[k] = (c == P) ? (float)gl[l] : Wp[(long long)l * ldw + c];
-    }
-    if (tid < 16) pre_d = (float)dinv[min(16 * ch + tid, L - 1)];
-  };
-  auto stash = [&](int ch, int buf) {   // branch-free: a clamped element index re-writes the last element with its own value
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      const int e = min(tid + 512 * k, nel - 1);
-      const int lr = e / ldw, c = e % ldw;
-      const bool lv = 16 * ch + lr < L;
-      Wb[buf * nel + e] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0f;
-    }
-    if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0f;
-  };
-  __syncthreads();   // acts
-  if (nchunk > 0) { fetch(0); stash(0, 0); }
-  __syncthreads();
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nchunk) fetch(ch + 1);
-    const float *B = Wb + buf * nel;
-    float dl[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) dl[s] = dch[16 * buf + 2 * s + half];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!run[q]) continue;   // wave-uniform, once per chunk and tile: the 16 operand reads, then the 8 products
-      float a[8], b[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int l = 2 * s + half;
-        a[s] = B[l * ldw + 32 * bi[q] + l31];
-        b[s] = B[l * ldw + 32 * bj[q] + l31];
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
-    }
-    if (ch + 1 < nchunk) stash(ch + 1, buf ^ 1);
-    __syncthreads();
-  }
-  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
-  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
-  const double *H = d.Hpp + m.H0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (wave + 8 * q >= ntile) continue;
-    const int jj = 32 * bj[q] + l31, jc = min(jj, P - 1);
-    const bool act_j = d.active[u0 + jc] != 0;
-    const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
-    double hv[16];
-    unsigned char act_i[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ii = 32 * bi[q] + (r & 3) + 8 * (r >> 2) + 4 * half, ic = min(ii, P - 1);
-      act_i[r] = d.active[u0 + ic];
-      hv[r] = H[(long long)ic * ldh + min(jc, ic)];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ii = 32 * bi[q] + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (ii < P && jj <= ii) {
-        const bool on = act_i[r] && act_j;
-        double val;
-        if (on) val = hv[r] - (double)acc[q][r] + (ii == jj ? dd_j : 0.0);
-        else val = (ii == jj) ? 1.0 : 0.0;
-        S[(long long)ii * ldh + jj] = val;
-      } else if (ii == P && jj < P) {
-        rhs[jj] = act_j ? (double)acc[q][r] - g_j : 0.0;
-      }
-    }
-  }
-}
-
 // fp64 product path, large batches: the window kernel on the fp64 matrix cores.  One workgroup (8 waves) per window; W is read
 // from HBM once, staged through LDS in double-buffered chunks of 16 landmarks (masked by the active flags, g_rho appended as
 // column P so that the tile row holding index P also produces the reduced right-hand side: no k_rhs pass).  Output tiles are
@@ -2071,7 +1740,10 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
 // D register r of lane l = D[(l/16) + 4r][l%16]; measured with tools/mfma_f64_layout.hip).  Operands straight from W,
 // 16 landmarks (4 products) per trip with all loads of a trip in flight; the reduced rhs is left to k_rhs.
 __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_max) {
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;     // tiles of one window on one XCD (see k_schur_mfma)
+  // XCD-aware tile -> workgroup map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles of one
+  // window get ids that are congruent mod 8: they all run on one XCD and the window's W (re-read by every tile) comes out of
+  // that L2 instead of being fetched 8 times over the fabric.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
   if (w >= d.nwin) return;
   if (d.lm[w].status || d.lm[w].ls_active) return;
@@ -2755,9 +2427,9 @@ template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev
     double b[6], wgt[6], gy[3], ac[3], r[6];
     const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
     for (int c = 0; c < 6; ++c) { b[c] = bp[c]; wgt[c] = m.imu_w[c]; }
-    for (int c = 0; c < 3; ++c) { gy[c] = (double)d.imu_meas_d[(size_t)c * d.Mtot + idx]; ac[c] = (double)d.imu_meas_d[(size_t)(3 + c) * d.Mtot + idx]; }
+    for (int c = 0; c < 3; ++c) { gy[c] = (double)d.imu_meas[(size_t)c * d.Mtot + idx]; ac[c] = (double)d.imu_meas[(size_t)(3 + c) * d.Mtot + idx]; }
     ImuJac<double> J;
-    imu_eval_core<double>(k, sc, (double)d.imu_ud[idx], m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, J);
+    imu_eval_core<double>(k, sc, (double)d.imu_u[idx], m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, J);
     for (int c = 0; c < 6; ++c) atomicAdd(&sums[c], fabs(r[c]));
   }
   for (int e = tid; e < m.NB * 6; e += 256) {
@@ -2798,8 +2470,8 @@ template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev
     const size_t V = (size_t)d.Vtot;
     double r[2];
     VisNullSink<double> sink;
-    visual_eval<double>(ki, kj, sci, scj, ui, uj, m.inv_dt, cal, lf.RrefT(), (double)d.v_obs_d[v], (double)d.v_obs_d[V + v], (double)d.v_obs_d[2 * V + v],
-                        (double)d.v_obs_d[3 * V + v], (double)rowi, (double)rowj, d.rho[m.lm0 + d.v_lm[v]], r, false, sink);
+    visual_eval<double>(ki, kj, sci, scj, ui, uj, m.inv_dt, cal, lf.RrefT(), (double)d.v_obs[v], (double)d.v_obs[V + v], (double)d.v_obs[2 * V + v],
+                        (double)d.v_obs[3 * V + v], (double)rowi, (double)rowj, d.rho[m.lm0 + d.v_lm[v]], r, false, sink);
     atomicAdd(&sums[12], fabs(r[0]));
     atomicAdd(&sums[13], fabs(r[1]));
   }

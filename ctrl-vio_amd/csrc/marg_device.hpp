@@ -60,7 +60,9 @@ __device__ inline int jacobi_packed(double *Apk, int nd, double *rot, double *cs
     __syncthreads();
     // converged: the oracle's test (one full sweep beyond ~1e-29 is what resolves the noise-level eigenvalues of a rank-deficient
     // A', which decide what falls under eps); stagnation just above it after many sweeps is accepted as the rounding floor
-    if (off <= 1e-60 || off <= 1e-32 * d2 || (sweep >= 12 && off <= 1e-28 * d2 && off > 0.25 * prev_off)) return sweep;
+    // (the floor of the off-diagonal mass is ~ n^2 eps^2 d2: at n = 180 that is 1.6e-27 d2, above a fixed 1e-28)
+    const double floor_rel = fmax(1e-28, 4.0 * (double)nd * (double)nd * 4.93e-32);
+    if (off <= 1e-60 || off <= 1e-32 * d2 || (sweep >= 12 && off <= floor_rel * d2 && off > 0.25 * prev_off)) return sweep;
     prev_off = off;
     for (int s = 0; s < steps; ++s) {
       if (tid < half) {

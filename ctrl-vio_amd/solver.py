@@ -18,19 +18,22 @@ class Solver:
     """One handle = one HIP stream + the HBM buffers of a batch of windows."""
 
     def __init__(self, device: int = 0, precision: str = "fp64", use_mfma: bool = True, check_every: int = 4,
-                 fp64_residuals: bool = True, host_threads: int = 0, use_graph: bool = True, line_search: bool = True,
+                 deterministic: int = -1, host_threads: int = 0, use_graph: bool = True, line_search: bool = True,
                  **tolerances):
-        """precision "fp64" = the product (all-fp64, like the reference); "fp32" = the mixed fast mode."""
+        """All-fp64, like the reference (`precision` is kept for call compatibility: only "fp64" exists).  deterministic: 1 = order-fixed
+        accumulation (bitwise reproducible), 0 = off, -1 = on for batches of <= 64 windows."""
+        if precision not in ("fp64", capi.FP64):
+            raise ValueError("only precision='fp64' exists (the mixed fp32 mode was removed: it missed the 1e-4 contract)")
         self._lib = capi.load_library()
         if self._lib.ctvio_device_count() <= 0:
             raise capi.CtvioError("no HIP device: ctrl-vio_amd has no CPU fallback")
         opt = capi.Options()
         self._lib.ctvio_default_options(C.byref(opt))
         opt.device = device
-        opt.precision = capi.FP64 if precision in ("fp64", capi.FP64) else capi.FP32
+        opt.precision = capi.FP64
         opt.use_mfma = int(bool(use_mfma))
         opt.check_every = int(check_every)
-        opt.fp64_residuals = int(bool(fp64_residuals))
+        opt.deterministic = int(deterministic)
         opt.host_threads = int(host_threads)
         opt.use_graph = int(bool(use_graph))
         opt.line_search = int(bool(line_search))

@@ -70,6 +70,12 @@ class Window:
     p_index: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     p_off: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     p_x0: np.ndarray = field(default_factory=lambda: np.zeros((0, 4)))
+    # optional per-block Cauchy width (V,) -- the reference picks CauchyLoss(1 | 2) per residual block
+    # (trajectory_estimator.cpp:320-323); None: cauchy_a for every block
+    v_cauchy: np.ndarray | None = None
+    # optional per-knot constancy flags (K,) uint8 -- SetParameterBlockConstant per AddControlPoints call
+    # (trajectory_estimator.cpp:134-138), on top of fixed_upto; None: none
+    knot_const: np.ndarray | None = None
 
     def normalize(self) -> "Window":
         """Coerce dtypes/shapes in place (contiguous, fp64 / int32 / int64)."""
@@ -91,6 +97,10 @@ class Window:
         self.pJ0 = _f64(self.pJ0, (n, n)); self.pr0 = _f64(self.pr0, (n,))
         self.p_kind = np.ascontiguousarray(self.p_kind, np.int32); self.p_index = np.ascontiguousarray(self.p_index, np.int32)
         self.p_off = np.ascontiguousarray(self.p_off, np.int32); self.p_x0 = _f64(self.p_x0, (-1, 4))
+        if self.v_cauchy is not None:
+            self.v_cauchy = _f64(self.v_cauchy, (self.v_lm.shape[0],))
+        if self.knot_const is not None:
+            self.knot_const = np.ascontiguousarray(self.knot_const, np.uint8).reshape(self.quat.shape[0])
         return self
 
     # sizes
@@ -120,12 +130,16 @@ class Window:
     _ARRAYS = ("quat", "pos", "bias", "rho", "q_CI", "p_CI", "gravity", "imu_w", "imu_t", "imu_gyro", "imu_acc",
                "imu_bias", "bc_i", "bc_j", "bc_w", "v_lm", "v_ti", "v_tj", "v_rowi", "v_rowj", "v_pi", "v_pj",
                "pJ0", "pr0", "p_kind", "p_index", "p_off", "p_x0")
+    _OPTIONAL = ("v_cauchy", "knot_const")
 
     def to_dict(self, prefix: str = "") -> dict:
         """Flat dict of numpy values (np.savez-able); inverse of from_dict."""
         self.normalize()
         d = {prefix + k: np.asarray(getattr(self, k)) for k in self._ARRAYS}
         d.update({prefix + k: np.asarray(getattr(self, k)) for k in self._SCALARS})
+        for k in self._OPTIONAL:
+            if getattr(self, k) is not None:
+                d[prefix + k] = np.asarray(getattr(self, k))
         return d
 
     @classmethod
@@ -136,6 +150,9 @@ class Window:
             kw[k] = v.item() if hasattr(v, "item") else v
         for k in ("fix_ld", "lock_bg", "lock_ba"):
             kw[k] = bool(kw[k])
+        for k in cls._OPTIONAL:
+            if prefix + k in d:
+                kw[k] = np.array(d[prefix + k])
         return cls(**kw).normalize()
 
     def state_vector(self) -> np.ndarray:

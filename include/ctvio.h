@@ -36,11 +36,10 @@ enum ctvio_status {
   CTVIO_ERR_STATE = 4       /* call order violated (e.g. solve before upload) */
 };
 
-/* CTVIO_FP64 (default, the product): every residual, Jacobian, product and factorisation in fp64, like the reference
- * (Ceres/Eigen are all double); reproduces the fp64 CPU reference's iterates, final state to ~1e-9.
- * CTVIO_FP32: mixed "fast" mode -- Jacobians, J^T J and the Schur complement in fp32 (residuals, costs, Cholesky in fp64);
- * the 15th iterate then agrees with the fp64 reference to ~1e-5 typically but NOT to 1e-4 on every window. */
-enum ctvio_precision { CTVIO_FP32 = 0, CTVIO_FP64 = 1 };
+/* CTVIO_FP64 (the only mode): every residual, Jacobian, product and factorisation in fp64, like the reference (Ceres / Eigen
+ * are all double); reproduces the fp64 CPU reference's iterates, final state to ~1e-9.  The mixed fp32 mode of rounds 1-2
+ * (CTVIO_FP32 = 0) missed the 1e-4 contract on one window in four and was removed: ctvio_create rejects it. */
+enum ctvio_precision { CTVIO_FP32_REMOVED = 0, CTVIO_FP64 = 1 };
 
 /* Kinds of parameter blocks kept by a marginalisation prior (reference
  * marginalization_factor.h:115-129 keep_block_*; sizes 4->local 3, 3, 3, 3, 1). */
@@ -51,8 +50,8 @@ enum { CTVIO_PK_ROT = 0, CTVIO_PK_POS = 1, CTVIO_PK_BG = 2, CTVIO_PK_BA = 3, CTV
  * ctvio_default_options.                                                                        */
 typedef struct ctvio_options {
   int32_t device;               /* HIP device ordinal */
-  int32_t precision;            /* ctvio_precision of the residual/Jacobian kernels */
-  int32_t use_mfma;             /* Schur SYRK on v_mfma_f32_32x32x2_f32 (FP32 only) */
+  int32_t precision;            /* CTVIO_FP64 */
+  int32_t use_mfma;             /* 1 (default): products on v_mfma_f64_16x16x4_f64; 0: vector-ALU cross-check kernels */
   int32_t check_every;          /* host polls "all windows terminated" every n LM iterations */
   double function_tolerance;    /* 1e-6  Ceres defaults, see SURVEY.md Appendix A */
   double gradient_tolerance;    /* 1e-10 */
@@ -62,11 +61,11 @@ typedef struct ctvio_options {
   double min_relative_decrease; /* 1e-3 */
   double min_lm_diagonal, max_lm_diagonal; /* 1e-6, 1e32 */
   int32_t max_consecutive_invalid_steps;   /* 5 */
-  int32_t fp64_residuals;       /* FP32 only, default 1: residuals, gradient right-hand sides and costs are evaluated in fp64
-                                   (Jacobians, J^T J and the Schur complement stay fp32) */
+  int32_t deterministic;        /* 1: order-fixed accumulation everywhere (no floating-point atomics): two runs of the same batch
+                                   are bitwise equal; -1 (default): on for batches of <= 64 windows, off beyond; 0: off */
   int32_t host_threads;         /* host threads that validate / pack a batch (ctvio_set_batch, ctvio_upload); 0 = min(cores, 16) */
   int32_t use_graph;            /* 1 (default): the launch sequence of one LM pass is captured into a hipGraph and replayed */
-  int32_t line_search;          /* 1 (default, CTVIO_FP64 only): Ceres' projected Armijo line search of bounds-constrained problems
+  int32_t line_search;          /* 1 (default): Ceres' projected Armijo line search of bounds-constrained problems
                                    (a free line delay has bounds: trajectory_estimator.cpp:311-318 => Minimizer is_constrained) */
 } ctvio_options;
 
@@ -83,12 +82,12 @@ typedef struct ctvio_window {
   double ld, ld_lo, ld_hi;      /* trajectory_->line_delay, ld_lower, ld_upper (trajectory.h:55-62,99-103) */
   int32_t fix_ld;               /* trajectory_->fix_ld (trajectory_estimator.cpp:312-318) */
   int32_t lock_bg, lock_ba;     /* options.lock_wb / lock_ab (trajectory_estimator.cpp:236-245) */
-  int32_t fixed_upto;           /* SetFixedIndex(idx) / lock_traj (trajectory_estimator.cpp:134-138); -1 none */
+  int32_t fixed_upto;           /* SetFixedIndex(idx) / lock_traj (trajectory_estimator.cpp:134-138); -1 none (see also knot_const) */
   double q_CI[4], p_CI[3];      /* ImageFeatureDelayFactor::S_CtoI / p_CinI (image_feature_factor.h:273-274) */
   double gravity[3];            /* AddIMUMeasurementAnalytic gravity argument */
   double imu_w[6];              /* info_vec (opt_weight.h:124-126) */
   double img_w;                 /* ImageFeatureDelayFactor::sqrt_info = img_w*I2 (trajectory_manager.cpp:57) */
-  double cauchy_a;              /* ceres::CauchyLoss(a) (trajectory_estimator.cpp:321-322); <= 0 : none */
+  double cauchy_a;              /* ceres::CauchyLoss(a) of every visual block without an entry in v_cauchy; <= 0 : none */
   /* AddIMUMeasurementAnalytic (trajectory_estimator.h:102-106) x M */
   const int64_t *imu_t; const double *imu_gyro, *imu_acc; const int32_t *imu_bias;
   /* AddBiasFactor (trajectory_estimator.h:109-112) x NB : r = w .* (b_j - b_i), dt = 1 */
@@ -101,6 +100,12 @@ typedef struct ctvio_window {
   const double *pr0;            /* pn */
   const int32_t *p_kind, *p_index, *p_off; /* pnb: block kind, knot/frame index, column offset (keep_block_idx - m) */
   const double *p_x0;           /* pnb*4: keep_block_data (quaternion x,y,z,w or 3-vector / scalar, zero padded) */
+  /* per residual block: the reference creates one loss per AddImageFeatureDelayAnalytic call, CauchyLoss(marg_this_feature ?
+   * 1 : 2) (trajectory_estimator.cpp:320-323).  V entries (<= 0: no loss for that block) or NULL: cauchy_a for every block. */
+  const double *v_cauchy;
+  /* per knot: constancy is decided per AddControlPoints call (trajectory_estimator.cpp:134-138), so the constant knots need not
+   * be a prefix.  K flags (non-zero: SetParameterBlockConstant) or NULL; applied on top of fixed_upto. */
+  const uint8_t *knot_const;
 } ctvio_window;
 
 /* Replaces ceres::Solver::Summary (callers only print BriefReport(): trajectory_manager.cpp:314,455). */

@@ -34,6 +34,44 @@
 
 namespace ctvio {
 
+// Sophus::SE3d stand-in of this Eigen-free boundary: unit quaternion (x, y, z, w) + translation, with the group product.
+struct SE3 {
+  double q[4] = {0, 0, 0, 1};
+  double p[3] = {0, 0, 0};
+  void rotate(const double v[3], double out[3]) const {   // R(q) v
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * (y * v[2] - z * v[1]), ty = 2 * (z * v[0] - x * v[2]), tz = 2 * (x * v[1] - y * v[0]);
+    out[0] = v[0] + w * tx + (y * tz - z * ty); out[1] = v[1] + w * ty + (z * tx - x * tz); out[2] = v[2] + w * tz + (x * ty - y * tx);
+  }
+};
+inline SE3 operator*(const SE3 &a, const SE3 &b) {
+  SE3 r;
+  r.q[0] = a.q[3] * b.q[0] + a.q[0] * b.q[3] + a.q[1] * b.q[2] - a.q[2] * b.q[1];
+  r.q[1] = a.q[3] * b.q[1] - a.q[0] * b.q[2] + a.q[1] * b.q[3] + a.q[2] * b.q[0];
+  r.q[2] = a.q[3] * b.q[2] + a.q[0] * b.q[1] - a.q[1] * b.q[0] + a.q[2] * b.q[3];
+  r.q[3] = a.q[3] * b.q[3] - a.q[0] * b.q[0] - a.q[1] * b.q[1] - a.q[2] * b.q[2];
+  const double n = std::sqrt(r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3]);
+  for (double &c : r.q) c /= n;
+  double t[3];
+  a.rotate(b.p, t);
+  for (int i = 0; i < 3; ++i) r.p[i] = t[i] + a.p[i];
+  return r;
+}
+// reference src/utils/parameter_struct.h (ExtrinsicParam: so3 / p / q / se3 / t_offset) and IMUState (:67-78)
+struct ExtrinsicParam {
+  double q[4] = {0, 0, 0, 1};   // sensor -> IMU rotation (x, y, z, w)
+  double p[3] = {0, 0, 0};      // sensor origin in the IMU frame
+  double t_offset = 0.0;
+  SE3 se3() const { SE3 s; for (int i = 0; i < 4; ++i) s.q[i] = q[i]; for (int i = 0; i < 3; ++i) s.p[i] = p[i]; return s; }
+};
+enum SensorType { IMUSensor = 0, CameraSensor };   // trajectory.h:30-34
+struct IMUState {
+  int64_t timestamp = 0;
+  double p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};
+};
+
+class SolverCache;
+
 // ---- Se3Spline<4>/Trajectory storage surface (reference src/spline/se3_spline.h:108-356, trajectory.h:38-116).
 // Knots live in two deques (stable addresses under push_back, like so3_spline.h:410 / rd_spline.h:317).
 class Trajectory {
@@ -54,6 +92,48 @@ class Trajectory {
   }
   std::array<double, 4> &getKnotSO3(size_t i) { return so3_.at(i); }   // .data() = (x,y,z,w), se3_spline.h:271
   std::array<double, 3> &getKnotPos(size_t i) { return pos_.at(i); }   // se3_spline.h:283
+  const std::array<double, 4> &getKnotSO3(size_t i) const { return so3_.at(i); }
+  const std::array<double, 3> &getKnotPos(size_t i) const { return pos_.at(i); }
+  // se3_spline.h:128-144, 212-216, 248-265 (SE3 overloads used at trajectory_manager.cpp:114, 514; odometry_manager.cpp:443)
+  SE3 getKnot(size_t i) const { SE3 s; for (int c = 0; c < 4; ++c) s.q[c] = so3_.at(i)[c]; for (int c = 0; c < 3; ++c) s.p[c] = pos_.at(i)[c]; return s; }
+  SE3 getLastKnot() const { return getKnot(numKnots() - 1); }
+  void setKnot(const SE3 &pose, int i) { setKnotSO3(pose.q, i); setKnotPos(pose.p, i); }
+  void setKnotSO3(const double q_xyzw[4], int i) { for (int c = 0; c < 4; ++c) so3_.at(i)[c] = q_xyzw[c]; }
+  void setKnotPos(const double p[3], int i) { for (int c = 0; c < 3; ++c) pos_.at(i)[c] = p[c]; }
+  void knots_push_back(const SE3 &knot) { knots_push_back(knot.q, knot.p); }
+  void extendKnotsTo(int64_t t_ns, const SE3 &initial_knot) { extendKnotsTo(t_ns, initial_knot.q, initial_knot.p); }
+  // trajectory.h:64-74: sensor -> IMU extrinsics by sensor type; the camera's also feeds ImageFeatureDelayFactor::S_CtoI / p_CinI
+  // (trajectory_manager.cpp:42,51-62), i.e. q_CI / p_CI below
+  void SetSensorExtrinsics(SensorType type, const ExtrinsicParam &EP_StoI) {
+    EP_StoI_[type] = EP_StoI;
+    if (type == CameraSensor) { for (int c = 0; c < 4; ++c) q_CI[c] = EP_StoI.q[c]; for (int c = 0; c < 3; ++c) p_CI[c] = EP_StoI.p[c]; }
+  }
+  ExtrinsicParam &GetSensorEP(SensorType type) { return EP_StoI_.at(type); }
+  std::map<SensorType, ExtrinsicParam> &GetSensorEPs() { return EP_StoI_; }
+  void SetDataStartTime(int64_t time) { data_start_time_ = time; }   // trajectory.h:94-96
+  int64_t GetDataStartTime() const { return data_start_time_; }
+  // ---- trajectory queries (se3_spline.h:361-399, trajectory.cpp:27-55), evaluated ON THE DEVICE: the knots the query times touch are
+  //      shipped as a factor-free window to this thread's cached solver handle (ctvio_spline_eval / ctvio_sensor_pose).  A time
+  //      outside [minTimeNs, maxTimeNs) throws (the reference asserts).  The batched forms take n times at once.
+  void QueryNs(int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3, const ExtrinsicParam *EP_StoI = nullptr) const;
+  SE3 poseNs(int64_t t_ns) const { double o[7]; QueryNs(1, &t_ns, o, nullptr, nullptr, nullptr); return from7(o); }
+  void transVelWorld(int64_t t_ns, double v[3]) const { QueryNs(1, &t_ns, nullptr, v, nullptr, nullptr); }
+  void rotVelBody(int64_t t_ns, double w[3]) const { QueryNs(1, &t_ns, nullptr, nullptr, w, nullptr); }
+  void transAccelWorld(int64_t t_ns, double a[3]) const { QueryNs(1, &t_ns, nullptr, nullptr, nullptr, a); }
+  void GetIMUState(int64_t time, IMUState &imu_state) const {   // trajectory.cpp:27-37
+    double o[7];
+    QueryNs(1, &time, o, imu_state.v, nullptr, nullptr);
+    imu_state.timestamp = time;
+    for (int c = 0; c < 3; ++c) imu_state.p[c] = o[c];
+    for (int c = 0; c < 4; ++c) imu_state.q[c] = o[3 + c];
+  }
+  SE3 GetSensorPose(int64_t time_ns, const ExtrinsicParam &EP_StoI) const {   // trajectory.cpp:39-56: pose_I_to_G * EP_StoI.se3
+    double o[7];
+    QueryNs(1, &time_ns, o, nullptr, nullptr, nullptr, &EP_StoI);
+    return from7(o);
+  }
+  SE3 GetCameraPose(int64_t timestamp) const { return GetSensorPose(timestamp, EP_StoI_.at(CameraSensor)); }   // trajectory.h:87-90
+  int device = 0;   // HIP device of the queries
   // computeTIndexNs (se3_spline.h:458-461 -> rd_spline.h:117-133): (u, first active knot)
   std::pair<double, size_t> computeTIndexNs(int64_t t_ns) const {
     const int64_t st = t_ns - t0_ns_;
@@ -68,7 +148,9 @@ class Trajectory {
 
  private:
   friend class TrajectoryEstimator;
-  int64_t dt_ns_, t0_ns_;
+  static SE3 from7(const double o[7]) { SE3 s; for (int c = 0; c < 3; ++c) s.p[c] = o[c]; for (int c = 0; c < 4; ++c) s.q[c] = o[3 + c]; return s; }
+  int64_t dt_ns_, t0_ns_, data_start_time_ = -1;
+  std::map<SensorType, ExtrinsicParam> EP_StoI_;
   std::deque<std::array<double, 4>> so3_;
   std::deque<std::array<double, 3>> pos_;
 };
@@ -87,7 +169,7 @@ struct TrajectoryEstimatorOptions {
   int ctrl_to_be_opt_now = 0, ctrl_to_be_opt_later = 0;   // :60-64  knots with index < ctrl_to_be_opt_later are marginalised
   bool show_residual_summary = false;               // :66
   double image_weight = 800.0;  // ImageFeatureDelayFactor::sqrt_info (trajectory_manager.cpp:55-61)
-  int precision = CTVIO_FP64;   // the product path (all-fp64, like the reference); CTVIO_FP32 = mixed fast mode
+  int precision = CTVIO_FP64;   // all-fp64, like the reference (the only mode)
   int device = 0;
 };
 
@@ -153,6 +235,34 @@ class SolverCache {
   std::vector<Item> items_;
 };
 
+inline void Trajectory::QueryNs(int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3,
+                                const ExtrinsicParam *EP_StoI) const {
+  if (n <= 0) return;
+  int64_t lo = t_ns[0], hi = t_ns[0];
+  for (int i = 1; i < n; ++i) { lo = std::min(lo, t_ns[i]); hi = std::max(hi, t_ns[i]); }
+  if (lo < minTimeNs() || hi >= maxTimeNs()) throw std::out_of_range("trajectory query time not in [minTimeNs, maxTimeNs)");
+  const int k0 = (int)((lo - t0_ns_) / dt_ns_), k1 = (int)((hi - t0_ns_) / dt_ns_) + 3, K = k1 - k0 + 1;
+  std::vector<double> quat(4 * (size_t)K), pos(3 * (size_t)K);
+  for (int k = 0; k < K; ++k) {
+    for (int c = 0; c < 4; ++c) quat[4 * k + c] = so3_[k0 + k][c];
+    for (int c = 0; c < 3; ++c) pos[3 * k + c] = pos_[k0 + k][c];
+  }
+  const double bias0[6] = {0, 0, 0, 0, 0, 0};
+  ctvio_window w{};
+  w.K = K; w.F = 1; w.t0_ns = t0_ns_ + (int64_t)k0 * dt_ns_; w.dt_ns = dt_ns_;
+  w.quat = quat.data(); w.pos = pos.data(); w.bias = bias0; w.fix_ld = 1; w.fixed_upto = -1;
+  w.q_CI[3] = 1.0;
+  ctvio_solver *s = SolverCache::get(device, CTVIO_FP64);
+  auto chk = [](int rc) { if (rc) throw std::runtime_error(std::string(ctvio_status_string(rc)) + ": " + ctvio_last_error()); };
+  chk(ctvio_set_batch(s, 1, &w));
+  if (EP_StoI) {
+    if (vel3 || omega3 || acc3) throw std::invalid_argument("sensor-pose queries return the pose only");
+    chk(ctvio_sensor_pose(s, 0, n, t_ns, EP_StoI->q, EP_StoI->p, pose7));
+  } else {
+    chk(ctvio_spline_eval(s, 0, n, t_ns, pose7, vel3, omega3, acc3));
+  }
+}
+
 class TrajectoryEstimator {
  public:
   // TrajectoryEstimator(Trajectory::Ptr, TrajectoryEstimatorOptions&)  trajectory_estimator.h:76-77
@@ -162,7 +272,8 @@ class TrajectoryEstimator {
     (void)ld_ns;
   }
   // void SetFixedIndex(int idx)  trajectory_estimator.h:90.  As in the reference, constancy is decided when a factor adds its
-  // knots (AddControlPoints, trajectory_estimator.cpp:134-138): only knots touched by factors added AFTER this call are fixed.
+  // knots (AddControlPoints, trajectory_estimator.cpp:134-138: SetParameterBlockConstant for knots <= idx, never undone): a knot
+  // is constant iff SOME factor touched it while the index (or lock_traj) covered it -- not necessarily a prefix.
   void SetFixedIndex(int idx) { fixed_idx_ = idx; }
 
   // trajectory_estimator.h:102-106 / .cpp:219-263.  gyro_bias / accel_bias: pointers to 3 doubles; identical pointers
@@ -197,6 +308,7 @@ class TrajectoryEstimator {
     v_pi_.push_back(pi[0] / pi[2]); v_pi_.push_back(pi[1] / pi[2]);
     v_pj_.push_back(pj[0] / pj[2]); v_pj_.push_back(pj[1] / pj[2]);
     v_marg_.push_back(opt_.is_marg_state && marg_this_feature);
+    v_cauchy_.push_back(marg_this_feature ? 1.0 : 2.0);   // one CauchyLoss per residual block (trajectory_estimator.cpp:320-323)
     const int64_t pad = (int64_t)(0.039 * 1e9);   // spans [t, t + 0.039 s] (trajectory_estimator.cpp:299)
     for (int64_t t : {ti, tj}) touch((int)traj_->computeTIndexNs(t).second, (int)traj_->computeTIndexNs(t + pad).second + 3);
   }
@@ -347,7 +459,8 @@ class TrajectoryEstimator {
   struct Packed {
     ctvio_window w{};
     int kmin = 0;
-    std::vector<double> quat, pos, bias, rho, imu_gyro, imu_acc, bc_w, v_pi, v_pj, p_x0;
+    std::vector<double> quat, pos, bias, rho, imu_gyro, imu_acc, bc_w, v_pi, v_pj, p_x0, v_cauchy;
+    std::vector<uint8_t> knot_const;
     std::vector<int64_t> imu_t, v_ti, v_tj;
     std::vector<int32_t> imu_bias, bc_i, bc_j, v_lm, v_rowi, v_rowj, p_kind, p_index, p_off;
     std::vector<int> bias_map, bias_unmap, lm_map;   // adaptor bias / landmark index -> index in this window (-1: absent), and back
@@ -355,14 +468,23 @@ class TrajectoryEstimator {
   static void check(int rc) {
     if (rc) throw std::runtime_error(std::string(ctvio_status_string(rc)) + ": " + ctvio_last_error());
   }
+  // AddControlPoints (trajectory_estimator.cpp:114-141) for knots k0..k1
   void touch(int k0, int k1) {
     kmin_ = std::min(kmin_, k0); kmax_ = std::max(kmax_, k1);
-    if (fixed_idx_ >= 0) fixed_touched_ = std::max(fixed_touched_, std::min(k1, fixed_idx_));   // knots <= fixed_idx_ added while it was set
-    else unfixed_low_ = std::min(unfixed_low_, k0);
+    const int last = std::min(k1, (int)traj_->numKnots() - 1);
+    for (int k = std::max(k0, 0); k <= last; ++k)
+      if (opt_.lock_traj || (fixed_idx_ >= 0 && k <= fixed_idx_)) {
+        if ((int)knot_const_.size() <= k) knot_const_.resize((size_t)k + 1, 0);
+        knot_const_[k] = 1;
+      }
   }
+  // the prior's blocks are handed to AddResidualBlock directly (trajectory_estimator.cpp:334-348): registered, never set constant
   void touch_prior(const std::vector<double *> &blocks, const MarginalizationInfo *info) {
     for (size_t b = 0; b < blocks.size(); ++b)
-      if (info->keep_block_size[b] == 4 || knot_of_.count(blocks[b])) { const int k = knot_of_.at(blocks[b]); touch(k, k); }
+      if (info->keep_block_size[b] == 4 || knot_of_.count(blocks[b])) {
+        const int k = knot_of_.at(blocks[b]);
+        kmin_ = std::min(kmin_, k); kmax_ = std::max(kmax_, k);
+      }
   }
   int bias_index(double *bg, double *ba) {
     auto it = bias_of_.find(bg);
@@ -393,7 +515,8 @@ class TrajectoryEstimator {
     }
   }
   // marg_only: the factors flagged marg_this_factor + the prior of PrepareMarginalizationInfo, CauchyLoss(1)
-  // (trajectory_estimator.cpp:320-322); otherwise every factor + the prior of AddMarginalizationFactor, CauchyLoss(2).
+  // (every visual block with the CauchyLoss width it was added with: 1 when marg_this_feature, else 2, trajectory_estimator.cpp:320-323);
+  // otherwise every factor + the prior of AddMarginalizationFactor.
   void pack(Packed &pk, bool marg_only, bool all_factors = false) {
     if (kmin_ > kmax_) throw std::logic_error("no factor touches the trajectory");
     const int kmin = std::max(0, kmin_), kmax = std::min((int)traj_->numKnots() - 1, std::max(kmax_, kmin + 3));
@@ -440,6 +563,7 @@ class TrajectoryEstimator {
       pk.v_lm.push_back(pk.lm_map[v_lm_[v]]); pk.v_ti.push_back(v_ti_[v]); pk.v_tj.push_back(v_tj_[v]);
       pk.v_rowi.push_back(v_rowi_[v]); pk.v_rowj.push_back(v_rowj_[v]);
       for (int c = 0; c < 2; ++c) { pk.v_pi.push_back(v_pi_[2 * v + c]); pk.v_pj.push_back(v_pj_[2 * v + c]); }
+      pk.v_cauchy.push_back(v_cauchy_[v]);
     }
     ctvio_window &w = pk.w;
     w.K = K; w.F = F; w.L = L; w.M = (int)pk.imu_t.size(); w.NB = (int)pk.bc_i.size(); w.V = (int)pk.v_lm.size();
@@ -447,19 +571,17 @@ class TrajectoryEstimator {
     w.quat = pk.quat.data(); w.pos = pk.pos.data(); w.bias = pk.bias.data(); w.rho = pk.rho.data();
     w.ld = traj_->line_delay; w.ld_lo = traj_->ld_lower; w.ld_hi = traj_->ld_upper; w.fix_ld = traj_->fix_ld;
     w.lock_bg = opt_.lock_wb; w.lock_ba = opt_.lock_ab;
-    // constant knots: the library takes a prefix [0, fixed_upto]; what AddControlPoints produces is a prefix too as long as
-    // SetFixedIndex was called before the factors (or after all of them: nothing fixed, the reference's InitTrajectory)
-    if (opt_.lock_traj) w.fixed_upto = K - 1;
-    else if (fixed_touched_ < 0) w.fixed_upto = -1;
-    else {
-      if (unfixed_low_ <= fixed_touched_) throw std::logic_error("SetFixedIndex between Add* calls: the constant knots are not a prefix");
-      w.fixed_upto = fixed_touched_ - kmin;
-    }
+    // constant knots: per-knot flags as AddControlPoints set them (any set, not only a prefix)
+    w.fixed_upto = -1;
+    pk.knot_const.assign((size_t)K, 0);
+    for (int k = 0; k < K; ++k) pk.knot_const[k] = (kmin + k < (int)knot_const_.size()) ? knot_const_[kmin + k] : 0;
+    w.knot_const = pk.knot_const.data();
     for (int c = 0; c < 4; ++c) w.q_CI[c] = traj_->q_CI[c];
     for (int c = 0; c < 3; ++c) { w.p_CI[c] = traj_->p_CI[c]; w.gravity[c] = gravity_[c]; }
     for (int c = 0; c < 6; ++c) w.imu_w[c] = imu_w_[c];
     w.img_w = opt_.image_weight;
-    w.cauchy_a = marg_only ? 1.0 : 2.0;  // CauchyLoss(marg_this_feature ? 1 : 2), trajectory_estimator.cpp:320-322
+    w.cauchy_a = 2.0;
+    w.v_cauchy = pk.v_cauchy.data();   // CauchyLoss(marg_this_feature ? 1 : 2) per block, trajectory_estimator.cpp:320-323
     w.imu_t = pk.imu_t.data(); w.imu_gyro = pk.imu_gyro.data(); w.imu_acc = pk.imu_acc.data(); w.imu_bias = pk.imu_bias.data();
     w.bc_i = pk.bc_i.data(); w.bc_j = pk.bc_j.data(); w.bc_w = pk.bc_w.data();
     w.v_lm = pk.v_lm.data(); w.v_ti = pk.v_ti.data(); w.v_tj = pk.v_tj.data(); w.v_rowi = pk.v_rowi.data(); w.v_rowj = pk.v_rowj.data();
@@ -481,14 +603,15 @@ class TrajectoryEstimator {
 
   Trajectory *traj_;
   TrajectoryEstimatorOptions opt_;
-  int fixed_idx_ = -1, fixed_touched_ = -1, unfixed_low_ = 1 << 30;
+  int fixed_idx_ = -1;
+  std::vector<uint8_t> knot_const_;   // per global knot index: SetParameterBlockConstant was called for it
   int kmin_ = 1 << 30, kmax_ = -1;
   std::unordered_map<const double *, int> knot_of_, bias_of_, lm_of_;
   std::vector<std::pair<double *, double *>> bias_ptr_;
   std::vector<double *> lm_ptr_;
   double gravity_[3] = {0, 0, 9.80766}, imu_w_[6] = {250, 250, 250, 12.5, 12.5, 12.5};
   std::vector<int64_t> imu_t_, v_ti_, v_tj_;
-  std::vector<double> imu_gyro_, imu_acc_, bc_w_, v_pi_, v_pj_;
+  std::vector<double> imu_gyro_, imu_acc_, bc_w_, v_pi_, v_pj_, v_cauchy_;
   std::vector<int32_t> imu_bias_, bc_i_, bc_j_, v_lm_, v_rowi_, v_rowj_;
   std::vector<char> imu_marg_, bc_marg_, v_marg_;
   const MarginalizationInfo *prior_ = nullptr, *marg_prior_ = nullptr;

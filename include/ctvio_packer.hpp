@@ -7,6 +7,7 @@
 //   visual block order, row rounding   src/estimator/trajectory_manager.cpp:358-383
 //   IMU samples of the window          src/estimator/trajectory_manager.cpp:322-325, 386-394
 //   depth copy-back and failure flag   src/visual_odometry/feature_manager.cpp:110-143
+//   MARGIN_OLD factor / drop-set selection (UpdateVIOPrior)  src/estimator/trajectory_manager.cpp:141-262
 #pragma once
 #include <array>
 #include <cmath>
@@ -86,6 +87,37 @@ inline VisualBlocks pack_visual(const std::vector<FeatureTrack> &tracks, const s
   }
   return o;
 }
+
+// ---- UpdateVIOPrior(MARGIN_OLD): what enters the marginalisation and what is dropped (trajectory_manager.cpp:141-262).
+struct MargOldSelection {
+  int ctrl_to_be_opt_now = 0, ctrl_to_be_opt_later = 0;   // :149-154: first active knot at timestamps[0] / timestamps[1]
+  std::vector<double *> drop_param_set;                    // :166-174: knots in [now, later) (rotation, position) + the oldest bias pair
+  std::vector<int> drop_set;                               // :176-187: their positions in the previous prior's parameter blocks
+};
+// Traj: computeTIndexNs(t).second, getKnotSO3(i).data(), getKnotPos(i).data().  bg0 / ba0 = para_bg_vec[0] / para_ba_vec[0].
+template <class Traj>
+inline MargOldSelection marg_old_selection(Traj &traj, int64_t t_frame0, int64_t t_frame1, double *bg0, double *ba0,
+                                           const std::vector<double *> &last_marginalization_parameter_blocks) {
+  MargOldSelection o;
+  o.ctrl_to_be_opt_now = (int)traj.computeTIndexNs(t_frame0).second;
+  o.ctrl_to_be_opt_later = (int)traj.computeTIndexNs(t_frame1).second;
+  for (int i = o.ctrl_to_be_opt_now; i < o.ctrl_to_be_opt_later; ++i) {
+    o.drop_param_set.push_back(traj.getKnotSO3(i).data());
+    o.drop_param_set.push_back(traj.getKnotPos(i).data());
+  }
+  o.drop_param_set.push_back(bg0);
+  o.drop_param_set.push_back(ba0);
+  for (int j = 0; j < (int)last_marginalization_parameter_blocks.size(); ++j)
+    for (double *d : o.drop_param_set)
+      if (last_marginalization_parameter_blocks[j] == d) { o.drop_set.push_back(j); break; }
+  return o;
+}
+// [2] image (:203-241): every candidate feature's blocks are added; marg_this_factor for the features anchored at the oldest frame
+// whose inverse depth came out positive
+inline bool marg_this_feature(int start_frame, double inv_depth) { return start_frame == 0 && inv_depth > 0; }
+// [3] IMU (:243-256): samples in [opt_min_time, timestamps[1]), all with marg_this_factor and bias index 0
+inline bool imu_in_marg_old(int64_t t, int64_t opt_min, int64_t t_frame1) { return t >= opt_min && t < t_frame1; }
+// [4] bias (:258-266): the single factor (0, 1), marg_this_factor
 
 // FeatureManager::setDepth: depth = 1 / rho; ok[l] = false (SolveFail) when the depth came out negative
 inline void depths_from_solution(const std::vector<double> &rho, std::vector<double> &depth, std::vector<uint8_t> &ok) {

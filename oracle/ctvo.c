@@ -672,7 +672,7 @@ double ctvo_cost(const ctvo_window *w) {
   }
   for (int v = 0; v < w->V; ++v) {
     ctvo_visual_block(w, v, r, NULL, NULL, NULL);
-    cost += robustify(w->cauchy_a, 2, 0, r, NULL);
+    cost += robustify(w->v_cauchy ? w->v_cauchy[v] : w->cauchy_a, 2, 0, r, NULL);
   }
   for (int b = 0; b < w->NB; ++b) {
     ctvo_bias_block(w, b, r, NULL);
@@ -724,7 +724,7 @@ double ctvo_build_normal(const ctvo_window *w, double *H, double *g) {
     int32_t si, sj;
     ctvo_visual_block(w, v, r, Jv, &si, &sj);
     jn_apply(Jv, 2 * 50, g_jn_vis);
-    cost += robustify(w->cauchy_a, 2, 50, r, Jv);
+    cost += robustify(w->v_cauchy ? w->v_cauchy[v] : w->cauchy_a, 2, 50, r, Jv);
     for (int k = 0; k < 4; ++k)
       for (int c = 0; c < 3; ++c) {
         idx[3 * k + c] = 6 * (si + k) + c; idx[12 + 3 * k + c] = 6 * (si + k) + 3 + c;
@@ -804,6 +804,9 @@ void ctvo_active_mask(const ctvo_window *w, uint8_t *active) {
   }
   for (int k = 0; k <= w->fixed_upto && k < K; ++k)
     for (int c = 0; c < 6; ++c) active[6 * k + c] = 0;
+  if (w->knot_const)   /* per-knot SetParameterBlockConstant (trajectory_estimator.cpp:134-138): need not be a prefix */
+    for (int k = 0; k < K; ++k)
+      if (w->knot_const[k]) for (int c = 0; c < 6; ++c) active[6 * k + c] = 0;
   for (int f = 0; f < w->F; ++f)
     for (int c = 0; c < 3; ++c) {
       if (w->lock_bg) active[6 * K + 6 * f + c] = 0;

@@ -62,6 +62,12 @@ typedef struct ctvo_window {
   double *pr0;              /* pn */
   int32_t *p_kind, *p_index, *p_off;  /* pnb */
   double *p_x0;             /* pnb*4 */
+  /* per residual block: CauchyLoss(marg_this_feature ? 1 : 2), one loss object per AddImageFeatureDelayAnalytic call
+   * (trajectory_estimator.cpp:320-323).  V entries (<= 0: none) or NULL: cauchy_a for every block. */
+  double *v_cauchy;
+  /* per knot: SetParameterBlockConstant is decided per AddControlPoints call (trajectory_estimator.cpp:134-138);
+   * K flags or NULL, on top of fixed_upto. */
+  uint8_t *knot_const;
 } ctvo_window;
 
 typedef struct ctvo_summary {

@@ -38,7 +38,7 @@ class _CWindow(C.Structure):
         ("v_lm", C.c_void_p), ("v_ti", C.c_void_p), ("v_tj", C.c_void_p), ("v_rowi", C.c_void_p), ("v_rowj", C.c_void_p),
         ("v_pi", C.c_void_p), ("v_pj", C.c_void_p),
         ("pJ0", C.c_void_p), ("pr0", C.c_void_p), ("p_kind", C.c_void_p), ("p_index", C.c_void_p), ("p_off", C.c_void_p),
-        ("p_x0", C.c_void_p),
+        ("p_x0", C.c_void_p), ("v_cauchy", C.c_void_p), ("knot_const", C.c_void_p),
     ]
 
 
@@ -94,6 +94,9 @@ class OracleWindow:
         c.v_rowi, c.v_rowj, c.v_pi, c.v_pj = _p(w.v_rowi), _p(w.v_rowj), _p(w.v_pi), _p(w.v_pj)
         c.pJ0 = self._pJ0_cm.ctypes.data_as(C.c_void_p) if w.pn else None
         c.pr0, c.p_kind, c.p_index, c.p_off, c.p_x0 = _p(w.pr0), _p(w.p_kind), _p(w.p_index), _p(w.p_off), _p(w.p_x0)
+        vc, kc = getattr(w, "v_cauchy", None), getattr(w, "knot_const", None)
+        c.v_cauchy = _p(vc) if vc is not None else None
+        c.knot_const = _p(kc) if kc is not None else None
         self.c = c
 
     def _sync_in(self):

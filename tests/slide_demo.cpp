@@ -118,33 +118,22 @@ int main(int argc, char **argv) {
       ctvio::TrajectoryEstimatorOptions option;
       option.image_weight = img_w;
       option.is_marg_state = true;
-      option.ctrl_to_be_opt_now = (int)traj.computeTIndexNs(timestamps[0]).second;
-      option.ctrl_to_be_opt_later = (int)traj.computeTIndexNs(timestamps[1]).second;
+      // the selection rules of UpdateVIOPrior(MARGIN_OLD) come from include/ctvio_packer.hpp
+      const ctvio::MargOldSelection sel = ctvio::marg_old_selection(traj, timestamps[0], timestamps[1], para_bg[0], para_ba[0],
+                                                                    last_marginalization_parameter_blocks);
+      option.ctrl_to_be_opt_now = sel.ctrl_to_be_opt_now;
+      option.ctrl_to_be_opt_later = sel.ctrl_to_be_opt_later;
       ctvio::TrajectoryEstimator estimator(&traj, option);
-      if (have_prior) {   // [1] prior: drop the knots in [now, later) and the oldest bias
-        std::vector<double *> drop_param_set;
-        for (int i = option.ctrl_to_be_opt_now; i < option.ctrl_to_be_opt_later; ++i) {
-          drop_param_set.push_back(traj.getKnotSO3(i).data());
-          drop_param_set.push_back(traj.getKnotPos(i).data());
-        }
-        drop_param_set.push_back(para_bg[0]);
-        drop_param_set.push_back(para_ba[0]);
-        std::vector<int> drop_set;
-        for (int j = 0; j < (int)last_marginalization_parameter_blocks.size(); ++j)
-          for (double *d : drop_param_set)
-            if (last_marginalization_parameter_blocks[j] == d) { drop_set.push_back(j); break; }
-        if (!drop_set.empty()) estimator.PrepareMarginalizationInfo(&last_marginalization_info, last_marginalization_parameter_blocks, drop_set);
-      }
+      if (have_prior && !sel.drop_set.empty())   // [1] prior: drop the knots in [now, later) and the oldest bias
+        estimator.PrepareMarginalizationInfo(&last_marginalization_info, last_marginalization_parameter_blocks, sel.drop_set);
       for (const Obs &o : obs) {   // [2] image: features anchored at the oldest frame are marginalised
         if (!candidate(o.lm) || o.tj > timestamps[WIN - 1]) continue;
-        const bool marg_this_factor = (anchor_t[o.lm] == timestamps[0]) && para_Feature[o.lm] > 0;
+        const bool marg_this_factor = ctvio::marg_this_feature((int)(anchor_t[o.lm] / FRAME_DT) - k, para_Feature[o.lm]);
         estimator.AddImageFeatureDelayAnalytic(o.ti, o.rowi, o.pi, o.tj, o.rowj, o.pj, &para_Feature[o.lm], &traj.line_delay, false, marg_this_factor);
       }
-      for (const auto &v : imu) {   // [3] IMU before the second keyframe
-        if (v.timestamp < opt_min_time) continue;
-        if (v.timestamp >= timestamps[1]) break;
-        estimator.AddIMUMeasurementAnalytic(v, gravity, para_bg[0], para_ba[0], imu_w, true);
-      }
+      for (const auto &v : imu)   // [3] IMU before the second keyframe
+        if (ctvio::imu_in_marg_old(v.timestamp, opt_min_time, timestamps[1]))
+          estimator.AddIMUMeasurementAnalytic(v, gravity, para_bg[0], para_ba[0], imu_w, true);
       estimator.AddBiasFactor(para_bg[0], para_bg[1], para_ba[0], para_ba[1], 1.0, &sqrt_info_bias[0], true);   // [4]
       have_prior = estimator.SaveMarginalizationInfo(last_marginalization_info, last_marginalization_parameter_blocks);
       std::cout << "prior " << k << ": n = " << last_marginalization_info.n << ", blocks = " << last_marginalization_parameter_blocks.size() << std::endl;
@@ -161,5 +150,29 @@ int main(int argc, char **argv) {
   for (int f = 0; f < F; ++f) out << bg[f][0] << " " << bg[f][1] << " " << bg[f][2] << " " << ba[f][0] << " " << ba[f][1] << " " << ba[f][2] << "\n";
   for (int l = 0; l < L; ++l) out << para_Feature[l] << "\n";
   out << traj.line_delay << "\n";
+  // the consumers' side of the solve (trajectory_manager.cpp:108-120, odometry_manager.cpp:287): queries on the optimised spline,
+  // evaluated on the device through ctvio::Trajectory
+  ctvio::ExtrinsicParam EP_CtoI;
+  for (int c = 0; c < 4; ++c) EP_CtoI.q[c] = traj.q_CI[c];
+  for (int c = 0; c < 3; ++c) EP_CtoI.p[c] = traj.p_CI[c];
+  traj.SetSensorExtrinsics(ctvio::CameraSensor, EP_CtoI);
+  traj.SetDataStartTime(12345);
+  const int64_t tq = traj.maxTimeNs() - (int64_t)(0.05 * 1e9);
+  const ctvio::SE3 cam = traj.GetCameraPose(tq);
+  ctvio::IMUState ist;
+  traj.GetIMUState(tq, ist);
+  const ctvio::SE3 last = traj.getLastKnot();
+  traj.setKnot(traj.getKnot(traj.numKnots() - 1), (int)traj.numKnots() - 1);
+  out << tq << " " << traj.GetDataStartTime() << "\n";
+  for (double v : cam.p) out << v << " ";
+  for (double v : cam.q) out << v << " ";
+  out << "\n";
+  for (double v : ist.p) out << v << " ";
+  for (double v : ist.q) out << v << " ";
+  for (double v : ist.v) out << v << " ";
+  out << "\n";
+  for (double v : last.p) out << v << " ";
+  for (double v : last.q) out << v << " ";
+  out << "\n";
   return 0;
 }

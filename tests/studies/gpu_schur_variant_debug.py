@@ -1,7 +1,7 @@
 """Diagnostics (GPU box): big-batch vs small-batch vs oracle for K = 26 / 27 windows; CTVIO_SCHUR_TILES=1 forces the tile Schur."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 cv = importlib.import_module("ctrl-vio_amd")
 import pyctvo

@@ -48,7 +48,7 @@ def test_struct_layout_matches_header(cv):
         decl = decl.replace("typedef struct ctvio_window {", "").strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(int32_t|int64_t|double)\s*", "", decl)
+        decl = re.sub(r"^(const\s+)?(int32_t|int64_t|uint8_t|double)\s*", "", decl)
         for part in decl.split(","):
             part = part.strip().lstrip("*").strip()
             part = re.sub(r"\[\d+\]", "", part)

@@ -127,3 +127,44 @@ def test_gauge_restore_against_scipy():
         np.testing.assert_array_equal(qq[:k], q[:k])
         np.testing.assert_array_equal(pp[:k], p[:k])
         np.testing.assert_allclose(pp[k], t0, atol=1e-12)
+
+
+def test_per_block_cauchy_and_knot_mask_in_the_oracle(cv, oracle):
+    """ctvo_window.v_cauchy / knot_const (per residual block CauchyLoss width, per knot constancy: trajectory_estimator.cpp:320-323,
+    134-138): uniform per-block widths reproduce the window-wide width; the dense normal equations of a mixed assignment equal the sum
+    of the two single-width builds restricted to their blocks; a prefix mask reproduces fixed_upto; a non-prefix mask freezes exactly
+    the flagged knots."""
+    w = cv.synth.make_window("tiny", seed=11)
+    H2, g2, c2 = oracle.OracleWindow(w.copy()).build_normal()
+    wu = w.copy(); wu.v_cauchy = np.full(w.V, 2.0)
+    Hu, gu, cu = oracle.OracleWindow(wu).build_normal()
+    assert cu == c2 and np.array_equal(Hu, H2) and np.array_equal(gu, g2)
+    w1 = w.copy(); w1.cauchy_a = 1.0
+    H1, g1, c1 = oracle.OracleWindow(w1).build_normal()
+    mask = (np.arange(w.V) % 3 == 0)
+    wm = w.copy(); wm.v_cauchy = np.where(mask, 1.0, 2.0)
+    Hm, gm, cm = oracle.OracleWindow(wm).build_normal()
+
+    def only(wsrc, sel, a):   # the window with the visual blocks `sel` only, width a, no other factor
+        x = wsrc.copy()
+        for n in ("v_lm", "v_ti", "v_tj", "v_rowi", "v_rowj", "v_pi", "v_pj"):
+            setattr(x, n, getattr(x, n)[sel])
+        x.cauchy_a = a; x.v_cauchy = None
+        x.imu_t = x.imu_t[:0]; x.imu_gyro = x.imu_gyro[:0]; x.imu_acc = x.imu_acc[:0]; x.imu_bias = x.imu_bias[:0]
+        x.bc_i = x.bc_i[:0]; x.bc_j = x.bc_j[:0]; x.bc_w = x.bc_w[:0]
+        x.pJ0 = np.zeros((0, 0)); x.pr0 = np.zeros(0); x.p_kind = x.p_kind[:0]; x.p_index = x.p_index[:0]; x.p_off = x.p_off[:0]; x.p_x0 = x.p_x0[:0]
+        return oracle.OracleWindow(x.normalize()).build_normal()
+    Ha, ga, ca = only(w, mask, 1.0); Hb, gb, cb = only(w, ~mask, 2.0); Hc, gc, cc = only(w, mask, 2.0)
+    np.testing.assert_allclose(Hm, H2 - Hc + Ha, rtol=0, atol=1e-9 * np.abs(H2).max())
+    np.testing.assert_allclose(gm, g2 - gc + ga, rtol=0, atol=1e-9 * np.abs(g2).max())
+    assert cm == pytest.approx(c2 - cc + ca, rel=1e-12)
+    # knot masks
+    wf = w.copy(); wf.fixed_upto = 2
+    wk = w.copy(); wk.knot_const = (np.arange(w.K) <= 2).astype(np.uint8)
+    sa = oracle.OracleWindow(wf).solve(15); sb = oracle.OracleWindow(wk).solve(15)
+    assert sa.iterations == sb.iterations and sa.final_cost == sb.final_cost and np.array_equal(wf.quat, wk.quat)
+    wn = w.copy(); wn.knot_const = np.zeros(w.K, np.uint8); wn.knot_const[[1, 4]] = 1
+    q0, p0 = wn.quat.copy(), wn.pos.copy()
+    oracle.OracleWindow(wn).solve(15)
+    assert np.array_equal(wn.quat[[1, 4]], q0[[1, 4]]) and np.array_equal(wn.pos[[1, 4]], p0[[1, 4]])
+    assert np.abs(wn.quat[[0, 2, 3]] - q0[[0, 2, 3]]).max() > 0
