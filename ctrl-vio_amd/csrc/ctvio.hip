@@ -132,6 +132,8 @@ template <class T> class SolverImpl : public SolverBase {
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<T, 16, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<T, 8, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -536,8 +538,16 @@ template <class T> class SolverImpl : public SolverBase {
       ph_end();
     }
     ph_begin(PH_CHOL);
-    // fewer windows than CUs: 8 waves per window (latency); otherwise 4, two windows per CU (throughput)
-    if (nw <= 192) hipLaunchKernelGGL((k_cholesky_solve<T, 8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
+    // P <= 223: the register-resident tile kernel (S read once, nothing written back; 16 waves per window) for batches smaller than
+    // the chip, where latency counts; large batches: the panel kernel with 4 waves, two windows per CU (throughput); windows beyond
+    // 223 unknowns: the panel kernel, with 8 waves when there are fewer windows than CUs
+    if (chol_tiles()) {
+      const int ntr = d.maxP / 16 + 1;
+      const size_t lds = (size_t)(2 * ntr * 272 + 32 * ntr + 4) * sizeof(double);
+      if (chol_tiles() == 2) hipLaunchKernelGGL((k_cholesky_tiles<T, 8, 14>), dim3(nw), dim3(512), lds, stream_, d);   // (A/B variant: 8 waves x 14 tiles)
+      else hipLaunchKernelGGL((k_cholesky_tiles<T, 16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
+    }
+    else if (nw <= 192) hipLaunchKernelGGL((k_cholesky_solve<T, 8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
     else hipLaunchKernelGGL((k_cholesky_solve<T, 4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
@@ -549,6 +559,12 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_assemble_vis_lds(int parts);
   void launch_assemble_vis_glb(int parts);
   bool schur_makes_rhs() const { return schur_rhs_done_; }
+  // CTVIO_CHOL_TILES = 0 / 1 forces the choice (A/B measurements); default: batches of <= 256 windows
+  int chol_tiles() const {
+    if (dev_.maxP > 223) return 0;
+    if (const char *e = std::getenv("CTVIO_CHOL_TILES")) return e[0] - '0';
+    return dev_.nwin <= 256 ? 1 : 0;
+  }
   bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
   void launch_cost(bool candidate, int force) {
     const Dev<T> &d = dev_;
@@ -592,7 +608,7 @@ template <class T> class SolverImpl : public SolverBase {
   // assembly variants run).  Two batches with identical totals can differ in these (e.g. the same sum K split differently).
   std::vector<long long> launch_signature() const {
     return {(long long)vis_lds_, (long long)vis_glb_, (long long)any_vis_lds_, (long long)any_vis_glb_, (long long)maxK_, (long long)max_schur_tiles_,
-            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_};
+            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles()};
   }
   int ensure_graph() {
     const std::vector<long long> sig = launch_signature();

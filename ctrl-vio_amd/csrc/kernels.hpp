@@ -2155,6 +2155,200 @@ template <class T, int NW> __global__ __launch_bounds__(64 * NW) __attribute__((
 #undef CTV_STAMP
 }
 
+// ---- Register-resident tile Cholesky (windows with P <= 223): the whole lower triangle of the reduced system lives in the
+// VGPRs of ONE workgroup as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (tile t = i (i + 1) / 2 + j, i >= j,
+// belongs to wave t % NW, slot t / NW: 105 tiles at P = 211 -> 7 slots x 4 registers per lane on 16 waves).  S is read from HBM
+// exactly once and never written back; the right-hand side rides along as row P (so y = L^-1 b falls out of the factorisation).
+// Per 16-column panel k:
+//   A. the owner of the diagonal tile moves it through LDS into row-per-lane form and factors it with 16 v_readlane pivots
+//      (lanes 0-15 the rows, lanes 16-31 the columns of the inverse: the fused scheme of k_cholesky_solve), leaves L_kk^-1 in LDS;
+//   C. the owners of the tiles below it form L_ik = A_ik L_kk^-T (4 MFMAs; the accumulator -> operand transposition goes through
+//      the tile's slice of the LDS panel) and publish L_ik there;
+//   E. every owner of a trailing tile (i, j), j > k, subtracts L_ik L_jk^T (4 MFMAs, operands from the LDS panel).
+// Back-substitution L^T x = y runs over the tiles still in registers: x_b = L_bb^-T t_b, then t_j -= L_bj^T x_b by the single
+// owner of tile (b, j) -- no atomics anywhere, the summation order is fixed (bitwise reproducible).
+// Pivots with index >= P (the rhs row, padding rows) are forced to 1 and never flagged.
+template <int J, int C> __device__ __forceinline__ void chol16_row_updates(double (&v)[16], int lo, int hi) {
+  if constexpr (C + 3 <= 15) {
+    chol_bcast_update4<C>(v[C], v[C + 1], v[C + 2], v[C + 3], v[J], lo, hi);
+    chol16_row_updates<J, C + 4>(v, lo, hi);
+  } else if constexpr (C <= 15) {
+    chol_bcast_update<C>(v[C], v[J], lo, hi);
+    chol16_row_updates<J, C + 1>(v, lo, hi);
+  }
+}
+template <int J> __device__ __forceinline__ void chol16_from(double (&v)[16], double di, int nreal, int &bad) {
+  v[J] *= di;
+  const int lo = __double2loint(v[J]), hi = __double2hiint(v[J]);
+  if constexpr (J < 15) {
+    chol_bcast_update_first<J + 1>(v[J + 1], v[J], lo, hi);
+    double di_next = 1.0;
+    if (J + 1 < nreal) di_next = chol_pivot_rsqrt(readlane_d(v[J + 1], J + 1), bad);   // (uniform branch)
+    if constexpr (J < 14) chol16_row_updates<J, J + 2>(v, lo, hi);
+    chol16_from<J + 1>(v, di_next, nreal, bad);
+  }
+}
+__device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
+
+template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_tiles(Dev<T> d) {
+  constexpr int NT = 64 * NW, TS = 16 * 17;    // a 16 x 16 block in LDS: row stride 17
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status || lm.ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int NTR = P / 16 + 1, ntiles = NTR * (NTR + 1) / 2, ip = P / 16, rp = P % 16;   // the rhs row P sits in tile row ip, local row rp
+  extern __shared__ __attribute__((aligned(16))) double smt[];
+  double *Li = smt;                    // [NTR][TS] inverses of the diagonal blocks, Li[b][j * 17 + k] = Linv_b[j][k]
+  double *Pn = Li + NTR * TS;          // [NTR][TS] panel: Pn[i][m * 17 + c] = L_ik[m][c] of the current panel
+  double *tv = Pn + NTR * TS;          // [16 NTR] y, then the running right-hand side of the back-substitution
+  double *xs = tv + 16 * NTR;          // [16 NTR] solution
+  int &s_fail = *reinterpret_cast<int *>(xs + 16 * NTR);
+  const double *S = d.S + m.H0, *y = d.rhs + m.p0;
+  if (tid == 0) s_fail = 0;
+  for (int i = tid; i < 16 * NTR; i += NT) tv[i] = 0.0;
+  // ---- this wave's tiles (SGPRs) and their contents
+  int ti[NS], tj[NS];
+  f64x4 acc[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int t = wave + NW * q;
+    int a, b;
+    tile_decode(min(t, ntiles - 1), a, b);
+    ti[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? a : -1);
+    tj[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? b : 1 << 20);   // (never equal to a panel, never a trailing tile: ti < tj)
+    // unconditional loads on clamped addresses straight into the tile registers; fixed up below
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rc = min(16 * a + q4 + 4 * r, P - 1);
+      acc[q][r] = S[(long long)rc * ldh + min(16 * b + l15, rc)];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    if (ti[q] < 0) continue;
+    const int col = 16 * tj[q] + l15;
+    if (ti[q] == tj[q]) {             // diagonal tile: the upper half is not stored in S
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = (col <= 16 * ti[q] + q4 + 4 * r) ? acc[q][r] : 0.0;
+    }
+    if (ti[q] == ip) {                // tile row of the rhs row P; identity beyond it
+      const double yv = y[min(col, P - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ip + q4 + 4 * r;
+        acc[q][r] = row < P ? acc[q][r] : (row == P ? (col < P ? yv : 0.0) : (row == col ? 1.0 : 0.0));
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < NTR; ++k) {
+    // ---- A. diagonal tile (k, k)
+    const int td = k * (k + 1) / 2 + k, od = td % NW, sd = td / NW;
+    if (wave == od) {
+      double *Dg = Li + k * TS;
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (q == sd) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Dg[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double v[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double a = Dg[l15 * 17 + c];
+        v[c] = lane < 16 ? (c <= lane ? a : 0.0) : (c == l15 ? 1.0 : 0.0);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();      // every lane has read its row before the block is overwritten with the inverse
+      const int nreal = P - 16 * k;         // pivots below this are real; the rhs row and the padding rows are not factored
+      int bad = 0;
+      double di0 = 1.0;
+      if (nreal > 0) di0 = chol_pivot_rsqrt(readlane_d(v[0], 0), bad);
+      chol16_from<0>(v, di0, nreal, bad);
+      if (lane >= 16 && lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Dg[i * 17 + l15] = v[i];   // Linv[i][column l15]
+      }
+      if (k == ip && lane == rp) {          // the part of y inside the last diagonal tile: L[P][16 ip + c], c < rp
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < rp) tv[16 * ip + c] = v[c];
+      }
+      if (lane == 0 && bad) s_fail = 1;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    // ---- C. L_ik = A_ik L_kk^-T for the tiles below the diagonal one
+    const double *Lk = Li + k * TS;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (tj[q] != k || ti[q] <= k) continue;   // (uniform)
+      double *blk = Pn + ti[q] * TS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double a[4], b[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { a[s4] = blk[l15 * 17 + 4 * s4 + q4]; b[s4] = Lk[l15 * 17 + 4 * s4 + q4]; }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();          // operands are in registers before the slice is overwritten
+      f64x4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], c, 0, 0, 0);
+      acc[q] = c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = c[r];
+      if (ti[q] == ip && q4 == (rp & 3)) tv[16 * k + l15] = f64x4_get(c, rp >> 2);   // y: row P of L
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    // ---- E. trailing tiles (i, j), j > k: A_ij -= L_ik L_jk^T
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (ti[q] < 0 || tj[q] <= k || tj[q] >= (1 << 20)) continue;   // (uniform)
+      const double *pa = Pn + ti[q] * TS + l15 * 17 + q4, *pb = Pn + tj[q] * TS + l15 * 17 + q4;
+      double a[4], b[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { a[s4] = -pa[4 * s4]; b[s4] = pb[4 * s4]; }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
+    }
+    // (the next panel's step C overwrites the LDS panel only after the barrier that follows its step A)
+  }
+  __syncthreads();
+  // ---- back-substitution L^T x = y over the tiles in registers
+  for (int b = NTR - 1; b >= 0; --b) {
+    if (wave == (b % NW) && lane < 16) {
+      const double *Lb = Li + b * TS;
+      double xa = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) xa += Lb[kk * 17 + lane] * tv[16 * b + kk];   // x_b[j] = sum_k Linv[k][j] t[k]
+      xs[16 * b + lane] = xa;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (ti[q] != b || tj[q] >= b) continue;   // tiles (b, j), j < b: t_j -= L_bj^T x_b
+      double part = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part += acc[q][r] * xs[16 * b + q4 + 4 * r];
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      if (q4 == 0) tv[16 * tj[q] + l15] -= part;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+  }
+  double *x = d.delta + m.u0;
+  for (int i = tid; i < P; i += NT) x[i] = xs[i];
+  if (tid == 0) lm.chol_fail = s_fail;
+}
+
 // delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
 // model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres' -(J y)^T (r + J y / 2) when
 // (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
