@@ -412,12 +412,15 @@ template <class T> class SolverImpl : public SolverBase {
     state_doubles_ = (size_t)7 * K0 + 6 * F0 + L0 + nw;
     off = 0;
     const size_t o_cstate = seg(8 * state_doubles_), o_snap = seg(8 * state_doubles_);
-    const size_t o_kd = seg(8 * 3 * (size_t)K0), o_ckd = seg(8 * 3 * (size_t)K0), o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
+    const size_t o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
     const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
+    const size_t o_imu_cost = seg(8 * (size_t)std::max(G0, 1)), o_vis_cost = seg(8 * ((Vt + 63) / 64)), o_misc_cost = seg(8 * (size_t)nw);
     const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt);
-    const size_t o_Hpp = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
+    // two normal-equation sets (current linearisation / speculative linearisation at the candidate, Lm::cur)
+    const size_t o_Hpp = seg(8 * (size_t)H0), o_Hpp1 = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
-    const size_t o_W = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_g = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
+    const size_t o_W = seg(sizeof(T) * (size_t)W0), o_W1 = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_Hll1 = seg(8 * (size_t)L0),
+                 o_g = seg(8 * (size_t)U0), o_g1 = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
                  o_cscale = seg(8 * (size_t)U0), o_lm = seg(sizeof(Lm) * (size_t)nw), o_nact = seg(16), o_dbg = seg(8 * 64);
     const size_t o_zero1 = off;   // ---- ... to here
     const size_t o_rhs = seg(8 * (size_t)Pp0), o_dd = seg(8 * (size_t)U0), o_dinv = seg(8 * (size_t)L0);
@@ -430,9 +433,12 @@ template <class T> class SolverImpl : public SolverBase {
 #define CTV_W(type, o) reinterpret_cast<type *>(wb + (o))
     d.cquat = CTV_W(double, o_cstate); d.cpos = d.cquat + (size_t)4 * K0; d.cbias = d.cpos + (size_t)3 * K0; d.crho = d.cbias + (size_t)6 * F0; d.cld = d.crho + L0;
     snap_ = CTV_W(double, o_snap);
-    d.kd = CTV_W(double, o_kd); d.ckd = CTV_W(double, o_ckd); d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
+    d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
+    d.imu_cost = CTV_W(double, o_imu_cost); d.vis_cost = CTV_W(double, o_vis_cost); d.misc_cost = CTV_W(double, o_misc_cost);
     d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs);
-    d.Hpp = CTV_W(double, o_Hpp); d.S = CTV_W(double, o_S); d.W = CTV_W(T, o_W); d.Hll = CTV_W(double, o_Hll); d.g = CTV_W(double, o_g);
+    d.HppS[0] = CTV_W(double, o_Hpp); d.HppS[1] = CTV_W(double, o_Hpp1); d.S = CTV_W(double, o_S);
+    d.WS[0] = CTV_W(T, o_W); d.WS[1] = CTV_W(T, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
+    d.gS[0] = CTV_W(double, o_g); d.gS[1] = CTV_W(double, o_g1);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
     d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;
     d.rhs = CTV_W(double, o_rhs); d.dd = CTV_W(double, o_dd); d.dinv = CTV_W(double, o_dinv); d.chol_inv = CTV_W(double, o_chol_inv);
@@ -489,40 +495,41 @@ template <class T> class SolverImpl : public SolverBase {
     pev_phase_.clear();
     pev_used_ = 0;
   }
-  void launch_linearize() {
+  // Linearisation of every window the mode selects (kernels.hpp: LIN_AT_X / LIN_SPEC / COST_AT_X) into its normal-equation set;
+  // the cost partials of the evaluated state come out on the way.
+  void launch_linearize(int mode) {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
     constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
-    hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0);
+    hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode);
     ph_end();
-    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, 2);
     ph_begin(PH_IMU_LIN);
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
-    if (d.Gtot) launch_imu_linearize(imu_lds);
+    if (d.Gtot) launch_imu_linearize(imu_lds, mode);
     ph_end();
     ph_begin(PH_VIS_LIN);
-    if (d.Vtot) {
-      hipLaunchKernelGGL((k_vis_eval<T, true>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, d.quat, d.pos, d.rho, d.ld, d.kd, 0);
-    }
+    if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode);
     ph_end();
   }
-  void launch_assemble() {
+  void launch_assemble(int mode) {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
     ph_begin(PH_ASM_VIS);
     {  // few windows: split each window's items over several workgroups to fill the chip
       const int parts = vis_parts();
-      if (any_vis_lds_) launch_assemble_vis_lds(parts);
-      if (any_vis_glb_) launch_assemble_vis_glb(parts);
+      if (any_vis_lds_) launch_assemble_vis_lds(parts, mode);
+      if (any_vis_glb_) launch_assemble_vis_glb(parts, mode);
     }
     ph_end();
     ph_begin(PH_ASM_REST);
-    if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d);
-    hipLaunchKernelGGL((k_misc<T, true>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, d.quat, d.pos, d.bias, d.ld, 0);
-    hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
+    if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d, mode);
+    hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode);
+    hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();
   }
+  // Trust-region step of every window that starts a new iteration (damping, Schur complement, Cholesky, back-substitution), then the
+  // candidate x (+) alpha delta of every window with a valid step (also those inside the line search: new alpha, same delta).
   void launch_step() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
@@ -551,13 +558,13 @@ template <class T> class SolverImpl : public SolverBase {
     else hipLaunchKernelGGL((k_cholesky_solve<T, 4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_backsub<T>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
+    hipLaunchKernelGGL((k_step_finish<T>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
     ph_end();
   }
   void launch_schur();
-  void launch_imu_linearize(size_t vals_lds);
-  void launch_assemble_vis_lds(int parts);
-  void launch_assemble_vis_glb(int parts);
+  void launch_imu_linearize(size_t vals_lds, int mode);
+  void launch_assemble_vis_lds(int parts, int mode);
+  void launch_assemble_vis_glb(int parts, int mode);
   bool schur_makes_rhs() const { return schur_rhs_done_; }
   // CTVIO_CHOL_TILES = 0 / 1 forces the choice (A/B measurements); default: batches of <= 256 windows
   int chol_tiles() const {
@@ -566,41 +573,36 @@ template <class T> class SolverImpl : public SolverBase {
     return dev_.nwin <= 256 ? 1 : 0;
   }
   bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
-  void launch_cost(bool candidate, int force) {
-    const Dev<T> &d = dev_;
-    const double *q = candidate ? d.cquat : d.quat, *p = candidate ? d.cpos : d.pos, *b = candidate ? d.cbias : d.bias;
-    const double *r = candidate ? d.crho : d.rho, *l = candidate ? d.cld : d.ld;
-    const double *kd = candidate ? d.ckd : d.kd;
-    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d, candidate ? 1 : 0);
-    if (d.Mtot) {
-      hipLaunchKernelGGL((k_imu_cost<T>), dim3(nblk(d.Mtot, 256)), dim3(256), 0, stream_, d, q, p, b, kd, force);
-    }
-    if (d.Vtot) {
-      hipLaunchKernelGGL((k_vis_eval<T, false>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, q, p, r, l, kd, force);
-    }
-    hipLaunchKernelGGL((k_misc<T, false>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, q, p, b, l, force);
-  }
   int n_state() const { return dev_.Ktot + dev_.Ftot + dev_.Ltot + dev_.nwin; }
 
-  // One PASS of the device-resident LM: every running window advances by one phase -- a new trust-region iteration
-  // (linearise at x if a step was accepted, damp, Schur, Cholesky, back-substitute, candidate, cost, accept / reject), or,
-  // for a window inside Ceres' projected line search, one trial step (linearise at the candidate, interpolate alpha,
-  // candidate, cost, Armijo test).  The launch list is fixed: kernels skip windows that are not in the matching phase.
+  // One PASS of the device-resident LM: every running window advances by one phase -- a new trust-region iteration (damp, Schur,
+  // Cholesky, back-substitute, candidate) or, inside Ceres' projected line search, one trial step (candidate at the new alpha) --
+  // and the candidate is evaluated ONCE: speculative linearisation into the window's other normal-equation set, cost as a
+  // by-product; k_lm_control accepts / rejects / continues the search and swaps the sets on acceptance.  The launch list is fixed:
+  // kernels skip windows that are not in the matching phase.
   void launch_pass() {
     Dev<T> &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
-    launch_linearize();
-    launch_assemble();
     (void)hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_);
     hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
-    if (d.line_search) hipLaunchKernelGGL((k_ls_step<T>), dim3(nw), dim3(64), 0, stream_, d);
     launch_step();
+    launch_linearize(LIN_SPEC);
+    launch_assemble(LIN_SPEC);
     ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_update<T, false>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
-    launch_cost(true, 0);
-    hipLaunchKernelGGL((k_lm_control<T>), dim3(wb), dim3(64), 0, stream_, d);
-    hipLaunchKernelGGL((k_update<T, true>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL((k_lm_control<T>), dim3(nw), dim3(64), 0, stream_, d);
+    hipLaunchKernelGGL((k_accept<T>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
     ph_end();
+  }
+  // The first linearisation of a solve (and of the diagnostic entries): knot-pair constants, normal equations and cost of the
+  // current state in set 0, Jacobi scaling.
+  void launch_initial(double mu, int keep_scale) {
+    Dev<T> &d = dev_;
+    const int nw = d.nwin, wb = nblk(nw, 64);
+    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, mu, keep_scale);
+    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
+    launch_linearize(LIN_AT_X);
+    launch_assemble(LIN_AT_X);
+    hipLaunchKernelGGL((k_initial_cost<T>), dim3(nw), dim3(64), 0, stream_, d, 0);
   }
   // The pass as a hipGraph (captured once per batch shape: the kernel arguments are the Dev struct, so equal shapes in the
   // grow-only arenas give identical graphs), replayed instead of ~25 launches.
@@ -637,9 +639,7 @@ template <class T> class SolverImpl : public SolverBase {
     const bool graph = opt_.use_graph && !profiling_ && !d.dbg;
     if (graph) { const int rc = ensure_graph(); if (rc != CTVIO_OK) return rc; }
     HIPCHK(hipEventRecord(ev_[8], stream_));
-    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 0);
-    launch_cost(false, 1);
-    hipLaunchKernelGGL((k_set_initial_cost<T>), dim3(wb), dim3(64), 0, stream_, d);
+    launch_initial(opt_.initial_radius, 0);
     // max_iters + 1 passes finish every window that never enters the line search (the last pass only finalises); the host
     // looks at the "windows still running" counter every check_every passes and keeps launching while any is left
     const int check = std::max(1, opt_.check_every);
@@ -754,24 +754,20 @@ template <class T> class SolverImpl : public SolverBase {
     Dev<T> &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     set_params(1);
-    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 0);
-    launch_cost(false, 1);
-    hipLaunchKernelGGL((k_set_initial_cost<T>), dim3(wb), dim3(64), 0, stream_, d);
-    launch_linearize();
-    launch_assemble();
+    launch_initial(opt_.initial_radius, 0);
     const WinMeta &m = meta_[id];
     const int P = m.P;
     if (Hpp) {
-      HIPCHK(hipMemcpy2DAsync(Hpp, sizeof(double) * (size_t)P, d.Hpp + m.H0, sizeof(double) * (size_t)m.ldh, sizeof(double) * (size_t)P, (size_t)P,
+      HIPCHK(hipMemcpy2DAsync(Hpp, sizeof(double) * (size_t)P, d.HppS[0] + m.H0, sizeof(double) * (size_t)m.ldh, sizeof(double) * (size_t)P, (size_t)P,
                               hipMemcpyDeviceToHost, stream_));
     }
     std::vector<T> Wh;
     if (W && m.L) {
       Wh.resize((size_t)m.Lpad * m.ldw);
-      HIPCHK(hipMemcpyAsync(Wh.data(), d.W + m.W0, sizeof(T) * Wh.size(), hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipMemcpyAsync(Wh.data(), d.WS[0] + m.W0, sizeof(T) * Wh.size(), hipMemcpyDeviceToHost, stream_));
     }
-    if (Hll && m.L) HIPCHK(hipMemcpyAsync(Hll, d.Hll + m.lm0, sizeof(double) * m.L, hipMemcpyDeviceToHost, stream_));
-    if (g) HIPCHK(hipMemcpyAsync(g, d.g + m.u0, sizeof(double) * m.N, hipMemcpyDeviceToHost, stream_));
+    if (Hll && m.L) HIPCHK(hipMemcpyAsync(Hll, d.HllS[0] + m.lm0, sizeof(double) * m.L, hipMemcpyDeviceToHost, stream_));
+    if (g) HIPCHK(hipMemcpyAsync(g, d.gS[0] + m.u0, sizeof(double) * m.N, hipMemcpyDeviceToHost, stream_));
     Lm lm;
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -792,7 +788,11 @@ template <class T> class SolverImpl : public SolverBase {
     const int wb = nblk(d.nwin, 64);
     set_params(1);
     hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 1);
-    launch_cost(false, 1);
+    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
+    if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(T), COST_AT_X);
+    if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
+    hipLaunchKernelGGL((k_misc<T>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X);
+    hipLaunchKernelGGL((k_initial_cost<T>), dim3(d.nwin), dim3(64), 0, stream_, d, 1);
     Lm lm;
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -806,10 +806,7 @@ template <class T> class SolverImpl : public SolverBase {
     Dev<T> &d = dev_;
     const int wb = nblk(d.nwin, 64);
     set_params(1);
-    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, mu, 0);
-    launch_cost(false, 1);
-    launch_linearize();
-    launch_assemble();
+    launch_initial(mu, 0);
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
     hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
     launch_step();
@@ -859,11 +856,7 @@ template <class T> class SolverImpl : public SolverBase {
     }
     // normal equations of every window at its current state
     set_params(1);
-    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 0);
-    launch_cost(false, 1);
-    hipLaunchKernelGGL((k_set_initial_cost<T>), dim3(wb), dim3(64), 0, stream_, d);
-    launch_linearize();
-    launch_assemble();
+    launch_initial(opt_.initial_radius, 0);
     HIPCHK(mg_meta_.upload(metas, stream_));
     if (iscr.empty()) iscr.push_back(0);
     HIPCHK(mg_idx_.upload(iscr, stream_));
@@ -1074,22 +1067,22 @@ template <class T> class SolverImpl : public SolverBase {
   int maxK_ = 0, max_schur_tiles_ = 0;
 };
 
-template <> void SolverImpl<double>::launch_imu_linearize(size_t lds) {
+template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) {
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
-  if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d);
-  else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
+  else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
 }
-template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts) {
+template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts, int mode) {
   const Dev<double> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
-  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
+  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
 }
 // windows whose packed Hessian does not fit in LDS (K > 25): run products on the MFMA units, added to Hpp with global atomics
-template <> void SolverImpl<double>::launch_assemble_vis_glb(int parts) {
+template <> void SolverImpl<double>::launch_assemble_vis_glb(int parts, int mode) {
   const Dev<double> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
-  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d);
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
+  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
 }
 template <> void SolverImpl<double>::launch_schur() {
   const Dev<double> &d = dev_;

@@ -47,12 +47,17 @@ struct Lm {
   double step2, xnorm2, cand_xnorm2;
   unsigned long long gmax_bits; // max-norm of x - Plus(x, -g) as the bit pattern of a non-negative double
   int32_t iter, invalid, status; // status 0 = running, else 1 + termination code
-  int32_t need_lin, scaled, last_ok, step_valid, chol_fail, accept;
-  int32_t nsucc, nunsucc, pad;
+  int32_t cur;                   // which of the two normal-equation sets holds the linearisation at the CURRENT state (the other one
+                                 // receives the speculative linearisation at the candidate and becomes current on acceptance)
+  int32_t scaled, last_ok, step_valid, chol_fail, accept;
+  int32_t nsucc, nunsucc, have_grad;   // have_grad: the candidate of this pass was linearised (not just costed)
+  unsigned long long cand_gmax_bits;   // gradient max-norm at the candidate (becomes gmax_bits on acceptance)
+  double cand_gd;                      // g(candidate) . delta: directional derivative at the trial point of the line search
   // Ceres' projected Armijo line search of bounds-constrained problems (TrustRegionMinimizer::DoLineSearch, line_search.cc):
-  // ls_on = the reduced program has a bounded parameter (free line delay); ls_active 0 = not searching, 1 = searching (the
-  // next pass linearises at the CANDIDATE to get the directional derivative of the current trial), 2 = search failed, the full
-  // step is being re-evaluated.  alpha = step size of the candidate x (+) alpha * delta.
+  // ls_on = the reduced program has a bounded parameter (free line delay); ls_active 0 = not searching, 1 = searching (alpha holds
+  // the next trial step), 2 = search failed, the full step is being re-evaluated, 3 = the first trial failed Armijo on a pass that
+  // only costed the candidate (last iteration): the same trial is linearised next pass to get its directional derivative.
+  // alpha = step size of the candidate x (+) alpha * delta.
   int32_t ls_on, ls_active, ls_iters, ls_prev_valid, ls_cur_valid, nls_steps, nls_reduced, pad2;
   double alpha, ls_gd0, ls_dmax;          // g . delta at x (initial directional derivative), max-norm of delta
   double ls_cur_x, ls_cur_v, ls_cur_g, ls_prev_x, ls_prev_v, ls_prev_g;
@@ -71,17 +76,19 @@ template <class T> struct Dev {
   double *quat, *pos, *bias, *rho, *ld;
   double *cquat, *cpos, *cbias, *crho, *cld;
   const int32_t *knot_win, *bias_win, *lm_win;
-  // per consecutive knot pair (k, k+1), filled by k_knot_prep once per state: d = log(R_k^-1 R_k+1) in fp64 for the
-  // current (kd) and the candidate (ckd) state, Jr^-1(d) in T for the current state
-  double *kd, *ckd;      // [Ktot][3]
-  double *lkd;           // [Ktot][3] the same at the state being LINEARISED (current, or the candidate of a window in line search)
-  T *kjri;               // [Ktot][9] Jr^-1(d) at the linearised state
+  // per consecutive knot pair (k, k+1) of the state about to be linearised (the initial state: k_knot_prep; every candidate:
+  // k_step_finish): d = log(R_k^-1 R_k+1) and Jr^-1(d) -- shared by all residual blocks of the window
+  double *lkd;           // [Ktot][3]
+  T *kjri;               // [Ktot][9]
   // IMU factors (sorted by group)
   const ImuGroup *groups;
   const int32_t *imu_grp;
   const T *imu_u;        // [Mtot] normalised time in the segment
   const T *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
   T *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
+  double *imu_cost;      // [Gtot] 1/2 |r|^2 of the group's samples; vis_cost [Vtot / 64] robustified cost of the wave's blocks;
+  double *vis_cost;      // misc_cost [nwin] bias chain + prior: summed per window in a fixed order by k_lm_control (no atomics)
+  double *misc_cost;
   // visual factors
   const int32_t *v_win, *v_lm;
   const int64_t *v_ti, *v_tj;   // relative to the window's t0
@@ -108,10 +115,10 @@ template <class T> struct Dev {
   const int32_t *pcol;   // [sum pn] unknown index of each prior dimension
   const int32_t *p_kind, *p_index, *p_off;
   const double *p_x0;
-  // normal equations
-  double *Hpp;           // [sum P*P] lower triangle used
-  T *W;                  // Hpl^T, landmark-major
-  double *Hll, *g;       // [Ltot], [Utot]
+  // normal equations, two sets (Lm::cur): linearisation at the current state / speculative linearisation at the candidate
+  double *HppS[2];       // [sum P*ldh] lower triangle used
+  T *WS[2];              // Hpl^T, landmark-major
+  double *HllS[2], *gS[2];   // [Ltot], [Utot]
   double *S, *rhs;       // Schur complement (lower) and its right-hand side [sum P]
   double *chol_inv;      // [nwin][chol_nblk][32][32] inverses of the diagonal blocks of the Cholesky factor (row-major)
   int32_t chol_nblk;

@@ -18,10 +18,20 @@
 
 namespace ctv {
 
-// A window is (re)linearised when a step was accepted (need_lin) -- or, inside Ceres' projected line search, at the CANDIDATE
-// x (+) alpha delta, whose directional derivative the cubic interpolation of the next trial step needs (ls_active == 1).
-__device__ __forceinline__ bool lin_needed(const Lm &lm) { return lm.status == 0 && (lm.need_lin != 0 || lm.ls_active == 1); }
-__device__ __forceinline__ bool lin_at_candidate(const Lm &lm) { return lm.ls_active == 1; }
+// SPECULATIVE LINEARISATION.  Every pass evaluates the candidate x (+) alpha delta exactly once -- residuals, Jacobians and the
+// normal equations together, into the normal-equation set that is NOT the current one (Lm::cur).  The cost at the candidate is
+// a by-product (per-group / per-wave partial sums, added up in a fixed order by k_lm_control); on acceptance the sets swap and the
+// next iteration starts from a finished linearisation; on rejection the current set is still intact.  The trial points of
+// Ceres' projected line search need value and gradient anyway.  Only the last allowed iteration (nothing can follow it) is
+// costed without Jacobians.  Modes of the linearisation kernels:
+enum { LIN_AT_X = 0,      // the current state into the current set (the first linearisation of a solve, diagnostics)
+       LIN_SPEC = 1,      // the candidate into the other set (every pass)
+       COST_AT_X = 2 };   // residuals of the current state only (ctvio_cost)
+__device__ __forceinline__ bool lin_run(const Lm &lm, int mode) { return lm.status == 0 && (mode != LIN_SPEC || lm.step_valid != 0); }
+__device__ __forceinline__ bool lin_cost_only(const Lm &lm, int mode, const LmParams &p) {
+  return mode == COST_AT_X || (mode == LIN_SPEC && lm.iter >= p.max_iters && lm.ls_active == 0);
+}
+__device__ __forceinline__ int lin_target(const Lm &lm, int mode) { return mode == LIN_SPEC ? 1 - lm.cur : lm.cur; }
 
 // local column -> unknown index maps
 __device__ __forceinline__ int imu_col(int c, int s, int K, int bias) {
@@ -94,26 +104,15 @@ template <class T> __global__ void k_lm_init(Dev<T> d, double mu, int keep_scale
   lm.cost = lm.cand_cost = lm.initial_cost = 0;
   lm.mu = mu; lm.nu = 2.0; lm.model_change = 0;
   lm.step2 = lm.xnorm2 = lm.cand_xnorm2 = 0;
-  lm.gmax_bits = 0ull;
-  lm.iter = 0; lm.invalid = 0; lm.status = 0;
-  lm.need_lin = 1; lm.scaled = keep_scale ? lm.scaled : 0; lm.last_ok = 1; lm.step_valid = 0; lm.chol_fail = 0; lm.accept = 0;
-  lm.nsucc = lm.nunsucc = 0;
+  lm.gmax_bits = 0ull; lm.cand_gmax_bits = 0ull; lm.cand_gd = 0;
+  lm.iter = 0; lm.invalid = 0; lm.status = 0; lm.cur = 0;
+  lm.scaled = keep_scale ? lm.scaled : 0; lm.last_ok = 1; lm.step_valid = 0; lm.chol_fail = 0; lm.accept = 0;
+  lm.nsucc = lm.nunsucc = 0; lm.have_grad = 0;
   const WinMeta &m = d.wins[w];
   lm.ls_on = (d.line_search && !m.fix_ld && d.active[m.u0 + m.P - 1]) ? 1 : 0;   // Program::IsBoundsConstrained of the reduced program
   lm.ls_active = 0; lm.ls_iters = 0; lm.ls_prev_valid = lm.ls_cur_valid = 0; lm.nls_steps = lm.nls_reduced = 0;
   lm.alpha = 1.0; lm.ls_gd0 = 0; lm.ls_dmax = 0;
   lm.ls_cur_x = lm.ls_cur_v = lm.ls_cur_g = lm.ls_prev_x = lm.ls_prev_v = lm.ls_prev_g = 0;
-}
-template <class T> __global__ void k_set_initial_cost(Dev<T> d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.nwin) return;
-  Lm &lm = d.lm[w];
-  lm.cost = lm.initial_cost = lm.cand_cost;
-  lm.cand_cost = 0;
-}
-template <class T> __global__ void k_force_lin(Dev<T> d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < d.nwin) { d.lm[w].need_lin = 1; d.lm[w].status = 0; d.lm[w].ls_active = 0; }
 }
 
 // FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration.
@@ -122,57 +121,13 @@ template <class T> __global__ void k_begin_iter(Dev<T> d) {
   if (w >= d.nwin) return;
   Lm &lm = d.lm[w];
   if (lm.status) return;
-  if (lm.ls_active) { atomicAdd(d.n_active, 1); return; }   // inside the line search: no new LM iteration (see k_ls_step)
-  if (lm.need_lin) { lm.scaled = 1; lm.need_lin = 0; }
+  if (lm.ls_active) { atomicAdd(d.n_active, 1); return; }   // inside the line search: no new LM iteration
   if (lm.iter >= d.prm.max_iters) { lm.status = 1 + 0; return; }
   if (lm.last_ok && __longlong_as_double((long long)lm.gmax_bits) <= d.prm.gtol) { lm.status = 1 + 1; return; }
   if (lm.mu <= d.prm.min_radius) { lm.status = 1 + 4; return; }
   lm.iter += 1;
-  lm.cand_cost = 0; lm.step2 = 0; lm.cand_xnorm2 = 0;
   lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0; lm.alpha = 1.0;
   atomicAdd(d.n_active, 1);
-}
-
-// ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful / LM radius update.
-template <class T> __global__ void k_lm_control(Dev<T> d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.nwin) return;
-  Lm &lm = d.lm[w];
-  if (lm.status || !lm.step_valid) return;
-  lm.accept = 0;
-  if (lm.ls_on && lm.ls_active != 2) {
-    // ArmijoLineSearch::DoSearch (Ceres line_search.cc): the trial alpha is kept when
-    // f(alpha) <= f(0) + sufficient_decrease * alpha * f'(0); an invalid (non-finite) value counts as a failure
-    const bool valid = isfinite(lm.cand_cost);
-    const bool ok = valid && !(lm.cand_cost > lm.cost + 1e-4 * lm.ls_gd0 * lm.alpha);
-    if (!ok) {
-      if (!lm.ls_active) { lm.ls_active = 1; lm.ls_iters = 0; lm.ls_prev_valid = 0; lm.ls_cur_x = 1.0; }
-      lm.ls_cur_v = lm.cand_cost; lm.ls_cur_valid = valid ? 1 : 0;
-      if (++lm.ls_iters >= 20) { lm.ls_active = 2; lm.nls_steps += lm.ls_iters; }   // max_num_line_search_step_size_iterations: the full step is kept
-      return;   // next pass: gradient at this trial point, interpolated step, new candidate (k_ls_step)
-    }
-    if (lm.ls_active) { lm.nls_steps += lm.ls_iters; lm.nls_reduced += 1; }
-  }
-  const bool searched = lm.ls_active != 0;   // H and g were overwritten by the trial-point linearisations
-  lm.ls_active = 0;
-  const double step_norm = sqrt(lm.step2), x_norm = sqrt(lm.xnorm2);
-  if (step_norm <= d.prm.ptol * (x_norm + d.prm.ptol)) { lm.status = 1 + 2; return; }
-  const double cost_change = lm.cost - lm.cand_cost;
-  if (fabs(cost_change) <= d.prm.ftol * lm.cost) { lm.status = 1 + 3; return; }
-  const double rel = cost_change / lm.model_change;
-  if (rel > d.prm.min_rel_dec && isfinite(lm.cand_cost)) {
-    lm.accept = 1;
-    lm.cost = lm.cand_cost;
-    lm.xnorm2 = lm.cand_xnorm2;
-    const double t = 2.0 * rel - 1.0;
-    double f = 1.0 - t * t * t;
-    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
-    lm.mu = fmin(lm.mu / f, d.prm.max_radius);
-    lm.nu = 2.0; lm.last_ok = 1; lm.nsucc += 1; lm.need_lin = 1;
-  } else {
-    lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1;
-    if (searched) lm.need_lin = 1;   // back at x: its normal equations have to be rebuilt
-  }
 }
 
 // ---- interpolation of the next trial step (Ceres polynomial.cc: FindInterpolatingPolynomial / MinimizePolynomial)
@@ -265,71 +220,137 @@ __device__ inline double ls_minimize_interpolating(const LsSample *s, int ns, do
   return best_x;
 }
 
-// One line-search pass of a window, between its trial-point linearisation and the next candidate: directional derivative
-// g(x (+) alpha delta) . delta of the current trial, next alpha by cubic / quintic interpolation contracted into
-// [1e-3, 0.6] x alpha (ArmijoLineSearch::DoSearch + LineSearch::InterpolatingPolynomialMinimizingStepSize), min-step test.
-// One wave per window.
-template <class T> __global__ __launch_bounds__(64) void k_ls_step(Dev<T> d) {
+// Sum of the cost partials of window w over the 64 lanes of one wave, in a fixed order (lane-strided partial sums, then a butterfly):
+// every lane returns the same total.  IMU groups, visual waves (a window's block slots start on a wave boundary), bias chain + prior.
+template <class T> __device__ __forceinline__ double window_cost_sum(const Dev<T> &d, const WinMeta &m, int w, int lane) {
+  double c = 0.0;
+  for (int g = lane; g < m.ngrp; g += 64) c += d.imu_cost[m.grp0 + g];
+  const int vw0 = m.vis0 >> 6, nvw = m.Vp >> 6;
+  for (int i = lane; i < nvw; i += 64) c += d.vis_cost[vw0 + i];
+  if (lane == 0) c += d.misc_cost[w];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  return c;
+}
+
+// After the first linearisation of a solve (LIN_AT_X): cost of the initial state, Jacobi scaling is in place.
+template <class T> __global__ __launch_bounds__(64) void k_initial_cost(Dev<T> d, int as_candidate) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
-  if (lm.status || lm.ls_active == 0) return;
+  if (lm.status) return;
+  const double c = window_cost_sum(d, d.wins[w], w, threadIdx.x);
+  if (threadIdx.x != 0) return;
+  if (as_candidate) { lm.cand_cost = c; return; }   // ctvio_cost
+  lm.cost = lm.initial_cost = c;
+  lm.cand_cost = 0;
+  lm.scaled = 1;
+}
+
+// One wave per window, after the candidate of this pass has been evaluated: cost of the candidate (fixed-order sum of the
+// partials), its directional derivative g(candidate) . delta, then
+//   * ArmijoLineSearch::DoSearch + LineSearch::InterpolatingPolynomialMinimizingStepSize (Ceres line_search.cc) for windows whose
+//     reduced program is bounds-constrained: the trial is kept when f(alpha) <= f(0) + 1e-4 alpha f'(0); a sample whose value or
+//     gradient is not finite is invalid and fails; otherwise the next trial step comes from the cubic / quintic interpolation,
+//     contracted into [1e-3, 0.6] x alpha, and the window stays in the search (ls_active = 1);
+//   * ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful / LM radius update; on acceptance the speculative
+//     normal equations become the current ones (cur ^= 1).
+template <class T> __global__ __launch_bounds__(64) void k_lm_control(Dev<T> d) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status || !lm.step_valid) return;
   const WinMeta &m = d.wins[w];
-  const int lane = threadIdx.x;
+  const bool have_grad = !lin_cost_only(lm, LIN_SPEC, d.prm);
+  const double cand_cost = window_cost_sum(d, m, w, lane);
   double gd = 0.0;
-  if (lm.ls_active == 1)
+  if (lm.ls_on && have_grad) {
+    const double *gc = d.gS[1 - lm.cur] + m.u0, *dl = d.delta + m.u0;
     for (int j = lane; j < m.N; j += 64)
-      if (d.active[m.u0 + j]) gd += d.g[m.u0 + j] * d.delta[m.u0 + j];
-  for (int off = 32; off > 0; off >>= 1) gd += __shfl_down(gd, off);
-  if (lane != 0) return;
-  lm.cand_cost = 0; lm.step2 = 0; lm.cand_xnorm2 = 0;
-  if (lm.ls_active == 2) { lm.alpha = 1.0; return; }   // failed search: Ceres keeps the full step
-  lm.ls_cur_g = gd;
-  const bool cur_ok = lm.ls_cur_valid && isfinite(gd);
-  const double lo = 1e-3 * lm.ls_cur_x, hi = 0.6 * lm.ls_cur_x;   // max_step_contraction, min_step_contraction
-  double step;
-  if (!cur_ok) {
-    step = fmin(fmax(lm.ls_cur_x * 0.5, lo), hi);
-  } else {
-    LsSample s[3];
-    int ns = 0;
-    s[ns++] = LsSample{0.0, lm.cost, lm.ls_gd0};
-    s[ns++] = LsSample{lm.ls_cur_x, lm.ls_cur_v, lm.ls_cur_g};
-    if (lm.ls_prev_valid) s[ns++] = LsSample{lm.ls_prev_x, lm.ls_prev_v, lm.ls_prev_g};
-    step = ls_minimize_interpolating(s, ns, lo, hi);
+      if (d.active[m.u0 + j]) gd += gc[j] * dl[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gd += __shfl_xor(gd, off);
   }
-  if (step * lm.ls_dmax < 1e-9) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return; }   // min_line_search_step_size
-  lm.ls_prev_x = lm.ls_cur_x; lm.ls_prev_v = lm.ls_cur_v; lm.ls_prev_g = lm.ls_cur_g; lm.ls_prev_valid = cur_ok ? 1 : 0;
-  lm.ls_cur_x = step;
-  lm.alpha = step;
+  if (lane != 0) return;
+  lm.cand_cost = cand_cost;
+  lm.cand_gd = gd;
+  lm.have_grad = have_grad ? 1 : 0;
+  lm.accept = 0;
+  if (lm.ls_on && lm.ls_active != 2) {
+    const bool valid = isfinite(cand_cost) && (!have_grad || isfinite(gd));
+    const bool ok = valid && !(cand_cost > lm.cost + 1e-4 * lm.ls_gd0 * lm.alpha);
+    if (!ok) {
+      if (!have_grad) { lm.ls_active = 3; return; }   // (last iteration, costed only) the same trial again, linearised
+      if (lm.ls_active != 1) { lm.ls_active = 1; lm.ls_iters = 0; lm.ls_prev_valid = 0; lm.ls_cur_x = 1.0; }
+      lm.ls_cur_v = cand_cost; lm.ls_cur_g = gd; lm.ls_cur_valid = valid ? 1 : 0;
+      if (++lm.ls_iters >= 20) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return; }   // max_num_line_search_step_size_iterations: the full step is kept
+      const double lo = 1e-3 * lm.ls_cur_x, hi = 0.6 * lm.ls_cur_x;   // max_step_contraction, min_step_contraction
+      double step;
+      if (!valid) {
+        step = fmin(fmax(lm.ls_cur_x * 0.5, lo), hi);
+      } else {
+        LsSample sp[3];
+        int ns = 0;
+        sp[ns++] = LsSample{0.0, lm.cost, lm.ls_gd0};
+        sp[ns++] = LsSample{lm.ls_cur_x, lm.ls_cur_v, lm.ls_cur_g};
+        if (lm.ls_prev_valid) sp[ns++] = LsSample{lm.ls_prev_x, lm.ls_prev_v, lm.ls_prev_g};
+        step = ls_minimize_interpolating(sp, ns, lo, hi);
+      }
+      if (step * lm.ls_dmax < 1e-9) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return; }   // min_line_search_step_size
+      lm.ls_prev_x = lm.ls_cur_x; lm.ls_prev_v = lm.ls_cur_v; lm.ls_prev_g = lm.ls_cur_g; lm.ls_prev_valid = valid ? 1 : 0;
+      lm.ls_cur_x = step;
+      lm.alpha = step;
+      return;   // next pass: candidate at the new alpha
+    }
+    if (lm.ls_active == 1) { lm.nls_steps += lm.ls_iters; lm.nls_reduced += 1; }
+  }
+  lm.ls_active = 0;
+  const double step_norm = sqrt(lm.step2), x_norm = sqrt(lm.xnorm2);
+  if (step_norm <= d.prm.ptol * (x_norm + d.prm.ptol)) { lm.status = 1 + 2; return; }
+  const double cost_change = lm.cost - cand_cost;
+  if (fabs(cost_change) <= d.prm.ftol * lm.cost) { lm.status = 1 + 3; return; }
+  const double rel = cost_change / lm.model_change;
+  if (rel > d.prm.min_rel_dec && isfinite(cand_cost)) {
+    lm.accept = 1;
+    lm.cost = cand_cost;
+    lm.xnorm2 = lm.cand_xnorm2;
+    const double t = 2.0 * rel - 1.0;
+    double f = 1.0 - t * t * t;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    lm.mu = fmin(lm.mu / f, d.prm.max_radius);
+    lm.nu = 2.0; lm.last_ok = 1; lm.nsucc += 1;
+    if (have_grad) { lm.cur ^= 1; lm.gmax_bits = lm.cand_gmax_bits; }   // the speculative linearisation is the current one now
+  } else {
+    lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ zero
-template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part) {
+template <class T> __global__ void k_zero_normal(Dev<T> d, int single_part, int mode) {
   const int w = blockIdx.y;
-  if (!lin_needed(d.lm[w])) return;
+  const Lm &lm = d.lm[w];
+  if (!lin_run(lm, mode) || lin_cost_only(lm, mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
+  const int tg = lin_target(lm, mode);
+  double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
   const long long nH = (long long)m.P * m.ldh;
   const long long stride = (long long)gridDim.x * blockDim.x;
   // with a single k_assemble_vis part the LDS path overwrites the whole knot x knot block and the line-delay row
   // (plain stores, issued after this kernel), so only the bias rows and the line-delay row need zeroing
   const long long first = (m.vis_lds && single_part) ? (long long)6 * m.K * m.ldh : 0;
-  for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) d.Hpp[m.H0 + i] = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) d.g[m.u0 + i] = 0.0;
-  // W, Hll and g[P..N) are written (not accumulated) by k_vis_eval<LIN>
-  if (blockIdx.x == 0 && threadIdx.x == 0 && !lin_at_candidate(d.lm[w])) d.lm[w].gmax_bits = 0ull;
+  for (long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nH; i += stride) Hpp[i] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += stride) g[i] = 0.0;
+  // W, Hll and g[P..N) are written (not accumulated) by k_vis_eval
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (mode == LIN_SPEC) d.lm[w].cand_gmax_bits = 0ull; else d.lm[w].gmax_bits = 0ull; }
 }
 
-// Knot-pair constants of every window for one state (see Dev::kd): one thread per knot.
-// mode 0: current state -> kd; 1: candidate -> ckd; 2: the state each window is about to be linearised at -> lkd, kjri.
-template <class T> __global__ void k_knot_prep(Dev<T> d, int mode) {
+// Knot-pair constants (Dev::lkd, kjri) of every window at its CURRENT state, before the first linearisation of a solve (the
+// candidates' are formed by k_step_finish): one thread per knot.
+template <class T> __global__ void k_knot_prep(Dev<T> d) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= d.Ktot) return;
   const int w = d.knot_win[g];
   const WinMeta &m = d.wins[w];
   if (g - m.knot0 >= m.K - 1) return;   // the last knot of a window starts no pair
-  const double *quat = mode == 0 ? d.quat : (mode == 1 ? d.cquat : (lin_at_candidate(d.lm[w]) ? d.cquat : d.quat));
-  double *kd = mode == 0 ? d.kd : (mode == 1 ? d.ckd : d.lkd);
-  knot_pair_const<T>(quat + 4 * g, quat + 4 * g + 4, kd + 3 * g, mode == 2 ? d.kjri + 9 * g : nullptr);
+  knot_pair_const<T>(d.quat + 4 * g, d.quat + 4 * g + 4, d.lkd + 3 * g, d.kjri + 9 * g);
 }
 
 // ------------------------------------------------------------------------------------------------ IMU
@@ -353,18 +374,20 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane evaluates one sample and
 // its 6 Jacobian rows + residual; then the wave forms the group's 31 x 31 block A^T A = [J^T J, J^T r; r^T J, r^T r].
 // The tile is stored, not accumulated -- no atomics, deterministic.
-template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_imu_linearize(Dev<T> d) {
+template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_imu_linearize(Dev<T> d, int mode) {
   constexpr int KCH = 6 * CHUNK, KS = KCH + 4;
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   T *A = reinterpret_cast<T *>(smraw);
   const ImuGroup grp = d.groups[blockIdx.x];
   const int w = grp.win;
-  if (!lin_needed(d.lm[w])) return;
+  if (!lin_run(d.lm[w], mode)) return;
+  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x;
   Knots4<T> k;
   LocalFrame<T> lf;
-  const bool at_cand = lin_at_candidate(d.lm[w]);
+  const bool at_cand = mode == LIN_SPEC;
+  double csum = 0.0;
   const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
   lf.init(s_quat, s_pos, m.knot0 + grp.s);
   lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
@@ -395,7 +418,9 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
     const int kmax = (6 * nval + 3) & ~3;
     ImuLdsSink<T> sink{A, lane, KS};
     if (lane < nval) {
-      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, true, sink);
+      imu_eval<T>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, jac, sink);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) csum += 0.5 * (double)(r[i] * r[i]);
       sink.put_col(30, r);
       sink.put_col(31, zero6);
     } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
@@ -419,6 +444,10 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+  if (lane == 0) d.imu_cost[blockIdx.x] = csum;
+  if (!jac) return;
   T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -433,15 +462,17 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
 // 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
 // tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
 // B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
-__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
+__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   double *A = reinterpret_cast<double *>(smraw);   // [64][33]
   const ImuGroup grp = d.groups[blockIdx.x];
   const int w = grp.win;
-  if (!lin_needed(d.lm[w])) return;
+  if (!lin_run(d.lm[w], mode)) return;
+  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
-  const bool at_cand = lin_at_candidate(d.lm[w]);
+  const bool at_cand = mode == LIN_SPEC;
+  double csum = 0.0;
   const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
   Knots4<double> k;
   LocalFrame<double> lf;
@@ -458,6 +489,25 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
   const double idt = m.inv_dt;
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   const size_t Mt = (size_t)d.Mtot;
+  if (!jac) {   // residuals only (a separate, small code path: the full one below keeps its compile-time `want_jac = true`)
+    for (int c0 = 0; c0 < grp.count; c0 += 64) {
+      const bool live = c0 + lane < grp.count;
+      const int idx = m.imu0 + grp.start + min(c0 + lane, grp.count - 1);
+      double gy[3], ac[3], r[6], wl[6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
+      ImuJac<double> J;
+      imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, false, J);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+    if (lane == 0) d.imu_cost[blockIdx.x] = csum;
+    return;
+  }
   for (int c0 = 0; c0 < grp.count; c0 += 64) {
     const int nval = min(64, grp.count - c0);
     const bool live = lane < nval;
@@ -472,6 +522,8 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
     for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
     ImuJac<double> J;
     imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, true, J);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
     const int kmax = (nval + 3) & ~3;
     // ---- accelerometer rows: 32 columns, tiles (0,0), (1,0), (1,1)
 #pragma unroll
@@ -506,6 +558,10 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
       }
     }
   }
+  // ---- the group's share of the cost: fixed-order sum over the lanes (butterfly), one store
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+  if (lane == 0) d.imu_cost[blockIdx.x] = csum;
   // ---- combine in LDS into the full symmetric 32 x 32 tile, then one coalesced store
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -536,16 +592,16 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d) {
 
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
 // (Two waves per SIMD with the overflow spilled to scratch was measured 3x slower: 1690 vs 540 us per 1024 windows.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d) { imu_linearize_f64_body(d); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode) { imu_linearize_f64_body(d, mode); }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
-template <class T> __global__ void k_assemble_imu(Dev<T> d) {
+template <class T> __global__ void k_assemble_imu(Dev<T> d, int mode) {
   const ImuGroup grp = d.groups[blockIdx.x];
   const int w = grp.win;
-  if (!lin_needed(d.lm[w])) return;
+  if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
-  const int K = m.K, P = m.P, u0 = m.u0, ldh = m.ldh;
-  const long long H0 = m.H0;
+  const int K = m.K, P = m.P, ldh = m.ldh, tg = lin_target(d.lm[w], mode);
+  double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
   const T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
   if (m.vis_lds) {
     // the knot x knot part is accumulated in LDS by k_assemble_vis; what is left is the bias rows (6 x 24 against the
@@ -561,60 +617,18 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d) {
     else return;
     const double v = (double)tile[a * 32 + b];
     const int ga = imu_col(a, grp.s, K, grp.bias);
-    if (b == 30) { atomicAdd(&d.g[u0 + ga], v); return; }
+    if (b == 30) { atomicAdd(&g[ga], v); return; }
     const int gb = imu_col(b, grp.s, K, grp.bias);
-    atomicAdd(&d.Hpp[H0 + (long long)max(ga, gb) * ldh + min(ga, gb)], v);
+    atomicAdd(&Hpp[(long long)max(ga, gb) * ldh + min(ga, gb)], v);
     return;
   }
   for (int e = threadIdx.x; e < 31 * 30; e += blockDim.x) {
     const int b = e / 30, a = e % 30;  // a < 30 : unknown row; b <= 30
     const double v = (double)tile[a * 32 + b];
     const int ga = imu_col(a, grp.s, K, grp.bias);
-    if (b == 30) { atomicAdd(&d.g[u0 + ga], v); continue; }
+    if (b == 30) { atomicAdd(&g[ga], v); continue; }
     const int gb = imu_col(b, grp.s, K, grp.bias);
-    if (ga >= gb) atomicAdd(&d.Hpp[H0 + (long long)ga * ldh + gb], v);
-  }
-}
-
-// Residual-only pass: one lane per IMU sample, cost accumulated in fp64.
-template <class T> __global__ __launch_bounds__(256) void k_imu_cost(Dev<T> d, const double *quat, const double *pos, const double *bias, const double *kd, int force) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  double c = 0.0;
-  int w = -1;
-  if (idx < d.Mtot) {
-    const ImuGroup grp = d.groups[d.imu_grp[idx]];
-    w = grp.win;
-    if (d.lm[w].status == 0 && (d.lm[w].step_valid || force)) {
-      const WinMeta &m = d.wins[w];
-      Knots4<T> k;
-      LocalFrame<T> lf;
-      lf.init(quat, pos, m.knot0 + grp.s);
-      lf.load(quat, pos, m.knot0 + grp.s, k);
-      SegConst<T> sc;
-      seg_const_load(kd + 3 * (m.knot0 + grp.s), (const T *)nullptr, sc, false);
-      T b[6], wgt[6], gy[3], ac[3], r[6];
-      const double *bp = bias + 6 * (m.bias0 + grp.bias);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { b[i] = (T)bp[i]; wgt[i] = (T)m.imu_w[i]; }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
-      NullSink<T> ns;
-      imu_eval<T>(k, sc, d.imu_u[idx], (T)m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, ns);
-      T s = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) s += r[i] * r[i];
-      c = 0.5 * (double)s;
-    } else {
-      w = -1;
-    }
-  }
-  // wave reduction when the whole wave belongs to one window, else per-lane atomics
-  const int w0 = __shfl(w, 0);
-  if (__all(w == w0)) {
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0 && w0 >= 0) atomicAdd(&d.lm[w0].cand_cost, c);
-  } else if (w >= 0) {
-    atomicAdd(&d.lm[w].cand_cost, c);
+    if (ga >= gb) atomicAdd(&Hpp[(long long)ga * ldh + gb], v);
   }
 }
 
@@ -666,55 +680,32 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
   u = (double)(tau % m.dt_ns) / (double)m.dt_ns;
 }
 
-// One lane per visual block.  LIN: evaluate r~, J~ (robust-corrected) and materialise them (SoA, coalesced);
-// otherwise residual only.  Cost contributions are reduced per wave and added in fp64.
+// One lane per visual block, landmark-major: evaluate r~, J~ (robust-corrected), materialise J~ block-major and form the rows of W,
+// Hll, g_rho of the wave's landmarks into the normal-equation set the mode selects.  The wave's share of the cost goes to
+// Dev::vis_cost (a window's block slots start on a wave boundary: one window per wave).  A window on its last allowed iteration is
+// only costed (residuals, no Jacobians, nothing else written).
 template <class T>
-__device__ __forceinline__ double vis_residual(const Dev<T> &d, const WinMeta &m, int v, int si, int sj, double ui, double uj, int rowi, int rowj,
-                                               const double *quat, const double *pos, const double *kd, double rho_l, T r[2]) {
-  Knots4<T> ki, kj;
-  SegConst<T> sci, scj;
-  seg_const_load(kd + 3 * (m.knot0 + si), (const T *)nullptr, sci, false);
-  seg_const_load(kd + 3 * (m.knot0 + sj), (const T *)nullptr, scj, false);
-  LocalFrame<T> lf;
-  lf.init(quat, pos, m.knot0 + si);
-  lf.load(quat, pos, m.knot0 + si, ki);
-  lf.load(quat, pos, m.knot0 + sj, kj);
-  Calib<T> cal;
-  cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
-  cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
-  cal.img_w = (T)m.img_w;
-  cal.cauchy_a = (T)vis_cauchy(d, m, v);
-  const size_t V = (size_t)d.Vtot;
-  T o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = d.v_obs[(size_t)i * V + v];
-  VisNullSink<T> sink;
-  return (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, lf.RrefT(), o[0], o[1], o[2], o[3], (T)rowi, (T)rowj, (T)rho_l, r,
-                                 false, sink);
-}
-
-template <class T, bool LIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, const double *quat, const double *pos, const double *rho, const double *ldp, const double *kd, int force) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, int mode) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  // LIN: the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
-  constexpr int LDS_BYTES = LIN ? 64 * VT_LD * (int)sizeof(T) : 16;   // (>= one fp64 row of the largest window: 642 doubles)
+  // the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
+  constexpr int LDS_BYTES = 64 * VT_LD * (int)sizeof(T);   // (>= one fp64 row of the largest window: 642 doubles)
   __shared__ __attribute__((aligned(16))) unsigned char smt[LDS_BYTES];
   T *wcs = reinterpret_cast<T *>(smt);
+  const bool at_cand = mode == LIN_SPEC;
+  const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *rho = at_cand ? d.crho : d.rho, *ldp = at_cand ? d.cld : d.ld;
+  const double *kd = d.lkd;
   double c = 0.0;
-  int w = -1, ksi = 0, ksj = 0, my_lm = -1;
-  int mP = 0, mldw = 0, mK6 = 0, mlm0 = 0, mu0 = 0, mW0lo = 0, mW0hi = 0;   // LIN: the lane's window, for the landmark rows
-  bool on = false;
+  int w = -1, ksi = 0, ksj = 0, my_lm = -1, tg = 0;
+  int mP = 0, mldw = 0, mK6 = 0, mlm0 = 0, mu0 = 0, mW0lo = 0, mW0hi = 0;   // the lane's window, for the landmark rows
+  bool on = false, costed = false;
   if (v < d.Vtot) {
     w = d.v_win[v];
     const Lm &lm = d.lm[max(w, 0)];
-    const bool run = w >= 0 && (LIN ? lin_needed(lm) : (lm.status == 0 && (lm.step_valid || force)));
+    const bool run = w >= 0 && lin_run(lm, mode);
     if (run) {
       const WinMeta &m = d.wins[w];
-      if (LIN) {   // the state this window is linearised at (its candidate while it is in the line search)
-        const bool at_cand = lin_at_candidate(lm);
-        quat = at_cand ? d.cquat : d.quat; pos = at_cand ? d.cpos : d.pos; rho = at_cand ? d.crho : d.rho; ldp = at_cand ? d.cld : d.ld;
-        kd = d.lkd;
-      }
+      const bool jac = !lin_cost_only(lm, mode, d.prm);
+      tg = lin_target(lm, mode);
       int si, sj;
       double ui, uj;
       const double ld = ldp[w];
@@ -737,31 +728,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       const size_t V = (size_t)d.Vtot;
       const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
       T r[2];
-      if (LIN) {
+      SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+      seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
+      seg_const_lazy(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
+      if (jac) {
         VisTileSink<T> sink{wcs + VT_LD * threadIdx.x};
         on = true;
         my_lm = d.v_lm[v];
         mP = m.P; mldw = m.ldw; mK6 = 6 * m.K; mlm0 = m.lm0; mu0 = m.u0; mW0lo = (int)(m.W0 & 0xffffffffll); mW0hi = (int)(m.W0 >> 32);
-        SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
-        seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
-        seg_const_lazy(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
         c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
                                    d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
         sink.J[52] = r[0]; sink.J[53] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
         ksi = si; ksj = sj;
       } else {
-        T rd[2];
-        c = vis_residual<T>(d, m, v, si, sj, ui, uj, rowi, rowj, quat, pos, kd, rho[m.lm0 + d.v_lm[v]], rd);
+        VisNullSink<T> nsink;
+        costed = true;
+        c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
+                                   d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, false, nsink);
       }
     } else {
       w = -1;
     }
   }
-  if (LIN) {
+  {
     const int lane = threadIdx.x;
     const unsigned long long on_mask = __ballot(on);
+    if (on_mask != 0 || __any(costed)) {       // the wave's share of the cost: fixed-order sum over the lanes, one store
+      double cs = c;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) cs += __shfl_xor(cs, off);
+      if (lane == 0) d.vis_cost[blockIdx.x] = cs;
+    }
     if (on_mask == 0) return;                  // (wave-uniform)
+    const int tgw = __builtin_amdgcn_readfirstlane(__shfl(tg, __ffsll((long long)on_mask) - 1));   // normal-equation set of the wave's window
+    T *Wset = d.WS[tgw];
+    double *Hllset = d.HllS[tgw], *gset = d.gS[tgw];
     // One wave per workgroup: LDS hand-overs only need the wave's own LDS operations to have completed.  (__syncthreads() also
     // waits for vmcnt(0), i.e. for the J~ and W stores in flight to be acknowledged -- ~5 us per barrier here, measured.)
 #define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
         int4 mt;
         mt.x = __builtin_amdgcn_readlane(mymt.x, q); mt.y = __builtin_amdgcn_readlane(mymt.y, q);
         mt.z = __builtin_amdgcn_readlane(mymt.z, q); mt.w = __builtin_amdgcn_readlane(mymt.w, q);
-        T *Wr = d.W + (((long long)mt.w << 32) | (unsigned int)mt.z);
+        T *Wr = Wset + (((long long)mt.w << 32) | (unsigned int)mt.z);
         const double *row = rows + (size_t)q * ldmax;
         // pairs of columns (K6 is even, the row starts on a 256-byte boundary): two stores cover K <= 42
         VecN<T, 2> rv[2];
@@ -900,23 +902,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       }
       if (lane < nr) {
         const int2 hgi = rhg[c0 + lane];                     // x: index into Hll, y: index into g
-        d.Hll[hgi.x] = hg[2 * lane];
-        d.g[hgi.y] = hg[2 * lane + 1];
+        Hllset[hgi.x] = hg[2 * lane];
+        gset[hgi.y] = hg[2 * lane + 1];
       }
       LDS_SYNC();
       if (dbg && lane == 0) { dbg[4 + 2 * (c0 / NR)] = clock64(); dbg[10] = nlm * 1000000ll + (long long)(LDS_BYTES / 8); dbg[11] = NR * 1000 + ldmax; }
     }
 #undef LDS_SYNC
-  } else {
-    // (padding slots and blocks of windows that are not evaluated carry w = -1 and c = 0)
-    const unsigned long long live = __ballot(w >= 0);
-    const int w0 = live ? __shfl(w, __ffsll((long long)live) - 1) : -1;
-    if (__all(w == w0 || w < 0)) {
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-      if ((threadIdx.x & 63) == 0 && w0 >= 0) atomicAdd(&d.lm[w0].cand_cost, c);
-    } else if (w >= 0) {
-      atomicAdd(&d.lm[w].cand_cost, c);
-    }
   }
 }
 
@@ -930,12 +922,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
 // knots (reference image_feature_factor.h:165-180,215,233): every ordered column pair whose unknowns satisfy
 // g(a) >= g(b) is added, so shared knots sum correctly.  Landmark terms (W row, Hll, g_rho) stay per block.
 // Windows whose packed Hessian does not fit in LDS (vis_lds = 0) add straight into Hpp.
-template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d) {
+template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev<T> d, int mode) {
   constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;   // even row stride: 8-byte aligned pairs
   const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
-  if (!lin_needed(d.lm[w])) return;
+  if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
+  const int tgset = lin_target(d.lm[w], mode);
   // fields used after LDS/global atomics are copied to registers: the compiler must otherwise re-read them from
   // memory every time (a store could alias), one L2 round trip each
   const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0, ldh = m.ldh;
@@ -957,7 +950,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   const size_t V = (size_t)d.Vtot;
   const int per_round = NW * nparts;
   const int rounds = (nvitem + per_round - 1) / per_round;
-  double *Hg = d.Hpp + m.H0;
+  double *Hg = d.HppS[tgset] + m.H0;
   const int ti = lane >> 3, tj = lane & 7;
   // local column c (0..47 knot columns, 48 line delay, 49 residual) -> first of its two staging rows
   int rowa[7], rowb[7];
@@ -1098,7 +1091,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   if (!LDSH) __syncthreads();
   for (int i = tid; i < K6 + 1; i += 512) {
     const double gv = gs[i];
-    if (gv != 0.0) atomicAdd(&d.g[u0 + (i < K6 ? i : P - 1)], gv);
+    if (gv != 0.0) atomicAdd(&d.gS[tgset][u0 + (i < K6 ? i : P - 1)], gv);
   }
   CTV_STAMP();
 #undef CTV_STAMP
@@ -1117,7 +1110,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 template <class T> struct MfmaAcc;
 template <> struct MfmaAcc<double> { typedef f64x4 type; };
 __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d) {
+template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d, int mode) {
   constexpr bool F64 = sizeof(T) == 8;
   typedef typename MfmaAcc<T>::type acc_t;
   constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH;
@@ -1128,8 +1121,9 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   static_assert(24 % RPP == 0, "source regions must start on a pass boundary");
   const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
-  if (!lin_needed(d.lm[w])) return;
+  if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
+  const int tgset = lin_target(d.lm[w], mode);
   const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0, ldh = m.ldh;
   if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
   if (!LDSH && m.V == 0) return;
@@ -1183,7 +1177,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   // and is scattered once (the scatter costs as much as the products of an item: ~5 k cycles, measured)
   const int it0 = (int)((long long)nvitem * (part * NW + wave) / per_round);
   const int rounds = (int)((long long)nvitem * (part * NW + wave + 1) / per_round) - it0;
-  double *Hg = d.Hpp + m.H0;
+  double *Hg = d.HppS[tgset] + m.H0;
   const int q4 = lane >> 4, l15 = lane & 15, bsel = q4 >> 1, rr = q4 & 1;   // MFMA k index = 2 * (block of the pair) + residual row
   const int sc = lane % CH, srr = lane / CH;                               // staging: column (block) and row parity of this lane
   long long *dbg = (d.dbg && w == 0 && part == 0) ? d.dbg + 48 : nullptr;
@@ -1432,7 +1426,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   CTV_STAMP();
   for (int i = tid; i < K6 + 1; i += 512) {
     const double gv = gs[i];
-    if (gv != 0.0) atomicAdd(&d.g[u0 + (i < K6 ? i : P - 1)], gv);
+    if (gv != 0.0) atomicAdd(&d.gS[tgset][u0 + (i < K6 ? i : P - 1)], gv);
   }
   CTV_STAMP();
 #undef CTV_STAMP
@@ -1452,14 +1446,18 @@ __device__ __forceinline__ const double *prior_block_ptr(const WinMeta &m, int k
 
 // BiasFactor (trajectory_value_factor.h:45-99) and MarginalizationFactor (marginalization_factor.cpp:326-373), fp64.
 // With the prior written r = r0 + J0 dx:  J^T r = J0^T r0 + (J0^T J0) dx,  |r|^2 = r0^T r0 + 2 b0.dx + dx^T (J0^T J0) dx.
-// LIN: add to Hpp / g.  Otherwise: cost only (into lm.cand_cost).
-template <class T, bool LIN>
-__global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, const double *pos, const double *bias, const double *ldp, int force) {
+// Adds to Hpp / g of the set the mode selects (not on a cost-only pass) and stores the window's cost share (Dev::misc_cost).
+template <class T>
+__global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode) {
   const int w = blockIdx.x;
   const Lm &lm = d.lm[w];
-  if (LIN ? !lin_needed(lm) : !(lm.status == 0 && (lm.step_valid || force))) return;
+  if (!lin_run(lm, mode)) return;
+  const bool LIN = !lin_cost_only(lm, mode, d.prm);
   const WinMeta &m = d.wins[w];
-  if (LIN && lin_at_candidate(lm)) { quat = d.cquat; pos = d.cpos; bias = d.cbias; ldp = d.cld; }
+  const bool at_cand = mode == LIN_SPEC;
+  const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *bias = at_cand ? d.cbias : d.bias, *ldp = at_cand ? d.cld : d.ld;
+  const int tg = lin_target(lm, mode);
+  double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
   extern __shared__ __attribute__((aligned(16))) double smd[];
   double *dx = smd;                 // [pn]
   __shared__ double red[256];
@@ -1473,12 +1471,12 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
     cost += 0.5 * r * r;
     if (LIN) {
       const int ii = 6 * m.K + 6 * bi + k, jj = 6 * m.K + 6 * bj + k;
-      atomicAdd(&d.g[m.u0 + ii], -wv * r);
-      atomicAdd(&d.g[m.u0 + jj], wv * r);
-      atomicAdd(&d.Hpp[m.H0 + (long long)ii * m.ldh + ii], wv * wv);
-      atomicAdd(&d.Hpp[m.H0 + (long long)jj * m.ldh + jj], wv * wv);
+      atomicAdd(&g[ii], -wv * r);
+      atomicAdd(&g[jj], wv * r);
+      atomicAdd(&Hpp[(long long)ii * m.ldh + ii], wv * wv);
+      atomicAdd(&Hpp[(long long)jj * m.ldh + jj], wv * wv);
       const int hi = max(ii, jj), lo = min(ii, jj);
-      atomicAdd(&d.Hpp[m.H0 + (long long)hi * m.ldh + lo], -wv * wv);
+      atomicAdd(&Hpp[(long long)hi * m.ldh + lo], -wv * wv);
     }
   }
   const int n = m.pn;
@@ -1505,73 +1503,75 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, const double *quat, cons
       double hd = 0.0;
       for (int j = 0; j < n; ++j) hd += pH[(size_t)i * n + j] * dx[j];
       cost += dx[i] * (b0[i] + 0.5 * hd);
-      if (LIN && pcol[i] >= 0) atomicAdd(&d.g[m.u0 + pcol[i]], b0[i] + hd);
+      if (LIN && pcol[i] >= 0) atomicAdd(&g[pcol[i]], b0[i] + hd);
     }
     if (tid == 0) cost += 0.5 * d.pc0[w];
     if (LIN) {
       for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e % n;
         const int ci = pcol[i], cj = pcol[j];
-        if (ci >= 0 && cj >= 0 && ci >= cj) atomicAdd(&d.Hpp[m.H0 + (long long)ci * m.ldh + cj], pH[e]);
+        if (ci >= 0 && cj >= 0 && ci >= cj) atomicAdd(&Hpp[(long long)ci * m.ldh + cj], pH[e]);
       }
     }
   }
-  if (!LIN) {
-    red[tid] = cost;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    if (tid == 0) atomicAdd(&d.lm[w].cand_cost, red[0]);
-  }
+  red[tid] = cost;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+  if (tid == 0) d.misc_cost[w] = red[0];
 }
 
 // Jacobi scaling (computed once, at iteration 0: Ceres jacobi_scaling), gradient max-norm of
 // x - Plus(x, -g) (Ceres gradient_max_norm) and |x|^2 of the reduced program.
-template <class T> __global__ void k_post_linearize(Dev<T> d) {
+template <class T> __global__ void k_post_linearize(Dev<T> d, int mode) {
   const int w = blockIdx.y;
   Lm &lm = d.lm[w];
-  if (!lin_needed(lm) || lin_at_candidate(lm)) return;   // trial points of the line search only need g
+  if (!lin_run(lm, mode) || lin_cost_only(lm, mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m.N) return;
+  const bool at_cand = mode == LIN_SPEC;
+  const int tg = lin_target(lm, mode);
   const bool act = d.active[m.u0 + j] != 0;
-  if (!lm.scaled) {
-    const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.ldh + j] : d.Hll[m.lm0 + j - m.P];
+  if (!at_cand && !lm.scaled) {
+    const double h = (j < m.P) ? d.HppS[tg][m.H0 + (long long)j * m.ldh + j] : d.HllS[tg][m.lm0 + j - m.P];
     d.cscale[m.u0 + j] = act ? 1.0 / (1.0 + sqrt(fmax(h, 0.0))) : 1.0;
   }
   if (!act) return;
-  const double *g = d.g + m.u0;
+  const double *g = d.gS[tg] + m.u0;
+  const double *squat = at_cand ? d.cquat : d.quat, *spos = at_cand ? d.cpos : d.pos, *sbias = at_cand ? d.cbias : d.bias,
+               *srho = at_cand ? d.crho : d.rho, *sld = at_cand ? d.cld : d.ld;
   double gm = 0.0, x2 = 0.0;
   const int K6 = 6 * m.K;
   if (j < K6) {
     const int k = j / 6, c = j % 6;
     if (c == 0) {  // rotation block: ambient difference q - q*exp(-g)
-      const double *q = d.quat + 4 * (m.knot0 + k);
+      const double *q = squat + 4 * (m.knot0 + k);
       const Q4<double> q0 = qmk<double>(q[0], q[1], q[2], q[3]);
       const Q4<double> q1 = qmul(q0, so3_exp(mk<double>(-g[j], -g[j + 1], -g[j + 2])));
       gm = fmax(fmax(fabs(q0.x - q1.x), fabs(q0.y - q1.y)), fmax(fabs(q0.z - q1.z), fabs(q0.w - q1.w)));
       x2 = q0.x * q0.x + q0.y * q0.y + q0.z * q0.z + q0.w * q0.w;
     } else if (c >= 3) {
       gm = fabs(g[j]);
-      const double p = d.pos[3 * (m.knot0 + k) + c - 3];
+      const double p = spos[3 * (m.knot0 + k) + c - 3];
       x2 = p * p;
     }
   } else if (j < m.P - 1) {
     gm = fabs(g[j]);
-    const double b = d.bias[6 * m.bias0 + (j - K6)];
+    const double b = sbias[6 * m.bias0 + (j - K6)];
     x2 = b * b;
   } else if (j == m.P - 1) {
-    const double ld = d.ld[w];
+    const double ld = sld[w];
     double nl = ld - g[j];
     if (!m.fix_ld) nl = fmin(fmax(nl, m.ld_lo), m.ld_hi);
     gm = fabs(ld - nl);
     x2 = ld * ld;
   } else {
     gm = fabs(g[j]);
-    const double r = d.rho[m.lm0 + j - m.P];
+    const double r = srho[m.lm0 + j - m.P];
     x2 = r * r;
   }
-  if (gm > 0.0) atomicMax(&lm.gmax_bits, (unsigned long long)__double_as_longlong(gm));
-  if (lm.iter == 0 && x2 > 0.0) atomicAdd(&lm.xnorm2, x2);
+  if (gm > 0.0) atomicMax(at_cand ? &lm.cand_gmax_bits : &lm.gmax_bits, (unsigned long long)__double_as_longlong(gm));
+  if (!at_cand && lm.iter == 0 && x2 > 0.0) atomicAdd(&lm.xnorm2, x2);
 }
 
 // ------------------------------------------------------------------------------------------------ Schur + solve
@@ -1586,7 +1586,7 @@ template <class T> __global__ void k_damping(Dev<T> d) {
   if (j >= m.N) return;
   const bool act = d.active[m.u0 + j] != 0;
   const double c = d.cscale[m.u0 + j];
-  const double h = (j < m.P) ? d.Hpp[m.H0 + (long long)j * m.ldh + j] : d.Hll[m.lm0 + j - m.P];
+  const double h = (j < m.P) ? d.HppS[d.lm[w].cur][m.H0 + (long long)j * m.ldh + j] : d.HllS[d.lm[w].cur][m.lm0 + j - m.P];
   double s = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
   const double dd = act ? s / (lm.mu * c * c) : 0.0;
   d.dd[m.u0 + j] = dd;
@@ -1618,8 +1618,8 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   int *tlist = reinterpret_cast<int *>(dch + 32);   // [8 NTQ] tiles with products (bi << 8 | bj), any order
   int &tcount = tlist[8 * NTQ];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
-  const double *Wp = d.W + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.g + u0 + P;
+  const double *Wp = d.WS[d.lm[w].cur] + m.W0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
   for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0 : 0.0;
   if (tid == 0) tcount = 0;
   // W is non-zero only in the knot columns [0, 6K) and the line-delay column P - 1 (plus the rhs row P): a tile has products
@@ -1697,11 +1697,11 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   }
   // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
   double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
-  const double *H = d.Hpp + m.H0;
+  const double *H = d.HppS[d.lm[w].cur] + m.H0;
   auto write_tile = [&](int ti, int tj, const f64x4 &av) {
     const int jj = 16 * tj + l15, jc = min(jj, P - 1);
     const bool act_j = d.active[u0 + jc] != 0;
-    const double dd_j = d.dd[u0 + jc], g_j = d.g[u0 + jc];
+    const double dd_j = d.dd[u0 + jc], g_j = d.gS[d.lm[w].cur][u0 + jc];
     double hv[4];
     unsigned char act_i[4];
 #pragma unroll
@@ -1757,7 +1757,7 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
   const int i = min(16 * bi + l15, ldw - 1), j = min(16 * bj + l15, ldw - 1);
   const double ai = (16 * bi + l15 < P && d.active[u0 + min(i, P - 1)]) ? 1.0 : 0.0;
   const double aj = (16 * bj + l15 < P && d.active[u0 + min(j, P - 1)]) ? 1.0 : 0.0;
-  const double *Wp = d.W + m.W0;
+  const double *Wp = d.WS[d.lm[w].cur] + m.W0;
   const double *dinv = d.dinv + m.lm0;
   // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
   const bool nz_i = (16 * bi < K6) || (P - 1 >= 16 * bi && P - 1 < 16 * bi + 16);
@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
     }
   }
   double *S = d.S + m.H0;
-  const double *H = d.Hpp + m.H0;
+  const double *H = d.HppS[d.lm[w].cur] + m.H0;
   const int jj = 16 * bj + l15, jc = min(jj, P - 1);
   const bool act_j = d.active[u0 + jc] != 0;
   const double dd_j = d.dd[u0 + jc];
@@ -1813,10 +1813,10 @@ template <class T> __global__ void k_schur_generic(Dev<T> d) {
   const bool on = d.active[m.u0 + ii] && d.active[m.u0 + jj];
   double val;
   if (on) {
-    const T *Wp = d.W + m.W0;
+    const T *Wp = d.WS[d.lm[w].cur] + m.W0;
     double acc = 0.0;
     for (int l = 0; l < m.L; ++l) acc += (double)Wp[(long long)l * m.ldw + ii] * (double)Wp[(long long)l * m.ldw + jj] * d.dinv[m.lm0 + l];
-    val = d.Hpp[m.H0 + (long long)ii * m.ldh + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
+    val = d.HppS[d.lm[w].cur][m.H0 + (long long)ii * m.ldh + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
   } else {
     val = (ii == jj) ? 1.0 : 0.0;
   }
@@ -1833,15 +1833,15 @@ template <class T> __global__ __launch_bounds__(256) void k_rhs(Dev<T> d) {
   const int i = blockIdx.x * 64 + li;
   double v = 0.0;
   if (i < m.P && d.active[m.u0 + i]) {
-    const T *Wp = d.W + m.W0 + i;
-    const double *dinv = d.dinv + m.lm0, *gl = d.g + m.u0 + m.P;
+    const T *Wp = d.WS[d.lm[w].cur] + m.W0 + i;
+    const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + m.u0 + m.P;
     for (int l = sl; l < m.L; l += 4) v += (double)Wp[(long long)l * m.ldw] * (dinv[l] * gl[l]);
   }
   part[sl][li] = v;
   __syncthreads();
   if (sl == 0 && i < m.P) {
     const double s = part[0][li] + part[1][li] + part[2][li] + part[3][li];
-    d.rhs[m.p0 + i] = d.active[m.u0 + i] ? s - d.g[m.u0 + i] : 0.0;
+    d.rhs[m.p0 + i] = d.active[m.u0 + i] ? s - d.gS[d.lm[w].cur][m.u0 + i] : 0.0;
   }
 }
 
@@ -2352,19 +2352,26 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
 // delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
 // model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres' -(J y)^T (r + J y / 2) when
 // (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
-template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
+// Then, in the same workgroup (one per window): the candidate x (+) alpha delta of this pass (Plus: q <- q exp(d),
+// ceres_local_param.h:137-145; additive elsewhere; the line delay projected on its box, trajectory_estimator.cpp:316-317), |step|^2 and
+// |x|^2 of the reduced program (fixed-order block reductions, no atomics) and the knot-pair constants of the candidate for the
+// linearisation that follows.  Windows inside the line search skip the solve part: their step is the same, only alpha changed.
+template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d) {
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
-  if (lm.status || lm.ls_active) return;
+  if (lm.status) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, N = m.N, u0 = m.u0, lm0 = m.lm0, ldw = m.ldw;
   extern __shared__ __attribute__((aligned(16))) double xs[];   // [P] pose step
   __shared__ double red[4], red_gd[4], red_dm[4];
-  __shared__ int bad;
+  __shared__ int bad, s_go;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (lm.ls_active) {
+    if (tid == 0) s_go = lm.step_valid;
+  } else {
   double *x = d.delta + u0;
-  const double *g = d.g + u0, *dd = d.dd + u0;
-  const T *Wp = d.W + m.W0;
+  const double *g = d.gS[d.lm[w].cur] + u0, *dd = d.dd + u0;
+  const T *Wp = d.WS[d.lm[w].cur] + m.W0;
   for (int i = tid; i < P; i += 256) xs[i] = x[i];
   if (tid == 0) bad = 0;
   __syncthreads();
@@ -2437,106 +2444,93 @@ template <class T> __global__ __launch_bounds__(256) void k_backsub(Dev<T> d) {
       if (++lm.invalid >= d.prm.max_invalid) lm.status = 1 + 5;
       else { lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1; }
     }
+    s_go = valid ? 1 : 0;
+  }
+  }   // (solve part)
+  __syncthreads();
+  if (!s_go) return;
+  // ---- candidate = Plus(x, alpha delta)
+  {
+    const double al = lm.alpha;   // 1, or the trial step size of the projected line search
+    const double *dl = d.delta + u0;
+    const uint8_t *act = d.active + u0;
+    double step2 = 0.0, x2 = 0.0;
+    const int nst = m.K + m.F + L + 1;
+    for (int t = tid; t < nst; t += 256) {
+      if (t < m.K) {
+        const int gk = m.knot0 + t;
+        const bool ar = act[6 * t] != 0, ap = act[6 * t + 3] != 0;
+        const Q4<double> q0 = qmk<double>(d.quat[4 * gk], d.quat[4 * gk + 1], d.quat[4 * gk + 2], d.quat[4 * gk + 3]);
+        Q4<double> q1 = q0;
+        if (ar) q1 = qmul(q0, so3_exp(mk<double>(al * dl[6 * t], al * dl[6 * t + 1], al * dl[6 * t + 2])));
+        d.cquat[4 * gk] = q1.x; d.cquat[4 * gk + 1] = q1.y; d.cquat[4 * gk + 2] = q1.z; d.cquat[4 * gk + 3] = q1.w;
+        if (ar) {
+          step2 += (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) + (q1.z - q0.z) * (q1.z - q0.z) + (q1.w - q0.w) * (q1.w - q0.w);
+          x2 += q1.x * q1.x + q1.y * q1.y + q1.z * q1.z + q1.w * q1.w;
+        }
+        for (int c = 0; c < 3; ++c) {
+          const double p0 = d.pos[3 * gk + c], p1 = ap ? p0 + al * dl[6 * t + 3 + c] : p0;
+          d.cpos[3 * gk + c] = p1;
+          if (ap) { step2 += (p1 - p0) * (p1 - p0); x2 += p1 * p1; }
+        }
+      } else if (t < m.K + m.F) {
+        const int f = t - m.K, gf = m.bias0 + f, u = 6 * m.K + 6 * f;
+        for (int c = 0; c < 6; ++c) {
+          const bool a = act[u + c] != 0;
+          const double b0 = d.bias[6 * gf + c], b1 = a ? b0 + al * dl[u + c] : b0;
+          d.cbias[6 * gf + c] = b1;
+          if (a) { step2 += (b1 - b0) * (b1 - b0); x2 += b1 * b1; }
+        }
+      } else if (t < m.K + m.F + L) {
+        const int l = t - m.K - m.F;
+        const bool a = act[P + l] != 0;
+        const double r0 = d.rho[lm0 + l], r1 = a ? r0 + al * dl[P + l] : r0;
+        d.crho[lm0 + l] = r1;
+        if (a) { step2 += (r1 - r0) * (r1 - r0); x2 += r1 * r1; }
+      } else {
+        const bool a = act[P - 1] != 0;
+        const double l0 = d.ld[w];
+        double l1 = a ? l0 + al * dl[P - 1] : l0;
+        if (a && !m.fix_ld) l1 = fmin(fmax(l1, m.ld_lo), m.ld_hi);
+        d.cld[w] = l1;
+        if (a) { step2 += (l1 - l0) * (l1 - l0); x2 += l1 * l1; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { step2 += __shfl_xor(step2, off); x2 += __shfl_xor(x2, off); }
+    __syncthreads();   // (red / red_gd of the solve part have been consumed)
+    if (lane == 0) { red[wave] = step2; red_gd[wave] = x2; }
+    __syncthreads();   // also: the candidate knots are visible to the whole workgroup
+    if (tid == 0) {
+      lm.step2 = (red[0] + red[1]) + (red[2] + red[3]);
+      lm.cand_xnorm2 = (red_gd[0] + red_gd[1]) + (red_gd[2] + red_gd[3]);
+    }
+  }
+  // ---- knot-pair constants of the candidate (shared by all residual blocks of the linearisation that follows)
+  for (int t = tid; t < m.K - 1; t += 256) {
+    const int gk = m.knot0 + t;
+    knot_pair_const<T>(d.cquat + 4 * gk, d.cquat + 4 * gk + 4, d.lkd + 3 * gk, d.kjri + 9 * gk);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ update
-// candidate = Plus(x, delta): q <- q*exp(d) (ceres_local_param.h:137-145), additive elsewhere, line delay
-// projected on its box (trajectory_estimator.cpp:316-317).  ACCEPT: copy candidate -> current where accepted.
-template <class T, bool ACCEPT> __global__ void k_update(Dev<T> d) {
+// Accepted candidates become the current state (the whole state is one contiguous array: quat | pos | bias | rho | ld).
+template <class T> __global__ void k_accept(Dev<T> d) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  double step2 = 0.0, x2 = 0.0;
-  int w = -1;
   if (t < d.Ktot) {
-    w = d.knot_win[t];
-    const Lm &lm = d.lm[w];
-    if (ACCEPT) {
-      if (lm.accept) {
-        for (int c = 0; c < 4; ++c) d.quat[4 * t + c] = d.cquat[4 * t + c];
-        for (int c = 0; c < 3; ++c) d.pos[3 * t + c] = d.cpos[3 * t + c];
-      }
-      return;
-    }
-    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
-    const WinMeta &m = d.wins[w];
-    const int k = t - m.knot0;
-    const double al = lm.alpha;   // 1, or the trial step size of the projected line search
-    double dl[6];
-    for (int c = 0; c < 6; ++c) dl[c] = al * d.delta[m.u0 + 6 * k + c];
-    const bool ar = d.active[m.u0 + 6 * k] != 0, ap = d.active[m.u0 + 6 * k + 3] != 0;
-    const Q4<double> q0 = qmk<double>(d.quat[4 * t], d.quat[4 * t + 1], d.quat[4 * t + 2], d.quat[4 * t + 3]);
-    Q4<double> q1 = q0;
-    if (ar) q1 = qmul(q0, so3_exp(mk<double>(dl[0], dl[1], dl[2])));
-    d.cquat[4 * t] = q1.x; d.cquat[4 * t + 1] = q1.y; d.cquat[4 * t + 2] = q1.z; d.cquat[4 * t + 3] = q1.w;
-    if (ar) {
-      step2 += (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) + (q1.z - q0.z) * (q1.z - q0.z) + (q1.w - q0.w) * (q1.w - q0.w);
-      x2 += q1.x * q1.x + q1.y * q1.y + q1.z * q1.z + q1.w * q1.w;
-    }
-    for (int c = 0; c < 3; ++c) {
-      const double p0 = d.pos[3 * t + c], p1 = ap ? p0 + dl[3 + c] : p0;
-      d.cpos[3 * t + c] = p1;
-      if (ap) { step2 += (p1 - p0) * (p1 - p0); x2 += p1 * p1; }
-    }
+    if (!d.lm[d.knot_win[t]].accept) return;
+    for (int c = 0; c < 4; ++c) d.quat[4 * t + c] = d.cquat[4 * t + c];
+    for (int c = 0; c < 3; ++c) d.pos[3 * t + c] = d.cpos[3 * t + c];
   } else if (t < d.Ktot + d.Ftot) {
     const int f = t - d.Ktot;
-    w = d.bias_win[f];
-    const Lm &lm = d.lm[w];
-    if (ACCEPT) {
-      if (lm.accept) for (int c = 0; c < 6; ++c) d.bias[6 * f + c] = d.cbias[6 * f + c];
-      return;
-    }
-    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
-    const WinMeta &m = d.wins[w];
-    const int u = 6 * m.K + 6 * (f - m.bias0);
-    for (int c = 0; c < 6; ++c) {
-      const bool a = d.active[m.u0 + u + c] != 0;
-      const double b0 = d.bias[6 * f + c], b1 = a ? b0 + lm.alpha * d.delta[m.u0 + u + c] : b0;
-      d.cbias[6 * f + c] = b1;
-      if (a) { step2 += (b1 - b0) * (b1 - b0); x2 += b1 * b1; }
-    }
+    if (!d.lm[d.bias_win[f]].accept) return;
+    for (int c = 0; c < 6; ++c) d.bias[6 * f + c] = d.cbias[6 * f + c];
   } else if (t < d.Ktot + d.Ftot + d.Ltot) {
     const int l = t - d.Ktot - d.Ftot;
-    w = d.lm_win[l];
-    const Lm &lm = d.lm[w];
-    if (ACCEPT) {
-      if (lm.accept) d.rho[l] = d.crho[l];
-      return;
-    }
-    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
-    const WinMeta &m = d.wins[w];
-    const int u = m.P + (l - m.lm0);
-    const bool a = d.active[m.u0 + u] != 0;
-    const double r0 = d.rho[l], r1 = a ? r0 + lm.alpha * d.delta[m.u0 + u] : r0;
-    d.crho[l] = r1;
-    if (a) { step2 += (r1 - r0) * (r1 - r0); x2 += r1 * r1; }
+    if (d.lm[d.lm_win[l]].accept) d.rho[l] = d.crho[l];
   } else if (t < d.Ktot + d.Ftot + d.Ltot + d.nwin) {
-    w = t - d.Ktot - d.Ftot - d.Ltot;
-    const Lm &lm = d.lm[w];
-    if (ACCEPT) {
-      if (lm.accept) d.ld[w] = d.cld[w];
-      return;
-    }
-    if (lm.status || !lm.step_valid) { w = -1; goto reduce; }
-    const WinMeta &m = d.wins[w];
-    const bool a = d.active[m.u0 + m.P - 1] != 0;
-    const double l0 = d.ld[w];
-    double l1 = a ? l0 + lm.alpha * d.delta[m.u0 + m.P - 1] : l0;
-    if (a && !m.fix_ld) l1 = fmin(fmax(l1, m.ld_lo), m.ld_hi);
-    d.cld[w] = l1;
-    if (a) { step2 += (l1 - l0) * (l1 - l0); x2 += l1 * l1; }
-  }
-reduce:
-  if (!ACCEPT) {
-    // |step|^2 and |x|^2 per window: one atomic pair per wave when the wave lies inside one window (same-address atomics
-    // from every thread serialise in L2)
-    const int w0 = __shfl(w, 0);
-    if (__all(w == w0)) {
-      for (int off = 32; off > 0; off >>= 1) { step2 += __shfl_down(step2, off); x2 += __shfl_down(x2, off); }
-      if ((threadIdx.x & 63) == 0 && w0 >= 0) { atomicAdd(&d.lm[w0].step2, step2); atomicAdd(&d.lm[w0].cand_xnorm2, x2); }
-    } else if (w >= 0) {
-      atomicAdd(&d.lm[w].step2, step2);
-      atomicAdd(&d.lm[w].cand_xnorm2, x2);
-    }
+    const int w = t - d.Ktot - d.Ftot - d.Ltot;
+    if (d.lm[w].accept) d.ld[w] = d.cld[w];
   }
 }
 

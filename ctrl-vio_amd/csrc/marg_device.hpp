@@ -158,16 +158,17 @@ template <class T> __global__ __launch_bounds__(256) void k_marginalize(Dev<T> d
   int *rank = pq + MARG_MAXD;          // [MARG_MAXD]
   const int32_t *im = iscr + mm.idx0, *ik = im + m;
   double *A = scr + mm.A0, *Vm = scr + mm.V0, *X = scr + mm.X0, *Y = scr + mm.Y0, *rot = scr + mm.rot0, *bp = scr + mm.b0;
-  const double *g = d.g + wm.u0;
+  const int cset = d.lm[blockIdx.x].cur;   // the normal-equation set that holds the linearisation at the current state
+  const double *g = d.gS[cset] + wm.u0;
   // ---- dense symmetric A (N x N) from the structured normal equations: [Hpp W^T; W diag(Hll)]
   {
-    const double *H = d.Hpp + wm.H0;
-    const T *Wp = d.W + wm.W0;
+    const double *H = d.HppS[cset] + wm.H0;
+    const T *Wp = d.WS[cset] + wm.W0;
     for (long long e = tid; e < (long long)N * N; e += 256) {
       const int i = (int)(e / N), j = (int)(e % N);
       double v;
       if (i < P && j < P) v = H[(long long)max(i, j) * wm.ldh + min(i, j)];
-      else if (i >= P && j >= P) v = (i == j) ? d.Hll[wm.lm0 + i - P] : 0.0;
+      else if (i >= P && j >= P) v = (i == j) ? d.HllS[cset][wm.lm0 + i - P] : 0.0;
       else v = (double)Wp[(long long)(max(i, j) - P) * wm.ldw + min(i, j)];
       A[e] = v;
     }
