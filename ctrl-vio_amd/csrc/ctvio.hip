@@ -533,9 +533,6 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_step() {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
-    ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_damping<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d);
-    ph_end();
     ph_begin(PH_SCHUR);
     launch_schur();
     ph_end();
@@ -558,7 +555,9 @@ template <class T> class SolverImpl : public SolverBase {
     else hipLaunchKernelGGL((k_cholesky_solve<T, 4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_step_finish<T>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
+    // (fewer windows than CUs: 16 waves per window shorten the landmark back-substitution from 7 trips to 2)
+    if (nw <= 192) hipLaunchKernelGGL((k_step_finish<T, 16>), dim3(nw), dim3(1024), (size_t)d.maxP * sizeof(double), stream_, d);
+    else hipLaunchKernelGGL((k_step_finish<T, 4>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
     ph_end();
   }
   void launch_schur();
@@ -584,13 +583,14 @@ template <class T> class SolverImpl : public SolverBase {
     Dev<T> &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     (void)hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_);
-    hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
+    ph_begin(PH_REST);
+    hipLaunchKernelGGL((k_begin_iter<T>), dim3(nw), dim3(256), 0, stream_, d);
+    ph_end();
     launch_step();
     launch_linearize(LIN_SPEC);
     launch_assemble(LIN_SPEC);
     ph_begin(PH_REST);
     hipLaunchKernelGGL((k_lm_control<T>), dim3(nw), dim3(64), 0, stream_, d);
-    hipLaunchKernelGGL((k_accept<T>), dim3(nblk(n_state(), 256)), dim3(256), 0, stream_, d);
     ph_end();
   }
   // The first linearisation of a solve (and of the diagnostic entries): knot-pair constants, normal equations and cost of the
@@ -808,7 +808,7 @@ template <class T> class SolverImpl : public SolverBase {
     set_params(1);
     launch_initial(mu, 0);
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
-    hipLaunchKernelGGL((k_begin_iter<T>), dim3(wb), dim3(64), 0, stream_, d);
+    hipLaunchKernelGGL((k_begin_iter<T>), dim3(d.nwin), dim3(256), 0, stream_, d);
     launch_step();
     const WinMeta &m = meta_[id];
     Lm lm;
@@ -1100,8 +1100,9 @@ template <> void SolverImpl<double>::launch_schur() {
       else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       schur_rhs_done_ = true;
     } else {
-      const int nt2 = (d.maxP + 15) / 16, ntile2 = nt2 * (nt2 + 1) / 2;
+      const int nt2 = d.maxP / 16 + 1, ntile2 = nt2 * (nt2 + 1) / 2;   // tile rows up to index P (the rhs row)
       hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile2);
+      schur_rhs_done_ = true;
     }
   } else {
     hipLaunchKernelGGL((k_schur_generic<double>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);

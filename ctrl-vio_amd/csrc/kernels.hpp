@@ -115,21 +115,6 @@ template <class T> __global__ void k_lm_init(Dev<T> d, double mu, int keep_scale
   lm.ls_cur_x = lm.ls_cur_v = lm.ls_cur_g = lm.ls_prev_x = lm.ls_prev_v = lm.ls_prev_g = 0;
 }
 
-// FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration.
-template <class T> __global__ void k_begin_iter(Dev<T> d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.nwin) return;
-  Lm &lm = d.lm[w];
-  if (lm.status) return;
-  if (lm.ls_active) { atomicAdd(d.n_active, 1); return; }   // inside the line search: no new LM iteration
-  if (lm.iter >= d.prm.max_iters) { lm.status = 1 + 0; return; }
-  if (lm.last_ok && __longlong_as_double((long long)lm.gmax_bits) <= d.prm.gtol) { lm.status = 1 + 1; return; }
-  if (lm.mu <= d.prm.min_radius) { lm.status = 1 + 4; return; }
-  lm.iter += 1;
-  lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0; lm.alpha = 1.0;
-  atomicAdd(d.n_active, 1);
-}
-
 // ---- interpolation of the next trial step (Ceres polynomial.cc: FindInterpolatingPolynomial / MinimizePolynomial)
 struct LsSample { double x, v, g; };
 __device__ inline double ls_poly_eval(const double *p, int n, double x) {
@@ -246,6 +231,63 @@ template <class T> __global__ __launch_bounds__(64) void k_initial_cost(Dev<T> d
   lm.scaled = 1;
 }
 
+// Decision of one window after its candidate has been evaluated (lane 0 of k_lm_control): returns 1 when the candidate is accepted.
+template <class T> __device__ inline int lm_decide(const Dev<T> &d, Lm &lm, double cand_cost, double gd, bool have_grad) {
+  lm.cand_cost = cand_cost;
+  lm.cand_gd = gd;
+  lm.have_grad = have_grad ? 1 : 0;
+  lm.accept = 0;
+  if (lm.ls_on && lm.ls_active != 2) {
+    const bool valid = isfinite(cand_cost) && (!have_grad || isfinite(gd));
+    const bool ok = valid && !(cand_cost > lm.cost + 1e-4 * lm.ls_gd0 * lm.alpha);
+    if (!ok) {
+      if (!have_grad) { lm.ls_active = 3; return 0; }   // (last iteration, costed only) the same trial again, linearised
+      if (lm.ls_active != 1) { lm.ls_active = 1; lm.ls_iters = 0; lm.ls_prev_valid = 0; lm.ls_cur_x = 1.0; }
+      lm.ls_cur_v = cand_cost; lm.ls_cur_g = gd; lm.ls_cur_valid = valid ? 1 : 0;
+      if (++lm.ls_iters >= 20) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return 0; }   // max_num_line_search_step_size_iterations: the full step is kept
+      const double lo = 1e-3 * lm.ls_cur_x, hi = 0.6 * lm.ls_cur_x;   // max_step_contraction, min_step_contraction
+      double step;
+      if (!valid) {
+        step = fmin(fmax(lm.ls_cur_x * 0.5, lo), hi);
+      } else {
+        LsSample sp[3];
+        int ns = 0;
+        sp[ns++] = LsSample{0.0, lm.cost, lm.ls_gd0};
+        sp[ns++] = LsSample{lm.ls_cur_x, lm.ls_cur_v, lm.ls_cur_g};
+        if (lm.ls_prev_valid) sp[ns++] = LsSample{lm.ls_prev_x, lm.ls_prev_v, lm.ls_prev_g};
+        step = ls_minimize_interpolating(sp, ns, lo, hi);
+      }
+      if (step * lm.ls_dmax < 1e-9) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return 0; }   // min_line_search_step_size
+      lm.ls_prev_x = lm.ls_cur_x; lm.ls_prev_v = lm.ls_cur_v; lm.ls_prev_g = lm.ls_cur_g; lm.ls_prev_valid = valid ? 1 : 0;
+      lm.ls_cur_x = step;
+      lm.alpha = step;
+      return 0;   // next pass: candidate at the new alpha
+    }
+    if (lm.ls_active == 1) { lm.nls_steps += lm.ls_iters; lm.nls_reduced += 1; }
+  }
+  lm.ls_active = 0;
+  const double step_norm = sqrt(lm.step2), x_norm = sqrt(lm.xnorm2);
+  if (step_norm <= d.prm.ptol * (x_norm + d.prm.ptol)) { lm.status = 1 + 2; return 0; }
+  const double cost_change = lm.cost - cand_cost;
+  if (fabs(cost_change) <= d.prm.ftol * lm.cost) { lm.status = 1 + 3; return 0; }
+  const double rel = cost_change / lm.model_change;
+  if (rel > d.prm.min_rel_dec && isfinite(cand_cost)) {
+    lm.accept = 1;
+    lm.cost = cand_cost;
+    lm.xnorm2 = lm.cand_xnorm2;
+    const double t = 2.0 * rel - 1.0;
+    double f = 1.0 - t * t * t;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    lm.mu = fmin(lm.mu / f, d.prm.max_radius);
+    lm.nu = 2.0; lm.last_ok = 1; lm.nsucc += 1;
+    if (have_grad) { lm.cur ^= 1; lm.gmax_bits = lm.cand_gmax_bits; }   // the speculative linearisation is the current one now
+    return 1;
+  }
+  lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1;
+  return 0;
+}
+
+
 // One wave per window, after the candidate of this pass has been evaluated: cost of the candidate (fixed-order sum of the
 // partials), its directional derivative g(candidate) . delta, then
 //   * ArmijoLineSearch::DoSearch + LineSearch::InterpolatingPolynomialMinimizingStepSize (Ceres line_search.cc) for windows whose
@@ -269,58 +311,16 @@ template <class T> __global__ __launch_bounds__(64) void k_lm_control(Dev<T> d) 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gd += __shfl_xor(gd, off);
   }
-  if (lane != 0) return;
-  lm.cand_cost = cand_cost;
-  lm.cand_gd = gd;
-  lm.have_grad = have_grad ? 1 : 0;
-  lm.accept = 0;
-  if (lm.ls_on && lm.ls_active != 2) {
-    const bool valid = isfinite(cand_cost) && (!have_grad || isfinite(gd));
-    const bool ok = valid && !(cand_cost > lm.cost + 1e-4 * lm.ls_gd0 * lm.alpha);
-    if (!ok) {
-      if (!have_grad) { lm.ls_active = 3; return; }   // (last iteration, costed only) the same trial again, linearised
-      if (lm.ls_active != 1) { lm.ls_active = 1; lm.ls_iters = 0; lm.ls_prev_valid = 0; lm.ls_cur_x = 1.0; }
-      lm.ls_cur_v = cand_cost; lm.ls_cur_g = gd; lm.ls_cur_valid = valid ? 1 : 0;
-      if (++lm.ls_iters >= 20) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return; }   // max_num_line_search_step_size_iterations: the full step is kept
-      const double lo = 1e-3 * lm.ls_cur_x, hi = 0.6 * lm.ls_cur_x;   // max_step_contraction, min_step_contraction
-      double step;
-      if (!valid) {
-        step = fmin(fmax(lm.ls_cur_x * 0.5, lo), hi);
-      } else {
-        LsSample sp[3];
-        int ns = 0;
-        sp[ns++] = LsSample{0.0, lm.cost, lm.ls_gd0};
-        sp[ns++] = LsSample{lm.ls_cur_x, lm.ls_cur_v, lm.ls_cur_g};
-        if (lm.ls_prev_valid) sp[ns++] = LsSample{lm.ls_prev_x, lm.ls_prev_v, lm.ls_prev_g};
-        step = ls_minimize_interpolating(sp, ns, lo, hi);
-      }
-      if (step * lm.ls_dmax < 1e-9) { lm.ls_active = 2; lm.alpha = 1.0; lm.nls_steps += lm.ls_iters; return; }   // min_line_search_step_size
-      lm.ls_prev_x = lm.ls_cur_x; lm.ls_prev_v = lm.ls_cur_v; lm.ls_prev_g = lm.ls_cur_g; lm.ls_prev_valid = valid ? 1 : 0;
-      lm.ls_cur_x = step;
-      lm.alpha = step;
-      return;   // next pass: candidate at the new alpha
-    }
-    if (lm.ls_active == 1) { lm.nls_steps += lm.ls_iters; lm.nls_reduced += 1; }
-  }
-  lm.ls_active = 0;
-  const double step_norm = sqrt(lm.step2), x_norm = sqrt(lm.xnorm2);
-  if (step_norm <= d.prm.ptol * (x_norm + d.prm.ptol)) { lm.status = 1 + 2; return; }
-  const double cost_change = lm.cost - cand_cost;
-  if (fabs(cost_change) <= d.prm.ftol * lm.cost) { lm.status = 1 + 3; return; }
-  const double rel = cost_change / lm.model_change;
-  if (rel > d.prm.min_rel_dec && isfinite(cand_cost)) {
-    lm.accept = 1;
-    lm.cost = cand_cost;
-    lm.xnorm2 = lm.cand_xnorm2;
-    const double t = 2.0 * rel - 1.0;
-    double f = 1.0 - t * t * t;
-    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
-    lm.mu = fmin(lm.mu / f, d.prm.max_radius);
-    lm.nu = 2.0; lm.last_ok = 1; lm.nsucc += 1;
-    if (have_grad) { lm.cur ^= 1; lm.gmax_bits = lm.cand_gmax_bits; }   // the speculative linearisation is the current one now
-  } else {
-    lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1;
-  }
+  int accepted = 0;
+  if (lane == 0) accepted = lm_decide(d, lm, cand_cost, gd, have_grad);
+  accepted = __shfl(accepted, 0);
+  if (!accepted) return;
+  // the accepted candidate becomes the current state (the reference: Ceres writes through the parameter pointers)
+  for (int t = lane; t < 4 * m.K; t += 64) d.quat[4 * m.knot0 + t] = d.cquat[4 * m.knot0 + t];
+  for (int t = lane; t < 3 * m.K; t += 64) d.pos[3 * m.knot0 + t] = d.cpos[3 * m.knot0 + t];
+  for (int t = lane; t < 6 * m.F; t += 64) d.bias[6 * m.bias0 + t] = d.cbias[6 * m.bias0 + t];
+  for (int t = lane; t < m.L; t += 64) d.rho[m.lm0 + t] = d.crho[m.lm0 + t];
+  if (lane == 0) d.ld[w] = d.cld[w];
 }
 
 // ------------------------------------------------------------------------------------------------ zero
@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode) {
     const int *pcol = d.pcol + m.pv0;
     for (int i = tid; i < n; i += 256) {
       double hd = 0.0;
-      for (int j = 0; j < n; ++j) hd += pH[(size_t)i * n + j] * dx[j];
+      for (int j = 0; j < n; ++j) hd += pH[(size_t)j * n + i] * dx[j];   // (J0^T J0 is symmetric: column i, coalesced over the threads)
       cost += dx[i] * (b0[i] + 0.5 * hd);
       if (LIN && pcol[i] >= 0) atomicAdd(&g[pcol[i]], b0[i] + hd);
     }
@@ -1575,22 +1575,44 @@ template <class T> __global__ void k_post_linearize(Dev<T> d, int mode) {
 }
 
 // ------------------------------------------------------------------------------------------------ Schur + solve
-// LM diagonal D^2 = clamp(diag(J^T J), min, max) / mu on the Jacobi-scaled system (Ceres
-// LevenbergMarquardtStrategy::ComputeStep), expressed for the unscaled system: dd_j = clamp(c_j^2 H_jj)/(mu c_j^2).
-template <class T> __global__ void k_damping(Dev<T> d) {
-  const int w = blockIdx.y;
-  const Lm &lm = d.lm[w];
-  if (lm.status || lm.ls_active) return;
+// One workgroup per window.  Thread 0: FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration (windows
+// inside the line search only report that they are still running).  Then, for the windows that start an iteration: the LM diagonal
+// D^2 = clamp(diag(J^T J), min, max) / mu on the Jacobi-scaled system (Ceres LevenbergMarquardtStrategy::ComputeStep), expressed for
+// the unscaled system: dd_j = clamp(c_j^2 H_jj) / (mu c_j^2), and 1 / (Hll + dd) of the landmarks.
+template <class T> __global__ __launch_bounds__(256) void k_begin_iter(Dev<T> d) {
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  __shared__ int s_go;
+  if (threadIdx.x == 0) {
+    int go = 0;
+    if (!lm.status) {
+      if (lm.ls_active) atomicAdd(d.n_active, 1);   // inside the line search: no new LM iteration
+      else if (lm.iter >= d.prm.max_iters) lm.status = 1 + 0;
+      else if (lm.last_ok && __longlong_as_double((long long)lm.gmax_bits) <= d.prm.gtol) lm.status = 1 + 1;
+      else if (lm.mu <= d.prm.min_radius) lm.status = 1 + 4;
+      else {
+        lm.iter += 1;
+        lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0; lm.alpha = 1.0;
+        atomicAdd(d.n_active, 1);
+        go = 1;
+      }
+    }
+    s_go = go;
+  }
+  __syncthreads();
+  if (!s_go) return;
   const WinMeta &m = d.wins[w];
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m.N) return;
-  const bool act = d.active[m.u0 + j] != 0;
-  const double c = d.cscale[m.u0 + j];
-  const double h = (j < m.P) ? d.HppS[d.lm[w].cur][m.H0 + (long long)j * m.ldh + j] : d.HllS[d.lm[w].cur][m.lm0 + j - m.P];
-  double s = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
-  const double dd = act ? s / (lm.mu * c * c) : 0.0;
-  d.dd[m.u0 + j] = dd;
-  if (j >= m.P) d.dinv[m.lm0 + j - m.P] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
+  const double mu = lm.mu;
+  const double *Hd = d.HppS[lm.cur] + m.H0, *Hl = d.HllS[lm.cur] + m.lm0;
+  for (int j = threadIdx.x; j < m.N; j += 256) {
+    const bool act = d.active[m.u0 + j] != 0;
+    const double c = d.cscale[m.u0 + j];
+    const double h = (j < m.P) ? Hd[(long long)j * m.ldh + j] : Hl[j - m.P];
+    const double sc = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
+    const double dd = act ? sc / (mu * c * c) : 0.0;
+    d.dd[m.u0 + j] = dd;
+    if (j >= m.P) d.dinv[m.lm0 + j - m.P] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
+  }
 }
 
 __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> (bi >= bj), row-major over the lower triangle
@@ -1749,41 +1771,45 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
   if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
-  const int nt = (P + 15) / 16;
-  if (tile >= nt * (nt + 1) / 2) return;
+  const int nt = P / 16 + 1;   // tile rows up to index P: the rhs rides along as row P (g_rho on the A side), so the tile row that
+  if (tile >= nt * (nt + 1) / 2) return;   // holds it also produces W^T diag(dinv) g_rho -- no separate k_rhs pass
   int bi, bj;
   tile_decode(tile, bi, bj);
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const int i = min(16 * bi + l15, ldw - 1), j = min(16 * bj + l15, ldw - 1);
+  const bool rhs_lane = 16 * bi + l15 == P;
   const double ai = (16 * bi + l15 < P && d.active[u0 + min(i, P - 1)]) ? 1.0 : 0.0;
   const double aj = (16 * bj + l15 < P && d.active[u0 + min(j, P - 1)]) ? 1.0 : 0.0;
   const double *Wp = d.WS[d.lm[w].cur] + m.W0;
-  const double *dinv = d.dinv + m.lm0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
   // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
-  const bool nz_i = (16 * bi < K6) || (P - 1 >= 16 * bi && P - 1 < 16 * bi + 16);
+  const bool nz_i = (16 * bi < K6) || (P >= 16 * bi && P - 1 < 16 * bi + 16);
   const bool nz_j = (16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16);
   const int lend = (nz_i && nz_j) ? L : 0;   // L == 0: the loop (and its clamped row L - 1) is skipped
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
   for (int l0 = 0; l0 < lend; l0 += 16) {
-    double wa[4], wb[4], dv[4];
+    double wa[4], wb[4], dv[4], gv[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {   // unconditional loads on clamped rows, masked below
       const int lc = min(l0 + 4 * s + q4, L - 1);
       wa[s] = Wp[(long long)lc * ldw + i];
       wb[s] = Wp[(long long)lc * ldw + j];
       dv[s] = dinv[lc];
+      gv[s] = gl[lc];
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wa[s] = rhs_lane ? gv[s] : wa[s] * ai;   // (unconditional loads, selected afterwards)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bool lv = l0 + 4 * s + q4 < L;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s] * ai, lv ? wb[s] * aj * dv[s] : 0.0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], lv ? wb[s] * aj * dv[s] : 0.0, acc, 0, 0, 0);
     }
   }
-  double *S = d.S + m.H0;
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
   const double *H = d.HppS[d.lm[w].cur] + m.H0;
   const int jj = 16 * bj + l15, jc = min(jj, P - 1);
   const bool act_j = d.active[u0 + jc] != 0;
-  const double dd_j = d.dd[u0 + jc];
+  const double dd_j = d.dd[u0 + jc], g_j = d.gS[d.lm[w].cur][u0 + jc];
   double hv[4];
   unsigned char act_i[4];
 #pragma unroll
@@ -1798,6 +1824,8 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev<double> d, int ntile_
     if (ii < P && jj <= ii) {
       const bool on = act_i[r] && act_j;
       S[(long long)ii * ldh + jj] = on ? hv[r] - acc[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+    } else if (ii == P && jj < P) {
+      rhs[jj] = act_j ? acc[r] - g_j : 0.0;   // reduced right-hand side: -g_p + W^T diag(dinv) g_rho
     }
   }
 }
@@ -2356,14 +2384,15 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
 // ceres_local_param.h:137-145; additive elsewhere; the line delay projected on its box, trajectory_estimator.cpp:316-317), |step|^2 and
 // |x|^2 of the reduced program (fixed-order block reductions, no atomics) and the knot-pair constants of the candidate for the
 // linearisation that follows.  Windows inside the line search skip the solve part: their step is the same, only alpha changed.
-template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d) {
+template <class T, int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev<T> d) {
+  constexpr int NT = 64 * NWV;
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
   if (lm.status) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, N = m.N, u0 = m.u0, lm0 = m.lm0, ldw = m.ldw;
   extern __shared__ __attribute__((aligned(16))) double xs[];   // [P] pose step
-  __shared__ double red[4], red_gd[4], red_dm[4];
+  __shared__ double red[NWV], red_gd[NWV], red_dm[NWV];
   __shared__ int bad, s_go;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (lm.ls_active) {
@@ -2372,11 +2401,11 @@ template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d
   double *x = d.delta + u0;
   const double *g = d.gS[d.lm[w].cur] + u0, *dd = d.dd + u0;
   const T *Wp = d.WS[d.lm[w].cur] + m.W0;
-  for (int i = tid; i < P; i += 256) xs[i] = x[i];
+  for (int i = tid; i < P; i += NT) xs[i] = x[i];
   if (tid == 0) bad = 0;
   __syncthreads();
   // delta_rho_l = -(g_l + W_l . delta_p) / (Hll_l + D_l): a wave takes 8 rows of W per pass, 32 loads per lane in flight
-  for (int l0 = 8 * wave; l0 < L; l0 += 32) {
+  for (int l0 = 8 * wave; l0 < L; l0 += 8 * NWV) {
     double acc8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
@@ -2423,7 +2452,7 @@ template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d
   }
   __syncthreads();
   double mc = 0.0, gd = 0.0, dm = 0.0;   // model change; g . delta and |delta|_inf for the projected line search
-  for (int j = tid; j < N; j += 256) {
+  for (int j = tid; j < N; j += NT) {
     const double dj = x[j];
     if (!isfinite(dj)) bad = 1;
     if (d.active[u0 + j]) { mc += 0.5 * dj * (dd[j] * dj - g[j]); gd += g[j] * dj; dm = fmax(dm, fabs(dj)); }
@@ -2431,13 +2460,13 @@ template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d
   for (int off = 32; off > 0; off >>= 1) { mc += __shfl_down(mc, off); gd += __shfl_down(gd, off); dm = fmax(dm, __shfl_down(dm, off)); }
   if (lane == 0) { red[wave] = mc; red_gd[wave] = gd; red_dm[wave] = dm; }
   __syncthreads();
-  if (tid == 0) red[0] = (red[0] + red[1]) + (red[2] + red[3]);
-  __syncthreads();
   if (tid == 0) {
-    lm.model_change = red[0];
-    lm.ls_gd0 = (red_gd[0] + red_gd[1]) + (red_gd[2] + red_gd[3]);
-    lm.ls_dmax = fmax(fmax(red_dm[0], red_dm[1]), fmax(red_dm[2], red_dm[3]));
-    const bool valid = !lm.chol_fail && !bad && (red[0] > 0.0);
+    double mc_t = 0.0, gd_t = 0.0, dm_t = 0.0;
+    for (int q = 0; q < NWV; ++q) { mc_t += red[q]; gd_t += red_gd[q]; dm_t = fmax(dm_t, red_dm[q]); }   // fixed order
+    lm.model_change = mc_t;
+    lm.ls_gd0 = gd_t;
+    lm.ls_dmax = dm_t;
+    const bool valid = !lm.chol_fail && !bad && (mc_t > 0.0);
     if (valid) { lm.step_valid = 1; lm.invalid = 0; }
     else {
       lm.step_valid = 0;
@@ -2456,7 +2485,7 @@ template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d
     const uint8_t *act = d.active + u0;
     double step2 = 0.0, x2 = 0.0;
     const int nst = m.K + m.F + L + 1;
-    for (int t = tid; t < nst; t += 256) {
+    for (int t = tid; t < nst; t += NT) {
       if (t < m.K) {
         const int gk = m.knot0 + t;
         const bool ar = act[6 * t] != 0, ap = act[6 * t + 3] != 0;
@@ -2502,38 +2531,20 @@ template <class T> __global__ __launch_bounds__(256) void k_step_finish(Dev<T> d
     if (lane == 0) { red[wave] = step2; red_gd[wave] = x2; }
     __syncthreads();   // also: the candidate knots are visible to the whole workgroup
     if (tid == 0) {
-      lm.step2 = (red[0] + red[1]) + (red[2] + red[3]);
-      lm.cand_xnorm2 = (red_gd[0] + red_gd[1]) + (red_gd[2] + red_gd[3]);
+      double s2 = 0.0, x2t = 0.0;
+      for (int q = 0; q < NWV; ++q) { s2 += red[q]; x2t += red_gd[q]; }   // fixed order
+      lm.step2 = s2;
+      lm.cand_xnorm2 = x2t;
     }
   }
   // ---- knot-pair constants of the candidate (shared by all residual blocks of the linearisation that follows)
-  for (int t = tid; t < m.K - 1; t += 256) {
+  for (int t = tid; t < m.K - 1; t += NT) {
     const int gk = m.knot0 + t;
     knot_pair_const<T>(d.cquat + 4 * gk, d.cquat + 4 * gk + 4, d.lkd + 3 * gk, d.kjri + 9 * gk);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ update
-// Accepted candidates become the current state (the whole state is one contiguous array: quat | pos | bias | rho | ld).
-template <class T> __global__ void k_accept(Dev<T> d) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < d.Ktot) {
-    if (!d.lm[d.knot_win[t]].accept) return;
-    for (int c = 0; c < 4; ++c) d.quat[4 * t + c] = d.cquat[4 * t + c];
-    for (int c = 0; c < 3; ++c) d.pos[3 * t + c] = d.cpos[3 * t + c];
-  } else if (t < d.Ktot + d.Ftot) {
-    const int f = t - d.Ktot;
-    if (!d.lm[d.bias_win[f]].accept) return;
-    for (int c = 0; c < 6; ++c) d.bias[6 * f + c] = d.cbias[6 * f + c];
-  } else if (t < d.Ktot + d.Ftot + d.Ltot) {
-    const int l = t - d.Ktot - d.Ftot;
-    if (d.lm[d.lm_win[l]].accept) d.rho[l] = d.crho[l];
-  } else if (t < d.Ktot + d.Ftot + d.Ltot + d.nwin) {
-    const int w = t - d.Ktot - d.Ftot - d.Ltot;
-    if (d.lm[w].accept) d.ld[w] = d.cld[w];
-  }
-}
-
 // 4-DoF gauge restore after a solve (reference TrajectoryManager::double2vector, trajectory_manager.cpp:485-516): one rigid
 // transform puts the yaw and the position of knot `knot[w]` back to their pre-solve values (q0, t0) and is applied to
 // knots knot..K-1.  One workgroup per requested window; all fp64.  Utility::R2ypr / ypr2R: visual_odometry/utility.h:74-113.

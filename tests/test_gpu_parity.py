@@ -81,11 +81,12 @@ def test_solve_fp64_reproduces_oracle_iterates(cv, oracle):
 N_SEEDS = 32
 
 
-@pytest.mark.parametrize("cfg", ["config1", "config2", "config3"])
+@pytest.mark.parametrize("cfg", ["config1", "config2", "config3", "tumrs"])
 def test_product_parity_every_window(cv, oracle, cfg):
     """BASELINE target: final state within 1e-4 (relative) of the fp64 reference solve with identical Ceres settings (15
     iterations, function tolerance 1e-6, projected line search) on EVERY window -- 32 seeds per config, solved as one batch
-    by the product path (all-fp64 HIP).  The same restated solver runs on both sides, so the device must reproduce the
+    by the product path (all-fp64 HIP); "tumrs" is the reference's native operating point (200 Hz IMU: 10 samples per group; <= 150
+    features per frame).  The same restated solver runs on both sides, so the device must reproduce the
     reference's decisions: iteration count, successful / unsuccessful steps and line-search steps are compared exactly; the
     contract bound is 1e-4, the engineering bound asserted on top of it is 1e-6 (measured ~1e-9)."""
     ws = [cv.synth.make_window(cfg, seed=1000 + i) for i in range(N_SEEDS)]

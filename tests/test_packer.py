@@ -94,3 +94,23 @@ def test_cpp_packer_matches_python(tmp_path):
     np.testing.assert_allclose(v_pi[:V], ref["v_pi"], rtol=1e-15); np.testing.assert_allclose(v_pj[:V], ref["v_pj"], rtol=1e-15)
     np.testing.assert_allclose(rho[:n_lm.value], ref["rho"], rtol=1e-15)
     assert np.array_equal(owner[:n_lm.value], ref["track_of_landmark"])
+
+
+def test_native_tumrs_window_shape(cv):
+    """synth "tumrs" = the reference's own operating point (config/tumrs/cam_tumrs.yaml:23-25, config/ct_odometry_tumrs.yaml:13,
+    parameters.h:8): 11 frames at 10 Hz, 200 Hz IMU (10 samples per (segment, bias) group), at most 150 features in any frame."""
+    w = cv.synth.make_window("tumrs", seed=1000)
+    assert (w.F, w.M, w.K) == (11, 200, 24)
+    assert np.all(np.diff(w.imu_t) == 5_000_000)
+    groups = {}
+    for s_, b in zip(w.imu_t // w.dt_ns, w.imu_bias):
+        groups[(int(s_), int(b))] = groups.get((int(s_), int(b)), 0) + 1
+    assert len(groups) == 20 and set(groups.values()) == {10}
+    per = np.zeros(w.F, int)
+    for l in range(w.L):
+        sel = w.v_lm == l
+        for f in set((w.v_tj[sel] // 100_000_000).tolist()) | set((w.v_ti[sel] // 100_000_000).tolist()):
+            per[f] += 1
+    assert per.max() <= 150 and per.max() >= 120
+    n_obs = np.bincount(w.v_lm, minlength=w.L) + 1
+    assert n_obs.min() >= 2 and n_obs.max() >= 10
