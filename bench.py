@@ -57,8 +57,10 @@ def algorithmic_bytes(w, phase, fp_bytes):
     if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
         return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
     # a visual block's J~ is stored compactly: 2 r + 52 J (rotation, inverse depth, line delay) + 14 (P~, blending coefficients)
-    if phase == "k_vis_eval":        # SURVEY 8d per block: 284 B in + (r, compact J~) out; the rows of W (knot + line-delay columns), Hll, g_rho
-        return V * (284 + 68 * fp_bytes) + L * ((6 * K + 1) * fp_bytes + 16)
+    if phase == "k_vis_eval":        # what HBM must move: per block its own inputs (2 times, 2 rows, 4 observations, landmark / window index,
+        # loss width: 72 B -- the knots are shared by the window's blocks and come out of cache: counted once per window) + (r, compact
+        # J~) out; the rows of W (knot + line-delay columns), Hll, g_rho
+        return V * (72 + 68 * fp_bytes) + K * 7 * 8 + L * (8 + (6 * K + 1) * fp_bytes + 16)
     if phase == "k_assemble_vis":    # compact J~ and r~ read once (the depth column is not needed) + keys + slot list + packed fp64 Hessian flushed once
         K6 = 6 * K   # + the knot x knot part (24 x 24) of every IMU group tile, added into the same LDS Hessian
         return V * (66 * fp_bytes + 12) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
@@ -85,6 +87,48 @@ def algorithmic_flops(w, phase):
     return 0
 
 
+def structural_schur_flops(w):
+    """Products the Schur SYRK actually has: W carries no bias columns, so only the (6K + 1) knot / line-delay columns (plus the rhs
+    column that rides along) meet: (6K + 1)(6K + 2) L against SURVEY's nominal P (P + 1) L."""
+    return (6 * w.K + 1) * (6 * w.K + 2) * w.L
+
+
+def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device, with_oracle):
+    """Device-resident rate of another BASELINE config on one handle, plus the state error of nseed distinct windows against the oracle."""
+    import ctypes as C
+    import numpy as np
+    uniq = [cv.synth.make_window(config, seed=1000 + i) for i in range(max(nuniq, nseed))]
+    out = {"windows_per_launch": nwin, "distinct_windows": nuniq}
+    with cv.Solver(device=device) as sv:
+        wl = [uniq[i % nuniq].copy() for i in range(nwin)]
+        sv.set_windows(wl)
+        sv.snapshot_state()
+        sv.solve_raw(iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sv.restore_state()
+            sv.solve_raw(iters)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["solves_per_s"] = nwin * steps / dt
+        out["ms_per_launch"] = 1e3 * dt / steps
+        if with_oracle:
+            import pyctvo
+            batch = [uniq[i].copy() for i in range(nseed)]
+            sv.set_windows(batch)
+            sms = sv.solve(iters)
+            errs = []
+            for i in range(nseed):
+                ref = uniq[i].copy()
+                so = pyctvo.OracleWindow(ref).solve(iters)
+                assert sms[i]["iterations"] == so.iterations, (config, i, sms[i], so.iterations)
+                errs.append(cv.rel_state_error(batch[i], ref)["state"])
+            out["max_rel_state_err"] = float(max(errs))
+            out["parity_windows"] = nseed
+    return out
+
+
 def respawn_under_torchrun(args):
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -109,6 +153,7 @@ def main():
     ap.add_argument("--gpu-slots", type=int, default=0, help="handles allowed inside ctvio_solve at once (0: half of the streams, at least 1)")
     ap.add_argument("--host-threads", type=int, default=0, help="packing threads per handle (0: cores / streams, at most 16)")
     ap.add_argument("--device-resident-only", action="store_true", help="time the device-resident solve instead (diagnostics)")
+    ap.add_argument("--quick", action="store_true", help="skip the side measurements (single window, configs 3 / 5, tumrs, 8-rank host share)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -296,12 +341,61 @@ def main():
         out["roofline"] = kernel_line(dom)
         out["roofline"]["measured"] = "HIP events on the solver's stream around every launch, other handles idle"
         out["roofline_kernels"] = [kernel_line(i) for i in sorted(range(6), key=lambda i: -ms[i]) if n[i] > 0 and names[i] in kmap]
-        fl = w_ref.P * (w_ref.P + 1) * w_ref.L * per[0]      # SYRK count
+        fl = w_ref.P * (w_ref.P + 1) * w_ref.L * per[0]      # nominal SYRK count
+        fls = sum(structural_schur_flops(w) for w in wl0)    # the products W actually has (no bias columns)
         avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
-        out["roofline_mfma"] = {"kernel": kmap["k_schur_mfma"], "bound": "mfma", "achieved": fl / avg_schur / 1e12, "peak": pk,
-                                "unit": "TFLOP/s", "frac": fl / avg_schur / 1e12 / pk, "avg_launch_us": 1e6 * avg_schur, "flops_per_launch": fl}
+        out["roofline_mfma"] = {"kernel": kmap["k_schur_mfma"], "bound": "mfma", "achieved": fls / avg_schur / 1e12, "peak": pk,
+                                "unit": "TFLOP/s", "frac": fls / avg_schur / 1e12 / pk, "avg_launch_us": 1e6 * avg_schur,
+                                "flops_per_launch": fls, "flop_count": "structural: (6K + 1)(6K + 2) L (W has no bias columns)",
+                                "nominal_flops_per_launch": fl, "nominal_frac": fl / avg_schur / 1e12 / pk}
         out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}   # handle 0 only
         # ---- parity of what was timed + CPU baseline: the oracle solves a sample of the same windows on one host core
+        # ---- the reference's operating mode: ONE window per solve (one UpdateTrajectory per image, odometry_manager.cpp:268-277)
+        if world == 1 and not args.quick and not resident_headline:
+            with cv.Solver(device=local, host_threads=1) as s1:
+                w1 = uniq[0].copy()
+                keep1 = []
+                c1 = (cv.capi.CWindow * 1)()
+                c1[0] = cv.capi.to_cwindow(w1, keep1)
+                o1 = (np.zeros((w1.K, 4)), np.zeros((w1.K, 3)), np.zeros((w1.F, 6)), np.zeros(max(w1.L, 1)), np.zeros(1))
+
+                def one():
+                    cv.capi.check(lib.ctvio_set_batch(s1._h, 1, C.cast(c1, C.c_void_p)))
+                    cv.capi.check(lib.ctvio_solve(s1._h, args.iters, None))
+                    cv.capi.check(lib.ctvio_get_batch_state(s1._h, *[cv.capi._p(a) for a in o1]))
+                for _ in range(3):
+                    one()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    one()
+                torch.cuda.synchronize()
+                out["single_window_ms"] = 1e3 * (time.perf_counter() - t0) / 40
+                cv.capi.check(lib.ctvio_set_batch(s1._h, 1, C.cast(c1, C.c_void_p)))   # back to the initial guess
+                s1.snapshot_state()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    s1.restore_state()
+                    s1.solve_raw(args.iters)
+                torch.cuda.synchronize()
+                out["single_window_device_resident_ms"] = 1e3 * (time.perf_counter() - t0) / 40
+            ora = not args.no_cpu_baseline
+            out["config3"] = side_config(cv, lib, torch, "config3", 1024, 16, args.iters, 2, 8, local, ora)
+            out["config5"] = side_config(cv, lib, torch, "config5", 128, 8, args.iters, 2, 8, local, ora)
+            out["tumrs"] = side_config(cv, lib, torch, "tumrs", 2048, 16, args.iters, 2, 8, local, ora)
+            wt = cv.synth.make_window("tumrs", seed=1000)
+            out["tumrs"]["imu_lane_utilisation"] = wt.M / (64.0 * imu_groups(wt))   # one 64-lane pass per (segment, bias) group
+            # ---- what an 8-rank run leaves one rank on the host: pack threads = cores / (streams x 8)
+            ht8 = max(1, (os.cpu_count() or 8) // (nstream * 8))
+            for sv in solvers:
+                sv.close()
+            solvers.clear()
+            for si in range(nstream):
+                solvers.append(cv.Solver(device=local, precision=args.precision, host_threads=ht8))
+            steps(1)
+            t8 = timed(3, False)
+            out["host_share_of_an_8_rank_run"] = {"pack_threads_per_stream": ht8, "end_to_end_solves_per_s": args.windows * 3 / t8,
+                                                  "end_to_end_over_device_resident": args.windows * 3 / t8 / out["device_resident_solves_per_s"]}
         out["parity"] = None
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the scaling runs must not wait on a CPU loop

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -1201,6 +1203,75 @@ int32_t ctvio_sensor_pose(ctvio_solver *s, int32_t id, int32_t n, const int64_t 
   if (!q_SI || !p_SI || (n && !pose7)) return ctv::fail(CTVIO_ERR_INVALID, "ctvio_sensor_pose: null argument");
   return s->impl->spline_eval(id, n, t_ns, pose7, nullptr, nullptr, nullptr, q_SI, p_SI);
 }
+// ---- multi-device host entry: w mod G, one host thread + solver handle per device
+int32_t ctvio_shard_of(int32_t window_id, int32_t n_devices) { return n_devices > 0 ? window_id % n_devices : 0; }
+int32_t ctvio_shard_count(int32_t n, int32_t device, int32_t n_devices) {
+  if (n_devices <= 0 || device < 0 || device >= n_devices || n <= 0) return 0;
+  return n / n_devices + (device < n % n_devices ? 1 : 0);
+}
+namespace {
+std::mutex g_shard_mu;
+std::vector<ctvio_solver *> g_shard_solvers;   // one per device ordinal, created on first use
+}
+void ctvio_sharded_release(void) {
+  std::lock_guard<std::mutex> lk(g_shard_mu);
+  for (auto *sv : g_shard_solvers) ctvio_destroy(sv);
+  g_shard_solvers.clear();
+}
+int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t n, const ctvio_window *wins, int32_t max_iterations,
+                            ctvio_summary *out, double *quat, double *pos, double *bias, double *rho, double *ld) {
+  if (n <= 0 || !wins) return ctv::fail(CTVIO_ERR_INVALID, "empty batch");
+  const int ndev = ctvio_device_count();
+  if (ndev <= 0) return ctv::fail(CTVIO_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+  const int G = std::min(n_devices > 0 ? std::min(n_devices, ndev) : ndev, n);
+  std::lock_guard<std::mutex> lk(g_shard_mu);   // one sharded solve at a time per process (the handles are shared)
+  if ((int)g_shard_solvers.size() < G) g_shard_solvers.resize((size_t)G, nullptr);
+  // offsets of every window in the caller's concatenated state arrays
+  std::vector<size_t> k0((size_t)n + 1, 0), f0((size_t)n + 1, 0), l0((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) { k0[i + 1] = k0[i] + (size_t)std::max(wins[i].K, 0); f0[i + 1] = f0[i] + (size_t)std::max(wins[i].F, 0); l0[i + 1] = l0[i] + (size_t)std::max(wins[i].L, 0); }
+  std::vector<int> rcs((size_t)G, CTVIO_OK);
+  std::vector<std::string> errs((size_t)G);
+  auto work = [&](int g) {
+    auto failed = [&](int rc) { rcs[g] = rc; errs[g] = "device " + std::to_string(g) + ": " + ctvio_last_error(); };   // (thread-local error text)
+    if (!g_shard_solvers[g]) {
+      ctvio_options o;
+      if (opt) o = *opt; else ctvio_default_options(&o);
+      o.device = g;
+      if (const int rc = ctvio_create(&o, &g_shard_solvers[g])) return failed(rc);
+    }
+    ctvio_solver *sv = g_shard_solvers[g];
+    std::vector<ctvio_window> mine;
+    std::vector<int> ids;
+    for (int i = g; i < n; i += G) { mine.push_back(wins[i]); ids.push_back(i); }
+    const int nm = (int)mine.size();
+    if (const int rc = ctvio_set_batch(sv, nm, mine.data())) return failed(rc);
+    std::vector<ctvio_summary> sm((size_t)nm);
+    if (const int rc = ctvio_solve(sv, max_iterations, sm.data())) return failed(rc);
+    size_t K = 0, F = 0, L = 0;
+    for (const auto &w : mine) { K += w.K; F += w.F; L += w.L; }
+    std::vector<double> q(4 * K), p(3 * K), b(6 * F), r(std::max<size_t>(L, 1)), l((size_t)nm);
+    if (const int rc = ctvio_get_batch_state(sv, q.data(), p.data(), b.data(), r.data(), l.data())) return failed(rc);
+    size_t ka = 0, fa = 0, la = 0;
+    for (int j = 0; j < nm; ++j) {
+      const int i = ids[j];
+      const ctvio_window &w = mine[j];
+      if (out) out[i] = sm[j];
+      if (quat) std::memcpy(quat + 4 * k0[i], q.data() + 4 * ka, sizeof(double) * 4 * w.K);
+      if (pos) std::memcpy(pos + 3 * k0[i], p.data() + 3 * ka, sizeof(double) * 3 * w.K);
+      if (bias) std::memcpy(bias + 6 * f0[i], b.data() + 6 * fa, sizeof(double) * 6 * w.F);
+      if (rho && w.L) std::memcpy(rho + l0[i], r.data() + la, sizeof(double) * w.L);
+      if (ld) ld[i] = l[j];
+      ka += w.K; fa += w.F; la += w.L;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+  work(0);
+  for (auto &t : th) t.join();
+  for (int g = 0; g < G; ++g) if (rcs[g] != CTVIO_OK) return ctv::fail(rcs[g], errs[g]);
+  return CTVIO_OK;
+}
+
 int32_t ctvio_last_timing(ctvio_solver *s, double *ms8, int32_t *launches8) { CHK_S; return s->impl->last_timing(ms8, launches8); }
 int32_t ctvio_snapshot_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(0); }
 int32_t ctvio_restore_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(1); }

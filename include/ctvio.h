@@ -211,6 +211,20 @@ int32_t ctvio_marginalize_batch(ctvio_solver *s, const int8_t *role, double eps,
  * knot[i] = computeTIndexNs(timestamps[0]).second - index of the window's first knot (reference :324-329). */
 int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0);
 
+/* ---- every GPU of the node from one C / C++ process (windows are independent units; device g owns the windows
+ * {w : w mod G = g}, one host thread + one solver handle / HIP stream per device, no inter-GPU traffic during the solves) ----
+ * ctvio_solve_sharded: ctvio_set_batch + ctvio_solve + ctvio_get_batch_state of the n windows spread over n_devices devices
+ * (0: all visible ones; device ordinals 0 .. n_devices - 1; opt->device is ignored).  out (n summaries) and the state arrays are in
+ * the caller's WINDOW order, laid out like ctvio_get_batch_state (quat: sum K x 4, pos: sum K x 3, bias: sum F x 6, rho: sum L,
+ * ld: n); any of them may be NULL.  The per-device handles are created on first use and kept for the next call (grow-only
+ * arenas); ctvio_sharded_release frees them.  Python ranks use torch.distributed + ctrl-vio_amd/sharding.py for the same rule. */
+int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t n, const ctvio_window *wins, int32_t max_iterations,
+                            ctvio_summary *out, double *quat, double *pos, double *bias, double *rho, double *ld);
+void ctvio_sharded_release(void);
+/* The partition itself (no device needed): owner of window w, and how many of n windows device g gets. */
+int32_t ctvio_shard_of(int32_t window_id, int32_t n_devices);
+int32_t ctvio_shard_count(int32_t n, int32_t device, int32_t n_devices);
+
 /* Kernel timing of the next ctvio_solve calls with HIP events recorded on the solver's stream around every
  * launch group (adds a few microseconds per launch: use a dedicated profiling solve, not the timed one). */
 int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on);

@@ -45,7 +45,36 @@ def corrected_normal(w):
     return J.T @ J, J.T @ rs, float(cost), J, n_imu, n_vis
 
 
+LM_CASES = (("lm_tiny_seed7", "tiny", 7, {}),                                   # no step is shortened
+            ("lm_tiny_rs_seed3020", "tiny", 3020, dict(img_h=640, ld_true=3.0e-5)),   # rolling-shutter stress: 4 steps shortened by the line search
+            ("lm_tiny_rs_seed3028", "tiny", 3028, dict(img_h=640, ld_true=3.0e-5)),   # 12 shortened steps and one unsuccessful step
+            ("lm_config1_seed1001", "config1", 1001, {}))
+
+
+def lm_fixtures():
+    """(d) per-iteration history of the INDEPENDENT NumPy restatement of Ceres 1.14's trust-region loop + projected Armijo line search
+    (oracle/np_ceres.py: FD Jacobians, numpy.linalg / numpy.roots): accept / reject sequence, costs, radii, step sizes."""
+    import np_ceres
+    import pyctvo
+    for name, cfg, seed, kw in LM_CASES:
+        w0 = cv.synth.make_window(cfg, seed=seed, **kw)
+        active = pyctvo.OracleWindow(w0.copy()).active_mask()   # structure only (which unknowns are referenced and not constant)
+        wf, h = np_ceres.solve(w0, active, 15)
+        d = w0.to_dict("w_")
+        d.update(wf.to_dict("f_"))
+        d.update(hist_cost=np.array(h["cost"]), hist_accepted=np.array(h["accepted"], np.int8), hist_radius=np.array(h["radius"]),
+                 hist_alpha=np.array(h["alpha"]), hist_ls_iters=np.array(h["ls_iters"], np.int32), iterations=h["iterations"],
+                 termination=h["termination"], num_successful=h["num_successful"], num_unsuccessful=h["num_unsuccessful"],
+                 num_line_search_steps=h["num_line_search_steps"], num_line_search_reduced=h["num_line_search_reduced"],
+                 final_cost=h["final_cost"], final_radius=h["final_radius"])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        print(name, {k: h[k] for k in ("iterations", "termination", "num_successful", "num_unsuccessful", "num_line_search_steps",
+                                       "num_line_search_reduced", "final_cost", "final_radius")})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "lm":
+        return lm_fixtures()
     # ---- (a) tiny window: per-block residuals, FD Jacobians, dense H/g/cost at x0
     w = cv.synth.make_window("tiny", seed=7)
     w.ld = 13000.5e-9          # half-ns margin: int64(ld*1e9) is unambiguous
@@ -83,6 +112,7 @@ def main():
         d3.update(final_cost=npo.cost(wf), nfev=res.nfev, status=res.status)
         np.savez_compressed(os.path.join(OUT, f"{cfg}_seed{seed}_converged.npz"), **d3)
         print(cfg, "scipy cost", d3["final_cost"], "status", res.status, res.message, "nfev", res.nfev)
+    lm_fixtures()
 
 
 def solve_with_fd(w0, active):

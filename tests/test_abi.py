@@ -68,3 +68,23 @@ def test_adaptor_header_compiles_standalone():
     src = open(os.path.join(root, "include", "ctvio.h")).read()
     includes = re.findall(r"#\s*include\s*[<\"]([^>\"]+)[>\"]", src)
     assert all(not inc.startswith(("hip", "torch", "ATen", "c10")) for inc in includes), includes
+
+
+def test_cxx_shard_partition_matches_the_python_rule(cv):
+    """ctvio_shard_of / ctvio_shard_count (the partition behind ctvio_solve_sharded: window w -> device w mod G) against
+    ctrl-vio_amd/sharding.shard -- no device, no process group needed."""
+    lib = cv.capi.load_library()
+    for n in (1, 7, 64, 65):
+        for G in (1, 2, 3, 8):
+            owners = [lib.ctvio_shard_of(w, G) for w in range(n)]
+            for g in range(G):
+                mine = [w for w in range(n) if owners[w] == g]
+                assert mine == list(cv.sharding.shard(n, g, G))
+                assert lib.ctvio_shard_count(n, g, G) == len(mine)
+            assert sum(lib.ctvio_shard_count(n, g, G) for g in range(G)) == n
+    if lib.ctvio_device_count() <= 0:     # without a GPU the sharded entry fails loudly like every other one
+        w = cv.synth.make_window("tiny", seed=1)
+        keep = []
+        arr = (cv.capi.CWindow * 1)()
+        arr[0] = cv.capi.to_cwindow(w, keep)
+        assert lib.ctvio_solve_sharded(None, 0, 1, C.cast(arr, C.c_void_p), 5, None, None, None, None, None, None) == 2

@@ -554,3 +554,56 @@ def test_per_block_cauchy_and_non_prefix_constant_knots(cv, oracle):
     assert cv.rel_state_error(wg, wo)["state"] < 1e-6
     np.testing.assert_array_equal(wg.quat[[0, 1, 5, 9]], w0.quat[[0, 1, 5, 9]])
     np.testing.assert_array_equal(wg.pos[[0, 1, 5, 9]], w0.pos[[0, 1, 5, 9]])
+
+
+@pytest.mark.parametrize("name", ["lm_tiny_seed7", "lm_tiny_rs_seed3020", "lm_tiny_rs_seed3028", "lm_config1_seed1001"])
+def test_hip_path_reproduces_the_independent_lm_history(cv, golden_dir, name):
+    """The device-resident LM (trust region + projected Armijo line search, speculative linearisation) against the committed
+    per-iteration fixtures of the independent NumPy restatement of Ceres 1.14's loop (oracle/np_ceres.py, FD Jacobians): the same
+    iteration count, accept / reject counts, line-search step counts and termination; cost, radius and state to the fixture's
+    finite-difference accuracy."""
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    w = cv.Window.from_dict(d, "w_")
+    wf = cv.Window.from_dict(d, "f_")
+    term = {"NO_CONVERGENCE": "max-iterations", "CONVERGENCE_GRADIENT": "gradient-tolerance", "CONVERGENCE_PARAMETER": "parameter-tolerance",
+            "CONVERGENCE_FUNCTION": "function-tolerance", "CONVERGENCE_RADIUS": "min-radius", "FAILURE": "failure"}[str(d["termination"])]
+    with cv.Solver() as s:
+        s.set_windows([w])
+        sm = s.solve(15)[0]
+    assert sm["iterations"] == int(d["iterations"]) and sm["termination"] == term
+    assert (sm["num_successful"], sm["num_unsuccessful"]) == (int(d["num_successful"]), int(d["num_unsuccessful"]))
+    assert (sm["num_line_search_steps"], sm["num_line_search_reduced"]) == (int(d["num_line_search_steps"]), int(d["num_line_search_reduced"]))
+    assert sm["final_cost"] == pytest.approx(float(d["final_cost"]), rel=1e-5)
+    assert sm["final_radius"] == pytest.approx(float(d["final_radius"]), rel=1e-2)
+    assert cv.rel_state_error(w, wf)["state"] < 2e-5
+
+
+def test_cxx_sharded_entry_on_the_visible_devices(cv):
+    """ctvio_solve_sharded (one host thread + solver handle per device, window w -> device w mod G): a ragged batch through it equals
+    the same batch through one handle, window by window, in the caller's order (one device on the test box: G = 1; asking for more
+    devices than exist is clamped)."""
+    import ctypes as C
+    lib = cv.capi.load_library()
+    ws = [cv.synth.make_window("config1", seed=1000 + i) for i in range(3)] + [cv.synth.make_window("tiny", seed=5), cv.synth.make_window("config2", seed=1003)]
+    with cv.Solver() as s:
+        ref = [w.copy() for w in ws]
+        s.set_windows(ref)
+        sms = s.solve(15)
+    keep = []
+    arr = (cv.capi.CWindow * len(ws))()
+    for i, w in enumerate(ws):
+        arr[i] = cv.capi.to_cwindow(w, keep)
+    K = sum(w.K for w in ws); F = sum(w.F for w in ws); L = sum(w.L for w in ws)
+    q = np.zeros((K, 4)); p = np.zeros((K, 3)); b = np.zeros((F, 6)); r = np.zeros(L); ld = np.zeros(len(ws))
+    sm = (cv.capi.Summary * len(ws))()
+    for ndev in (0, 1, 8):
+        cv.capi.check(lib.ctvio_solve_sharded(None, ndev, len(ws), C.cast(arr, C.c_void_p), 15, C.cast(sm, C.c_void_p),
+                                              cv.capi._p(q), cv.capi._p(p), cv.capi._p(b), cv.capi._p(r), cv.capi._p(ld)))
+        k = f = l = 0
+        for i, w in enumerate(ref):
+            assert sm[i].iterations == sms[i]["iterations"] and sm[i].final_cost == pytest.approx(sms[i]["final_cost"], rel=1e-10)
+            got = ws[i].copy()
+            got.quat, got.pos, got.bias, got.rho, got.ld = q[k:k + w.K], p[k:k + w.K], b[f:f + w.F], r[l:l + w.L], float(ld[i])
+            assert cv.rel_state_error(got, w)["state"] < 1e-7, i
+            k += w.K; f += w.F; l += w.L
+    lib.ctvio_sharded_release()
