@@ -140,6 +140,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -264,6 +266,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_pJ0 = seg(8 * (size_t)pH0), o_pr0 = seg(8 * (size_t)pv0);
     const size_t o_pH = seg(8 * (size_t)pH0), o_pb0 = seg(8 * (size_t)pv0), o_pc0 = seg(8 * (size_t)nw), o_p_x0 = seg(8 * 4 * (size_t)pb);
     const size_t o_pcol = seg(4 * (size_t)pv0), o_p_kind = seg(4 * (size_t)pb), o_p_index = seg(4 * (size_t)pb), o_p_off = seg(4 * (size_t)pb);
+    const size_t o_pinv = seg(4 * (size_t)Pp0), o_bgl_off = seg(4 * ((size_t)F0 + nw)), o_bgl = seg(4 * (size_t)std::max(G0, 1));
     const size_t o_active = seg((size_t)U0);
     const size_t in_bytes = off;
     bool grew = false;
@@ -290,6 +293,7 @@ template <class T> class SolverImpl : public SolverBase {
            *h_p_x0 = CTV_H(double, o_p_x0);
     int32_t *h_pcol = CTV_H(int32_t, o_pcol), *h_p_kind = CTV_H(int32_t, o_p_kind), *h_p_index = CTV_H(int32_t, o_p_index), *h_p_off = CTV_H(int32_t, o_p_off);
     uint8_t *h_active = CTV_H(uint8_t, o_active);
+    int32_t *h_pinv = CTV_H(int32_t, o_pinv), *h_bgl_off = CTV_H(int32_t, o_bgl_off), *h_bgl = CTV_H(int32_t, o_bgl);
     // ---- second pass: every window fills its own slices
     parallel_for(nw, nth, [&](int wi) {
       const ctvio_window &w = *wins[wi];
@@ -387,6 +391,18 @@ template <class T> class SolverImpl : public SolverBase {
         std::memcpy(h_p_off + m.pblk0, w.p_off, 4 * (size_t)w.pnb); std::memcpy(h_p_x0 + (size_t)4 * m.pblk0, w.p_x0, 8 * 4 * (size_t)w.pnb);
       }
       active_mask(&w, t, m.P, col, h_active + m.u0);
+      // inverse column map of the prior, and the IMU groups of every bias state (group order) -- read by the store-semantics assembly
+      std::fill(h_pinv + m.p0, h_pinv + m.p0 + m.P, -1);
+      for (int i = 0; i < n; ++i) h_pinv[m.p0 + col[i]] = i;
+      {
+        int32_t *off = h_bgl_off + m.bias0 + wi;
+        std::fill(off, off + w.F + 1, 0);
+        for (int gi = 0; gi < m.ngrp; ++gi) off[h_groups[m.grp0 + gi].bias + 1]++;
+        for (int f = 0; f < w.F; ++f) off[f + 1] += off[f];
+        std::vector<int32_t> fill(off, off + w.F);
+        for (int gi = 0; gi < m.ngrp; ++gi) h_bgl[m.grp0 + fill[h_groups[m.grp0 + gi].bias]++] = m.grp0 + gi;
+        for (int f = 0; f <= w.F; ++f) off[f] += m.grp0;   // absolute positions in bgl
+      }
     });
     // ---- device pointers of the input arena
     Dev<T> &d = dev_;
@@ -406,10 +422,15 @@ template <class T> class SolverImpl : public SolverBase {
     d.pH = CTV_D(double, o_pH); d.pb0 = CTV_D(double, o_pb0); d.pc0 = CTV_D(double, o_pc0); d.p_x0 = CTV_D(double, o_p_x0);
     d.pcol = CTV_D(int32_t, o_pcol); d.p_kind = CTV_D(int32_t, o_p_kind); d.p_index = CTV_D(int32_t, o_p_index); d.p_off = CTV_D(int32_t, o_p_off);
     d.active = CTV_D(uint8_t, o_active);
+    d.pinv = CTV_D(int32_t, o_pinv); d.bgl_off = CTV_D(int32_t, o_bgl_off); d.bgl = CTV_D(int32_t, o_bgl);
 #undef CTV_H
 #undef CTV_D
     HIPCHK(hipMemcpyAsync(in_.dev, in_.host, in_bytes, hipMemcpyHostToDevice, stream_));
     in_bytes_ = in_bytes;
+    any_vis_lds_ = any_vis_glb_ = false;
+    for (const auto &mm : meta_) { if (mm.vis_lds) any_vis_lds_ = true; else if (mm.V > 0) any_vis_glb_ = true; }
+    deterministic_ = opt_.deterministic > 0 || (opt_.deterministic < 0 && nw <= 64);
+    maxK_ = maxK;
     // ---- work arena (device only)
     state_doubles_ = (size_t)7 * K0 + 6 * F0 + L0 + nw;
     off = 0;
@@ -417,6 +438,10 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
     const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
     const size_t o_imu_cost = seg(8 * (size_t)std::max(G0, 1)), o_vis_cost = seg(8 * ((Vt + 63) / 64)), o_misc_cost = seg(8 * (size_t)nw);
+    // packed partial Hessians of the multi-part store-semantics assembly (knot triangle + line-delay row + gradient per part)
+    const size_t part_stride = ((size_t)6 * maxK * (6 * maxK + 1) / 2 + 2 * (6 * (size_t)maxK + 1) + 7) & ~(size_t)7;
+    const int nparts_alloc = store_path() ? vis_parts() : 1;
+    const size_t o_pgrad = seg(8 * (size_t)std::max(pv0, 1)), o_Hpart = seg(nparts_alloc > 1 ? 8 * part_stride * nparts_alloc * (size_t)nw : 8);
     const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt);
     // two normal-equation sets (current linearisation / speculative linearisation at the candidate, Lm::cur)
     const size_t o_Hpp = seg(8 * (size_t)H0), o_Hpp1 = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
@@ -437,6 +462,7 @@ template <class T> class SolverImpl : public SolverBase {
     snap_ = CTV_W(double, o_snap);
     d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
     d.imu_cost = CTV_W(double, o_imu_cost); d.vis_cost = CTV_W(double, o_vis_cost); d.misc_cost = CTV_W(double, o_misc_cost);
+    d.pgrad = CTV_W(double, o_pgrad); d.Hpart = CTV_W(double, o_Hpart); d.npart_stride = (int32_t)part_stride;
     d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs);
     d.HppS[0] = CTV_W(double, o_Hpp); d.HppS[1] = CTV_W(double, o_Hpp1); d.S = CTV_W(double, o_S);
     d.WS[0] = CTV_W(T, o_W); d.WS[1] = CTV_W(T, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
@@ -454,8 +480,6 @@ template <class T> class SolverImpl : public SolverBase {
     }
     chol_lds_ = chol_lds;
     snap_valid_ = false;
-    any_vis_lds_ = any_vis_glb_ = false;
-    for (const auto &mm : meta_) { if (mm.vis_lds) any_vis_lds_ = true; else if (mm.V > 0) any_vis_glb_ = true; }
     vis_lds_ = vis_lds_bytes;
     vis_glb_ = vis_glb_bytes;
     uploaded_ = true;
@@ -464,7 +488,21 @@ template <class T> class SolverImpl : public SolverBase {
 
   // ---------------------------------------------------------------------------------------- launches
   static int nblk(long long n, int b) { return (int)std::max<long long>((n + b - 1) / b, 1); }
-  int vis_parts() const { return std::min(8, std::max(1, 256 / std::max(dev_.nwin, 1))); }
+  // Workgroups per window of the visual assembly: batches smaller than the chip split a window's items over several parts.  In the
+  // deterministic mode a part is ONE wave (its LDS additions happen in program order) and there are more of them.
+  int vis_parts() const {
+    const int nw = std::max((int)meta_.size(), 1);
+    if (store_path()) return std::min(32, std::max(1, 512 / nw));
+    return std::min(8, std::max(1, 256 / nw));
+  }
+  // Store-semantics assembly tail (kernels.hpp: bias_rows_store; every entry written once, no atomics): the deterministic mode, when
+  // every window's packed Hessian is LDS resident.  (CTVIO_STORE_PATH=1 forces it for the throughput mode too: measured slower there,
+  // the bias-row gather costs more than the zeroing + atomic passes it replaces -- 14.5 vs 13.4 ms per 2048-window solve.)
+  bool store_path() const {
+    if (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_) return false;
+    if (const char *e = std::getenv("CTVIO_STORE_PATH")) return e[0] == '1';
+    return deterministic_;
+  }
   void set_params(int max_iters) {
     LmParams &p = dev_.prm;
     p.ftol = opt_.function_tolerance; p.gtol = opt_.gradient_tolerance; p.ptol = opt_.parameter_tolerance;
@@ -504,7 +542,8 @@ template <class T> class SolverImpl : public SolverBase {
     const int nw = d.nwin;
     constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
-    hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode);
+    if (!store_path()) hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode);
+    else hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
     ph_end();
     ph_begin(PH_IMU_LIN);
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
@@ -517,16 +556,26 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_assemble(int mode) {
     const Dev<T> &d = dev_;
     const int nw = d.nwin;
-    ph_begin(PH_ASM_VIS);
-    {  // few windows: split each window's items over several workgroups to fill the chip
-      const int parts = vis_parts();
-      if (any_vis_lds_) launch_assemble_vis_lds(parts, mode);
-      if (any_vis_glb_) launch_assemble_vis_glb(parts, mode);
+    const int parts = vis_parts();   // few windows: split each window's items over several workgroups to fill the chip
+    if (store_path()) {
+      // every entry of Hpp / g is written once, completely, with a plain store: no zeroing pass, no k_assemble_imu, no atomics
+      ph_begin(PH_ASM_VIS);
+      launch_assemble_vis_store(parts, mode);
+      if (parts > 1) hipLaunchKernelGGL((k_reduce_finalize<T>), dim3(deterministic_ ? 48 : 24, nw), dim3(256), 0, stream_, d, mode, parts);
+      else hipLaunchKernelGGL((k_bias_rows<T>), dim3(8, nw), dim3(256), 0, stream_, d, mode);
+      ph_end();
+      ph_begin(PH_ASM_REST);
+      hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
+      ph_end();
+      return;
     }
+    ph_begin(PH_ASM_VIS);
+    if (any_vis_lds_) launch_assemble_vis_lds(parts, mode);
+    if (any_vis_glb_) launch_assemble_vis_glb(parts, mode);
     ph_end();
     ph_begin(PH_ASM_REST);
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d, mode);
-    hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode);
+    hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0);
     hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();
   }
@@ -566,6 +615,11 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_imu_linearize(size_t vals_lds, int mode);
   void launch_assemble_vis_lds(int parts, int mode);
   void launch_assemble_vis_glb(int parts, int mode);
+  void launch_assemble_vis_store(int parts, int mode) {
+    const Dev<T> &d = dev_;
+    if (deterministic_) hipLaunchKernelGGL((k_assemble_vis_mfma<T, VCH, true, 1, true>), dim3(d.nwin, parts), dim3(64), vis_lds_, stream_, d, mode);
+    else hipLaunchKernelGGL((k_assemble_vis_mfma<T, VCH, true, 8, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
+  }
   bool schur_makes_rhs() const { return schur_rhs_done_; }
   // CTVIO_CHOL_TILES = 0 / 1 forces the choice (A/B measurements); default: batches of <= 256 windows
   int chol_tiles() const {
@@ -793,7 +847,7 @@ template <class T> class SolverImpl : public SolverBase {
     hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
     if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(T), COST_AT_X);
     if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
-    hipLaunchKernelGGL((k_misc<T>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X);
+    hipLaunchKernelGGL((k_misc<T>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0);
     hipLaunchKernelGGL((k_initial_cost<T>), dim3(d.nwin), dim3(64), 0, stream_, d, 1);
     Lm lm;
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));

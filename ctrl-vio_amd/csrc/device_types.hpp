@@ -113,6 +113,12 @@ template <class T> struct Dev {
   const double *pH, *pb0, *pc0;
   const double *pJ0, *pr0;   // the prior as given: J0 (column-major n x n at pH0) and r0 (at pv0) -- residual summary only
   const int32_t *pcol;   // [sum pn] unknown index of each prior dimension
+  const int32_t *pinv;   // [sum P] the inverse map: prior dimension of each pose unknown (-1: not in the prior)
+  double *pgrad;         // [sum pn] J0^T r0 + (J0^T J0) dx at the state being linearised (k_misc, store mode)
+  // per bias state: the IMU groups that carry it -- bgl_off [Ftot + nwin] (window w's F + 1 offsets start at bias0 + w), bgl [Gtot] group ids
+  const int32_t *bgl_off, *bgl;
+  double *Hpart;         // [nwin][parts][npart_stride] packed partial Hessians + gradients of the multi-part assembly
+  int32_t npart_stride, pad_np;
   const int32_t *p_kind, *p_index, *p_off;
   const double *p_x0;
   // normal equations, two sets (Lm::cur): linearisation at the current state / speculative linearisation at the candidate

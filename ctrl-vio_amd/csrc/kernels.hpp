@@ -223,11 +223,27 @@ template <class T> __global__ __launch_bounds__(64) void k_initial_cost(Dev<T> d
   const int w = blockIdx.x;
   Lm &lm = d.lm[w];
   if (lm.status) return;
-  const double c = window_cost_sum(d, d.wins[w], w, threadIdx.x);
-  if (threadIdx.x != 0) return;
+  const WinMeta &m = d.wins[w];
+  const int lane = threadIdx.x;
+  const double c = window_cost_sum(d, m, w, lane);
+  // |x|^2 over the ambient coordinates of the reduced program's parameter blocks (Ceres x_norm), lane-strided, fixed order
+  double x2 = 0.0;
+  const uint8_t *act = d.active + m.u0;
+  for (int k = lane; k < m.K; k += 64) {
+    const double *q = d.quat + 4 * (m.knot0 + k), *p = d.pos + 3 * (m.knot0 + k);
+    if (act[6 * k]) x2 += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    for (int cc = 0; cc < 3; ++cc) if (act[6 * k + 3 + cc]) x2 += p[cc] * p[cc];
+  }
+  for (int j = lane; j < 6 * m.F; j += 64) if (act[6 * m.K + j]) { const double b = d.bias[6 * m.bias0 + j]; x2 += b * b; }
+  for (int l = lane; l < m.L; l += 64) if (act[m.P + l]) { const double r = d.rho[m.lm0 + l]; x2 += r * r; }
+  if (lane == 0 && act[m.P - 1]) x2 += d.ld[w] * d.ld[w];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x2 += __shfl_xor(x2, off);
+  if (lane != 0) return;
   if (as_candidate) { lm.cand_cost = c; return; }   // ctvio_cost
   lm.cost = lm.initial_cost = c;
   lm.cand_cost = 0;
+  lm.xnorm2 = x2;
   lm.scaled = 1;
 }
 
@@ -1097,6 +1113,97 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 #undef CTV_STAMP
 }
 
+// ---- store-semantics tail of the assembly (product path, windows whose packed Hessian is LDS resident).  Every entry of Hpp / g is
+// formed completely by ONE thread and written with a plain store -- the knot x knot block and the line-delay row from the packed
+// (LDS or summed-partials) Hessian, the bias rows by a gather over the IMU group tiles of that bias state (fixed order), the bias
+// chain and the prior (J0^T J0 looked up through the inverse column map): no pre-zeroing pass, no floating-point atomics, and the
+// value does not depend on any execution order.  Entries no factor reaches are zeroed once at upload and never written.
+template <class T> __device__ __forceinline__ double prior_H(const Dev<T> &d, const WinMeta &m, int ga, int gb) {
+  if (m.pn <= 0) return 0.0;
+  const int pi = d.pinv[m.p0 + ga], pj = d.pinv[m.p0 + gb];
+  return (pi >= 0 && pj >= 0) ? d.pH[m.pH0 + (size_t)pi * m.pn + pj] : 0.0;
+}
+template <class T> __device__ __forceinline__ double prior_g(const Dev<T> &d, const WinMeta &m, int u) {
+  if (m.pn <= 0) return 0.0;
+  const int pi = d.pinv[m.p0 + u];
+  return pi >= 0 ? d.pgrad[m.pv0 + pi] : 0.0;
+}
+// packed index i of the knot block / line-delay row -> (row, column) unknowns
+__device__ __forceinline__ void packed_decode(int i, int tri, int K6, int P, int &ga, int &gb) {
+  if (i < tri) {
+    ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
+    ga += ((ga + 1) * (ga + 2) / 2 <= i) ? 1 : 0;      // the float estimate is off by at most one either way
+    ga -= (ga * (ga + 1) / 2 > i) ? 1 : 0;
+    gb = i - ga * (ga + 1) / 2;
+  } else {
+    ga = P - 1;
+    gb = (i - tri) < K6 ? (i - tri) : P - 1;
+  }
+}
+// Bias rows (and the bias columns of the line-delay row) of Hpp and the bias entries of g of window w: item e of [0, nitems)
+// handled by thread e of a grid-stride loop.  `bias` = the linearisation state (candidate or current).
+template <class T>
+__device__ __forceinline__ void bias_rows_store(const Dev<T> &d, const WinMeta &m, int tg, const double *bias, int first, int stride) {
+  const int K = m.K, F = m.F, P = m.P, K6 = 6 * K, ldh = m.ldh, nbr = 6 * F;
+  double *Hg = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
+  const int32_t *boff = d.bgl_off + m.bias0 + (int)(&m - d.wins);   // F + 1 offsets of this window's per-bias group lists
+  // items: rows r = K6 .. P - 2 with all columns c <= r (triangle over the bias rows, rectangle over the knot columns), then the
+  // line-delay row's bias columns, then the bias entries of g
+  const int n_rect = nbr * K6, n_tri = nbr * (nbr + 1) / 2, n_ld = nbr, n_g = nbr;
+  for (int e = first; e < n_rect + n_tri + n_ld + n_g; e += stride) {
+    if (e < n_rect + n_tri) {
+      int rb, c;   // rb: bias row index (0 .. 6F), c: column unknown
+      if (e < n_rect) { rb = e / K6; c = e - rb * K6; }
+      else {
+        const int t = e - n_rect;
+        int i2 = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        i2 += ((i2 + 1) * (i2 + 2) / 2 <= t) ? 1 : 0;
+        i2 -= (i2 * (i2 + 1) / 2 > t) ? 1 : 0;
+        rb = i2; c = K6 + t - i2 * (i2 + 1) / 2;
+      }
+      const int f = rb / 6, a = rb - 6 * f, r = K6 + rb;
+      double v = 0.0;
+      const int g0 = boff[f], g1 = boff[f + 1];
+      if (c < K6) {
+        const int k = c / 6, cc = c - 6 * k;
+        for (int q = g0; q < g1; ++q) {
+          const int gi = d.bgl[q];
+          const int sg = d.groups[gi].s;
+          if (k >= sg && k <= sg + 3) v += d.imu_tiles[(size_t)gi * 1024 + (24 + a) * 32 + (cc < 3 ? 3 * (k - sg) + cc : 12 + 3 * (k - sg) + cc - 3)];
+        }
+      } else {
+        const int cb = c - K6, f2 = cb / 6, a2 = cb - 6 * f2;
+        if (f2 == f)
+          for (int q = g0; q < g1; ++q) v += d.imu_tiles[(size_t)d.bgl[q] * 1024 + (24 + a) * 32 + 24 + a2];
+        if (a2 == a)
+          for (int b = 0; b < m.NB; ++b) {
+            const int bi = d.bc_i[m.bc0 + b], bj = d.bc_j[m.bc0 + b];
+            const double wv = d.bc_w[(size_t)(m.bc0 + b) * 6 + a];
+            if (f2 == f) { if (bi == f) v += wv * wv; if (bj == f) v += wv * wv; }
+            else if ((bi == f2 && bj == f) || (bi == f && bj == f2)) v -= wv * wv;
+          }
+      }
+      Hg[(long long)r * ldh + c] = v + prior_H(d, m, r, c);
+    } else if (e < n_rect + n_tri + n_ld) {
+      const int c = K6 + e - n_rect - n_tri;
+      Hg[(long long)(P - 1) * ldh + c] = prior_H(d, m, P - 1, c);
+    } else {
+      const int rb = e - n_rect - n_tri - n_ld, f = rb / 6, a = rb - 6 * f, r = K6 + rb;
+      double v = 0.0;
+      for (int q = boff[f]; q < boff[f + 1]; ++q) v += d.imu_tiles[(size_t)d.bgl[q] * 1024 + (24 + a) * 32 + 30];
+      for (int b = 0; b < m.NB; ++b) {
+        const int bi = d.bc_i[m.bc0 + b], bj = d.bc_j[m.bc0 + b];
+        if (bi != f && bj != f) continue;
+        const double wv = d.bc_w[(size_t)(m.bc0 + b) * 6 + a];
+        const double rr = wv * (bias[6 * (m.bias0 + bj) + a] - bias[6 * (m.bias0 + bi) + a]);
+        if (bi == f) v -= wv * rr;
+        if (bj == f) v += wv * rr;
+      }
+      g[r] = v + prior_g(d, m, r);
+    }
+  }
+}
+
 // fp32 visual assembly on the matrix cores (windows whose packed Hessian is LDS resident).  Same decomposition as
 // k_assemble_vis (items of <= CH blocks per frame pair, runs of equal knot quadruples inside an item), but
 //   * the run's [J~_pose | r~]^T [J~_pose | r~] (50 x 50, padded to 64 = 4 x 4 tiles of 16; the lower 10 tiles) is formed
@@ -1110,10 +1217,15 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
 template <class T> struct MfmaAcc;
 template <> struct MfmaAcc<double> { typedef f64x4 type; };
 __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis_mfma(Dev<T> d, int mode) {
+// NW = waves per workgroup: 8, or 1 in the deterministic mode (all LDS additions of a partial Hessian then come from one wave, in program
+// order).  STORE (LDS-resident windows of the product path): store-semantics tail -- with one part the workgroup finishes the window
+// itself (prior added on the way out, bias rows gathered); with several parts every part writes its packed partial Hessian to
+// Dev::Hpart and k_reduce_finalize sums them in part order.
+template <class T, int CH, bool LDSH, int NW = 8, bool STORE = false> __global__ __launch_bounds__(64 * NW) void k_assemble_vis_mfma(Dev<T> d, int mode) {
   constexpr bool F64 = sizeof(T) == 8;
   typedef typename MfmaAcc<T>::type acc_t;
-  constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH;
+  constexpr int CHP = CH + 2, RPP = 64 / CH, NT = 64 * NW;
+  static_assert(!STORE || LDSH, "the store-semantics tail needs the LDS-resident Hessian");
   // staged rows per item: 0..95 pose columns (row = 2 * column + residual row), 98/99 line delay, 100/101 residual, 102..115 the
   // compact position data (P~ 6 rows, cp0 4, cp1 4).  Only 66 of them come from HBM -- the 48 position rows (24..47, 72..95)
   // are rebuilt in LDS from rows 102..115, the inverse-depth rows 96/97 are not needed here.
@@ -1143,7 +1255,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
   // first NGI groups are issued before the LDS Hessian is zeroed and added right after -- at the end of the kernel they
   // were three exposed memory round trips (24 k of 243 k cycles, measured)
   constexpr int NGI = 3;
-  T tv[NGI][9];
+  T tv[NGI][9], tgv[NGI];   // tgv: the group's gradient entries of the knot rows (tile column 30), store-semantics tail only
   int gs_[NGI], gb_[NGI];
   if (LDSH) {
 #pragma unroll
@@ -1154,9 +1266,10 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       const T *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
 #pragma unroll
       for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; tv[u][q] = ngrp > 0 ? tile[(e / 24) * 32 + e % 24] : T(0); }
+      tgv[u] = (STORE && ngrp > 0) ? tile[min(lane, 23) * 32 + 30] : T(0);
     }
   }
-  for (int i = 2 * tid; i < ((nH + 3) & ~3); i += 1024) *reinterpret_cast<double2 *>(Hs + i) = double2{0.0, 0.0};
+  for (int i = 2 * tid; i < ((nH + 3) & ~3); i += 2 * NT) *reinterpret_cast<double2 *>(Hs + i) = double2{0.0, 0.0};
   __syncthreads();
   if (LDSH) {
 #pragma unroll
@@ -1168,6 +1281,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
         const int ga = imu_col(a, gs_[u], K, gb_[u]), gb = imu_col(b, gs_[u], K, gb_[u]);
         if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], (double)tv[u][q]);
       }
+      if (STORE && lane < 24) atomicAdd(&Hs[nHh + imu_col(lane, gs_[u], K, gb_[u])], (double)tgv[u]);   // (gs = Hs + nHh)
     }
   }
   T *Js = stage + wave * SROWS * CHP;
@@ -1397,39 +1511,99 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
       const int ga = imu_col(a, grp.s, K, grp.bias), gb = imu_col(b, grp.s, K, grp.bias);
       if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], (double)tv[u]);
     }
+    if (STORE && lane < 24) atomicAdd(&gs[imu_col(lane, grp.s, K, grp.bias)], (double)tile[lane * 32 + 30]);
   }
   __syncthreads();
   CTV_STAMP();
-  for (int i0 = tid; LDSH && i0 < nHh; i0 += 4 * 512) {     // 4 entries per trip: the LDS reads first, then decode + store
+  if constexpr (STORE) {
+    if (nparts > 1) {   // this part's packed Hessian + gradient: summed with the others, in part order, by k_reduce_finalize
+      double *dst = d.Hpart + ((size_t)w * nparts + part) * d.npart_stride;
+      for (int i = tid; i < nH; i += NT) dst[i] = Hs[i];
+      return;
+    }
+    double *gq = d.gS[tgset] + u0;
+    for (int i0 = tid; i0 < nHh; i0 += 4 * NT) {     // 4 entries per trip: the LDS reads first, then decode + prior + store
+      double hv4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hv4[u] = Hs[min(i0 + NT * u, nHh - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + NT * u;
+        if (i >= nHh) continue;
+        int ga, gb;
+        packed_decode(i, tri, K6, P, ga, gb);
+        Hg[(long long)ga * ldh + gb] = hv4[u] + prior_H(d, m, ga, gb);
+      }
+    }
+    for (int i = tid; i < K6 + 1; i += NT) { const int uu = i < K6 ? i : P - 1; gq[uu] = gs[i] + prior_g(d, m, uu); }
+    return;   // (the bias rows: k_bias_rows -- a gather with dependent loads wants more waves per CU than this kernel's LDS allows)
+  }
+  for (int i0 = tid; LDSH && i0 < nHh; i0 += 4 * NT) {     // 4 entries per trip: the LDS reads first, then decode + store
     double hv4[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) hv4[u] = Hs[min(i0 + 512 * u, nHh - 1)];
+    for (int u = 0; u < 4; ++u) hv4[u] = Hs[min(i0 + NT * u, nHh - 1)];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + 512 * u;
+      const int i = i0 + NT * u;
       const double hv = hv4[u];
       if (i >= nHh || (nparts > 1 && hv == 0.0)) continue;
       int ga, gb;
-      if (i < tri) {
-        ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
-        ga += ((ga + 1) * (ga + 2) / 2 <= i) ? 1 : 0;      // the float estimate is off by at most one either way
-        ga -= (ga * (ga + 1) / 2 > i) ? 1 : 0;
-        gb = i - ga * (ga + 1) / 2;
-      } else {
-        ga = P - 1;
-        gb = (i - tri) < K6 ? (i - tri) : P - 1;
-      }
+      packed_decode(i, tri, K6, P, ga, gb);
       if (nparts > 1) atomicAdd(&Hg[(long long)ga * ldh + gb], hv);
       else Hg[(long long)ga * ldh + gb] = hv;  // first writer after k_zero_normal; later kernels add atomically
     }
   }
   CTV_STAMP();
-  for (int i = tid; i < K6 + 1; i += 512) {
+  for (int i = tid; i < K6 + 1; i += NT) {
     const double gv = gs[i];
     if (gv != 0.0) atomicAdd(&d.gS[tgset][u0 + (i < K6 ? i : P - 1)], gv);
   }
   CTV_STAMP();
 #undef CTV_STAMP
+}
+
+// Bias rows of the single-part store-semantics assembly: grid (blocks, windows).
+template <class T> __global__ __launch_bounds__(256) void k_bias_rows(Dev<T> d, int mode) {
+  const int w = blockIdx.y;
+  if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
+  const WinMeta &m = d.wins[w];
+  if (!m.vis_lds) return;
+  bias_rows_store(d, m, lin_target(d.lm[w], mode), mode == LIN_SPEC ? d.cbias : d.bias, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Several parts per window (batches smaller than the chip; the deterministic mode): sum of the parts' packed Hessians in part
+// order, prior added, plain stores; the bias rows by gather.  Grid (blocks, windows).
+template <class T> __global__ __launch_bounds__(256) void k_reduce_finalize(Dev<T> d, int mode, int nparts) {
+  const int w = blockIdx.y;
+  if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
+  const WinMeta &m = d.wins[w];
+  if (!m.vis_lds) return;
+  const int tg = lin_target(d.lm[w], mode);
+  const int P = m.P, K6 = 6 * m.K, tri = K6 * (K6 + 1) / 2, nHh = tri + K6 + 1, nH = nHh + K6 + 1, ldh = m.ldh;
+  double *Hg = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
+  const double *src = d.Hpart + (size_t)w * nparts * d.npart_stride;
+  const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int i = first; i < nH; i += stride) {
+    double v = 0.0;
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {   // eight loads in flight, added in part order
+      double t8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t8[q] = src[(size_t)(p + q) * d.npart_stride + i];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += t8[q];
+    }
+    for (; p < nparts; ++p) v += src[(size_t)p * d.npart_stride + i];
+    if (i < nHh) {
+      int ga, gb;
+      packed_decode(i, tri, K6, P, ga, gb);
+      Hg[(long long)ga * ldh + gb] = v + prior_H(d, m, ga, gb);
+    } else {
+      const int uu = (i - nHh) < K6 ? (i - nHh) : P - 1;
+      g[uu] = v + prior_g(d, m, uu);
+    }
+  }
+  bias_rows_store(d, m, tg, mode == LIN_SPEC ? d.cbias : d.bias, first, stride);
 }
 
 // ------------------------------------------------------------------------------------------------ bias chain + prior
@@ -1447,12 +1621,14 @@ __device__ __forceinline__ const double *prior_block_ptr(const WinMeta &m, int k
 // BiasFactor (trajectory_value_factor.h:45-99) and MarginalizationFactor (marginalization_factor.cpp:326-373), fp64.
 // With the prior written r = r0 + J0 dx:  J^T r = J0^T r0 + (J0^T J0) dx,  |r|^2 = r0^T r0 + 2 b0.dx + dx^T (J0^T J0) dx.
 // Adds to Hpp / g of the set the mode selects (not on a cost-only pass) and stores the window's cost share (Dev::misc_cost).
+// store != 0 (store-semantics assembly tail): nothing is added here -- the prior's gradient J0^T r0 + (J0^T J0) dx goes to Dev::pgrad,
+// and the assembly looks the prior and the chain up when it writes each entry.
 template <class T>
-__global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode) {
+__global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode, int store) {
   const int w = blockIdx.x;
   const Lm &lm = d.lm[w];
   if (!lin_run(lm, mode)) return;
-  const bool LIN = !lin_cost_only(lm, mode, d.prm);
+  const bool LIN = !lin_cost_only(lm, mode, d.prm) && !store;
   const WinMeta &m = d.wins[w];
   const bool at_cand = mode == LIN_SPEC;
   const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *bias = at_cand ? d.cbias : d.bias, *ldp = at_cand ? d.cld : d.ld;
@@ -1503,6 +1679,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode) {
       double hd = 0.0;
       for (int j = 0; j < n; ++j) hd += pH[(size_t)j * n + i] * dx[j];   // (J0^T J0 is symmetric: column i, coalesced over the threads)
       cost += dx[i] * (b0[i] + 0.5 * hd);
+      if (store) d.pgrad[m.pv0 + i] = b0[i] + hd;
       if (LIN && pcol[i] >= 0) atomicAdd(&g[pcol[i]], b0[i] + hd);
     }
     if (tid == 0) cost += 0.5 * d.pc0[w];
@@ -1517,7 +1694,12 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode) {
   red[tid] = cost;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-  if (tid == 0) d.misc_cost[w] = red[0];
+  if (tid == 0) {
+    d.misc_cost[w] = red[0];
+    if (store && !lin_cost_only(lm, mode, d.prm)) {   // (the generic path resets these in k_zero_normal)
+      if (mode == LIN_SPEC) d.lm[w].cand_gmax_bits = 0ull; else d.lm[w].gmax_bits = 0ull;
+    }
+  }
 }
 
 // Jacobi scaling (computed once, at iteration 0: Ceres jacobi_scaling), gradient max-norm of
@@ -1571,7 +1753,7 @@ template <class T> __global__ void k_post_linearize(Dev<T> d, int mode) {
     x2 = r * r;
   }
   if (gm > 0.0) atomicMax(at_cand ? &lm.cand_gmax_bits : &lm.gmax_bits, (unsigned long long)__double_as_longlong(gm));
-  if (!at_cand && lm.iter == 0 && x2 > 0.0) atomicAdd(&lm.xnorm2, x2);
+  (void)x2;   // |x|^2 of the initial state: k_initial_cost (fixed-order sum)
 }
 
 // ------------------------------------------------------------------------------------------------ Schur + solve

@@ -152,26 +152,28 @@ def test_large_batch_schur_variants_k26_k27(cv, oracle, dt_ms, K):
     """The other instantiations of the per-window fp64 Schur kernel: K = 26 (66 tiles with products: 14 accumulators per wave,
     k_schur_window_f64<5,14>) and K = 27 (164 compact W columns: <7,14>); both also take the global-atomic MFMA visual assembly
     (K > 25).  10 frames so that P <= 224.  207 windows (3 distinct, 69 copies each) against the same 3 in a small batch (tile
-    Schur kernel) and against the oracle.  (Seed 1201 is left out: with this knot spacing its solution is determined to 1e-4
-    only -- two runs of the SAME kernels differ by that much through the order of the atomic additions,
-    tests/gpu_schur_variant_debug.py.)"""
-    base = [cv.synth.make_window("config1", seed=sd, F=10, dt_ns=dt_ms * 1_000_000) for sd in (1200, 1202, 1203)]
+    Schur kernel) and against the oracle.  Seed 1201 is part of the set: with this knot spacing its solution is determined to ~1e-4
+    only (the 15th iterate moves by that much under ANY change of the summation order: big-batch kernels vs small-batch kernels vs
+    the oracle), so it gets its own bound, 1e-3, while the well-determined seeds keep 1e-6."""
+    seeds = (1200, 1202, 1203, 1201)
+    base = [cv.synth.make_window("config1", seed=sd, F=10, dt_ns=dt_ms * 1_000_000) for sd in seeds]
     assert base[0].K == K and base[0].P <= 224
     with cv.Solver() as s:
         small = [w.copy() for w in base]
         s.set_windows(small)
         sm_small = s.solve(15)
-        big = [base[i % 3].copy() for i in range(207)]
+        big = [base[i % 4].copy() for i in range(208)]
         s.set_windows(big)
         sm_big = s.solve(15)
-    for i in range(207):
-        assert sm_big[i]["iterations"] == sm_small[i % 3]["iterations"]
-        assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 3]["final_cost"], rel=1e-8)
-        assert cv.rel_state_error(big[i], small[i % 3])["state"] < 1e-6, i
-    for i in range(3):
+    tol = lambda i: 1e-3 if seeds[i % 4] == 1201 else 1e-6
+    for i in range(208):
+        assert sm_big[i]["iterations"] == sm_small[i % 4]["iterations"]
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 4]["final_cost"], rel=1e-8 if seeds[i % 4] != 1201 else 1e-6)
+        assert cv.rel_state_error(big[i], small[i % 4])["state"] < tol(i), i
+    for i in range(4):
         wo = base[i].copy()
         oracle.OracleWindow(wo).solve(15)
-        assert cv.rel_state_error(big[i], wo)["state"] < 1e-6
+        assert cv.rel_state_error(big[i], wo)["state"] < tol(i)
 
 
 def test_golden_converged_state(cv, golden_dir):
@@ -505,17 +507,49 @@ def test_golden_edge_fixtures_through_the_hip_path(cv, oracle, golden_dir, name,
 
 def test_config5_large_window_vs_oracle(cv, oracle):
     """BASELINE configs[4]: 30 KF / 1000 landmarks / 6000 IMU (K = 64, P = 571, dense N = 1571): the product path against the
-    oracle's solve, iterate for iterate."""
-    w0 = cv.synth.make_window("config5", seed=1011)
-    wo = w0.copy()
-    sm_o = oracle.OracleWindow(wo).solve(15)
+    oracle's solve, iterate for iterate, on 8 seeds solved as one batch."""
+    ws = [cv.synth.make_window("config5", seed=1011 + i) for i in range(8)]
+    refs = [w.copy() for w in ws]
+    sms_o = [oracle.OracleWindow(r).solve(15) for r in refs]
     with cv.Solver() as s:
-        wg = w0.copy()
-        s.set_windows([wg])
-        sm = s.solve(15)[0]
-    assert (sm["iterations"], sm["num_successful"]) == (sm_o.iterations, sm_o.num_successful)
-    assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-9)
-    assert cv.rel_state_error(wg, wo)["state"] < 1e-6
+        batch = [w.copy() for w in ws]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    for i, (sm, so) in enumerate(zip(sms, sms_o)):
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), i
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        assert cv.rel_state_error(batch[i], refs[i])["state"] < 1e-6, i
+
+
+def test_deterministic_mode_is_bitwise_reproducible(cv):
+    """ctvio_options.deterministic (default: on for batches of <= 64 windows): order-fixed accumulation everywhere -- cost and step
+    reductions in fixed trees, the visual assembly in one-wave parts whose packed partial Hessians are summed in part order, bias rows /
+    chain / prior by gather, no floating-point atomics -- so two solves of the same 64-window batch agree BITWISE: summaries and every
+    state entry, and so do two separate solver handles.  (deterministic=0 on the same batch agrees to rounding only.)"""
+    ws = [cv.synth.make_window("config2" if i % 2 else "config3", seed=1300 + i) for i in range(64)]
+    runs = []
+    for rep in range(3):
+        with cv.Solver(deterministic=1) as s:
+            batch = [w.copy() for w in ws]
+            s.set_windows(batch)
+            sms = s.solve(15)
+            if rep == 0:                       # same handle, second solve from the same initial state
+                again = [w.copy() for w in ws]
+                s.set_windows(again)
+                sms2 = s.solve(15)
+                runs.append((sms2, again))
+        runs.append((sms, batch))
+    sm0, b0 = runs[0]
+    for sm, b in runs[1:]:
+        assert sm == sm0
+        for x, y in zip(b, b0):
+            assert np.array_equal(x.quat, y.quat) and np.array_equal(x.pos, y.pos) and np.array_equal(x.bias, y.bias)
+            assert np.array_equal(x.rho, y.rho) and x.ld == y.ld
+    with cv.Solver(deterministic=0) as s:      # the throughput mode: same answer to rounding
+        batch = [w.copy() for w in ws]
+        s.set_windows(batch)
+        s.solve(15)
+    assert max(cv.rel_state_error(x, y)["state"] for x, y in zip(batch, b0)) < 1e-6
 
 
 def test_rccl_gather_world_size_1(cv):
