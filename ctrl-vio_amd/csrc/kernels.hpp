@@ -2453,6 +2453,10 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
     }
   }
   __syncthreads();
+  long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of thread 0 at the phase boundaries
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
   for (int k = 0; k < NTR; ++k) {
     // ---- A. diagonal tile (k, k)
     const int td = k * (k + 1) / 2 + k, od = td % NW, sd = td / NW;
@@ -2467,10 +2471,13 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       double v[16];
+      int opaque0;   // a zero the compiler cannot see through: without it the 16 identity columns below are hoisted out of the panel
+      asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));   // loop as loop invariants and, for lack of registers, kept in scratch
+      const int lz = l15 + opaque0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const double a = Dg[l15 * 17 + c];
-        v[c] = lane < 16 ? (c <= lane ? a : 0.0) : (c == l15 ? 1.0 : 0.0);
+        v[c] = lane < 16 ? (c <= lz ? a : 0.0) : (c == lz ? 1.0 : 0.0);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();      // every lane has read its row before the block is overwritten with the inverse
@@ -2489,8 +2496,10 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
       }
       if (lane == 0 && bad) s_fail = 1;
     }
+    if (k < 4) CTV_STAMP();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
+    if (k < 4) CTV_STAMP();
     // ---- C. L_ik = A_ik L_kk^-T for the tiles below the diagonal one
     const double *Lk = Li + k * TS;
 #pragma unroll
@@ -2514,8 +2523,10 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
       for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = c[r];
       if (ti[q] == ip && q4 == (rp & 3)) tv[16 * k + l15] = f64x4_get(c, rp >> 2);   // y: row P of L
     }
+    if (k < 4) CTV_STAMP();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
+    if (k < 4) CTV_STAMP();
     // ---- E. trailing tiles (i, j), j > k: A_ij -= L_ik L_jk^T
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
@@ -2527,17 +2538,24 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
     }
+    // (K-step outermost, so that consecutive MFMAs go to different tiles, was measured slower: 5.7 k cycles for the first panel's
+    //  updates either way, and the diagonal tiles waited longer)
     // (the next panel's step C overwrites the LDS panel only after the barrier that follows its step A)
+    if (k < 4) CTV_STAMP();
   }
+  CTV_STAMP();
   __syncthreads();
+  CTV_STAMP();
   // ---- back-substitution L^T x = y over the tiles in registers
   for (int b = NTR - 1; b >= 0; --b) {
-    if (wave == (b % NW) && lane < 16) {
+    if (wave == (b % NW)) {   // x_b[j] = sum_k Linv[k][j] t[k]: lane (q4, j = l15) sums k = 4 q4 .. 4 q4 + 3, two shuffles add the quarters
       const double *Lb = Li + b * TS;
       double xa = 0.0;
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) xa += Lb[kk * 17 + lane] * tv[16 * b + kk];   // x_b[j] = sum_k Linv[k][j] t[k]
-      xs[16 * b + lane] = xa;
+      for (int kk = 0; kk < 4; ++kk) xa += Lb[(4 * q4 + kk) * 17 + l15] * tv[16 * b + 4 * q4 + kk];
+      xa += __shfl_xor(xa, 16);
+      xa += __shfl_xor(xa, 32);
+      if (q4 == 0) xs[16 * b + l15] = xa;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
@@ -2554,9 +2572,11 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
   }
+  CTV_STAMP();
   double *x = d.delta + m.u0;
   for (int i = tid; i < P; i += NT) x[i] = xs[i];
   if (tid == 0) lm.chol_fail = s_fail;
+#undef CTV_STAMP
 }
 
 // delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
