@@ -545,8 +545,14 @@ template <class T> class SolverImpl : public SolverBase {
     if (!store_path()) hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode);
     else hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
     ph_end();
-    ph_begin(PH_IMU_LIN);
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
+    if (opt_.use_mfma && d.Gtot && d.Vtot && !profiling_) {
+      // one launch for both evaluations (independent work: their latencies overlap on batches smaller than the chip); a profiled
+      // solve keeps them apart so that each gets its own timing
+      launch_linearize_merged(mode);
+      return;
+    }
+    ph_begin(PH_IMU_LIN);
     if (d.Gtot) launch_imu_linearize(imu_lds, mode);
     ph_end();
     ph_begin(PH_VIS_LIN);
@@ -564,9 +570,11 @@ template <class T> class SolverImpl : public SolverBase {
       if (parts > 1) hipLaunchKernelGGL((k_reduce_finalize<T>), dim3(deterministic_ ? 48 : 24, nw), dim3(256), 0, stream_, d, mode, parts);
       else hipLaunchKernelGGL((k_bias_rows<T>), dim3(8, nw), dim3(256), 0, stream_, d, mode);
       ph_end();
-      ph_begin(PH_ASM_REST);
-      hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
-      ph_end();
+      if (mode != LIN_SPEC) {   // (the candidate's gradient norm: k_pass_end)
+        ph_begin(PH_ASM_REST);
+        hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
+        ph_end();
+      }
       return;
     }
     ph_begin(PH_ASM_VIS);
@@ -576,7 +584,7 @@ template <class T> class SolverImpl : public SolverBase {
     ph_begin(PH_ASM_REST);
     if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d, mode);
     hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0);
-    hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
+    if (mode != LIN_SPEC) hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();
   }
   // Trust-region step of every window that starts a new iteration (damping, Schur complement, Cholesky, back-substitution), then the
@@ -613,6 +621,7 @@ template <class T> class SolverImpl : public SolverBase {
   }
   void launch_schur();
   void launch_imu_linearize(size_t vals_lds, int mode);
+  void launch_linearize_merged(int mode);
   void launch_assemble_vis_lds(int parts, int mode);
   void launch_assemble_vis_glb(int parts, int mode);
   void launch_assemble_vis_store(int parts, int mode) {
@@ -633,20 +642,17 @@ template <class T> class SolverImpl : public SolverBase {
   // One PASS of the device-resident LM: every running window advances by one phase -- a new trust-region iteration (damp, Schur,
   // Cholesky, back-substitute, candidate) or, inside Ceres' projected line search, one trial step (candidate at the new alpha) --
   // and the candidate is evaluated ONCE: speculative linearisation into the window's other normal-equation set, cost as a
-  // by-product; k_lm_control accepts / rejects / continues the search and swaps the sets on acceptance.  The launch list is fixed:
-  // kernels skip windows that are not in the matching phase.
+  // by-product; k_pass_end accepts / rejects / continues the search, swaps the sets on acceptance and starts the next iteration
+  // (continuation tests, LM diagonal).  The launch list is fixed: kernels skip windows that are not in the matching phase.
   void launch_pass() {
     Dev<T> &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
-    (void)hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_);
-    ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_begin_iter<T>), dim3(nw), dim3(256), 0, stream_, d);
-    ph_end();
     launch_step();
     launch_linearize(LIN_SPEC);
     launch_assemble(LIN_SPEC);
     ph_begin(PH_REST);
-    hipLaunchKernelGGL((k_lm_control<T>), dim3(nw), dim3(64), 0, stream_, d);
+    (void)hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_);   // windows that start another pass count themselves in k_pass_end
+    hipLaunchKernelGGL((k_pass_end<T>), dim3(nw), dim3(256), 0, stream_, d);
     ph_end();
   }
   // The first linearisation of a solve (and of the diagnostic entries): knot-pair constants, normal equations and cost of the
@@ -696,8 +702,10 @@ template <class T> class SolverImpl : public SolverBase {
     if (graph) { const int rc = ensure_graph(); if (rc != CTVIO_OK) return rc; }
     HIPCHK(hipEventRecord(ev_[8], stream_));
     launch_initial(opt_.initial_radius, 0);
-    // max_iters + 1 passes finish every window that never enters the line search (the last pass only finalises); the host
-    // looks at the "windows still running" counter every check_every passes and keeps launching while any is left
+    HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
+    hipLaunchKernelGGL((k_begin_iter<T>), dim3(nw), dim3(256), 0, stream_, d);   // the first iteration; later ones start in k_pass_end
+    // max_iters passes finish every window that never enters the line search; the host looks at the "windows that start another
+    // pass" counter every check_every passes and keeps launching while any is left
     const int check = std::max(1, opt_.check_every);
     const int pass_cap = (max_iters + 1) * 22 + 4;   // every LM iteration may take up to 20 trial steps + 1 re-evaluation
     int it = 0;
@@ -705,7 +713,7 @@ template <class T> class SolverImpl : public SolverBase {
       if (graph) HIPCHK(hipGraphLaunch(graph_exec_, stream_)); else launch_pass();
       ++it;
       if (it >= pass_cap) break;
-      if (it > max_iters || it % check == 0) {
+      if (it >= max_iters || it % check == 0) {
         int32_t *na = reinterpret_cast<int32_t *>(lm_host_ + lm_host_cap_ - 1);   // pinned scratch word
         HIPCHK(hipMemcpyAsync(na, d.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
@@ -1128,6 +1136,10 @@ template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) 
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
   if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
   else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
+}
+template <> void SolverImpl<double>::launch_linearize_merged(int mode) {
+  const Dev<double> &d = dev_;
+  hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode);
 }
 template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts, int mode) {
   const Dev<double> &d = dev_;

@@ -304,39 +304,54 @@ template <class T> __device__ inline int lm_decide(const Dev<T> &d, Lm &lm, doub
 }
 
 
-// One wave per window, after the candidate of this pass has been evaluated: cost of the candidate (fixed-order sum of the
-// partials), its directional derivative g(candidate) . delta, then
+// End of a pass, one workgroup per window.  For a window whose candidate has been evaluated: cost of the candidate (fixed-order sum
+// of the partials), gradient max-norm at the candidate and its directional derivative g(candidate) . delta, then
 //   * ArmijoLineSearch::DoSearch + LineSearch::InterpolatingPolynomialMinimizingStepSize (Ceres line_search.cc) for windows whose
 //     reduced program is bounds-constrained: the trial is kept when f(alpha) <= f(0) + 1e-4 alpha f'(0); a sample whose value or
 //     gradient is not finite is invalid and fails; otherwise the next trial step comes from the cubic / quintic interpolation,
 //     contracted into [1e-3, 0.6] x alpha, and the window stays in the search (ls_active = 1);
 //   * ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful / LM radius update; on acceptance the speculative
 //     normal equations become the current ones (cur ^= 1).
-template <class T> __global__ __launch_bounds__(64) void k_lm_control(Dev<T> d) {
-  const int w = blockIdx.x, lane = threadIdx.x;
+template <class T> __global__ __launch_bounds__(256) void k_pass_end(Dev<T> d) {
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   Lm &lm = d.lm[w];
-  if (lm.status || !lm.step_valid) return;
+  __shared__ double s_red[4];
+  __shared__ unsigned long long s_gmax[4];
+  __shared__ int s_acc, s_go;
   const WinMeta &m = d.wins[w];
-  const bool have_grad = !lin_cost_only(lm, LIN_SPEC, d.prm);
-  const double cand_cost = window_cost_sum(d, m, w, lane);
-  double gd = 0.0;
-  if (lm.ls_on && have_grad) {
-    const double *gc = d.gS[1 - lm.cur] + m.u0, *dl = d.delta + m.u0;
-    for (int j = lane; j < m.N; j += 64)
-      if (d.active[m.u0 + j]) gd += gc[j] * dl[j];
+  if (!lm.status && lm.step_valid) {   // (uniform: the window evaluated a candidate this pass)
+    const bool have_grad = !lin_cost_only(lm, LIN_SPEC, d.prm);
+    const int tg = 1 - lm.cur;
+    const double *gc = d.gS[tg] + m.u0, *dl = d.delta + m.u0;
+    // gradient max-norm at the candidate and g(candidate) . delta: block reductions in a fixed order (max is exact in any order)
+    double gd = 0.0, gm = 0.0;
+    if (have_grad)
+      for (int j = tid; j < m.N; j += 256)
+        if (d.active[m.u0 + j]) { gd += gc[j] * dl[j]; gm = fmax(gm, grad_norm_entry(d, m, w, j, gc, true)); }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) gd += __shfl_xor(gd, off);
+    for (int off = 32; off > 0; off >>= 1) { gd += __shfl_xor(gd, off); gm = fmax(gm, __shfl_xor(gm, off)); }
+    if (lane == 0) { s_red[wave] = gd; s_gmax[wave] = (unsigned long long)__double_as_longlong(gm); }
+    __syncthreads();
+    if (wave == 0) {
+      const double cand_cost = window_cost_sum(d, m, w, lane);
+      if (lane == 0) {
+        const double gdt = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        lm.cand_gmax_bits = max(max(s_gmax[0], s_gmax[1]), max(s_gmax[2], s_gmax[3]));   // (non-negative doubles order like their bit patterns)
+        s_acc = lm_decide(d, lm, cand_cost, lm.ls_on ? gdt : 0.0, have_grad);
+      }
+    }
+    __syncthreads();
+    if (s_acc) {   // the accepted candidate becomes the current state (the reference: Ceres writes through the parameter pointers)
+      for (int t = tid; t < 4 * m.K; t += 256) d.quat[4 * m.knot0 + t] = d.cquat[4 * m.knot0 + t];
+      for (int t = tid; t < 3 * m.K; t += 256) d.pos[3 * m.knot0 + t] = d.cpos[3 * m.knot0 + t];
+      for (int t = tid; t < 6 * m.F; t += 256) d.bias[6 * m.bias0 + t] = d.cbias[6 * m.bias0 + t];
+      for (int t = tid; t < m.L; t += 256) d.rho[m.lm0 + t] = d.crho[m.lm0 + t];
+      if (tid == 0) d.ld[w] = d.cld[w];
+    }
+    __syncthreads();
   }
-  int accepted = 0;
-  if (lane == 0) accepted = lm_decide(d, lm, cand_cost, gd, have_grad);
-  accepted = __shfl(accepted, 0);
-  if (!accepted) return;
-  // the accepted candidate becomes the current state (the reference: Ceres writes through the parameter pointers)
-  for (int t = lane; t < 4 * m.K; t += 64) d.quat[4 * m.knot0 + t] = d.cquat[4 * m.knot0 + t];
-  for (int t = lane; t < 3 * m.K; t += 64) d.pos[3 * m.knot0 + t] = d.cpos[3 * m.knot0 + t];
-  for (int t = lane; t < 6 * m.F; t += 64) d.bias[6 * m.bias0 + t] = d.cbias[6 * m.bias0 + t];
-  for (int t = lane; t < m.L; t += 64) d.rho[m.lm0 + t] = d.crho[m.lm0 + t];
-  if (lane == 0) d.ld[w] = d.cld[w];
+  // ---- the next iteration starts here: continuation tests, LM diagonal of the (possibly swapped) current normal equations
+  begin_iteration(d, w, &s_go);
 }
 
 // ------------------------------------------------------------------------------------------------ zero
@@ -478,10 +493,8 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
 // 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
 // tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
 // B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
-__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode) {
-  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  double *A = reinterpret_cast<double *>(smraw);   // [64][33]
-  const ImuGroup grp = d.groups[blockIdx.x];
+__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx) {
+  const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
   if (!lin_run(d.lm[w], mode)) return;
   const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
@@ -521,7 +534,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
-    if (lane == 0) d.imu_cost[blockIdx.x] = csum;
+    if (lane == 0) d.imu_cost[gidx] = csum;
     return;
   }
   for (int c0 = 0; c0 < grp.count; c0 += 64) {
@@ -577,7 +590,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   // ---- the group's share of the cost: fixed-order sum over the lanes (butterfly), one store
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
-  if (lane == 0) d.imu_cost[blockIdx.x] = csum;
+  if (lane == 0) d.imu_cost[gidx] = csum;
   // ---- combine in LDS into the full symmetric 32 x 32 tile, then one coalesced store
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -601,14 +614,17 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
-  double *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
+  double *tile = d.imu_tiles + (size_t)gidx * 1024;
 #pragma unroll
   for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
 }
 
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
 // (Two waves per SIMD with the overflow spilled to scratch was measured 3x slower: 1690 vs 540 us per 1024 windows.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode) { imu_linearize_f64_body(d, mode); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
+  imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+}
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
 template <class T> __global__ void k_assemble_imu(Dev<T> d, int mode) {
@@ -700,12 +716,12 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 // Hll, g_rho of the wave's landmarks into the normal-equation set the mode selects.  The wave's share of the cost goes to
 // Dev::vis_cost (a window's block slots start on a wave boundary: one window per wave).  A window on its last allowed iteration is
 // only costed (residuals, no Jacobians, nothing else written).
+constexpr int VIS_LDS_BYTES = 64 * VT_LD * 8;   // the J~ of a wave's 64 blocks (>= one fp64 row of the largest window: 642 doubles)
 template <class T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, int mode) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigned char *smt, int4 *rmeta, int2 *rhg, int vblock) {
+  const int v = vblock * 64 + threadIdx.x;
   // the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
-  constexpr int LDS_BYTES = 64 * VT_LD * (int)sizeof(T);   // (>= one fp64 row of the largest window: 642 doubles)
-  __shared__ __attribute__((aligned(16))) unsigned char smt[LDS_BYTES];
+  constexpr int LDS_BYTES = VIS_LDS_BYTES;
   T *wcs = reinterpret_cast<T *>(smt);
   const bool at_cand = mode == LIN_SPEC;
   const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *rho = at_cand ? d.crho : d.rho, *ldp = at_cand ? d.cld : d.ld;
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
       double cs = c;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) cs += __shfl_xor(cs, off);
-      if (lane == 0) d.vis_cost[blockIdx.x] = cs;
+      if (lane == 0) d.vis_cost[vblock] = cs;
     }
     if (on_mask == 0) return;                  // (wave-uniform)
     const int tgw = __builtin_amdgcn_readfirstlane(__shfl(tg, __ffsll((long long)on_mask) - 1));   // normal-equation set of the wave's window
@@ -783,13 +799,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
     // One wave per workgroup: LDS hand-overs only need the wave's own LDS operations to have completed.  (__syncthreads() also
     // waits for vmcnt(0), i.e. for the J~ and W stores in flight to be acknowledged -- ~5 us per barrier here, measured.)
 #define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
-    long long *dbg = (d.dbg && blockIdx.x == 1000) ? d.dbg + 32 : nullptr;
+    long long *dbg = (d.dbg && vblock == 1000) ? d.dbg + 32 : nullptr;
     if (dbg && lane == 0) dbg[0] = clock64() + (long long)(c * 0);
     LDS_SYNC();
     // ---- J~ goes out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs of
     //      entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
     {
-      T *dst = d.Jt + (size_t)(blockIdx.x * 64) * VT_ROWS;
+      T *dst = d.Jt + (size_t)(vblock * 64) * VT_ROWS;
       constexpr int HP = VT_ROWS / 2;            // pairs per block
 #pragma unroll 4
       for (int k = 0; k < HP; ++k) {             // 64 * HP pairs, 64 per store
@@ -861,8 +877,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
     double *rows = reinterpret_cast<double *>(smt);
     const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / (ldmax + 2)));
     double *hg = rows + (size_t)NR * ldmax;                            // [NR][2] Hll, g_rho
-    __shared__ int4 rmeta[64];                                         // per landmark of the wave: K6, P, W row offset
-    __shared__ int2 rhg[64];                                           //                           where Hll and g_rho go
+    // rmeta: per landmark of the wave K6, P, W row offset; rhg: where Hll and g_rho go
     int KC = mK6;                                                      // compact columns per row: knots + line delay
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) KC = max(KC, __shfl_xor(KC, off));
@@ -926,6 +941,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
     }
 #undef LDS_SYNC
   }
+}
+
+template <class T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, int mode) {
+  __shared__ __attribute__((aligned(16))) unsigned char smt[VIS_LDS_BYTES];
+  __shared__ int4 rmeta[64];
+  __shared__ int2 rhg[64];
+  vis_eval_body<T>(d, mode, smt, rmeta, rhg, blockIdx.x);
+}
+
+// Both evaluations in ONE launch: workgroups [0, Gtot) take an IMU group each, the others a wave of 64 visual block slots.  The two are
+// independent; for a batch smaller than the chip their single-wave latencies (23 us each for one window) overlap instead of adding
+// up, and large batches lose nothing.  The IMU rows use the head of the visual kernel's LDS buffer.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linearize_f64(Dev<double> d, int mode) {
+  __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
+  __shared__ int4 rmeta[64];
+  __shared__ int2 rhg[64];
+  if ((int)blockIdx.x < d.Gtot) imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
+  else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
 }
 
 // Visual assembly: gridDim.y workgroups (8 waves each) per window.  The host sorted the visual blocks by
@@ -1704,6 +1738,31 @@ __global__ __launch_bounds__(256) void k_misc(Dev<T> d, int mode, int store) {
 
 // Jacobi scaling (computed once, at iteration 0: Ceres jacobi_scaling), gradient max-norm of
 // x - Plus(x, -g) (Ceres gradient_max_norm) and |x|^2 of the reduced program.
+// |x - Plus(x, -g)| of unknown j (Ceres gradient_max_norm: ambient difference for a rotation block, the box of the line delay)
+template <class T> __device__ __forceinline__ double grad_norm_entry(const Dev<T> &d, const WinMeta &m, int w, int j, const double *g, bool at_cand) {
+  const double *squat = at_cand ? d.cquat : d.quat, *sld = at_cand ? d.cld : d.ld;
+  const int K6 = 6 * m.K;
+  if (j < K6) {
+    const int k = j / 6, c = j % 6;
+    if (c == 0) {  // rotation block: ambient difference q - q*exp(-g)
+      const double *q = squat + 4 * (m.knot0 + k);
+      const Q4<double> q0 = qmk<double>(q[0], q[1], q[2], q[3]);
+      const Q4<double> q1 = qmul(q0, so3_exp(mk<double>(-g[j], -g[j + 1], -g[j + 2])));
+      return fmax(fmax(fabs(q0.x - q1.x), fabs(q0.y - q1.y)), fmax(fabs(q0.z - q1.z), fabs(q0.w - q1.w)));
+    }
+    return c >= 3 ? fabs(g[j]) : 0.0;
+  }
+  if (j == m.P - 1) {
+    const double ld = sld[w];
+    double nl = ld - g[j];
+    if (!m.fix_ld) nl = fmin(fmax(nl, m.ld_lo), m.ld_hi);
+    return fabs(ld - nl);
+  }
+  return fabs(g[j]);
+}
+
+// After the first linearisation of a solve (LIN_AT_X): Jacobi scaling (computed once, at iteration 0: Ceres jacobi_scaling) and the
+// gradient max-norm of the initial state.  (Every later pass: k_pass_end.)
 template <class T> __global__ void k_post_linearize(Dev<T> d, int mode) {
   const int w = blockIdx.y;
   Lm &lm = d.lm[w];
@@ -1719,52 +1778,17 @@ template <class T> __global__ void k_post_linearize(Dev<T> d, int mode) {
     d.cscale[m.u0 + j] = act ? 1.0 / (1.0 + sqrt(fmax(h, 0.0))) : 1.0;
   }
   if (!act) return;
-  const double *g = d.gS[tg] + m.u0;
-  const double *squat = at_cand ? d.cquat : d.quat, *spos = at_cand ? d.cpos : d.pos, *sbias = at_cand ? d.cbias : d.bias,
-               *srho = at_cand ? d.crho : d.rho, *sld = at_cand ? d.cld : d.ld;
-  double gm = 0.0, x2 = 0.0;
-  const int K6 = 6 * m.K;
-  if (j < K6) {
-    const int k = j / 6, c = j % 6;
-    if (c == 0) {  // rotation block: ambient difference q - q*exp(-g)
-      const double *q = squat + 4 * (m.knot0 + k);
-      const Q4<double> q0 = qmk<double>(q[0], q[1], q[2], q[3]);
-      const Q4<double> q1 = qmul(q0, so3_exp(mk<double>(-g[j], -g[j + 1], -g[j + 2])));
-      gm = fmax(fmax(fabs(q0.x - q1.x), fabs(q0.y - q1.y)), fmax(fabs(q0.z - q1.z), fabs(q0.w - q1.w)));
-      x2 = q0.x * q0.x + q0.y * q0.y + q0.z * q0.z + q0.w * q0.w;
-    } else if (c >= 3) {
-      gm = fabs(g[j]);
-      const double p = spos[3 * (m.knot0 + k) + c - 3];
-      x2 = p * p;
-    }
-  } else if (j < m.P - 1) {
-    gm = fabs(g[j]);
-    const double b = sbias[6 * m.bias0 + (j - K6)];
-    x2 = b * b;
-  } else if (j == m.P - 1) {
-    const double ld = sld[w];
-    double nl = ld - g[j];
-    if (!m.fix_ld) nl = fmin(fmax(nl, m.ld_lo), m.ld_hi);
-    gm = fabs(ld - nl);
-    x2 = ld * ld;
-  } else {
-    gm = fabs(g[j]);
-    const double r = srho[m.lm0 + j - m.P];
-    x2 = r * r;
-  }
+  const double gm = grad_norm_entry(d, m, w, j, d.gS[tg] + m.u0, at_cand);
   if (gm > 0.0) atomicMax(at_cand ? &lm.cand_gmax_bits : &lm.gmax_bits, (unsigned long long)__double_as_longlong(gm));
-  (void)x2;   // |x|^2 of the initial state: k_initial_cost (fixed-order sum)
 }
 
 // ------------------------------------------------------------------------------------------------ Schur + solve
-// One workgroup per window.  Thread 0: FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration (windows
-// inside the line search only report that they are still running).  Then, for the windows that start an iteration: the LM diagonal
+// Start of an iteration, by the threads of one workgroup.  Thread 0: FinalizeIterationAndCheckIfMinimizerCanContinue (windows inside
+// the line search only report that they are still running).  Then, for the windows that start an iteration: the LM diagonal
 // D^2 = clamp(diag(J^T J), min, max) / mu on the Jacobi-scaled system (Ceres LevenbergMarquardtStrategy::ComputeStep), expressed for
 // the unscaled system: dd_j = clamp(c_j^2 H_jj) / (mu c_j^2), and 1 / (Hll + dd) of the landmarks.
-template <class T> __global__ __launch_bounds__(256) void k_begin_iter(Dev<T> d) {
-  const int w = blockIdx.x;
+template <class T> __device__ __forceinline__ void begin_iteration(const Dev<T> &d, int w, int *s_go) {
   Lm &lm = d.lm[w];
-  __shared__ int s_go;
   if (threadIdx.x == 0) {
     int go = 0;
     if (!lm.status) {
@@ -1779,14 +1803,14 @@ template <class T> __global__ __launch_bounds__(256) void k_begin_iter(Dev<T> d)
         go = 1;
       }
     }
-    s_go = go;
+    *s_go = go;
   }
   __syncthreads();
-  if (!s_go) return;
+  if (!*s_go) return;
   const WinMeta &m = d.wins[w];
   const double mu = lm.mu;
   const double *Hd = d.HppS[lm.cur] + m.H0, *Hl = d.HllS[lm.cur] + m.lm0;
-  for (int j = threadIdx.x; j < m.N; j += 256) {
+  for (int j = threadIdx.x; j < m.N; j += blockDim.x) {
     const bool act = d.active[m.u0 + j] != 0;
     const double c = d.cscale[m.u0 + j];
     const double h = (j < m.P) ? Hd[(long long)j * m.ldh + j] : Hl[j - m.P];
@@ -1795,6 +1819,11 @@ template <class T> __global__ __launch_bounds__(256) void k_begin_iter(Dev<T> d)
     d.dd[m.u0 + j] = dd;
     if (j >= m.P) d.dinv[m.lm0 + j - m.P] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
   }
+}
+// The first iteration of a solve (every later one starts at the end of the previous pass: k_pass_end).
+template <class T> __global__ __launch_bounds__(256) void k_begin_iter(Dev<T> d) {
+  __shared__ int s_go;
+  begin_iteration(d, blockIdx.x, &s_go);
 }
 
 __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> (bi >= bj), row-major over the lower triangle
