@@ -2568,7 +2568,11 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
       for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
     }
     // (K-step outermost, so that consecutive MFMAs go to different tiles, was measured slower: 5.7 k cycles for the first panel's
-    //  updates either way, and the diagonal tiles waited longer)
+    //  updates either way, and the diagonal tiles waited longer.  LOOK-AHEAD -- the owner of tile (k + 1, k + 1) updates that tile
+    //  first and factors it while the other waves do their updates, the LDS panel double buffered, its own remaining updates
+    //  deferred to the next panel -- was built and measured slower too: 1.63 vs 1.30 ms per 16 single-window factorisations,
+    //  13.5 vs 10.6 ms per 2048-window solve.  The pivot chain takes ~12 k cycles instead of ~7 k when the other 15 waves are
+    //  busy on the same SIMDs / LDS, s_setprio 3 does not change that, and step C grows by the pending updates.)
     // (the next panel's step C overwrites the LDS panel only after the barrier that follows its step A)
     if (k < 4) CTV_STAMP();
   }
