@@ -546,9 +546,9 @@ template <class T> class SolverImpl : public SolverBase {
     else hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
     ph_end();
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
-    if (opt_.use_mfma && d.Gtot && d.Vtot && !profiling_) {
+    if (opt_.use_mfma && d.Gtot && d.Vtot && !profiling_ && !std::getenv("CTVIO_SPLIT_LINEARIZE")) {
       // one launch for both evaluations (independent work: their latencies overlap on batches smaller than the chip); a profiled
-      // solve keeps them apart so that each gets its own timing
+      // solve (and CTVIO_SPLIT_LINEARIZE=1, for rocprofv3 runs) keeps them apart so that each gets its own timing
       launch_linearize_merged(mode);
       return;
     }
