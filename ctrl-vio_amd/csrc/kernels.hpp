@@ -2612,6 +2612,9 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
 #undef CTV_STAMP
 }
 
+// (Fusing this kernel into k_cholesky_tiles -- same workgroup, the pose step straight from LDS -- was built and measured: no gain for
+//  one window (3.09 vs 3.05 ms per solve) and slower for 2048 (15.4 vs 13.6 ms for the two phases): the fused kernel spills, and
+//  the landmark back-substitution wants more workgroups per CU than the tile kernel's registers allow.  Kept apart.)
 // delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
 // model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres' -(J y)^T (r + J y / 2) when
 // (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
