@@ -1134,7 +1134,8 @@ template <class T> class SolverImpl : public SolverBase {
 template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) {
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
-  if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
+  if (opt_.use_mfma && std::getenv("CTVIO_IMU_STAGED")) hipLaunchKernelGGL(k_imu_linearize_f64_staged, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
+  else if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
   else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
 }
 template <> void SolverImpl<double>::launch_linearize_merged(int mode) {

@@ -493,6 +493,9 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
 // 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
 // tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
 // B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
+// STAGED: values, then the gyro Jacobians and their three row phases, then the accelerometer Jacobians and theirs (factors.hpp:
+// imu_eval_values / imu_jac_gyro / imu_jac_accel) instead of the whole Jacobian up front.
+template <bool STAGED>
 __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx) {
   const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
@@ -514,8 +517,24 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { bias[i] = bp[i]; wgt[i] = m.imu_w[i]; }
-  const V3<double> grav = lf.rotate(m.gravity);
+  V3<double> grav = lf.rotate(m.gravity);
   const double idt = m.inv_dt;
+  if constexpr (STAGED) {
+    // the group's constants are the same in every lane: kept in SGPRs they cost no vector registers (the evaluation needs far more
+    // than 256 of those: every one saved is one AGPR round trip less).  A VALU instruction takes one scalar operand: these are
+    // the ones that meet a per-lane value in a product.
+    auto uni = [](double x) {
+      const long long b = __double_as_longlong(x);
+      const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+      return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k.p[i].x = uni(k.p[i].x); k.p[i].y = uni(k.p[i].y); k.p[i].z = uni(k.p[i].z); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { sc.d[i].x = uni(sc.d[i].x); sc.d[i].y = uni(sc.d[i].y); sc.d[i].z = uni(sc.d[i].z); }
+    k.q[0].x = uni(k.q[0].x); k.q[0].y = uni(k.q[0].y); k.q[0].z = uni(k.q[0].z); k.q[0].w = uni(k.q[0].w);
+    grav.x = uni(grav.x); grav.y = uni(grav.y); grav.z = uni(grav.z);
+  }
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   const size_t Mt = (size_t)d.Mtot;
   if (!jac) {   // residuals only (a separate, small code path: the full one below keeps its compile-time `want_jac = true`)
@@ -549,11 +568,56 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
     double wl[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
+    const int kmax = (nval + 3) & ~3;
+    if constexpr (STAGED) {
+      ImuMid<double> md;
+      imu_eval_values<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, r, md);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
+      {
+        M3<double> Jw[4];
+        imu_jac_gyro<double>(md, sc, Jw);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double row[16];
+          imu_row_gyro2<double>(Jw, wl, r, a, row);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          for (int k0 = 0; k0 < kmax; k0 += 4) {
+            const double v = A[(k0 + q4) * 17 + l15];
+            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gacc, 0, 0, 0);
+          }
+        }
+      }
+      {
+        M3<double> Ja[4], Rinv_g;
+        imu_jac_accel<double>(k, md, sc, RrefT, Ja, Rinv_g);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double row[32];
+          imu_row_accel2<double>(Ja, md.lamA, Rinv_g, wl, r, a, row);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int c = 0; c < 32; ++c) A[lane * 33 + c] = row[c];
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          for (int k0 = 0; k0 < kmax; k0 += 4) {
+            const double lo = A[(k0 + q4) * 33 + l15], hi = A[(k0 + q4) * 33 + 16 + l15];
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, acc11, 0, 0, 0);
+          }
+        }
+      }
+      continue;
+    }
     ImuJac<double> J;
     imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, true, J);
 #pragma unroll
     for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
-    const int kmax = (nval + 3) & ~3;
     // ---- accelerometer rows: 32 columns, tiles (0,0), (1,0), (1,1)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
@@ -623,7 +687,11 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
 // (Two waves per SIMD with the overflow spilled to scratch was measured 3x slower: 1690 vs 540 us per 1024 windows.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64_staged(Dev<double> d, int mode) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
+  imu_linearize_f64_body<true>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
@@ -958,7 +1026,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
   __shared__ int4 rmeta[64];
   __shared__ int2 rhg[64];
-  if ((int)blockIdx.x < d.Gtot) imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
+  if ((int)blockIdx.x < d.Gtot) imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
   else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
 }
 
