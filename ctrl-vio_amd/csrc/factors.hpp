@@ -266,6 +266,76 @@ template <class T> CTV_DI void imu_row_gyro2(const M3<T> (&Jw)[4], const T w[6],
   out[15] = r[a];
 }
 
+// ---- Third form (k_imu_linearize_f64's product path), algebraically the same Jacobian with the rotation chain of the accelerometer
+// rows rewritten: with A_i = exp(lamR[i+1] d_i), Apost_i = (A_i .. A_2)^T and R(t)^T = Apost_0 R_0^T,
+//   R(t)^T hat(a + g) R_0 A_0 .. A_{i-1} = Apost_i hat(b_i),   b_0 = R_0^T (a + g),  b_{i+1} = A_i^T b_i
+// (R hat(v) R^T = hat(R v) applied i + 1 times), so d(accel)/d(d_i) = lamR[i+1] Apost_i hat(b_i) Jr(-lamR[i+1] d_i): the very shape of the
+// gyro rows (Apost_i hat(omega_i) Jr) -- no rotation matrices of q_0 / A_0 / A_1, no running product.  Small-angle series only
+// (so3_exp_small / so3_Jr_small): the kernel checks |d_i| < 0.5 for the group and takes the general body otherwise.
+template <class T> struct ImuMid3 {
+  M3<T> Apost[3];           // Apost[i] = (A_i .. A_2)^T
+  M3<T> JrK[3];             // Jr(-lamR[i + 1] d_i)
+  V3<T> om1, om2;           // omega recursion
+  V3<T> b[3];               // b_i above
+  T lamR[4], lamW[4], lamA[4];
+};
+template <class T, class SC>
+CTV_DI void imu_eval_values3(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity, const T bias[6], const T gyro[3], const T acc[3],
+                             const T w[6], T r[6], ImuMid3<T> &md) {
+  basis<T, false, 2>(u, idt * idt, md.lamA);
+  basis<T, true, 0>(u, T(1), md.lamR);
+  basis<T, true, 1>(u, idt, md.lamW);
+  V3<T> accel = mk<T>(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accel = accel + md.lamA[i] * k.p[i];
+  Q4<T> Ainv[3], accq;
+#pragma unroll
+  for (int i = 2; i >= 0; --i) {
+    const V3<T> nkd = (-md.lamR[i + 1]) * sc.d[i];
+    Ainv[i] = so3_exp_small(nkd);
+    accq = i == 2 ? Ainv[2] : qmul_unit(accq, Ainv[i]);
+    md.Apost[i] = q2R(accq);
+    md.JrK[i] = so3_Jr_small(nkd);
+  }
+  V3<T> om3;
+  md.om1 = md.lamW[1] * sc.d[0];
+  md.om2 = qrot(Ainv[1], md.om1) + md.lamW[2] * sc.d[1];
+  om3 = qrot(Ainv[2], md.om2) + md.lamW[3] * sc.d[2];
+  md.b[0] = qrot(qconj(k.q[0]), accel + gravity);
+  md.b[1] = qrot(Ainv[0], md.b[0]);
+  md.b[2] = qrot(Ainv[1], md.b[1]);
+  const V3<T> a_pred = qrot(Ainv[2], md.b[2]);   // = R(t)^T (a + g)
+  r[0] = w[0] * (om3.x - (gyro[0] - bias[0]));
+  r[1] = w[1] * (om3.y - (gyro[1] - bias[1]));
+  r[2] = w[2] * (om3.z - (gyro[2] - bias[2]));
+  r[3] = w[3] * (a_pred.x - (acc[0] - bias[3]));
+  r[4] = w[4] * (a_pred.y - (acc[1] - bias[4]));
+  r[5] = w[5] * (a_pred.z - (acc[2] - bias[5]));
+}
+// M (3 x 3) against the knot-pair table: J[i] -= M JrI_i^T, J[i + 1] += M JrI_i
+template <class T, class SC> CTV_DI void imu_apply_pair(const M3<T> &M, const SC &sc, int i, M3<T> &Ji, M3<T> &Ji1, bool first) {
+  const M3<T> JrIi = sc.jri(i);
+  const M3<T> A = mulT(M, JrIi), B = mul(M, JrIi);
+#pragma unroll
+  for (int e = 0; e < 9; ++e) { Ji.m[e] = first ? -A.m[e] : Ji.m[e] - A.m[e]; Ji1.m[e] = B.m[e]; }
+}
+template <class T, class SC> CTV_DI void imu_jac_gyro3(const ImuMid3<T> &md, const SC &sc, M3<T> (&Jw)[4]) {
+  imu_apply_pair(scale(md.Apost[1], md.lamW[1]), sc, 0, Jw[0], Jw[1], true);
+  imu_apply_pair(add(scale(mul(mul_hat(md.Apost[1], md.om1), md.JrK[1]), md.lamR[2]), scale(md.Apost[2], md.lamW[2])), sc, 1, Jw[1], Jw[2], false);
+  M3<T> dod = scale(mul(mul_hat(md.Apost[2], md.om2), md.JrK[2]), md.lamR[3]);
+  dod.m[0] += md.lamW[3]; dod.m[4] += md.lamW[3]; dod.m[8] += md.lamW[3];
+  imu_apply_pair(dod, sc, 2, Jw[2], Jw[3], false);
+}
+// Cg = R_0^T RrefT (group constant): R(t)^T in the global frame = Apost_0 Cg
+template <class T, class SC>
+CTV_DI void imu_jac_accel3(const ImuMid3<T> &md, const SC &sc, const M3<T> &Cg, M3<T> (&Ja)[4], M3<T> &Rinv_g) {
+  Rinv_g = mul(md.Apost[0], Cg);
+  Ja[0] = mul_hat(md.Apost[0], md.b[0]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    imu_apply_pair(scale(mul(mul_hat(md.Apost[i], md.b[i]), md.JrK[i]), md.lamR[i + 1]), sc, i, Ja[i], Ja[i + 1], false);
+}
+
 // trajectory_value_factor.h:198-245, column by column
 template <class T, class Sink> CTV_DI void imu_emit_cols(const ImuJac<T> &J, const T w[6], Sink &sink) {
 #pragma unroll

@@ -535,6 +535,14 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
     k.q[0].x = uni(k.q[0].x); k.q[0].y = uni(k.q[0].y); k.q[0].z = uni(k.q[0].z); k.q[0].w = uni(k.q[0].w);
     grav.x = uni(grav.x); grav.y = uni(grav.y); grav.z = uni(grav.z);
   }
+  M3<double> Cg;   // R_0^T RrefT: the position-knot columns are lamA[k] * Apost_0 Cg (factors.hpp, third form)
+  if constexpr (STAGED) {
+    const M3<double> R0 = q2R(k.q[0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Cg.m[3 * i + j] = R0.m[i] * RrefT.m[j] + R0.m[3 + i] * RrefT.m[3 + j] + R0.m[6 + i] * RrefT.m[6 + j];
+  }
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   const size_t Mt = (size_t)d.Mtot;
   if (!jac) {   // residuals only (a separate, small code path: the full one below keeps its compile-time `want_jac = true`)
@@ -570,13 +578,13 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
     for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
     const int kmax = (nval + 3) & ~3;
     if constexpr (STAGED) {
-      ImuMid<double> md;
-      imu_eval_values<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, r, md);
+      ImuMid3<double> md;
+      imu_eval_values3<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, r, md);
 #pragma unroll
       for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
       {
         M3<double> Jw[4];
-        imu_jac_gyro<double>(md, sc, Jw);
+        imu_jac_gyro3<double>(md, sc, Jw);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           double row[16];
@@ -594,7 +602,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
       }
       {
         M3<double> Ja[4], Rinv_g;
-        imu_jac_accel<double>(k, md, sc, RrefT, Ja, Rinv_g);
+        imu_jac_accel3<double>(md, sc, Cg, Ja, Rinv_g);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           double row[32];
@@ -689,9 +697,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
 }
+// The staged body evaluates the small-angle series only: a group whose knot-pair logs reach 0.5 rad (28.6 degrees between two knots 50 ms
+// apart) takes the general body.
+__device__ __forceinline__ bool imu_group_small(const Dev<double> &d, int gidx) {
+  const ImuGroup grp = d.groups[gidx];
+  const double *kd = d.lkd + 3 * (d.wins[grp.win].knot0 + grp.s);
+  double m = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) m = fmax(m, kd[3 * i] * kd[3 * i] + kd[3 * i + 1] * kd[3 * i + 1] + kd[3 * i + 2] * kd[3 * i + 2]);
+  return m < 0.25;
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64_staged(Dev<double> d, int mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  imu_linearize_f64_body<true>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  if (imu_group_small(d, blockIdx.x)) imu_linearize_f64_body<true>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  else imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.

@@ -212,6 +212,41 @@ template <class T> CTV_DI M3<T> so3_Jr(V3<T> phi) {
   for (int i = 0; i < 9; ++i) J.m[i] += -a * H.m[i] + b * H2.m[i];
   return J;
 }
+// ---- the same functions for |phi| < 0.5 ONLY (the caller has checked the knot-pair logs of its spline segment: lambda in [0, 1] only
+// shrinks them), without the closed-form branch: straight-line code for the evaluation kernels.
+CTV_DI Q4<double> so3_exp_small(V3<double> w) {
+  const double h2 = 0.25 * dot(w, w);
+  const double im = 0.5 * (1.0 + h2 * (-1.0 / 6.0 + h2 * (1.0 / 120.0 + h2 * (-1.0 / 5040.0 + h2 * (1.0 / 362880.0 + h2 * (-1.0 / 39916800.0 +
+                    h2 * (1.0 / 6227020800.0 + h2 * (-1.0 / 1307674368000.0))))))));
+  const double re = 1.0 + h2 * (-0.5 + h2 * (1.0 / 24.0 + h2 * (-1.0 / 720.0 + h2 * (1.0 / 40320.0 + h2 * (-1.0 / 3628800.0 +
+                    h2 * (1.0 / 479001600.0 + h2 * (-1.0 / 87178291200.0)))))));
+  return qmk<double>(im * w.x, im * w.y, im * w.z, re);
+}
+// Jr = I - a hat + b hat^2 with hat^2 = phi phi^T - |phi|^2 I written out: 19 operations instead of a 3 x 3 product
+CTV_DI M3<double> so3_Jr_small(V3<double> phi) {
+  const double n2 = dot(phi, phi);
+  const double a = 0.5 + n2 * (-1.0 / 24.0 + n2 * (1.0 / 720.0 + n2 * (-1.0 / 40320.0 + n2 * (1.0 / 3628800.0 + n2 * (-1.0 / 479001600.0 +
+                   n2 * (1.0 / 87178291200.0 + n2 * (-1.0 / 20922789888000.0)))))));
+  const double b = 1.0 / 6.0 + n2 * (-1.0 / 120.0 + n2 * (1.0 / 5040.0 + n2 * (-1.0 / 362880.0 + n2 * (1.0 / 39916800.0 + n2 * (-1.0 / 6227020800.0 +
+                   n2 * (1.0 / 1307674368000.0 + n2 * (-1.0 / 355687428096000.0)))))));
+  const double bx = b * phi.x, by = b * phi.y, bz = b * phi.z, ax = a * phi.x, ay = a * phi.y, az = a * phi.z, d0 = 1.0 - b * n2;
+  const double xy = bx * phi.y, xz = bx * phi.z, yz = by * phi.z;
+  M3<double> J;
+  J.m[0] = d0 + bx * phi.x; J.m[1] = xy + az;         J.m[2] = xz - ay;
+  J.m[3] = xy - az;         J.m[4] = d0 + by * phi.y; J.m[5] = yz + ax;
+  J.m[6] = xz + ay;         J.m[7] = yz - ax;         J.m[8] = d0 + bz * phi.z;
+  return J;
+}
+// Product of two unit quaternions with Sophus' renormalisation 2 / (1 + n2) (so3.hpp:395-411) expanded around n2 = 1: the factors are
+// unit to rounding, e = n2 - 1 is a few ulp, and 1 - e/2 + e^2/4 equals the quotient to e^3/8 -- no division.
+CTV_DI Q4<double> qmul_unit(Q4<double> a, Q4<double> b) {
+  Q4<double> o = qmul_raw(a, b);
+  const double e = (o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w) - 1.0;
+  const double s = 1.0 + e * (-0.5 + 0.25 * e);
+  o.x *= s; o.y *= s; o.z *= s; o.w *= s;
+  return o;
+}
+
 // ---- Jr^-1: I + hat/2 + c*hat^2, c = 1/t^2 - (1+cos t)/(2 t sin t)   (sophus_utils.hpp:210-242)
 CTV_DI double jrinv_coeff(double n2) {
   if (n2 < 0.25)   // (1 - (t/2) cot(t/2)) / t^2 = sum |B_2k| t^(2k-2) / (2k)!, truncation < 1e-17
