@@ -37,6 +37,13 @@ template <class T, class TJ> struct SegConstLazy {
     return J;
   }
 };
+// The same with everything held by value in wave-uniform registers (the caller has made the values scalar): Jr^-1 costs no vector
+// registers and no loads inside the evaluation loop.
+template <class T> struct SegConstS {
+  V3<T> d[3];
+  M3<T> JrI[3];
+  CTV_DI const M3<T> &jri(int i) const { return JrI[i]; }
+};
 template <class T, class TJ> CTV_DI void seg_const_lazy(const double *kd, const TJ *kjri, SegConstLazy<T, TJ> &sc) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) sc.d[i] = mk<T>((T)kd[3 * i], (T)kd[3 * i + 1], (T)kd[3 * i + 2]);
@@ -336,6 +343,19 @@ CTV_DI void imu_jac_accel3(const ImuMid3<T> &md, const SC &sc, const M3<T> &Cg, 
     imu_apply_pair(scale(mul(mul_hat(md.Apost[i], md.b[i]), md.JrK[i]), md.lamR[i + 1]), sc, i, Ja[i], Ja[i + 1], false);
 }
 
+// Accelerometer row a in the product kernel's two-tile order: T0 = [rot k0..k3 (12) | ba (3) | r], T1 = [pos k0..k3 (12)] (columns 28..31 unused)
+template <class T> CTV_DI void imu_row_accel3(const M3<T> (&Ja)[4], const T lamA[4], const M3<T> &Rinv_g, const T w[6], const T r[6], int a, T out[28]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      out[3 * kk + b] = w[3 + a] * Ja[kk].m[3 * a + b];
+      out[16 + 3 * kk + b] = w[3 + a] * lamA[kk] * Rinv_g.m[3 * a + b];
+    }
+  out[12] = out[13] = out[14] = T(0);
+  out[12 + a] = w[3 + a];
+  out[15] = r[3 + a];
+}
 // trajectory_value_factor.h:198-245, column by column
 template <class T, class Sink> CTV_DI void imu_emit_cols(const ImuJac<T> &J, const T w[6], Sink &sink) {
 #pragma unroll

@@ -493,9 +493,6 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
 // 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
 // tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
 // B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
-// STAGED: values, then the gyro Jacobians and their three row phases, then the accelerometer Jacobians and theirs (factors.hpp:
-// imu_eval_values / imu_jac_gyro / imu_jac_accel) instead of the whole Jacobian up front.
-template <bool STAGED>
 __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx) {
   const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
@@ -517,32 +514,8 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { bias[i] = bp[i]; wgt[i] = m.imu_w[i]; }
-  V3<double> grav = lf.rotate(m.gravity);
+  const V3<double> grav = lf.rotate(m.gravity);
   const double idt = m.inv_dt;
-  if constexpr (STAGED) {
-    // the group's constants are the same in every lane: kept in SGPRs they cost no vector registers (the evaluation needs far more
-    // than 256 of those: every one saved is one AGPR round trip less).  A VALU instruction takes one scalar operand: these are
-    // the ones that meet a per-lane value in a product.
-    auto uni = [](double x) {
-      const long long b = __double_as_longlong(x);
-      const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-      return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { k.p[i].x = uni(k.p[i].x); k.p[i].y = uni(k.p[i].y); k.p[i].z = uni(k.p[i].z); }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { sc.d[i].x = uni(sc.d[i].x); sc.d[i].y = uni(sc.d[i].y); sc.d[i].z = uni(sc.d[i].z); }
-    k.q[0].x = uni(k.q[0].x); k.q[0].y = uni(k.q[0].y); k.q[0].z = uni(k.q[0].z); k.q[0].w = uni(k.q[0].w);
-    grav.x = uni(grav.x); grav.y = uni(grav.y); grav.z = uni(grav.z);
-  }
-  M3<double> Cg;   // R_0^T RrefT: the position-knot columns are lamA[k] * Apost_0 Cg (factors.hpp, third form)
-  if constexpr (STAGED) {
-    const M3<double> R0 = q2R(k.q[0]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Cg.m[3 * i + j] = R0.m[i] * RrefT.m[j] + R0.m[3 + i] * RrefT.m[3 + j] + R0.m[6 + i] * RrefT.m[6 + j];
-  }
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   const size_t Mt = (size_t)d.Mtot;
   if (!jac) {   // residuals only (a separate, small code path: the full one below keeps its compile-time `want_jac = true`)
@@ -577,51 +550,6 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
 #pragma unroll
     for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
     const int kmax = (nval + 3) & ~3;
-    if constexpr (STAGED) {
-      ImuMid3<double> md;
-      imu_eval_values3<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, r, md);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
-      {
-        M3<double> Jw[4];
-        imu_jac_gyro3<double>(md, sc, Jw);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          double row[16];
-          imu_row_gyro2<double>(Jw, wl, r, a, row);
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-          for (int k0 = 0; k0 < kmax; k0 += 4) {
-            const double v = A[(k0 + q4) * 17 + l15];
-            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gacc, 0, 0, 0);
-          }
-        }
-      }
-      {
-        M3<double> Ja[4], Rinv_g;
-        imu_jac_accel3<double>(md, sc, Cg, Ja, Rinv_g);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          double row[32];
-          imu_row_accel2<double>(Ja, md.lamA, Rinv_g, wl, r, a, row);
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int c = 0; c < 32; ++c) A[lane * 33 + c] = row[c];
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-          for (int k0 = 0; k0 < kmax; k0 += 4) {
-            const double lo = A[(k0 + q4) * 33 + l15], hi = A[(k0 + q4) * 33 + 16 + l15];
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, acc00, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, acc11, 0, 0, 0);
-          }
-        }
-      }
-      continue;
-    }
     ImuJac<double> J;
     imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, true, J);
 #pragma unroll
@@ -691,26 +619,245 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
 }
 
+// ---- The product path's body for the usual group (imu_group_fast: knot-pair logs below 0.5 rad, isotropic accelerometer weights).
+// Same wave-per-group scheme and row streaming as the general body above, with
+//   * the evaluation in stages (factors.hpp, third form): values, gyro Jacobians -> three row phases, accelerometer Jacobians -> three row
+//     phases, so the two 36-entry Jacobians are never live together; small-angle series, no branch in the loop;
+//   * global frame (the local frame of the general body is an fp32 device), Jr^-1 of the three knot pairs and their logs in SGPRs;
+//   * the accelerometer rows in two 16-column tiles T0 = [rot 12 | ba 3 | r], T1 = [pos 12]: T0^T T0 and T1^T T0 on the matrix cores,
+//     T1^T T1 = w^2 sum_s lamA_k lamA_k' I3 from ten per-lane sums (R(t)^T W^2 R(t) = w^2 I): 2 MFMAs per K-step instead of 3;
+//   * the next pass's measurements requested before the current pass is evaluated.
+// (fp64 MFMA and fp64 VALU instructions share one datapath on gfx950 -- tools/mfma_valu_overlap.hip: one wave's MFMAs and FMAs add up,
+//  two waves on a SIMD do not overlap them either -- so the kernel's time is the SUM of its vector and matrix work: both are cut here.)
+__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx) {
+  const ImuGroup grp = d.groups[gidx];
+  const int w = grp.win;
+  if (!lin_run(d.lm[w], mode)) return;
+  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
+  const WinMeta &m = d.wins[w];
+  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
+  const bool at_cand = mode == LIN_SPEC;
+  const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
+  auto uni = [](double x) {   // a wave-uniform value the compiler cannot prove uniform -> scalar registers
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  const int k0g = m.knot0 + grp.s;
+  Knots4<double> k;
+  {
+    const double *q = s_quat + 4 * k0g, *p = s_pos + 3 * k0g;
+    k.q[0] = qmk<double>(q[0], q[1], q[2], q[3]);   // (only q_0 is used: the other knots enter through the pair logs)
+    k.q[1] = k.q[2] = k.q[3] = k.q[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k.p[i] = mk<double>(p[3 * i] - p[0], p[3 * i + 1] - p[1], p[3 * i + 2] - p[2]);
+  }
+  SegConstS<double> sc;
+  {
+    const double *kd = d.lkd + 3 * k0g, *kj = d.kjri + 9 * k0g;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      sc.d[i] = mk<double>(uni(kd[3 * i]), uni(kd[3 * i + 1]), uni(kd[3 * i + 2]));
+#pragma unroll
+      for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = uni(kj[9 * i + e]);
+    }
+  }
+  double bias[6], wgt[6];
+  const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { bias[i] = bp[i]; wgt[i] = m.imu_w[i]; }
+  const V3<double> grav = mk<double>(m.gravity[0], m.gravity[1], m.gravity[2]);
+  const double idt = m.inv_dt;
+  const size_t Mt = (size_t)d.Mtot;
+  const int base = m.imu0 + grp.start;
+  double csum = 0.0;
+  if (!jac) {   // residuals only
+    for (int c0 = 0; c0 < grp.count; c0 += 64) {
+      const bool live = c0 + lane < grp.count;
+      const int idx = base + min(c0 + lane, grp.count - 1);
+      double gy[3], ac[3], r[6], wl[6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
+      ImuMid3<double> md;
+      imu_eval_values3<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, r, md);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+    if (lane == 0) d.imu_cost[gidx] = csum;
+    return;
+  }
+  M3<double> Cg;   // R_0^T: the position-knot columns are lamA[k] * Apost_0 R_0^T (factors.hpp, third form)
+  {
+    const M3<double> R0 = q2R(k.q[0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Cg.m[3 * i + j] = R0.m[3 * j + i];
+  }
+  f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
+  double spp[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double gyn[3], acn[3], un;   // the next pass's measurements, in flight while the current pass is evaluated
+  {
+    const int idx = base + min(lane, grp.count - 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+    un = d.imu_u[idx];
+  }
+  for (int c0 = 0; c0 < grp.count; c0 += 64) {
+    const int nval = min(64, grp.count - c0);
+    const bool live = lane < nval;
+    double gy[3], ac[3], r[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gy[i] = gyn[i]; ac[i] = acn[i]; }
+    const double u = un;
+    {
+      const int idx = base + min(c0 + 64 + lane, grp.count - 1);   // (clamped: the last pass re-reads a valid sample and drops it)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+      un = d.imu_u[idx];
+    }
+    // lanes past the end of the group evaluate a clamped sample with ZERO weights: every row of w .* [J | r] is then exactly zero
+    double wl[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
+    const int kmax = (nval + 3) & ~3;
+    ImuMid3<double> md;
+    imu_eval_values3<double>(k, sc, u, idt, grav, bias, gy, ac, wl, r, md);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
+    {
+      M3<double> Jw[4];
+      imu_jac_gyro3<double>(md, sc, Jw);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static
+        double row[16];
+        imu_row_gyro2<double>(Jw, wl, r, a, row);
+        __builtin_amdgcn_wave_barrier();   // the previous phase's operand reads are complete (consumed by its MFMAs)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the rows are in LDS
+        __builtin_amdgcn_wave_barrier();
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+          const double v = A[(k0 + q4) * 17 + l15];
+          gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gacc, 0, 0, 0);
+        }
+      }
+    }
+    {
+      M3<double> Ja[4], Rinv_g;
+      imu_jac_accel3<double>(md, sc, Cg, Ja, Rinv_g);
+      {
+        double la[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) la[kk] = wl[3] * md.lamA[kk];
+        int e = 0;
+#pragma unroll
+        for (int ka = 0; ka < 4; ++ka)
+#pragma unroll
+          for (int kb = 0; kb <= ka; ++kb) { spp[e] += la[ka] * la[kb]; ++e; }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double row[28];
+        imu_row_accel3<double>(Ja, md.lamA, Rinv_g, wl, r, a, row);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 28; ++c) A[lane * 33 + c] = row[c];   // (columns 28..31 feed accumulator rows nobody reads)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+          const double lo = A[(k0 + q4) * 33 + l15], hi = A[(k0 + q4) * 33 + 16 + l15];
+          acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, acc00, 0, 0, 0);
+          acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, acc10, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- the group's share of the cost: fixed-order sum over the lanes (butterfly), one store
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
+  if (lane == 0) d.imu_cost[gidx] = csum;
+  // ---- combine in LDS into the full symmetric 32 x 32 tile in the local column order [rot 12 | pos 12 | bg 3 | ba 3 | r | -]
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) A[i * 64 + lane] = 0.0;
+  {
+    // the ten sums over the 64 lanes in a fixed order, through the free half of the buffer: lane (e, part) adds 16 lanes' values, two
+    // butterfly steps join the four parts
+    double *S = A + 1024;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) S[e * 64 + lane] = spp[e];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int e = min(lane >> 2, 9), part = lane & 3;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += S[e * 64 + part * 16 + i];
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 40 && part == 0) S[640 + e] = t;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int c0 = l15 < 12 ? l15 : (l15 < 15 ? l15 + 15 : 30);   // T0 index -> local column (ba at 27..29)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = q4 + 4 * r;
+      const int r0 = t < 12 ? t : (t < 15 ? t + 15 : 30);
+      A[r0 * 32 + c0] = acc00[r];
+      if (t < 12) { A[(12 + t) * 32 + c0] = acc10[r]; A[c0 * 32 + 12 + t] = acc10[r]; }
+    }
+    // lane (ka, kb, b) < 48 places one entry of the pos x pos block
+    const int ka = lane / 12, kb = (lane / 3) & 3, b = lane % 3;
+    const int hi = max(ka, kb), lo = min(ka, kb);
+    if (lane < 48) A[(12 + 3 * ka + b) * 32 + 12 + 3 * kb + b] = A[1024 + 640 + hi * (hi + 1) / 2 + lo];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int tc = l15 < 12 ? l15 : (l15 < 15 ? l15 + 12 : 30);   // gyro tile index -> local column (bg at 24..26)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int grow = q4 + 4 * r;
+      const int tr = grow < 12 ? grow : (grow < 15 ? grow + 12 : 30);
+      A[tr * 32 + tc] += gacc[r];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  double *tile = d.imu_tiles + (size_t)gidx * 1024;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
+}
+
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
 // (Two waves per SIMD with the overflow spilled to scratch was measured 3x slower: 1690 vs 540 us per 1024 windows.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
 }
-// The staged body evaluates the small-angle series only: a group whose knot-pair logs reach 0.5 rad (28.6 degrees between two knots 50 ms
-// apart) takes the general body.
-__device__ __forceinline__ bool imu_group_small(const Dev<double> &d, int gidx) {
+// The fast body evaluates the small-angle series only: a group whose knot-pair logs reach 0.5 rad (28.6 degrees between two knots 50 ms
+// apart) takes the general body.  It also takes the pos x pos block from R(t)^T W^2 R(t) = w^2 I: isotropic accelerometer weights (the
+// reference's: one scalar per sensor) -- any other weighting takes the general body as well.
+__device__ __forceinline__ bool imu_group_fast(const Dev<double> &d, int gidx) {
   const ImuGroup grp = d.groups[gidx];
-  const double *kd = d.lkd + 3 * (d.wins[grp.win].knot0 + grp.s);
-  double m = 0.0;
+  const WinMeta &m = d.wins[grp.win];
+  const double *kd = d.lkd + 3 * (m.knot0 + grp.s);
+  double mx = 0.0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) m = fmax(m, kd[3 * i] * kd[3 * i] + kd[3 * i + 1] * kd[3 * i + 1] + kd[3 * i + 2] * kd[3 * i + 2]);
-  return m < 0.25;
+  for (int i = 0; i < 3; ++i) mx = fmax(mx, kd[3 * i] * kd[3 * i] + kd[3 * i + 1] * kd[3 * i + 1] + kd[3 * i + 2] * kd[3 * i + 2]);
+  return mx < 0.25 && m.imu_w[3] == m.imu_w[4] && m.imu_w[3] == m.imu_w[5];
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64_staged(Dev<double> d, int mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  if (imu_group_small(d, blockIdx.x)) imu_linearize_f64_body<true>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
-  else imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  if (imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  else imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
@@ -1045,7 +1192,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
   __shared__ int4 rmeta[64];
   __shared__ int2 rhg[64];
-  if ((int)blockIdx.x < d.Gtot) imu_linearize_f64_body<false>(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
+  if ((int)blockIdx.x < d.Gtot) imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
   else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
 }
 
