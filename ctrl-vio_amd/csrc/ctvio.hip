@@ -621,6 +621,9 @@ template <class T> class SolverImpl : public SolverBase {
   }
   void launch_schur();
   void launch_imu_linearize(size_t vals_lds, int mode);
+  // use_mfma = 2 (or CTVIO_IMU_GENERAL=1): every IMU group through the general body (k_imu_linearize_rest) -- the cross-check of the
+  // specialised one and the tests' way into the path that large knot-to-knot rotations / anisotropic accelerometer weights take
+  int imu_general_only() const { static const int env = std::getenv("CTVIO_IMU_GENERAL") ? 1 : 0; return (env || opt_.use_mfma == 2) ? 1 : 0; }
   void launch_linearize_merged(int mode);
   void launch_assemble_vis_lds(int parts, int mode);
   void launch_assemble_vis_glb(int parts, int mode);
@@ -1134,13 +1137,16 @@ template <class T> class SolverImpl : public SolverBase {
 template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) {
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
-  if (opt_.use_mfma && std::getenv("CTVIO_IMU_STAGED")) hipLaunchKernelGGL(k_imu_linearize_f64_staged, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
-  else if (opt_.use_mfma) hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode);
+  if (opt_.use_mfma) {
+    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)(64 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only());
+    hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only());
+  }
   else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
 }
 template <> void SolverImpl<double>::launch_linearize_merged(int mode) {
   const Dev<double> &d = dev_;
-  hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode);
+  hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode, imu_general_only());
+  hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only());
 }
 template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts, int mode) {
   const Dev<double> &d = dev_;

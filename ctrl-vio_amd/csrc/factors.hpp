@@ -286,15 +286,16 @@ template <class T> struct ImuMid3 {
   V3<T> b[3];               // b_i above
   T lamR[4], lamW[4], lamA[4];
 };
+// gc: the group's other constants, read where they are used (the kernel keeps them in LDS: one broadcast read each per pass instead of
+// a register pair for the whole loop): [0..11] knot positions relative to knot 0, [12..20] R_0^T (row major), [21..23] gravity, [24..29] bias
 template <class T, class SC>
-CTV_DI void imu_eval_values3(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity, const T bias[6], const T gyro[3], const T acc[3],
-                             const T w[6], T r[6], ImuMid3<T> &md) {
+CTV_DI void imu_eval_values3(const T *gc, const SC &sc, T u, T idt, const T gyro[3], const T acc[3], const T w[6], T r[6], ImuMid3<T> &md) {
   basis<T, false, 2>(u, idt * idt, md.lamA);
   basis<T, true, 0>(u, T(1), md.lamR);
   basis<T, true, 1>(u, idt, md.lamW);
-  V3<T> accel = mk<T>(0, 0, 0);
+  V3<T> ag = mk<T>(gc[21], gc[22], gc[23]);   // spline acceleration + gravity (world)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) accel = accel + md.lamA[i] * k.p[i];
+  for (int i = 1; i < 4; ++i) ag = ag + md.lamA[i] * mk<T>(gc[3 * i], gc[3 * i + 1], gc[3 * i + 2]);   // (p_0 - p_0 = 0)
   Q4<T> Ainv[3], accq;
 #pragma unroll
   for (int i = 2; i >= 0; --i) {
@@ -308,16 +309,17 @@ CTV_DI void imu_eval_values3(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T>
   md.om1 = md.lamW[1] * sc.d[0];
   md.om2 = qrot(Ainv[1], md.om1) + md.lamW[2] * sc.d[1];
   om3 = qrot(Ainv[2], md.om2) + md.lamW[3] * sc.d[2];
-  md.b[0] = qrot(qconj(k.q[0]), accel + gravity);
+  md.b[0] = mk<T>(gc[12] * ag.x + gc[13] * ag.y + gc[14] * ag.z, gc[15] * ag.x + gc[16] * ag.y + gc[17] * ag.z,
+                  gc[18] * ag.x + gc[19] * ag.y + gc[20] * ag.z);   // R_0^T (a + g)
   md.b[1] = qrot(Ainv[0], md.b[0]);
   md.b[2] = qrot(Ainv[1], md.b[1]);
   const V3<T> a_pred = qrot(Ainv[2], md.b[2]);   // = R(t)^T (a + g)
-  r[0] = w[0] * (om3.x - (gyro[0] - bias[0]));
-  r[1] = w[1] * (om3.y - (gyro[1] - bias[1]));
-  r[2] = w[2] * (om3.z - (gyro[2] - bias[2]));
-  r[3] = w[3] * (a_pred.x - (acc[0] - bias[3]));
-  r[4] = w[4] * (a_pred.y - (acc[1] - bias[4]));
-  r[5] = w[5] * (a_pred.z - (acc[2] - bias[5]));
+  r[0] = w[0] * (om3.x - (gyro[0] - gc[24]));
+  r[1] = w[1] * (om3.y - (gyro[1] - gc[25]));
+  r[2] = w[2] * (om3.z - (gyro[2] - gc[26]));
+  r[3] = w[3] * (a_pred.x - (acc[0] - gc[27]));
+  r[4] = w[4] * (a_pred.y - (acc[1] - gc[28]));
+  r[5] = w[5] * (a_pred.z - (acc[2] - gc[29]));
 }
 // M (3 x 3) against the knot-pair table: J[i] -= M JrI_i^T, J[i + 1] += M JrI_i
 template <class T, class SC> CTV_DI void imu_apply_pair(const M3<T> &M, const SC &sc, int i, M3<T> &Ji, M3<T> &Ji1, bool first) {
@@ -333,10 +335,14 @@ template <class T, class SC> CTV_DI void imu_jac_gyro3(const ImuMid3<T> &md, con
   dod.m[0] += md.lamW[3]; dod.m[4] += md.lamW[3]; dod.m[8] += md.lamW[3];
   imu_apply_pair(dod, sc, 2, Jw[2], Jw[3], false);
 }
-// Cg = R_0^T RrefT (group constant): R(t)^T in the global frame = Apost_0 Cg
+// R(t)^T = Apost_0 R_0^T (gc[12..20])
 template <class T, class SC>
-CTV_DI void imu_jac_accel3(const ImuMid3<T> &md, const SC &sc, const M3<T> &Cg, M3<T> (&Ja)[4], M3<T> &Rinv_g) {
-  Rinv_g = mul(md.Apost[0], Cg);
+CTV_DI void imu_jac_accel3(const ImuMid3<T> &md, const SC &sc, const T *gc, M3<T> (&Ja)[4], M3<T> &Rinv_g) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      Rinv_g.m[3 * i + j] = md.Apost[0].m[3 * i] * gc[12 + j] + md.Apost[0].m[3 * i + 1] * gc[15 + j] + md.Apost[0].m[3 * i + 2] * gc[18 + j];
   Ja[0] = mul_hat(md.Apost[0], md.b[0]);
 #pragma unroll
   for (int i = 0; i < 3; ++i)

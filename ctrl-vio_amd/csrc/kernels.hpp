@@ -629,7 +629,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
 //   * the next pass's measurements requested before the current pass is evaluated.
 // (fp64 MFMA and fp64 VALU instructions share one datapath on gfx950 -- tools/mfma_valu_overlap.hip: one wave's MFMAs and FMAs add up,
 //  two waves on a SIMD do not overlap them either -- so the kernel's time is the SUM of its vector and matrix work: both are cut here.)
-__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx) {
+__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [64][33] + 64 */, int gidx) {
   const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
   if (!lin_run(d.lm[w], mode)) return;
@@ -644,13 +644,27 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
   };
   const int k0g = m.knot0 + grp.s;
-  Knots4<double> k;
+  // the group's constants: knot-pair logs and Jr^-1 (used a dozen times per pass) in scalar registers, the rest (used once or twice per
+  // pass) in LDS behind the row buffer -- [0..11] knot positions relative to knot 0, [12..20] R_0^T, [21..23] gravity, [24..29] bias,
+  // [30..35] weights.  (All of them in scalar registers overflow the SGPR file: 250 v_readlane per pass to fetch them back.)
+  double *gc = A + 64 * 33;
   {
-    const double *q = s_quat + 4 * k0g, *p = s_pos + 3 * k0g;
-    k.q[0] = qmk<double>(q[0], q[1], q[2], q[3]);   // (only q_0 is used: the other knots enter through the pair logs)
-    k.q[1] = k.q[2] = k.q[3] = k.q[0];
+    const double *q = s_quat + 4 * k0g, *p = s_pos + 3 * k0g, *bp = s_bias + 6 * (m.bias0 + grp.bias);
+    const M3<double> R0 = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
+    double v = 0.0;
+    if (lane < 12) v = p[lane] - p[lane % 3];
+    else if (lane < 21) {   // R_0^T, row major (a select chain: no dynamically indexed register array)
+      const int e = lane - 12, src = 3 * (e % 3) + e / 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k.p[i] = mk<double>(p[3 * i] - p[0], p[3 * i + 1] - p[1], p[3 * i + 2] - p[2]);
+      for (int i = 0; i < 9; ++i) v = src == i ? R0.m[i] : v;
+    }
+    else if (lane < 24) v = m.gravity[lane - 21];
+    else if (lane < 30) v = bp[lane - 24];
+    else if (lane < 36) v = m.imu_w[lane - 30];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) gc[lane] = v;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
   }
   SegConstS<double> sc;
   {
@@ -662,11 +676,6 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
       for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = uni(kj[9 * i + e]);
     }
   }
-  double bias[6], wgt[6];
-  const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { bias[i] = bp[i]; wgt[i] = m.imu_w[i]; }
-  const V3<double> grav = mk<double>(m.gravity[0], m.gravity[1], m.gravity[2]);
   const double idt = m.inv_dt;
   const size_t Mt = (size_t)d.Mtot;
   const int base = m.imu0 + grp.start;
@@ -679,9 +688,9 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
+      for (int i = 0; i < 6; ++i) wl[i] = live ? gc[30 + i] : 0.0;
       ImuMid3<double> md;
-      imu_eval_values3<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, r, md);
+      imu_eval_values3<double>(gc, sc, d.imu_u[idx], idt, gy, ac, wl, r, md);
 #pragma unroll
       for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
     }
@@ -689,14 +698,6 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
     if (lane == 0) d.imu_cost[gidx] = csum;
     return;
-  }
-  M3<double> Cg;   // R_0^T: the position-knot columns are lamA[k] * Apost_0 R_0^T (factors.hpp, third form)
-  {
-    const M3<double> R0 = q2R(k.q[0]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Cg.m[3 * i + j] = R0.m[3 * j + i];
   }
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   double spp[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -723,10 +724,10 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     // lanes past the end of the group evaluate a clamped sample with ZERO weights: every row of w .* [J | r] is then exactly zero
     double wl[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
+    for (int i = 0; i < 6; ++i) wl[i] = live ? gc[30 + i] : 0.0;
     const int kmax = (nval + 3) & ~3;
     ImuMid3<double> md;
-    imu_eval_values3<double>(k, sc, u, idt, grav, bias, gy, ac, wl, r, md);
+    imu_eval_values3<double>(gc, sc, u, idt, gy, ac, wl, r, md);
 #pragma unroll
     for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
     {
@@ -749,7 +750,7 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     }
     {
       M3<double> Ja[4], Rinv_g;
-      imu_jac_accel3<double>(md, sc, Cg, Ja, Rinv_g);
+      imu_jac_accel3<double>(md, sc, gc, Ja, Rinv_g);
       {
         double la[4];
 #pragma unroll
@@ -838,10 +839,6 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
 
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
 // (Two waves per SIMD with the overflow spilled to scratch was measured 3x slower: 1690 vs 540 us per 1024 windows.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode) {
-  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
-}
 // The fast body evaluates the small-angle series only: a group whose knot-pair logs reach 0.5 rad (28.6 degrees between two knots 50 ms
 // apart) takes the general body.  It also takes the pos x pos block from R(t)^T W^2 R(t) = w^2 I: isotropic accelerometer weights (the
 // reference's: one scalar per sensor) -- any other weighting takes the general body as well.
@@ -854,10 +851,29 @@ __device__ __forceinline__ bool imu_group_fast(const Dev<double> &d, int gidx) {
   for (int i = 0; i < 3; ++i) mx = fmax(mx, kd[3 * i] * kd[3 * i] + kd[3 * i + 1] * kd[3 * i + 1] + kd[3 * i + 2] * kd[3 * i + 2]);
   return mx < 0.25 && m.imu_w[3] == m.imu_w[4] && m.imu_w[3] == m.imu_w[5];
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64_staged(Dev<double> d, int mode) {
+// The groups the fast body leaves out are picked up by k_imu_linearize_rest (one wave per WINDOW: its lanes look at the window's groups,
+// the wave then takes the flagged ones in turn -- 12 us per launch when there is nothing to do, which is the rule): the two bodies in
+// one kernel cost the fast one registers.
+// (general_only: every group through the general body -- ctvio_options.use_mfma = 2 / CTVIO_IMU_GENERAL=1, the tests' way into it)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode, int general_only) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  if (imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
-  else imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev<double> d, int mode, int general_only) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
+  const WinMeta &m = d.wins[blockIdx.x];
+  for (int g0 = 0; g0 < m.ngrp; g0 += 64) {
+    const int gl = g0 + (int)threadIdx.x;
+    const bool need = gl < m.ngrp && (general_only || !imu_group_fast(d, m.grp0 + gl));
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+      const int b = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), m.grp0 + g0 + b);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
@@ -1188,12 +1204,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
 // Both evaluations in ONE launch: workgroups [0, Gtot) take an IMU group each, the others a wave of 64 visual block slots.  The two are
 // independent; for a batch smaller than the chip their single-wave latencies (23 us each for one window) overlap instead of adding
 // up, and large batches lose nothing.  The IMU rows use the head of the visual kernel's LDS buffer.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linearize_f64(Dev<double> d, int mode) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linearize_f64(Dev<double> d, int mode, int general_only) {
   __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
   __shared__ int4 rmeta[64];
   __shared__ int2 rhg[64];
-  if ((int)blockIdx.x < d.Gtot) imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
-  else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
+  if ((int)blockIdx.x < d.Gtot) {
+    if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
+  } else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
 }
 
 // Visual assembly: gridDim.y workgroups (8 waves each) per window.  The host sorted the visual blocks by

@@ -31,7 +31,7 @@ class Solver:
         self._lib.ctvio_default_options(C.byref(opt))
         opt.device = device
         opt.precision = capi.FP64
-        opt.use_mfma = int(bool(use_mfma))
+        opt.use_mfma = int(use_mfma)   # 0 / 1 / 2 (include/ctvio.h)
         opt.check_every = int(check_every)
         opt.deterministic = int(deterministic)
         opt.host_threads = int(host_threads)

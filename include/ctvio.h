@@ -51,7 +51,9 @@ enum { CTVIO_PK_ROT = 0, CTVIO_PK_POS = 1, CTVIO_PK_BG = 2, CTVIO_PK_BA = 3, CTV
 typedef struct ctvio_options {
   int32_t device;               /* HIP device ordinal */
   int32_t precision;            /* CTVIO_FP64 */
-  int32_t use_mfma;             /* 1 (default): products on v_mfma_f64_16x16x4_f64; 0: vector-ALU cross-check kernels */
+  int32_t use_mfma;             /* 1 (default): products on v_mfma_f64_16x16x4_f64; 0: vector-ALU cross-check kernels;
+                                   2: as 1 with every IMU group evaluated by the general body (the one groups with knot-to-knot
+                                   rotations >= 0.5 rad or anisotropic accelerometer weights take): cross-check of the specialised body */
   int32_t check_every;          /* host polls "all windows terminated" every n LM iterations */
   double function_tolerance;    /* 1e-6  Ceres defaults, see SURVEY.md Appendix A */
   double gradient_tolerance;    /* 1e-10 */

@@ -41,6 +41,32 @@ def test_linearize_matches_oracle(cv, oracle, win_cfg1, prec, tol):
     assert np.abs((gg - g) / sc).max() < tol * np.abs(g / sc).max()
 
 
+@pytest.mark.parametrize("case", ["general_body", "anisotropic_accel", "large_rotation"])
+def test_imu_linearize_general_body(cv, oracle, win_cfg1, case):
+    """k_imu_linearize_f64 specialises the usual IMU group (knot-pair rotations < 0.5 rad, isotropic accelerometer weights); the others go
+    through the general body (k_imu_linearize_rest).  All three ways into it against the oracle: forced (use_mfma = 2), accelerometer weights
+    that differ per axis, and a window whose knots turn by ~0.7 rad from one to the next (beyond the small-angle series)."""
+    w = win_cfg1.copy()
+    mfma = 1
+    if case == "general_body":
+        mfma = 2
+    elif case == "anisotropic_accel":
+        w.imu_w = np.array([250.0, 250.0, 250.0, 12.5, 10.0, 15.0])
+    else:
+        from scipy.spatial.transform import Rotation as R
+        for k in range(w.quat.shape[0]):   # q_k <- q_k * exp(k * 0.7 e_z): consecutive knots 0.7 rad further apart
+            w.quat[k] = (R.from_quat(w.quat[k]) * R.from_rotvec([0.0, 0.0, 0.7 * k])).as_quat()
+    H, g, cost = oracle.OracleWindow(w.copy()).build_normal()
+    P = w.P
+    sc = _scaled(H)
+    with cv.Solver(use_mfma=mfma) as s:
+        s.set_windows([w])
+        Hg, Wg, Hllg, gg, costg = s.linearize(0)
+    assert costg == pytest.approx(cost, rel=1e-12)
+    assert np.abs((Hg - H[:P, :P]) / np.outer(sc[:P], sc[:P])).max() < 1e-10
+    assert np.abs((gg - g) / sc).max() < 1e-10 * np.abs(g / sc).max()
+
+
 @pytest.mark.parametrize("prec,tol", [("fp64", 1e-8)])
 @pytest.mark.parametrize("mfma", [True, False])
 def test_lm_step_matches_oracle(cv, oracle, win_cfg1, prec, tol, mfma):
