@@ -118,7 +118,7 @@ CTV_DI void imu_eval_core(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gr
   for (int i = 2; i >= 0; --i) {
     const V3<T> nkd = (-lamR[i + 1]) * sc.d[i];
     Ainv[i] = so3_exp(nkd);
-    accq = qmul(accq, Ainv[i]);
+    accq = qmul_unit(accq, Ainv[i]);
     if (want_jac) { Apost[i] = q2R(accq); JrK[i] = so3_Jr(nkd); }
   }
   V3<T> om[4];
@@ -126,7 +126,7 @@ CTV_DI void imu_eval_core(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gr
 #pragma unroll
   for (int i = 0; i < 3; ++i) om[i + 1] = qrot(Ainv[i], om[i]) + lamW[i + 1] * sc.d[i];
 
-  const Q4<T> Rinv_q = qmul(accq, qconj(k.q[0]));
+  const Q4<T> Rinv_q = qmul_unit(accq, qconj(k.q[0]));
   const V3<T> ag = accel + gravity;
   const V3<T> a_pred = qrot(Rinv_q, ag);
   r[0] = w[0] * (om[3].x - (gyro[0] - bias[0]));
@@ -197,7 +197,7 @@ CTV_DI void imu_eval_values(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> 
   for (int i = 2; i >= 0; --i) {
     const V3<T> nkd = (-md.lamR[i + 1]) * sc.d[i];
     md.Ainv[i] = so3_exp(nkd);
-    accq = qmul(accq, md.Ainv[i]);
+    accq = qmul_unit(accq, md.Ainv[i]);
     if (i == 2) md.Apost2 = q2R(accq);
     if (i == 1) md.Apost1 = q2R(accq);
     md.JrK[i] = so3_Jr(nkd);
@@ -207,7 +207,7 @@ CTV_DI void imu_eval_values(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> 
 #pragma unroll
   for (int i = 0; i < 3; ++i) om[i + 1] = qrot(md.Ainv[i], om[i]) + md.lamW[i + 1] * sc.d[i];
   md.om1 = om[1]; md.om2 = om[2];
-  md.Rinv_q = qmul(accq, qconj(k.q[0]));
+  md.Rinv_q = qmul_unit(accq, qconj(k.q[0]));
   md.ag = accel + gravity;
   const V3<T> a_pred = qrot(md.Rinv_q, md.ag);
   r[0] = w[0] * (om[3].x - (gyro[0] - bias[0]));
@@ -423,7 +423,8 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity
 }
 
 // ------------------------------------------------------------------------------------------------
-// SO(3) spline views on 4 knots.
+// SO(3) spline views on 4 knots.  (Products of unit quaternions -- normalised knots, exp() -- through qmul_unit: Sophus' renormalising
+// product without the division, so3.hpp.)
 // EvaluateRp (so3_spline_view.h:136-198): returns R(t); J[k] = per-knot 3x3 "partial" Jacobians.
 template <class T, class SC> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
   T c[4];
@@ -434,10 +435,10 @@ template <class T, class SC> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc
 #pragma unroll
   for (int i = 2; i >= 0; --i) {
     const V3<T> kd = c[i + 1] * sc.d[i];
-    accq = qmul(accq, so3_exp(neg(kd)));
+    accq = qmul_unit(accq, so3_exp(neg(kd)));
     if (want_jac) { JrK[i] = so3_Jr(kd); Apost[i] = q2R(accq); }
   }
-  const Q4<T> res = qmul(q[0], qconj(accq));
+  const Q4<T> res = qmul_unit(q[0], qconj(accq));
   if (want_jac) {
     J[0] = Apost[0];
 #pragma unroll
@@ -459,7 +460,7 @@ template <class T, class SC> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SC &s
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const V3<T> kd = c[i + 1] * sc.d[i];
-    S[i + 1] = qmul(S[i], so3_exp(kd));
+    S[i + 1] = qmul_unit(S[i], so3_exp(kd));
     if (want_jac) JrK[i] = so3_Jr(neg(kd));
   }
   if (want_jac) {
@@ -489,7 +490,7 @@ template <class T, class SC> CTV_DI Q4<T> eval_R(const Q4<T> q[4], const SC &sc,
   basis<T, true, 0>(u, T(1), c);
   Q4<T> res = q[0];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) res = qmul(res, so3_exp(c[i + 1] * sc.d[i]));
+  for (int i = 0; i < 3; ++i) res = qmul_unit(res, so3_exp(c[i + 1] * sc.d[i]));
   return res;
 }
 
@@ -512,7 +513,7 @@ template <class T, class SC, class F> CTV_DI void eval_Rp_jac_stream(const SC &s
     const M3<T> Jn = mul(Jh, JrIi);
     f(i + 1, i == 2 ? Jn : add(Jn, pending));
     pending = scale(mulT(Jh, JrIi), T(-1));
-    accq = qmul(accq, so3_exp(neg(kd)));
+    accq = qmul_unit(accq, so3_exp(neg(kd)));
     Ap = q2R(accq);
   }
   f(0, add(Ap, pending));
@@ -529,7 +530,7 @@ template <class T, class SC, class F> CTV_DI void eval_RTp_jac_stream(const Q4<T
     const M3<T> JrIi = sc.jri(i);
     f(i, sub(pending, mulT(Jh, JrIi)));
     pending = mul(Jh, JrIi);
-    S = qmul(S, so3_exp(kd));
+    S = qmul_unit(S, so3_exp(kd));
   }
   f(3, pending);
 }
@@ -570,7 +571,7 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, co
 
   const V3<T> p_G = qrot(S_IitoG, p_Ii) + p_IiinG;
   const Q4<T> S_ItoC = qconj(cal.q_CI);
-  const Q4<T> S_GtoCj = qmul(S_ItoC, S_GtoIj);
+  const Q4<T> S_GtoCj = qmul(S_ItoC, S_GtoIj);   // (the extrinsic is user input: Sophus' exact renormalisation)
   const V3<T> dpg = p_G - p_IjinG;
   const V3<T> x_j = qrot(S_GtoCj, dpg) - qrot(S_ItoC, cal.p_CI);
   const T dji = T(1) / x_j.z;
