@@ -740,8 +740,8 @@ template <class T> class SolverImpl : public SolverBase {
       HIPCHK(hipMemcpy(st, d.dbg, sizeof st, hipMemcpyDeviceToHost));
       std::fprintf(stderr, "[ctvio] cholesky clock64 deltas:");
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
-      std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> end phase of wave 1000, clock64 deltas (J~ copy-out | landmark contributions | per sweep: scatter, rows out):");
-      for (int i = 33; i < 40; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> wave 1000, clock64 deltas (evaluation | J~ copy-out | landmark contributions | per sweep: scatter, rows out):");
+      for (int i = 32; i < 40; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, " | landmarks %lld, rows per sweep %lld", st[42] / 1000000, st[43] / 1000);
       std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | per item of rounds 0, 1: staged, run products.., scatter | rounds | imu tiles | H flush | g flush):");
       for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);

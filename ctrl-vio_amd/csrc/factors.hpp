@@ -426,7 +426,7 @@ CTV_DI void imu_eval(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity
 // SO(3) spline views on 4 knots.  (Products of unit quaternions -- normalised knots, exp() -- through qmul_unit: Sophus' renormalising
 // product without the division, so3.hpp.)
 // EvaluateRp (so3_spline_view.h:136-198): returns R(t); J[k] = per-knot 3x3 "partial" Jacobians.
-template <class T, class SC> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
+template <class T, class SC, bool SMALL = false> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> accq = qmk<T>(0, 0, 0, 1);
@@ -435,8 +435,8 @@ template <class T, class SC> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc
 #pragma unroll
   for (int i = 2; i >= 0; --i) {
     const V3<T> kd = c[i + 1] * sc.d[i];
-    accq = qmul_unit(accq, so3_exp(neg(kd)));
-    if (want_jac) { JrK[i] = so3_Jr(kd); Apost[i] = q2R(accq); }
+    accq = qmul_unit(accq, so3_exp_sel<SMALL>(neg(kd)));
+    if (want_jac) { JrK[i] = so3_Jr_sel<SMALL>(kd); Apost[i] = q2R(accq); }
   }
   const Q4<T> res = qmul_unit(q[0], qconj(accq));
   if (want_jac) {
@@ -451,7 +451,7 @@ template <class T, class SC> CTV_DI Q4<T> eval_Rp(const Q4<T> q[4], const SC &sc
   return res;
 }
 // EvaluateRTp (so3_spline_view.h:208-276): returns R(t)^T.
-template <class T, class SC> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
+template <class T, class SC, bool SMALL = false> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SC &sc, T u, M3<T> J[4], bool want_jac) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> S[4];
@@ -460,8 +460,8 @@ template <class T, class SC> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SC &s
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const V3<T> kd = c[i + 1] * sc.d[i];
-    S[i + 1] = qmul_unit(S[i], so3_exp(kd));
-    if (want_jac) JrK[i] = so3_Jr(neg(kd));
+    S[i + 1] = qmul_unit(S[i], so3_exp_sel<SMALL>(kd));
+    if (want_jac) JrK[i] = so3_Jr_sel<SMALL>(neg(kd));
   }
   if (want_jac) {
     J[0] = q2R(S[0]);
@@ -475,13 +475,13 @@ template <class T, class SC> CTV_DI Q4<T> eval_RTp(const Q4<T> q[4], const SC &s
   return qconj(S[3]);
 }
 // VelocityBody value (so3_spline_view.h:356-411)
-template <class T, class SC> CTV_DI V3<T> eval_omega(const SC &sc, T u, T idt) {
+template <class T, class SC, bool SMALL = false> CTV_DI V3<T> eval_omega(const SC &sc, T u, T idt) {
   T c[4], dc[4];
   basis<T, true, 0>(u, T(1), c);
   basis<T, true, 1>(u, idt, dc);
   V3<T> rv = dc[1] * sc.d[0];
 #pragma unroll
-  for (int i = 1; i < 3; ++i) rv = qrot(so3_exp((-c[i + 1]) * sc.d[i]), rv) + dc[i + 1] * sc.d[i];
+  for (int i = 1; i < 3; ++i) rv = qrot(so3_exp_sel<SMALL>((-c[i + 1]) * sc.d[i]), rv) + dc[i + 1] * sc.d[i];
   return rv;
 }
 // R(t) only (So3Spline::evaluate, so3_spline.h:240-289)
@@ -500,7 +500,7 @@ template <class T, class SC> CTV_DI Q4<T> eval_R(const Q4<T> q[4], const SC &sc,
 //   EvaluateRp : J_3 = H_2 JrI_2 ; J_i = H_{i-1} JrI_{i-1} - H_i JrI_i^T ; J_0 = Apost_0 - H_0 JrI_0^T, H_i = c_{i+1} Apost_{i+1} Jr(c_{i+1} d_i):
 //                Apost is built from the last knot backwards, so the knots come out 3, 2, 1, 0.
 //   EvaluateRTp: H_i = c_{i+1} R(S_i) Jr(-c_{i+1} d_i), S built forwards: knots come out 0, 1, 2, 3.
-template <class T, class SC, class F> CTV_DI void eval_Rp_jac_stream(const SC &sc, T u, F &&f) {
+template <class T, class SC, bool SMALL = false, class F> CTV_DI void eval_Rp_jac_stream(const SC &sc, T u, F &&f) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> accq = qmk<T>(0, 0, 0, 1);
@@ -508,17 +508,17 @@ template <class T, class SC, class F> CTV_DI void eval_Rp_jac_stream(const SC &s
 #pragma unroll
   for (int i = 2; i >= 0; --i) {
     const V3<T> kd = c[i + 1] * sc.d[i];
-    const M3<T> Jh = scale(mul(Ap, so3_Jr(kd)), c[i + 1]);
+    const M3<T> Jh = scale(mul(Ap, so3_Jr_sel<SMALL>(kd)), c[i + 1]);
     const M3<T> JrIi = sc.jri(i);
     const M3<T> Jn = mul(Jh, JrIi);
     f(i + 1, i == 2 ? Jn : add(Jn, pending));
     pending = scale(mulT(Jh, JrIi), T(-1));
-    accq = qmul_unit(accq, so3_exp(neg(kd)));
+    accq = qmul_unit(accq, so3_exp_sel<SMALL>(neg(kd)));
     Ap = q2R(accq);
   }
   f(0, add(Ap, pending));
 }
-template <class T, class SC, class F> CTV_DI void eval_RTp_jac_stream(const Q4<T> q[4], const SC &sc, T u, F &&f) {
+template <class T, class SC, bool SMALL = false, class F> CTV_DI void eval_RTp_jac_stream(const Q4<T> q[4], const SC &sc, T u, F &&f) {
   T c[4];
   basis<T, true, 0>(u, T(1), c);
   Q4<T> S = q[0];
@@ -526,11 +526,11 @@ template <class T, class SC, class F> CTV_DI void eval_RTp_jac_stream(const Q4<T
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const V3<T> kd = c[i + 1] * sc.d[i];
-    const M3<T> Jh = scale(mul(q2R(S), so3_Jr(neg(kd))), c[i + 1]);
+    const M3<T> Jh = scale(mul(q2R(S), so3_Jr_sel<SMALL>(neg(kd))), c[i + 1]);
     const M3<T> JrIi = sc.jri(i);
     f(i, sub(pending, mulT(Jh, JrIi)));
     pending = mul(Jh, JrIi);
-    S = qmul_unit(S, so3_exp(kd));
+    S = qmul_unit(S, so3_exp_sel<SMALL>(kd));
   }
   f(3, pending);
 }
@@ -544,7 +544,9 @@ template <class T> struct Calib {
 // Visual block.  Local column order of J (2 x 50): rot_i (12) | pos_i (12) | rot_j (12) | pos_j (12) | rho | ld.
 // Outputs are already robust-corrected (r~ = sqrt(rho') r, J~ = sqrt(rho')(J - alpha/s r r^T J)); returns
 // the block's cost contribution rho(s)/2.  Emit::put(col, j0, j1) receives column `col` of J~ (both rows).
-template <class T, class Emit, class SC>
+// SMALL: every knot-pair log of both ends is below 0.5 rad (checked by the caller): series-only exp / Jr, no branches.
+// LOCAL = false: the knots are in the global frame (RrefT unused): the fp64 path needs no local frame.
+template <class T, class Emit, class SC, bool SMALL = false, bool LOCAL = true>
 CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, const SC &scj, T ui, T uj, T idt,
                      const Calib<T> &cal, const M3<T> &RrefT, T pix, T piy, T pjx, T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac,
                      Emit &emit) {
@@ -552,8 +554,8 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, co
   const V3<T> x_ci = mk<T>(pix * inv_d, piy * inv_d, inv_d);
   const V3<T> p_Ii = qrot(cal.q_CI, x_ci) + cal.p_CI;
 
-  const Q4<T> S_IitoG = eval_Rp<T, SC>(ki.q, sci, ui, (M3<T> *)nullptr, false);     // values only; the Jacobians are streamed below
-  const Q4<T> S_GtoIj = eval_RTp<T, SC>(kj.q, scj, uj, (M3<T> *)nullptr, false);
+  const Q4<T> S_IitoG = eval_Rp<T, SC, SMALL>(ki.q, sci, ui, (M3<T> *)nullptr, false);     // values only; the Jacobians are streamed below
+  const Q4<T> S_GtoIj = eval_RTp<T, SC, SMALL>(kj.q, scj, uj, (M3<T> *)nullptr, false);
   T cp0[4], cp1[4];
   basis<T, false, 0>(ui, T(1), cp0);
   basis<T, false, 0>(uj, T(1), cp1);
@@ -625,7 +627,7 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, co
         }
         lhsR0[3 * a + b] = -s0; lhsP0[3 * a + b] = s1; lhsR1[3 * a + b] = s2;
       }
-    {  // position columns back to the global frame: J_p = J_p' R_ref^T (see imu_eval)
+    if constexpr (LOCAL) {  // position columns back to the global frame: J_p = J_p' R_ref^T (see imu_eval)
       T g6[6];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -665,12 +667,12 @@ CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, co
         out(col0 + b, sw * a0, sw * a1);
       }
     };
-    eval_Rp_jac_stream<T, SC>(sci, ui, [&](int kk, const M3<T> &Jk) { rot_cols(3 * kk, lhsR0, Jk); });
-    eval_RTp_jac_stream<T, SC>(kj.q, scj, uj, [&](int kk, const M3<T> &Jk) { rot_cols(24 + 3 * kk, lhsR1, Jk); });
+    eval_Rp_jac_stream<T, SC, SMALL>(sci, ui, [&](int kk, const M3<T> &Jk) { rot_cols(3 * kk, lhsR0, Jk); });
+    eval_RTp_jac_stream<T, SC, SMALL>(kj.q, scj, uj, [&](int kk, const M3<T> &Jk) { rot_cols(24 + 3 * kk, lhsR1, Jk); });
   }
   // line delay (image_feature_factor.h:251-264)
   {
-    const V3<T> Om_i = eval_omega<T, SC>(sci, ui, idt), Om_j = eval_omega<T, SC>(scj, uj, idt);
+    const V3<T> Om_i = eval_omega<T, SC, SMALL>(sci, ui, idt), Om_j = eval_omega<T, SC, SMALL>(scj, uj, idt);
     const M3<T> RGIj = q2R(S_GtoIj);
     const V3<T> a1 = qrot(S_GtoIj, rowi * v_i - rowj * v_j);
     const V3<T> a2 = (-rowj) * cross(Om_j, mul(RGIj, dpg));

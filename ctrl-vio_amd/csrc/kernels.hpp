@@ -970,6 +970,7 @@ constexpr int VIS_LDS_BYTES = 64 * VT_LD * 8;   // the J~ of a wave's 64 blocks 
 template <class T>
 __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigned char *smt, int4 *rmeta, int2 *rhg, int vblock) {
   const int v = vblock * 64 + threadIdx.x;
+  const long long t_entry = d.dbg ? clock64() : 0ll;
   // the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
   constexpr int LDS_BYTES = VIS_LDS_BYTES;
   T *wcs = reinterpret_cast<T *>(smt);
@@ -996,12 +997,6 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
       vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
       si = max(0, min(si, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
       sj = max(0, min(sj, m.K - 4));
-      Knots4<T> ki, kj;
-      LocalFrame<T> lf;
-      lf.init(quat, pos, m.knot0 + si);       // both ends relative to the first active knot of the anchor end
-      lf.load(quat, pos, m.knot0 + si, ki);
-      lf.load(quat, pos, m.knot0 + sj, kj);
-      const M3<T> RrefT = lf.RrefT();
       Calib<T> cal;
       cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
       cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
@@ -1013,13 +1008,44 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
       SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
       seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
       seg_const_lazy(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
+      // The usual wave: every knot-pair log of its blocks' two ends below 0.5 rad -> series-only evaluation (no branch, no closed-form
+      // code on the path) in the GLOBAL frame, positions relative to the anchor end's first knot.  Otherwise (uniform choice: a ballot
+      // over the running lanes) the general form, in the local frame of that knot as the fp32 kernels had it.
+      double dmax = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dmax = fmax(dmax, fmax((double)dot(sci.d[i], sci.d[i]), (double)dot(scj.d[i], scj.d[i])));
+      const bool small = __ballot(dmax >= 0.25) == 0ull;
+      Knots4<T> ki, kj;
+      M3<T> RrefT = m3_id<T>();
+      if (jac && small) {
+        const double *qi = quat + 4 * (m.knot0 + si), *qj = quat + 4 * (m.knot0 + sj), *pi = pos + 3 * (m.knot0 + si), *pj = pos + 3 * (m.knot0 + sj);
+        ki.q[0] = qmk<T>((T)qi[0], (T)qi[1], (T)qi[2], (T)qi[3]);   // (only the first knot's rotation is used: the others enter through the pair logs)
+        kj.q[0] = qmk<T>((T)qj[0], (T)qj[1], (T)qj[2], (T)qj[3]);
+        ki.q[1] = ki.q[2] = ki.q[3] = ki.q[0];
+        kj.q[1] = kj.q[2] = kj.q[3] = kj.q[0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ki.p[i] = mk<T>((T)(pi[3 * i] - pi[0]), (T)(pi[3 * i + 1] - pi[1]), (T)(pi[3 * i + 2] - pi[2]));
+          kj.p[i] = mk<T>((T)(pj[3 * i] - pi[0]), (T)(pj[3 * i + 1] - pi[1]), (T)(pj[3 * i + 2] - pi[2]));
+        }
+      } else {
+        LocalFrame<T> lf;
+        lf.init(quat, pos, m.knot0 + si);       // both ends relative to the first active knot of the anchor end
+        lf.load(quat, pos, m.knot0 + si, ki);
+        lf.load(quat, pos, m.knot0 + sj, kj);
+        RrefT = lf.RrefT();
+      }
       if (jac) {
         VisTileSink<T> sink{wcs + VT_LD * threadIdx.x};
         on = true;
         my_lm = d.v_lm[v];
         mP = m.P; mldw = m.ldw; mK6 = 6 * m.K; mlm0 = m.lm0; mu0 = m.u0; mW0lo = (int)(m.W0 & 0xffffffffll); mW0hi = (int)(m.W0 >> 32);
-        c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
-                                   d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
+        if (small)
+          c = (double)visual_eval<T, VisTileSink<T>, SegConstLazy<T, T>, true, false>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v],
+                  d.v_obs[V + v], d.v_obs[2 * V + v], d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
+        else
+          c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
+                                     d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
         sink.J[52] = r[0]; sink.J[53] = r[1];
         d.vs[v] = si; d.vs[V + v] = sj;
         ksi = si; ksj = sj;
@@ -1050,7 +1076,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
     // waits for vmcnt(0), i.e. for the J~ and W stores in flight to be acknowledged -- ~5 us per barrier here, measured.)
 #define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
     long long *dbg = (d.dbg && vblock == 1000) ? d.dbg + 32 : nullptr;
-    if (dbg && lane == 0) dbg[0] = clock64() + (long long)(c * 0);
+    if (dbg && lane == 0) { dbg[-1] = t_entry; dbg[0] = clock64() + (long long)(c * 0); }
     LDS_SYNC();
     // ---- J~ goes out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs of
     //      entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
@@ -1101,7 +1127,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
     const unsigned long long heads = __ballot(head);
     const int ord = __popcll(heads & ((2ull << lane) - 1ull)) - 1;     // ordinal of this lane's landmark in the wave
     const int nlm = __popcll(heads);
-    int ldmax = mldw;                                                  // (a wave may hold the tail of one window and the head of the next)
+    int ldmax = mldw;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ldmax = max(ldmax, __shfl_xor(ldmax, off));
     ldmax = __builtin_amdgcn_readfirstlane(ldmax) | 1;   // odd row stride: ldw is a multiple of 32 doubles, which would put column g of EVERY row in the same LDS bank

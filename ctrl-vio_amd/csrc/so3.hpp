@@ -252,6 +252,16 @@ CTV_DI Q4<double> qmul_unit(Q4<double> a, Q4<double> b) {
 }
 CTV_DI Q4<float> qmul_unit(Q4<float> a, Q4<float> b) { return qmul(a, b); }
 
+// compile-time choice between the two (SMALL: the caller has bounded |phi| < 0.5)
+template <bool SMALL, class T> CTV_DI Q4<T> so3_exp_sel(V3<T> w) {
+  if constexpr (SMALL && sizeof(T) == 8) return so3_exp_small(w);
+  else return so3_exp(w);
+}
+template <bool SMALL, class T> CTV_DI M3<T> so3_Jr_sel(V3<T> phi) {
+  if constexpr (SMALL && sizeof(T) == 8) return so3_Jr_small(phi);
+  else return so3_Jr(phi);
+}
+
 // ---- Jr^-1: I + hat/2 + c*hat^2, c = 1/t^2 - (1+cos t)/(2 t sin t)   (sophus_utils.hpp:210-242)
 CTV_DI double jrinv_coeff(double n2) {
   if (n2 < 0.25)   // (1 - (t/2) cot(t/2)) / t^2 = sum |B_2k| t^(2k-2) / (2k)!, truncation < 1e-17

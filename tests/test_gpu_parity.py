@@ -64,6 +64,8 @@ def test_imu_linearize_general_body(cv, oracle, win_cfg1, case):
         Hg, Wg, Hllg, gg, costg = s.linearize(0)
     assert costg == pytest.approx(cost, rel=1e-12)
     assert np.abs((Hg - H[:P, :P]) / np.outer(sc[:P], sc[:P])).max() < 1e-10
+    assert np.abs((Wg - H[:P, P:]) / np.outer(sc[:P], sc[P:])).max() < 1e-10      # (large_rotation: the visual blocks' general form too)
+    assert np.abs(Hllg / np.diag(H)[P:] - 1).max() < 1e-10
     assert np.abs((gg - g) / sc).max() < 1e-10 * np.abs(g / sc).max()
 
 
