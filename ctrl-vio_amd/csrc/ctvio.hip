@@ -429,6 +429,8 @@ template <class T> class SolverImpl : public SolverBase {
     in_bytes_ = in_bytes;
     any_vis_lds_ = any_vis_glb_ = false;
     for (const auto &mm : meta_) { if (mm.vis_lds) any_vis_lds_ = true; else if (mm.V > 0) any_vis_glb_ = true; }
+    all_windows_have_imu_ = !meta_.empty();
+    for (const auto &mm : meta_) if (mm.ngrp == 0) all_windows_have_imu_ = false;
     deterministic_ = opt_.deterministic > 0 || (opt_.deterministic < 0 && nw <= 64);
     maxK_ = maxK;
     // ---- work arena (device only)
@@ -542,7 +544,7 @@ template <class T> class SolverImpl : public SolverBase {
     const int nw = d.nwin;
     constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
-    if (!store_path()) hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode);
+    if (!store_path()) { if (!imu_zero_mode()) hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode); }
     else hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
     ph_end();
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
@@ -623,6 +625,12 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_imu_linearize(size_t vals_lds, int mode);
   // use_mfma = 2 (or CTVIO_IMU_GENERAL=1): every IMU group through the general body (k_imu_linearize_rest) -- the cross-check of the
   // specialised one and the tests' way into the path that large knot-to-knot rotations / anisotropic accelerometer weights take
+  // The IMU linearisation kernels clear the accumulated parts of the normal equations on the side (kernels.hpp: imu_zero_share) when every
+  // window has IMU groups: 1 = bias rows only (one visual-assembly part stores the knot x knot block), 2 = everything; 0 = k_zero_normal.
+  int imu_zero_mode() const {
+    if (!opt_.use_mfma || store_path() || !all_windows_have_imu_ || std::getenv("CTVIO_ZERO_KERNEL")) return 0;
+    return vis_parts() == 1 ? 1 : 2;
+  }
   int imu_general_only() const { static const int env = std::getenv("CTVIO_IMU_GENERAL") ? 1 : 0; return (env || opt_.use_mfma == 2) ? 1 : 0; }
   void launch_linearize_merged(int mode);
   void launch_assemble_vis_lds(int parts, int mode);
@@ -675,7 +683,7 @@ template <class T> class SolverImpl : public SolverBase {
   // assembly variants run).  Two batches with identical totals can differ in these (e.g. the same sum K split differently).
   std::vector<long long> launch_signature() const {
     return {(long long)vis_lds_, (long long)vis_glb_, (long long)any_vis_lds_, (long long)any_vis_glb_, (long long)maxK_, (long long)max_schur_tiles_,
-            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles()};
+            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles(), (long long)imu_zero_mode()};
   }
   int ensure_graph() {
     const std::vector<long long> sig = launch_signature();
@@ -1130,7 +1138,7 @@ template <class T> class SolverImpl : public SolverBase {
   std::vector<long long> graph_sig_;
   bool deterministic_ = false;   // order-fixed accumulation for this batch (ctvio_options.deterministic)
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
-  bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false;
+  bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false, all_windows_have_imu_ = false;
   int maxK_ = 0, max_schur_tiles_ = 0;
 };
 
@@ -1138,15 +1146,15 @@ template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) 
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
   if (opt_.use_mfma) {
-    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)(64 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only());
-    hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only());
+    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)(64 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
+    hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
   }
   else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
 }
 template <> void SolverImpl<double>::launch_linearize_merged(int mode) {
   const Dev<double> &d = dev_;
-  hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode, imu_general_only());
-  hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only());
+  hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode, imu_general_only(), imu_zero_mode());
+  hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
 }
 template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts, int mode) {
   const Dev<double> &d = dev_;

@@ -486,6 +486,27 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
     for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
 }
 
+// The zeroing of the normal equations' accumulated parts, done by the IMU groups of the window instead of a pass of its own (k_zero_normal
+// is HBM-bound, ~100 us per 2048 windows; the stores cost this compute-bound kernel nothing): group gi of the window clears its
+// share of Hpp -- only the bias rows and the line-delay row when the single visual-assembly part overwrites the knot x knot block with plain
+// stores (zero_mode 1), everything otherwise (zero_mode 2) -- and the first group the gradient and the max-norm cell.  Every accumulating
+// kernel (k_assemble_vis*, k_assemble_imu, k_misc) is launched after the linearisation kernels.  zero_mode 0: k_zero_normal did it.
+__device__ __forceinline__ void imu_zero_share(const Dev<double> &d, int mode, const ImuGroup &grp, int gidx, int zero_mode) {
+  if (!zero_mode) return;
+  const int w = grp.win, lane = threadIdx.x;
+  const WinMeta &m = d.wins[w];
+  const int tg = lin_target(d.lm[w], mode);
+  double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
+  const int nH = m.P * m.ldh, first = (m.vis_lds && zero_mode == 1) ? 6 * m.K * m.ldh : 0;   // (ldh is a multiple of 16: both even)
+  const int gi = gidx - m.grp0, per = (((nH - first) / 2 + m.ngrp - 1) / m.ngrp) * 2;
+  const int lo = first + gi * per, hi = min(lo + per, nH);
+  for (int i = lo + 2 * lane; i < hi; i += 128) *reinterpret_cast<double2 *>(Hpp + i) = double2{0.0, 0.0};
+  if (gi == 0) {
+    for (int i = lane; i < m.P; i += 64) g[i] = 0.0;
+    if (lane == 0) { if (mode == LIN_SPEC) d.lm[w].cand_gmax_bits = 0ull; else d.lm[w].gmax_bits = 0ull; }
+  }
+}
+
 // All-fp64 product path: one wave per IMU group, 64 samples per pass (one per lane), A^T A on the fp64 matrix cores.
 // The 6 x 30 Jacobian of a sample stays in REGISTERS in factored form (ImuJac); its six rows are streamed through LDS one
 // row index at a time -- phase a: row a of all 64 samples ([64][33] doubles = 16.9 KB, so 8 waves fit a CU and every lane
@@ -493,11 +514,12 @@ template <class T, int CHUNK> __global__ __launch_bounds__(64) __attribute__((am
 // 16 x 16 tiles of the 32-column space, gyro rows (non-zero in rotation, gyro-bias and residual columns only) one 16 x 16
 // tile on compacted columns.  MFMA operand layout (measured, tools/mfma_f64_layout.hip): A lane l = X[k = l/16][i = l%16],
 // B lane l = Y[k = l/16][j = l%16], D register r of lane l = D[(l/16) + 4r][l%16].
-__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx) {
+__device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int mode, double *A /* LDS [64][33] */, int gidx, int zero_mode) {
   const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
   if (!lin_run(d.lm[w], mode)) return;
   const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
+  if (jac) imu_zero_share(d, mode, grp, gidx, zero_mode);
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const bool at_cand = mode == LIN_SPEC;
@@ -629,11 +651,12 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
 //   * the next pass's measurements requested before the current pass is evaluated.
 // (fp64 MFMA and fp64 VALU instructions share one datapath on gfx950 -- tools/mfma_valu_overlap.hip: one wave's MFMAs and FMAs add up,
 //  two waves on a SIMD do not overlap them either -- so the kernel's time is the SUM of its vector and matrix work: both are cut here.)
-__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [64][33] + 64 */, int gidx) {
+__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [64][33] + 64 */, int gidx, int zero_mode) {
   const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
   if (!lin_run(d.lm[w], mode)) return;
   const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
+  if (jac) imu_zero_share(d, mode, grp, gidx, zero_mode);
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const bool at_cand = mode == LIN_SPEC;
@@ -855,11 +878,11 @@ __device__ __forceinline__ bool imu_group_fast(const Dev<double> &d, int gidx) {
 // the wave then takes the flagged ones in turn -- 12 us per launch when there is nothing to do, which is the rule): the two bodies in
 // one kernel cost the fast one registers.
 // (general_only: every group through the general body -- ctvio_options.use_mfma = 2 / CTVIO_IMU_GENERAL=1, the tests' way into it)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode, int general_only) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode, int general_only, int zero_mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x);
+  if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x, zero_mode);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev<double> d, int mode, int general_only) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev<double> d, int mode, int general_only, int zero_mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   const WinMeta &m = d.wins[blockIdx.x];
   for (int g0 = 0; g0 < m.ngrp; g0 += 64) {
@@ -869,7 +892,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     while (todo) {
       const int b = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), m.grp0 + g0 + b);
+      imu_linearize_f64_body(d, mode, reinterpret_cast<double *>(smraw), m.grp0 + g0 + b, zero_mode);
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
     }
@@ -897,7 +920,9 @@ template <class T> __global__ void k_assemble_imu(Dev<T> d, int mode) {
       a = 24 + i; b = 24 + q - i * (i + 1) / 2;
     } else if (t < 195) { a = t - 165; b = 30; }
     else return;
-    const double v = (double)tile[a * 32 + b];
+    // (the tile is symmetric: the gradient column is read as row 30, next to the bias rows -- 7 consecutive rows of the tile instead of a
+    //  cache line of every row)
+    const double v = (double)(b == 30 ? tile[30 * 32 + a] : tile[a * 32 + b]);
     const int ga = imu_col(a, grp.s, K, grp.bias);
     if (b == 30) { atomicAdd(&g[ga], v); return; }
     const int gb = imu_col(b, grp.s, K, grp.bias);
@@ -1230,12 +1255,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_
 // Both evaluations in ONE launch: workgroups [0, Gtot) take an IMU group each, the others a wave of 64 visual block slots.  The two are
 // independent; for a batch smaller than the chip their single-wave latencies (23 us each for one window) overlap instead of adding
 // up, and large batches lose nothing.  The IMU rows use the head of the visual kernel's LDS buffer.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linearize_f64(Dev<double> d, int mode, int general_only) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linearize_f64(Dev<double> d, int mode, int general_only, int zero_mode) {
   __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
   __shared__ int4 rmeta[64];
   __shared__ int2 rhg[64];
   if ((int)blockIdx.x < d.Gtot) {
-    if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x);
+    if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, zero_mode);
   } else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
 }
 
