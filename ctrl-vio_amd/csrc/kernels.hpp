@@ -656,7 +656,6 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   const int w = grp.win;
   if (!lin_run(d.lm[w], mode)) return;
   const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
-  if (jac) imu_zero_share(d, mode, grp, gidx, zero_mode);
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const bool at_cand = mode == LIN_SPEC;
@@ -858,6 +857,8 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   double *tile = d.imu_tiles + (size_t)gidx * 1024;
 #pragma unroll
   for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
+  // (last: the memory counter is in-order, a load issued after these stores would wait for their acknowledgement)
+  imu_zero_share(d, mode, grp, gidx, zero_mode);
 }
 
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
