@@ -382,6 +382,22 @@ def main():
                     s1.solve_raw(args.iters)
                 torch.cuda.synchronize()
                 out["single_window_device_resident_ms"] = 1e3 * (time.perf_counter() - t0) / 40
+            # ---- what the bitwise-reproducible mode costs (ctvio_options.deterministic; the default for <= 64 windows): 64 windows both ways
+            det = {}
+            for name, flag in (("deterministic", 1), ("throughput", 0)):
+                with cv.Solver(device=local, deterministic=flag) as sd:
+                    sd.set_windows([uniq[i % nuniq].copy() for i in range(64)])
+                    sd.snapshot_state()
+                    sd.solve_raw(args.iters)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        sd.restore_state()
+                        sd.solve_raw(args.iters)
+                    torch.cuda.synchronize()
+                    det[name + "_ms_per_64_windows"] = 1e3 * (time.perf_counter() - t0) / 10
+            det["cost_ratio"] = det["deterministic_ms_per_64_windows"] / det["throughput_ms_per_64_windows"]
+            out["deterministic_mode"] = det
             ora = not args.no_cpu_baseline
             out["config3"] = side_config(cv, lib, torch, "config3", 1024, 16, args.iters, 2, 8, local, ora)
             out["config5"] = side_config(cv, lib, torch, "config5", 128, 8, args.iters, 2, 8, local, ora)

@@ -584,7 +584,7 @@ template <class T> class SolverImpl : public SolverBase {
     if (any_vis_glb_) launch_assemble_vis_glb(parts, mode);
     ph_end();
     ph_begin(PH_ASM_REST);
-    if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(d.Gtot), dim3(256), 0, stream_, d, mode);
+    if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(nw), dim3(256), 0, stream_, d, mode);
     hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0);
     if (mode != LIN_SPEC) hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();

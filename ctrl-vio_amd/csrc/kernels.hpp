@@ -901,36 +901,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
-template <class T> __global__ void k_assemble_imu(Dev<T> d, int mode) {
-  const ImuGroup grp = d.groups[blockIdx.x];
-  const int w = grp.win;
+// One workgroup per WINDOW walking its groups (one per group was 43 k workgroups of 195 useful threads: dispatch-bound).
+template <class T> __global__ __launch_bounds__(256) void k_assemble_imu(Dev<T> d, int mode) {
+  const int w = blockIdx.x;
   if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
-  const int K = m.K, P = m.P, ldh = m.ldh, tg = lin_target(d.lm[w], mode);
+  const int K = m.K, ldh = m.ldh, tg = lin_target(d.lm[w], mode);
   double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
-  const T *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
   if (m.vis_lds) {
     // the knot x knot part is accumulated in LDS by k_assemble_vis; what is left is the bias rows (6 x 24 against the
-    // knots, the 6 x 6 lower triangle) and the gradient: 195 entries, one per thread -- one load, one atomic
-    const int t = threadIdx.x;
-    int a, b;
-    if (t < 144) { a = 24 + t / 24; b = t % 24; }
-    else if (t < 165) {
-      const int q = t - 144;                     // lower triangle of the bias block, row-major
-      const int i = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : q < 10 ? 3 : q < 15 ? 4 : 5;
-      a = 24 + i; b = 24 + q - i * (i + 1) / 2;
-    } else if (t < 195) { a = t - 165; b = 30; }
-    else return;
-    // (the tile is symmetric: the gradient column is read as row 30, next to the bias rows -- 7 consecutive rows of the tile instead of a
-    //  cache line of every row)
-    const double v = (double)(b == 30 ? tile[30 * 32 + a] : tile[a * 32 + b]);
-    const int ga = imu_col(a, grp.s, K, grp.bias);
-    if (b == 30) { atomicAdd(&g[ga], v); return; }
-    const int gb = imu_col(b, grp.s, K, grp.bias);
-    atomicAdd(&Hpp[(long long)max(ga, gb) * ldh + min(ga, gb)], v);
+    // knots, the 6 x 6 lower triangle) and the gradient: 195 entries per group -- one load, one atomic each
+    for (int i = threadIdx.x; i < 195 * m.ngrp; i += 256) {
+      const int gi = i / 195, t = i - 195 * gi;
+      const ImuGroup grp = d.groups[m.grp0 + gi];
+      const T *tile = d.imu_tiles + (size_t)(m.grp0 + gi) * 1024;
+      int a, b;
+      if (t < 144) { a = 24 + t / 24; b = t % 24; }
+      else if (t < 165) {
+        const int q = t - 144;                     // lower triangle of the bias block, row-major
+        const int r = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : q < 10 ? 3 : q < 15 ? 4 : 5;
+        a = 24 + r; b = 24 + q - r * (r + 1) / 2;
+      } else { a = t - 165; b = 30; }
+      // (the tile is symmetric: the gradient column is read as row 30, next to the bias rows -- 7 consecutive rows of the tile instead of a
+      //  cache line of every row)
+      const double v = (double)(b == 30 ? tile[30 * 32 + a] : tile[a * 32 + b]);
+      const int ga = imu_col(a, grp.s, K, grp.bias);
+      if (b == 30) { atomicAdd(&g[ga], v); continue; }
+      const int gb = imu_col(b, grp.s, K, grp.bias);
+      atomicAdd(&Hpp[(long long)max(ga, gb) * ldh + min(ga, gb)], v);
+    }
     return;
   }
-  for (int e = threadIdx.x; e < 31 * 30; e += blockDim.x) {
+  for (int i = threadIdx.x; i < 31 * 30 * m.ngrp; i += 256) {
+    const int gi = i / 930, e = i - 930 * gi;
+    const ImuGroup grp = d.groups[m.grp0 + gi];
+    const T *tile = d.imu_tiles + (size_t)(m.grp0 + gi) * 1024;
     const int b = e / 30, a = e % 30;  // a < 30 : unknown row; b <= 30
     const double v = (double)tile[a * 32 + b];
     const int ga = imu_col(a, grp.s, K, grp.bias);
