@@ -42,7 +42,7 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}   # v_mfma_f32_32x32x2_f32 (gui
 
 def kernel_of_phase(precision):
     return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_eval<double>",
-            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve"}
+            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_tiles"}
 
 
 def imu_groups(w):
