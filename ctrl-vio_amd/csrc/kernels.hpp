@@ -1,15 +1,21 @@
-// kernels.hpp -- gfx950 kernels of the sliding-window solve.  One launch covers a whole batch of windows.
+// kernels.hpp -- gfx950 kernels of the sliding-window solve (all fp64).  One launch covers a whole batch of windows.
 //
-//   per state : k_knot_prep (d = log(R_k^-1 R_k+1) and Jr^-1(d) of every knot pair, shared by all blocks)
-//   linearise : k_imu_linearize_f64 (rows through LDS, per-group A^T A on the fp64 matrix cores; k_imu_linearize = fp32 mixed mode),
-//               k_vis_eval<LIN> (landmark-major: J~ block-major via LDS, the rows of W, Hll, g_rho formed in the same kernel)
-//   assemble  : k_zero_normal, k_assemble_vis_mfma (MFMA + fp64 LDS Hessian, or global atomics for K > 25; k_assemble_vis =
-//               register-tile variant), k_assemble_imu, k_misc<LIN> (bias chain + prior), k_post_linearize
-//   solve     : k_damping, k_schur_window_f64 (large batches) / k_schur_tile_f64 + k_rhs (small; k_schur_window / k_schur_mfma /
-//               k_schur_generic: fp32 mixed mode and vector fallback), k_cholesky_solve (fp64 MFMA), k_backsub
-//   update    : k_update<false|true>, k_imu_cost, k_vis_eval<cost>, k_misc<cost>
-//   control   : k_lm_init, k_set_initial_cost, k_begin_iter, k_lm_control   (Ceres 1.14 trust-region semantics)
-//   after     : k_gauge_restore (double2vector), k_spline_eval (trajectory query)
+//   per state : k_knot_prep (d = log(R_k^-1 R_k+1) and Jr^-1(d) of every knot pair, shared by all blocks; the candidate's table is made by
+//               k_step_finish)
+//   linearise : k_linearize_f64 = k_imu_linearize_f64 (one wave per IMU group: rows through LDS, per-group A^T A on the fp64 matrix
+//               cores; it also clears the accumulated parts of the normal equations) + k_vis_eval (landmark-major: J~ block-major via
+//               LDS, the rows of W, Hll, g_rho formed in the same kernel) in one launch; k_imu_linearize_rest (groups the specialised
+//               IMU body leaves out); k_imu_linearize<T, CHUNK> = vector-ALU cross-check (use_mfma = 0); k_zero_normal only for batches
+//               with an IMU-less window
+//   assemble  : k_assemble_vis_mfma (MFMA + fp64 LDS Hessian, or global atomics for K > 25; STORE = the order-fixed tail of the
+//               deterministic mode with k_reduce_finalize / k_bias_rows; k_assemble_vis = register-tile cross-check), k_assemble_imu,
+//               k_misc (bias chain + prior), k_post_linearize (first linearisation only)
+//   step      : k_schur_window_f64 (large batches) / k_schur_tile_f64 (small; both also produce the reduced rhs), k_schur_generic + k_rhs
+//               (vector fallback), k_cholesky_tiles (register-resident 16 x 16 tiles; k_cholesky_solve = panel kernel for P > 223),
+//               k_step_finish (back-substitution, candidate x (+) alpha delta, the candidate's knot-pair table)
+//   control   : k_lm_init, k_initial_cost, k_begin_iter, k_pass_end (gradient norm, cost, Ceres 1.14 accept / reject / terminate / Armijo,
+//               set swap, next iteration's damping)
+//   after     : k_gauge_restore (double2vector), k_spline_eval (trajectory query), k_residual_summary
 #pragma once
 #include <utility>
 
@@ -20,7 +26,7 @@ namespace ctv {
 
 // SPECULATIVE LINEARISATION.  Every pass evaluates the candidate x (+) alpha delta exactly once -- residuals, Jacobians and the
 // normal equations together, into the normal-equation set that is NOT the current one (Lm::cur).  The cost at the candidate is
-// a by-product (per-group / per-wave partial sums, added up in a fixed order by k_lm_control); on acceptance the sets swap and the
+// a by-product (per-group / per-wave partial sums, added up in a fixed order by k_pass_end); on acceptance the sets swap and the
 // next iteration starts from a finished linearisation; on rejection the current set is still intact.  The trial points of
 // Ceres' projected line search need value and gradient anyway.  Only the last allowed iteration (nothing can follow it) is
 // costed without Jacobians.  Modes of the linearisation kernels:
