@@ -662,7 +662,7 @@ template <class T> class SolverImpl : public SolverBase {
     launch_linearize(LIN_SPEC);
     launch_assemble(LIN_SPEC);
     ph_begin(PH_REST);
-    (void)hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_);   // windows that start another pass count themselves in k_pass_end
+    // (windows that start another pass count themselves in k_pass_end; the counter was cleared by k_step_finish)
     hipLaunchKernelGGL((k_pass_end<T>), dim3(nw), dim3(256), 0, stream_, d);
     ph_end();
   }

@@ -2941,6 +2941,9 @@ template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_
 template <class T, int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev<T> d) {
   constexpr int NT = 64 * NWV;
   const int w = blockIdx.x;
+  // the pass's "windows that start another pass" counter (k_pass_end adds to it, several launches later): cleared here instead of by a
+  // memset node of its own
+  if (w == 0 && threadIdx.x == 0) *d.n_active = 0;
   Lm &lm = d.lm[w];
   if (lm.status) return;
   const WinMeta &m = d.wins[w];
