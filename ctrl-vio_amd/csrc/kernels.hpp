@@ -1221,28 +1221,28 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
       }
       LDS_SYNC();
       if (dbg && lane == 0) dbg[3 + 2 * (c0 / NR)] = clock64();
-      // write-out, row by row (uniform loop: the row's window comes from LDS with broadcast reads), lane = compact column
-      const int4 mymt = rmeta[min(c0 + lane, 63)];           // lane q holds row q's window: x: K6, y: P, z/w: W row offset (elements)
-#pragma unroll 4
-      for (int q = 0; q < nr; ++q) {
-        int4 mt;
-        mt.x = __builtin_amdgcn_readlane(mymt.x, q); mt.y = __builtin_amdgcn_readlane(mymt.y, q);
-        mt.z = __builtin_amdgcn_readlane(mymt.z, q); mt.w = __builtin_amdgcn_readlane(mymt.w, q);
-        T *Wr = Wset + (((long long)mt.w << 32) | (unsigned int)mt.z);
-        const double *row = rows + (size_t)q * ldmax;
-        // pairs of columns (K6 is even, the row starts on a 256-byte boundary): two stores cover K <= 42
-        VecN<T, 2> rv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int c2 = min(2 * (lane + 64 * u), mt.x - 2);
-          rv[u].v[0] = (T)row[c2]; rv[u].v[1] = (T)row[c2 + 1];
+      // write-out: the nr rows' knot columns as ONE flat list of 16-byte column pairs (K6 is even, a row starts on a 256-byte boundary),
+      // 64 pairs per store instruction -- row by row it took three mostly empty stores per row, and under load a store costs ~100
+      // cycles whatever its width (16 rows: 48 stores; now 18 + 1).  The rows of a wave belong to one window: same K6.
+      {
+        const int npair = (KC - 1) >> 1;                       // column pairs per row
+        const int total = nr * npair;
+        int q = lane / npair, cp = lane - q * npair;           // (one division per lane; afterwards incremental)
+        for (int it = lane; it < total; it += 64) {
+          const int4 mt = rmeta[c0 + q];
+          T *Wr = Wset + (((long long)mt.w << 32) | (unsigned int)mt.z);
+          const double *row = rows + (size_t)q * ldmax;
+          VecN<T, 2> rv;
+          rv.v[0] = (T)row[2 * cp]; rv.v[1] = (T)row[2 * cp + 1];
+          *reinterpret_cast<VecN<T, 2> *>(Wr + 2 * cp) = rv;
+          cp += 64;
+          while (cp >= npair) { cp -= npair; ++q; }
         }
-        const double rl = row[mt.y - 1];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (2 * (lane + 64 * u) < mt.x) *reinterpret_cast<VecN<T, 2> *>(Wr + 2 * (lane + 64 * u)) = rv[u];
-        for (int i = lane + 256; i < mt.x; i += 64) Wr[i] = (T)row[i];     // K > 42
-        if (lane == 0) Wr[mt.y - 1] = (T)rl;
+        if (lane < nr) {                                       // the line-delay column of row `lane`
+          const int4 mt = rmeta[c0 + lane];
+          T *Wr = Wset + (((long long)mt.w << 32) | (unsigned int)mt.z);
+          Wr[mt.y - 1] = (T)rows[(size_t)lane * ldmax + mt.y - 1];
+        }
       }
       if (lane < nr) {
         const int2 hgi = rhg[c0 + lane];                     // x: index into Hll, y: index into g
