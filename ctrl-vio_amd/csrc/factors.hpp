@@ -170,99 +170,7 @@ CTV_DI void imu_eval_core(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gr
   }
 }
 
-// ---- The same evaluation in three stages, for the kernel that streams the Jacobian rows through LDS (k_imu_linearize_f64): values
-// first, then the gyro Jacobians, then the accelerometer Jacobians -- each stage's rows are consumed before the next stage starts, so
-// the 36 + 36 Jacobian entries of a sample are never live together (the monolithic form needs ~430 registers per lane).  The
-// expressions are those of imu_eval_core, operation for operation: the results are bit-identical.
-template <class T> struct ImuMid {
-  Q4<T> Ainv[3];            // exp(-lamR[i + 1] d_i)
-  M3<T> Apost1, Apost2;     // q2R of the partial products (Apost[3] = I)
-  M3<T> JrK[3];             // Jr(-lamR[i + 1] d_i)
-  V3<T> om1, om2;           // omega recursion
-  T lamR[4], lamW[4], lamA[4];
-  Q4<T> Rinv_q;
-  V3<T> ag;                 // accel + gravity
-};
-template <class T, class SC>
-CTV_DI void imu_eval_values(const Knots4<T> &k, const SC &sc, T u, T idt, V3<T> gravity, const T bias[6], const T gyro[3], const T acc[3],
-                            const T w[6], T r[6], ImuMid<T> &md) {
-  basis<T, false, 2>(u, idt * idt, md.lamA);
-  basis<T, true, 0>(u, T(1), md.lamR);
-  basis<T, true, 1>(u, idt, md.lamW);
-  V3<T> accel = mk<T>(0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) accel = accel + md.lamA[i] * k.p[i];
-  Q4<T> accq = qmk<T>(0, 0, 0, 1);
-#pragma unroll
-  for (int i = 2; i >= 0; --i) {
-    const V3<T> nkd = (-md.lamR[i + 1]) * sc.d[i];
-    md.Ainv[i] = so3_exp(nkd);
-    accq = qmul_unit(accq, md.Ainv[i]);
-    if (i == 2) md.Apost2 = q2R(accq);
-    if (i == 1) md.Apost1 = q2R(accq);
-    md.JrK[i] = so3_Jr(nkd);
-  }
-  V3<T> om[4];
-  om[0] = mk<T>(0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) om[i + 1] = qrot(md.Ainv[i], om[i]) + md.lamW[i + 1] * sc.d[i];
-  md.om1 = om[1]; md.om2 = om[2];
-  md.Rinv_q = qmul_unit(accq, qconj(k.q[0]));
-  md.ag = accel + gravity;
-  const V3<T> a_pred = qrot(md.Rinv_q, md.ag);
-  r[0] = w[0] * (om[3].x - (gyro[0] - bias[0]));
-  r[1] = w[1] * (om[3].y - (gyro[1] - bias[1]));
-  r[2] = w[2] * (om[3].z - (gyro[2] - bias[2]));
-  r[3] = w[3] * (a_pred.x - (acc[0] - bias[3]));
-  r[4] = w[4] * (a_pred.y - (acc[1] - bias[4]));
-  r[5] = w[5] * (a_pred.z - (acc[2] - bias[5]));
-}
-// gyro rows: d(omega)/d(d_j), split_spline_view.h:157-181
-template <class T, class SC> CTV_DI void imu_jac_gyro(const ImuMid<T> &md, const SC &sc, M3<T> (&Jw)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) Jw[i] = m3_zero<T>();
-  M3<T> dod = scale(md.Apost1, md.lamW[1]);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (i == 1) dod = add(scale(mul(mul_hat(md.Apost1, md.om1), md.JrK[1]), md.lamR[2]), scale(md.Apost2, md.lamW[2]));
-    if (i == 2) dod = add(scale(mul(mul_hat(md.Apost2, md.om2), md.JrK[2]), md.lamR[3]), scale(m3_id<T>(), md.lamW[3]));
-    const M3<T> JrIi = sc.jri(i);
-    Jw[i] = sub(Jw[i], mulT(dod, JrIi));
-    Jw[i + 1] = add(Jw[i + 1], mul(dod, JrIi));
-  }
-}
-// accel rows, split_spline_view.h:183-211
-template <class T, class SC>
-CTV_DI void imu_jac_accel(const Knots4<T> &k, const ImuMid<T> &md, const SC &sc, const M3<T> &RrefT, M3<T> (&Ja)[4], M3<T> &Rinv_g) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) Ja[i] = m3_zero<T>();
-  const M3<T> Rinv = q2R(md.Rinv_q);
-  Rinv_g = mul(Rinv, RrefT);
-  const M3<T> lhs = mul_hat(Rinv, md.ag);
-  M3<T> Racc = q2R(k.q[0]);
-  Ja[0] = add(Ja[0], mul(lhs, Racc));
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (i > 0) Racc = mulT(Racc, q2R(md.Ainv[i - 1]));
-    const M3<T> dad = scale(mul(mul(lhs, Racc), md.JrK[i]), md.lamR[i + 1]);
-    const M3<T> JrIi = sc.jri(i);
-    Ja[i] = sub(Ja[i], mulT(dad, JrIi));
-    Ja[i + 1] = add(Ja[i + 1], mul(dad, JrIi));
-  }
-}
-template <class T> CTV_DI void imu_row_accel2(const M3<T> (&Ja)[4], const T lamA[4], const M3<T> &Rinv_g, const T w[6], const T r[6], int a, T out[32]) {
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      out[3 * kk + b] = w[3 + a] * Ja[kk].m[3 * a + b];
-      out[12 + 3 * kk + b] = w[3 + a] * lamA[kk] * Rinv_g.m[3 * a + b];
-    }
-#pragma unroll
-  for (int c = 24; c < 32; ++c) out[c] = T(0);
-  out[27 + a] = w[3 + a];
-  out[30] = r[3 + a];
-}
+// Gyro row a on the product kernel's compact 16 columns [rot k0..k3 (12) | bg (3) | r]
 template <class T> CTV_DI void imu_row_gyro2(const M3<T> (&Jw)[4], const T w[6], const T r[6], int a, T out[16]) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
@@ -273,7 +181,8 @@ template <class T> CTV_DI void imu_row_gyro2(const M3<T> (&Jw)[4], const T w[6],
   out[15] = r[a];
 }
 
-// ---- Third form (k_imu_linearize_f64's product path), algebraically the same Jacobian with the rotation chain of the accelerometer
+// ---- Staged form (k_imu_linearize_f64's product path: values, then the gyro Jacobians, then the accelerometer Jacobians, each stage's
+// rows consumed before the next starts, so the two 36-entry Jacobians are never live together), algebraically the same Jacobian with the rotation chain of the accelerometer
 // rows rewritten: with A_i = exp(lamR[i+1] d_i), Apost_i = (A_i .. A_2)^T and R(t)^T = Apost_0 R_0^T,
 //   R(t)^T hat(a + g) R_0 A_0 .. A_{i-1} = Apost_i hat(b_i),   b_0 = R_0^T (a + g),  b_{i+1} = A_i^T b_i
 // (R hat(v) R^T = hat(R v) applied i + 1 times), so d(accel)/d(d_i) = lamR[i+1] Apost_i hat(b_i) Jr(-lamR[i+1] d_i): the very shape of the
