@@ -649,7 +649,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
 
 // ---- The product path's body for the usual group (imu_group_fast: knot-pair logs below 0.5 rad, isotropic accelerometer weights).
 // Same wave-per-group scheme and row streaming as the general body above, with
-//   * the evaluation in stages (factors.hpp, third form): values, gyro Jacobians -> three row phases, accelerometer Jacobians -> three row
+//   * the evaluation in stages (factors.hpp, staged form): values, gyro Jacobians -> three row phases, accelerometer Jacobians -> three row
 //     phases, so the two 36-entry Jacobians are never live together; small-angle series, no branch in the loop;
 //   * global frame (the local frame of the general body is an fp32 device), Jr^-1 of the three knot pairs and their logs in SGPRs;
 //   * the accelerometer rows in two 16-column tiles T0 = [rot 12 | ba 3 | r], T1 = [pos 12]: T0^T T0 and T1^T T0 on the matrix cores,
