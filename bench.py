@@ -76,7 +76,7 @@ def algorithmic_flops(w, phase):
     K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
     if phase == "k_imu_linearize":
         # per sample: J^T [J r] lower triangle -- 3 accel rows x 28 columns without the pos x pos block (12 x 13 / 2 products per row), which
-        # is w^2 sum lamA_k lamA_k' I3 (10 products per sample); 3 gyro rows x 16 columns -- + ~1.9 k for the evaluation in its third
+        # is w^2 sum lamA_k lamA_k' I3 (10 products per sample); 3 gyro rows x 16 columns -- + ~1.9 k for the evaluation in its staged
         # form (csrc/factors.hpp: 632 FMAs + 623 multiplies / adds per sample, counted in the ISA)
         return M * (2 * (3 * (28 * 29 // 2 - 12 * 13 // 2) + 10) + 2 * 3 * (16 * 17 // 2) + 1900)
     if phase == "k_vis_eval":        # ~3 k per block for r, J~ (two SO(3) spline poses and their Jacobians)
