@@ -312,7 +312,7 @@ template <class T> class SolverImpl : public SolverBase {
       for (int i = 0; i < w.M; ++i) {
         const int src = t.iorder[i];
         if (i == 0 || t.iseg[src] != t.iseg[t.iorder[i - 1]] || w.imu_bias[src] != w.imu_bias[t.iorder[i - 1]])
-          h_groups[++g] = ImuGroup{wi, t.iseg[src], w.imu_bias[src], i, 0};
+          h_groups[++g] = ImuGroup{wi, t.iseg[src], w.imu_bias[src], i, 0, m.knot0 + t.iseg[src], m.bias0 + w.imu_bias[src], m.imu0 + i};
         h_groups[g].count++;
         const size_t e = (size_t)m.imu0 + i;
         h_imu_grp[e] = g;
@@ -450,7 +450,7 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
     const size_t o_W = seg(sizeof(T) * (size_t)W0), o_W1 = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_Hll1 = seg(8 * (size_t)L0),
                  o_g = seg(8 * (size_t)U0), o_g1 = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
-                 o_cscale = seg(8 * (size_t)U0), o_lm = seg(sizeof(Lm) * (size_t)nw), o_nact = seg(16), o_dbg = seg(8 * 64);
+                 o_cscale = seg(8 * (size_t)U0), o_lm = seg(sizeof(Lm) * (size_t)nw), o_nact = seg(16), o_dbg = seg(8 * 128);
     const size_t o_zero1 = off;   // ---- ... to here
     const size_t o_rhs = seg(8 * (size_t)Pp0), o_dd = seg(8 * (size_t)U0), o_dinv = seg(8 * (size_t)L0);
     d.chol_nblk = (maxP + 31) / 32;
@@ -744,8 +744,11 @@ template <class T> class SolverImpl : public SolverBase {
     timing_[7] = ms;
     last_iters_ = it;
     if (d.dbg) {
-      long long st[64];
+      long long st[128];
       HIPCHK(hipMemcpy(st, d.dbg, sizeof st, hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[ctvio] imu fast body, group 5000, clock64 deltas (prologue | per pass: loads+values, gyro jac, gyro rows+MFMA, accel jac, accel rows+MFMA | .. | epilogue):");
+      for (int i = 65; i < 64 + 16 && st[i] != 0; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
+      std::fprintf(stderr, "\n");
       std::fprintf(stderr, "[ctvio] cholesky clock64 deltas:");
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> wave 1000, clock64 deltas (evaluation | J~ copy-out | landmark contributions | per sweep: scatter, rows out):");
@@ -1146,7 +1149,7 @@ template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) 
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
   if (opt_.use_mfma) {
-    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)(64 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
+    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
     hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
   }
   else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);

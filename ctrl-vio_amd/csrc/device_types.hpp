@@ -33,7 +33,10 @@ struct WinMeta {
 struct VisItem { int32_t start, count; };  // blocks Dev::vblk[start .. start + count): one frame pair, frame-pair order
 
 // A run of IMU samples sharing the same 4 active knots (segment s) and the same bias state.
-struct ImuGroup { int32_t win, s, bias, start, count; };
+struct ImuGroup {
+  int32_t win, s, bias, start, count;
+  int32_t kabs, babs, iabs;   // knot0 + s, bias0 + bias, imu0 + start: the group's own data can be requested before the window's record arrives
+};
 
 // Per-window Levenberg-Marquardt state (Ceres 1.14 TrustRegionMinimizer variables).
 // sensor-to-IMU extrinsic applied by k_spline_eval when on != 0 (reference ExtrinsicParam::se3)

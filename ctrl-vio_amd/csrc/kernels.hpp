@@ -647,6 +647,50 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
 }
 
+// The MFMA chains of one row phase, two K-steps per trip: the operands of step k + 1 are requested before the MFMAs of step k are issued
+// (clock stamps of one group, 3 gyro + 3 accelerometer row phases of a full pass: 6980 + 11372 cycles with the read of step k issued right
+// before its MFMA, 6364 + 10384 like this; three steps ahead -- four steps per trip, K rounded to 16 rows -- 6332 + 10828 and the partial
+// passes lose to the rounding: not kept; a second gyro accumulator changes nothing either: the chain is not waiting for its own results).
+// K is rounded up to a multiple of 8 rows: the rows past the last sample are zero rows (dead lanes write zeros), the buffer has 8 spare rows
+// for the last prefetch.
+// (The operand fetches and their waits are inline assembly: left to itself the compiler re-loads the carried operand at the top of the
+//  next trip -- one ds_read2, one wait, two MFMAs, the very serialisation this removes; volatile loads become flat loads with a full wait
+//  each.  The waits carry the operand as an in/out so that the MFMA that consumes it stays behind them; a final lgkmcnt(0) leaves nothing
+//  in flight that the compiler's own wait counting does not know about.)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void imu_chain_gyro(const double *A, int q4, int l15, int kmax, f64x4 &gacc) {
+  unsigned addr = (unsigned)(size_t)(A + q4 * 17 + l15);
+  double v0, v1;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v0) : "v"(addr));
+  for (int k0 = 0; k0 < kmax; k0 += 8) {
+    asm volatile("ds_read_b64 %0, %1 offset:544" : "=v"(v1) : "v"(addr));          // step k0 + 4 (4 rows of 17 doubles on)
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(v0));
+    gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, gacc, 0, 0, 0);
+    addr += 8 * 17 * 8;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v0) : "v"(addr));                     // step k0 + 8
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(v1));
+    gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, gacc, 0, 0, 0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0));
+}
+__device__ __forceinline__ void imu_chain_accel(const double *A, int q4, int l15, int kmax, f64x4 &acc00, f64x4 &acc10) {
+  unsigned addr = (unsigned)(size_t)(A + q4 * 33 + l15);
+  f64x2 o0, o1;   // (lo, hi) = columns l15 and 16 + l15 of four rows
+  asm volatile("ds_read2_b64 %0, %1 offset1:16" : "=v"(o0) : "v"(addr));
+  for (int k0 = 0; k0 < kmax; k0 += 8) {
+    asm volatile("ds_read2_b64 %0, %1 offset0:132 offset1:148" : "=v"(o1) : "v"(addr));   // step k0 + 4 (4 rows of 33 doubles on)
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(o0));
+    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(o0[0], o0[0], acc00, 0, 0, 0);
+    acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(o0[1], o0[0], acc10, 0, 0, 0);
+    addr += 8 * 33 * 8;
+    asm volatile("ds_read2_b64 %0, %1 offset1:16" : "=v"(o0) : "v"(addr));                   // step k0 + 8
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(o1));
+    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(o1[0], o1[0], acc00, 0, 0, 0);
+    acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(o1[1], o1[0], acc10, 0, 0, 0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0));
+}
+
 // ---- The product path's body for the usual group (imu_group_fast: knot-pair logs below 0.5 rad, isotropic accelerometer weights).
 // Same wave-per-group scheme and row streaming as the general body above, with
 //   * the evaluation in stages (factors.hpp, staged form): values, gyro Jacobians -> three row phases, accelerometer Jacobians -> three row
@@ -657,12 +701,9 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
 //   * the next pass's measurements requested before the current pass is evaluated.
 // (fp64 MFMA and fp64 VALU instructions share one datapath on gfx950 -- tools/mfma_valu_overlap.hip: one wave's MFMAs and FMAs add up,
 //  two waves on a SIMD do not overlap them either -- so the kernel's time is the SUM of its vector and matrix work: both are cut here.)
-__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [64][33] + 64 */, int gidx, int zero_mode) {
+__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [72][33] + 64 */, int gidx, int zero_mode) {
   const ImuGroup grp = d.groups[gidx];
   const int w = grp.win;
-  if (!lin_run(d.lm[w], mode)) return;
-  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
-  const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const bool at_cand = mode == LIN_SPEC;
   const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
@@ -671,29 +712,33 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
   };
-  const int k0g = m.knot0 + grp.s;
-  // the group's constants: knot-pair logs and Jr^-1 (used a dozen times per pass) in scalar registers, the rest (used once or twice per
-  // pass) in LDS behind the row buffer -- [0..11] knot positions relative to knot 0, [12..20] R_0^T, [21..23] gravity, [24..29] bias,
-  // [30..35] weights.  (All of them in scalar registers overflow the SGPR file: 250 v_readlane per pass to fetch them back.)
-  double *gc = A + 64 * 33;
+  // ---- everything the group record alone locates is requested first (clock stamps: the prologue was 10 k of a group's 55 k cycles, three
+  //      dependent round trips group -> window -> data; the window's record and LM state now travel in parallel with the data)
+  const int k0g = grp.kabs;
+  const size_t Mt = (size_t)d.Mtot;
+  const int base = grp.iabs;
+  double gyn[3], acn[3], un;   // the next pass's measurements, in flight while the current pass is evaluated
   {
-    const double *q = s_quat + 4 * k0g, *p = s_pos + 3 * k0g, *bp = s_bias + 6 * (m.bias0 + grp.bias);
+    const int idx = base + min(lane, grp.count - 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+    un = d.imu_u[idx];
+  }
+  double gcv = 0.0;   // this lane's entry of the LDS constants (below)
+  {
+    const double *q = s_quat + 4 * k0g, *p = s_pos + 3 * k0g, *bp = s_bias + 6 * grp.babs;
     const M3<double> R0 = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
-    double v = 0.0;
-    if (lane < 12) v = p[lane] - p[lane % 3];
+    if (lane < 12) gcv = p[lane] - p[lane % 3];
     else if (lane < 21) {   // R_0^T, row major (a select chain: no dynamically indexed register array)
       const int e = lane - 12, src = 3 * (e % 3) + e / 3;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) v = src == i ? R0.m[i] : v;
+      for (int i = 0; i < 9; ++i) gcv = src == i ? R0.m[i] : gcv;
     }
-    else if (lane < 24) v = m.gravity[lane - 21];
-    else if (lane < 30) v = bp[lane - 24];
-    else if (lane < 36) v = m.imu_w[lane - 30];
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 36) gc[lane] = v;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    else if (lane >= 24 && lane < 30) gcv = bp[lane - 24];
   }
+  // the group's constants: knot-pair logs and Jr^-1 (used a dozen times per pass) in scalar registers, the rest (used once or twice per
+  // pass) in LDS behind the row buffer -- [0..11] knot positions relative to knot 0, [12..20] R_0^T, [21..23] gravity, [24..29] bias,
+  // [30..35] weights.  (All of them in scalar registers overflow the SGPR file: 250 v_readlane per pass to fetch them back.)
   SegConstS<double> sc;
   {
     const double *kd = d.lkd + 3 * k0g, *kj = d.kjri + 9 * k0g;
@@ -704,9 +749,24 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
       for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = uni(kj[9 * i + e]);
     }
   }
+  // ---- the window: LM state and record
+  if (!lin_run(d.lm[w], mode)) return;
+  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
+  const WinMeta &m = d.wins[w];
+  long long *dbg = (d.dbg && gidx == 5000 && jac) ? d.dbg + 64 : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of lane 0 at the phase boundaries
+  int dbi = 0;
+#define CTV_ISTAMP(x) do { if (dbg && lane == 0 && dbi < 16) dbg[dbi++] = clock64() + (long long)((x) * 0.0); } while (0)
+  CTV_ISTAMP(0.0);
+  double *gc = A + 72 * 33;   // (8 spare rows behind the 64: the chains' last prefetch)
+  {
+    if (lane >= 21 && lane < 24) gcv = m.gravity[lane - 21];
+    else if (lane >= 30 && lane < 36) gcv = m.imu_w[lane - 30];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) gc[lane] = gcv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
   const double idt = m.inv_dt;
-  const size_t Mt = (size_t)d.Mtot;
-  const int base = m.imu0 + grp.start;
   double csum = 0.0;
   if (!jac) {   // residuals only
     for (int c0 = 0; c0 < grp.count; c0 += 64) {
@@ -729,14 +789,8 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   }
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   double spp[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  double gyn[3], acn[3], un;   // the next pass's measurements, in flight while the current pass is evaluated
-  {
-    const int idx = base + min(lane, grp.count - 1);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
-    un = d.imu_u[idx];
-  }
   for (int c0 = 0; c0 < grp.count; c0 += 64) {
+    CTV_ISTAMP(csum);
     const int nval = min(64, grp.count - c0);
     const bool live = lane < nval;
     double gy[3], ac[3], r[6];
@@ -758,9 +812,11 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     imu_eval_values3<double>(gc, sc, u, idt, gy, ac, wl, r, md);
 #pragma unroll
     for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
+    CTV_ISTAMP(csum);
     {
       M3<double> Jw[4];
       imu_jac_gyro3<double>(md, sc, Jw);
+      CTV_ISTAMP(Jw[3].m[8]);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static
         double row[16];
@@ -770,15 +826,14 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
         for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the rows are in LDS
         __builtin_amdgcn_wave_barrier();
-        for (int k0 = 0; k0 < kmax; k0 += 4) {
-          const double v = A[(k0 + q4) * 17 + l15];
-          gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gacc, 0, 0, 0);
-        }
+        imu_chain_gyro(A, q4, l15, kmax, gacc);
       }
     }
+    CTV_ISTAMP(gacc[0]);
     {
       M3<double> Ja[4], Rinv_g;
       imu_jac_accel3<double>(md, sc, gc, Ja, Rinv_g);
+      CTV_ISTAMP(Ja[3].m[8] + Rinv_g.m[8]);
       {
         double la[4];
 #pragma unroll
@@ -798,14 +853,11 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
         for (int c = 0; c < 28; ++c) A[lane * 33 + c] = row[c];   // (columns 28..31 feed accumulator rows nobody reads)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        for (int k0 = 0; k0 < kmax; k0 += 4) {
-          const double lo = A[(k0 + q4) * 33 + l15], hi = A[(k0 + q4) * 33 + 16 + l15];
-          acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, acc00, 0, 0, 0);
-          acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, lo, acc10, 0, 0, 0);
-        }
+        imu_chain_accel(A, q4, l15, kmax, acc00, acc10);
       }
     }
   }
+  CTV_ISTAMP(acc00[0] + acc10[0]);
   // ---- the group's share of the cost: fixed-order sum over the lanes (butterfly), one store
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
@@ -862,9 +914,12 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   __builtin_amdgcn_wave_barrier();
   double *tile = d.imu_tiles + (size_t)gidx * 1024;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) tile[i * 64 + lane] = A[i * 64 + lane];
+  for (int i = 0; i < 8; ++i)   // 16 bytes per lane: 8 stores of 1 KiB (under load a store costs ~100 cycles whatever its width)
+    *reinterpret_cast<double2 *>(tile + i * 128 + 2 * lane) = *reinterpret_cast<const double2 *>(A + i * 128 + 2 * lane);
   // (last: the memory counter is in-order, a load issued after these stores would wait for their acknowledgement)
   imu_zero_share(d, mode, grp, gidx, zero_mode);
+  CTV_ISTAMP(0.0);
+#undef CTV_ISTAMP
 }
 
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
