@@ -517,7 +517,8 @@ def test_imu_only_predict_named_entry(cv, oracle):
 def test_golden_edge_fixtures_through_the_hip_path(cv, oracle, golden_dir, name, prec, tol):
     """The committed edge fixtures (line delay at both bounds, rows 0 / 1023; made by the independent NumPy restatement) pushed
     through k_vis_eval / k_imu_linearize and the assembly: cost against the fixture's own value, dense H / g against the oracle
-    (which tests/test_oracle_golden.py pins block by block to the same fixtures)."""
+    (which tests/test_oracle_golden.py pins block by block to the same fixtures) and, where the fixture carries them, against the fixture's
+    own finite-difference H / g."""
     d = np.load(os.path.join(golden_dir, name))
     w = cv.Window.from_dict(d, "w_")
     H, g, cost = oracle.OracleWindow(w.copy()).build_normal()
@@ -531,6 +532,18 @@ def test_golden_edge_fixtures_through_the_hip_path(cv, oracle, golden_dir, name,
     assert np.abs((Wg - H[:P, P:]) / np.outer(sc[:P], sc[P:])).max() < tol
     assert np.abs(Hllg / np.diag(H)[P:] - 1).max() < tol
     assert np.abs((gg - g) / sc).max() < tol * max(np.abs(g / sc).max(), 1.0)
+    if "H" in d.files:
+        # the fixture's own dense normal equations (finite-difference Jacobians of the independent NumPy restatement), straight against
+        # the device's -- not via the oracle; tolerances = the finite-difference accuracy of the fixture (tests/test_oracle_golden.py)
+        Hd = np.zeros_like(d["H"])
+        Hd[:P, :P] = Hg; Hd[:P, P:] = Wg; Hd[P:, :P] = Wg.T; Hd[P:, P:] = np.diag(Hllg)
+        scf = np.sqrt(np.maximum(np.diag(d["H"]), 1e-30))
+        dn = np.abs(Hd / np.outer(scf, scf) - d["H"] / np.outer(scf, scf))
+        ld = P - 1
+        mask = np.ones(w.N, bool); mask[ld] = False
+        assert dn[np.ix_(mask, mask)].max() < 2e-5 and dn[ld].max() < 1e-4
+        gs = np.abs(d["g"]).max()
+        assert np.abs(gg - d["g"])[mask].max() / gs < 1e-5 and abs(gg[ld] - d["g"][ld]) / abs(d["g"][ld]) < 1e-4
 
 
 def test_config5_large_window_vs_oracle(cv, oracle):
