@@ -858,57 +858,51 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     }
   }
   CTV_ISTAMP(acc00[0] + acc10[0]);
-  // ---- the group's share of the cost: fixed-order sum over the lanes (butterfly), one store
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
-  if (lane == 0) d.imu_cost[gidx] = csum;
   // ---- combine in LDS into the full symmetric 32 x 32 tile in the local column order [rot 12 | pos 12 | bg 3 | ba 3 | r | -]
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < 16; ++i) A[i * 64 + lane] = 0.0;
   {
-    // the ten sums over the 64 lanes in a fixed order, through the free half of the buffer: lane (e, part) adds 16 lanes' values, two
-    // butterfly steps join the four parts
+    // eleven sums over the 64 lanes in a fixed order -- the ten of the pos x pos block and the group's share of the cost -- through the
+    // free half of the buffer: lane (e, part) adds 16 lanes' values, two butterfly steps join the four parts (one LDS round trip for all
+    // of them instead of a six-step butterfly per value)
     double *S = A + 1024;
 #pragma unroll
     for (int e = 0; e < 10; ++e) S[e * 64 + lane] = spp[e];
+    S[10 * 64 + lane] = csum;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    const int e = min(lane >> 2, 9), part = lane & 3;
+    const int e = min(lane >> 2, 10), part = lane & 3;
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += S[e * 64 + part * 16 + i];
     t += __shfl_xor(t, 1);
     t += __shfl_xor(t, 2);
     __builtin_amdgcn_wave_barrier();
-    if (lane < 40 && part == 0) S[640 + e] = t;
+    if (lane < 40 && part == 0) S[704 + e] = t;
+    if (lane == 40) d.imu_cost[gidx] = t;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   {
+    // T0 (accelerometer rows: rot 12 | ba 3 | r) and the gyro tile (rot 12 | bg 3 | r) share the accumulator layout: where neither index
+    // is a bias one the two land on the same entry and are added in registers; a bias index sends them to the ba / bg columns
     const int c0 = l15 < 12 ? l15 : (l15 < 15 ? l15 + 15 : 30);   // T0 index -> local column (ba at 27..29)
+    const int cg = l15 < 12 ? l15 : (l15 < 15 ? l15 + 12 : 30);   // gyro tile index -> local column (bg at 24..26)
+    const bool cb = l15 >= 12 && l15 < 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = q4 + 4 * r;
-      const int r0 = t < 12 ? t : (t < 15 ? t + 15 : 30);
-      A[r0 * 32 + c0] = acc00[r];
+      const int r0 = t < 12 ? t : (t < 15 ? t + 15 : 30), rg = t < 12 ? t : (t < 15 ? t + 12 : 30);
+      const bool shared = !cb && !(t >= 12 && t < 15);
+      A[r0 * 32 + c0] = shared ? acc00[r] + gacc[r] : acc00[r];
+      if (!shared) A[rg * 32 + cg] = gacc[r];
       if (t < 12) { A[(12 + t) * 32 + c0] = acc10[r]; A[c0 * 32 + 12 + t] = acc10[r]; }
     }
     // lane (ka, kb, b) < 48 places one entry of the pos x pos block
     const int ka = lane / 12, kb = (lane / 3) & 3, b = lane % 3;
     const int hi = max(ka, kb), lo = min(ka, kb);
-    if (lane < 48) A[(12 + 3 * ka + b) * 32 + 12 + 3 * kb + b] = A[1024 + 640 + hi * (hi + 1) / 2 + lo];
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  {
-    const int tc = l15 < 12 ? l15 : (l15 < 15 ? l15 + 12 : 30);   // gyro tile index -> local column (bg at 24..26)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int grow = q4 + 4 * r;
-      const int tr = grow < 12 ? grow : (grow < 15 ? grow + 12 : 30);
-      A[tr * 32 + tc] += gacc[r];
-    }
+    if (lane < 48) A[(12 + 3 * ka + b) * 32 + 12 + 3 * kb + b] = A[1024 + 704 + hi * (hi + 1) / 2 + lo];
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
