@@ -203,7 +203,7 @@ template <class T> class SolverImpl : public SolverBase {
     meta_.assign(nw, WinMeta());
     t0_.resize(nw);
     int64_t H0 = 0, W0 = 0, pH0 = 0;
-    int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0;
+    int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0, A0 = 0;
     int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0, maxK = 0, maxSchurTiles = 0;
     size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     for (int wi = 0; wi < nw; ++wi) {
@@ -214,6 +214,7 @@ template <class T> class SolverImpl : public SolverBase {
       m.P = 6 * w.K + 6 * w.F + 1; m.N = m.P + w.L; m.pn = w.pn; m.pnb = w.pnb;
       m.knot0 = K0; m.bias0 = F0; m.lm0 = L0; m.imu0 = M0; m.vis0 = V0; m.bc0 = B0; m.u0 = U0; m.p0 = Pp0;
       m.grp0 = G0; m.ngrp = tmp[wi].ngrp; m.vitem0 = I0; m.nvitem = tmp[wi].nvitem; m.Vp = tmp[wi].Vp;
+      m.anc0 = A0; m.A = tmp[wi].A;
       m.ldw = (m.P + 1 + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
       m.pv0 = pv0; m.pblk0 = pb; m.fix_ld = w.fix_ld; m.lock_bg = w.lock_bg; m.lock_ba = w.lock_ba; m.fixed_upto = w.fixed_upto;
       m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.ldh = (m.P + 15) / 16 * 16; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
@@ -230,7 +231,7 @@ template <class T> class SolverImpl : public SolverBase {
         vis_glb_bytes = std::max(vis_glb_bytes, need_glb);
       }
       K0 += w.K; F0 += w.F; L0 += w.L; M0 += w.M; V0 += m.Vp; B0 += w.NB; U0 += m.N; Pp0 += m.P; pv0 += w.pn; pb += w.pnb;
-      G0 += m.ngrp; I0 += m.nvitem;
+      G0 += m.ngrp; I0 += m.nvitem; A0 += m.A;
       H0 += (int64_t)m.P * m.ldh; W0 += (int64_t)m.Lpad * m.ldw; pH0 += (int64_t)w.pn * w.pn;
       maxN = std::max(maxN, m.N); maxP = std::max(maxP, m.P); maxPn = std::max(maxPn, w.pn);
       maxL = std::max(maxL, m.L); maxLdw = std::max(maxLdw, m.ldw); maxK = std::max(maxK, m.K);
@@ -248,7 +249,7 @@ template <class T> class SolverImpl : public SolverBase {
     }
     const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
     if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
-    const size_t Mt = (size_t)std::max(M0, 1), Vt = (size_t)std::max(V0, 1);
+    const size_t Mt = (size_t)std::max(M0, 1), Vt = (size_t)std::max(V0, 1), At = (size_t)std::max(A0, 1);
     Mtot_ = M0; Vtot_ = V0;
     // ---- input arena layout (host mirror + device)
     size_t off = 0;
@@ -258,10 +259,11 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_knot_win = seg(4 * (size_t)K0), o_bias_win = seg(4 * (size_t)F0), o_lm_win = seg(4 * (size_t)L0);
     const size_t o_groups = seg(sizeof(ImuGroup) * (size_t)G0), o_imu_grp = seg(4 * Mt);
     const size_t o_imu_u = seg(sizeof(T) * Mt), o_imu_meas = seg(sizeof(T) * 6 * Mt);
-    const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_rowi = seg(4 * Vt), o_v_rowj = seg(4 * Vt);
-    const size_t o_v_ti = seg(8 * Vt), o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(T) * 4 * Vt);
+    const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_anc = seg(4 * Vt), o_v_rowj = seg(4 * Vt);
+    const size_t o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(T) * 2 * Vt);
     const size_t o_v_cauchy = seg(8 * Vt);
-    const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_vblk = seg(4 * Vt);
+    const size_t o_a_win = seg(4 * At), o_a_lm = seg(4 * At), o_a_row = seg(4 * At), o_a_t = seg(8 * At), o_a_obs = seg(8 * 2 * At);
+    const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_vblk = seg(4 * Vt), o_vblk_anc = seg(4 * Vt);
     const size_t o_bc_win = seg(4 * (size_t)B0), o_bc_i = seg(4 * (size_t)B0), o_bc_j = seg(4 * (size_t)B0), o_bc_w = seg(8 * 6 * (size_t)B0);
     const size_t o_pJ0 = seg(8 * (size_t)pH0), o_pr0 = seg(8 * (size_t)pv0);
     const size_t o_pH = seg(8 * (size_t)pH0), o_pb0 = seg(8 * (size_t)pv0), o_pc0 = seg(8 * (size_t)nw), o_p_x0 = seg(8 * 4 * (size_t)pb);
@@ -283,10 +285,13 @@ template <class T> class SolverImpl : public SolverBase {
     int32_t *h_imu_grp = CTV_H(int32_t, o_imu_grp);
     T *h_imu_u = CTV_H(T, o_imu_u), *h_imu_meas = CTV_H(T, o_imu_meas), *h_v_obs = CTV_H(T, o_v_obs);
     double *h_v_cauchy = CTV_H(double, o_v_cauchy);
-    int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_rowi = CTV_H(int32_t, o_v_rowi), *h_v_rowj = CTV_H(int32_t, o_v_rowj);
-    int64_t *h_v_ti = CTV_H(int64_t, o_v_ti), *h_v_tj = CTV_H(int64_t, o_v_tj);
+    int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_anc = CTV_H(int32_t, o_v_anc), *h_v_rowj = CTV_H(int32_t, o_v_rowj);
+    int64_t *h_v_tj = CTV_H(int64_t, o_v_tj);
+    int32_t *h_a_win = CTV_H(int32_t, o_a_win), *h_a_lm = CTV_H(int32_t, o_a_lm), *h_a_row = CTV_H(int32_t, o_a_row);
+    int64_t *h_a_t = CTV_H(int64_t, o_a_t);
+    double *h_a_obs = CTV_H(double, o_a_obs);
     VisItem *h_vitems = CTV_H(VisItem, o_vitems);
-    int32_t *h_vblk = CTV_H(int32_t, o_vblk);
+    int32_t *h_vblk = CTV_H(int32_t, o_vblk), *h_vblk_anc = CTV_H(int32_t, o_vblk_anc);
     int32_t *h_bc_win = CTV_H(int32_t, o_bc_win), *h_bc_i = CTV_H(int32_t, o_bc_i), *h_bc_j = CTV_H(int32_t, o_bc_j);
     double *h_pJ0 = CTV_H(double, o_pJ0), *h_pr0 = CTV_H(double, o_pr0);
     double *h_bc_w = CTV_H(double, o_bc_w), *h_pH = CTV_H(double, o_pH), *h_pb0 = CTV_H(double, o_pb0), *h_pc0 = CTV_H(double, o_pc0),
@@ -324,20 +329,26 @@ template <class T> class SolverImpl : public SolverBase {
           h_imu_meas[(size_t)(3 + c) * Mt + e] = (T)w.imu_acc[3 * src + c];
         }
       }
-      // visual blocks: evaluation slots in landmark-major order (padding slots: window -1, harmless values)
+      // anchors (the i ends, landmark-major) and visual blocks: evaluation slots in landmark-major order (padding slots: window -1,
+      // harmless values)
+      for (int a = 0; a < m.A; ++a) {
+        const int v = t.anc_rep[a];
+        const size_t e = (size_t)m.anc0 + a;
+        h_a_win[e] = wi; h_a_lm[e] = w.v_lm[v]; h_a_row[e] = w.v_rowi[v]; h_a_t[e] = w.v_ti[v] - w.t0_ns;
+        h_a_obs[e] = w.v_pi[2 * v]; h_a_obs[At + e] = w.v_pi[2 * v + 1];
+      }
       for (int i = 0; i < m.Vp; ++i) {
         const int v = t.lord[i];
         const size_t e = (size_t)m.vis0 + i;
         if (v < 0) {
-          h_v_win[e] = -1; h_v_lm[e] = 0; h_v_ti[e] = 0; h_v_tj[e] = 0; h_v_rowi[e] = 0; h_v_rowj[e] = 0; h_v_cauchy[e] = 0.0;
-          for (int c = 0; c < 4; ++c) h_v_obs[(size_t)c * Vt + e] = T(0);
+          h_v_win[e] = -1; h_v_lm[e] = 0; h_v_anc[e] = m.anc0; h_v_tj[e] = 0; h_v_rowj[e] = 0; h_v_cauchy[e] = 0.0;
+          for (int c = 0; c < 2; ++c) h_v_obs[(size_t)c * Vt + e] = T(0);
           continue;
         }
-        h_v_win[e] = wi; h_v_lm[e] = w.v_lm[v];
-        h_v_ti[e] = w.v_ti[v] - w.t0_ns; h_v_tj[e] = w.v_tj[v] - w.t0_ns;
-        h_v_rowi[e] = w.v_rowi[v]; h_v_rowj[e] = w.v_rowj[v];
-        const double o4[4] = {w.v_pi[2 * v], w.v_pi[2 * v + 1], w.v_pj[2 * v], w.v_pj[2 * v + 1]};
-        for (int c = 0; c < 4; ++c) h_v_obs[(size_t)c * Vt + e] = (T)o4[c];
+        h_v_win[e] = wi; h_v_lm[e] = w.v_lm[v]; h_v_anc[e] = m.anc0 + t.anc_of[v];
+        h_v_tj[e] = w.v_tj[v] - w.t0_ns;
+        h_v_rowj[e] = w.v_rowj[v];
+        h_v_obs[e] = (T)w.v_pj[2 * v]; h_v_obs[Vt + e] = (T)w.v_pj[2 * v + 1];
         h_v_cauchy[e] = w.v_cauchy ? w.v_cauchy[v] : w.cauchy_a;
       }
       // the assembly's items: <= VCH blocks of one frame pair, frame-pair order, as lists of slots (vblk)
@@ -348,8 +359,9 @@ template <class T> class SolverImpl : public SolverBase {
         if (fresh) h_vitems[++it] = VisItem{m.vis0 + i, 0};
         h_vitems[it].count++;
         h_vblk[(size_t)m.vis0 + i] = m.vis0 + t.vpos[v];
+        h_vblk_anc[(size_t)m.vis0 + i] = m.anc0 + t.anc_of[v];
       }
-      for (int i = w.V; i < m.Vp; ++i) h_vblk[(size_t)m.vis0 + i] = m.vis0;   // (unused tail of the window's list)
+      for (int i = w.V; i < m.Vp; ++i) { h_vblk[(size_t)m.vis0 + i] = m.vis0; h_vblk_anc[(size_t)m.vis0 + i] = m.anc0; }   // (unused tail of the window's list)
       for (int b = 0; b < w.NB; ++b) { h_bc_win[m.bc0 + b] = wi; h_bc_i[m.bc0 + b] = w.bc_i[b]; h_bc_j[m.bc0 + b] = w.bc_j[b]; }
       if (w.NB) std::memcpy(h_bc_w + (size_t)6 * m.bc0, w.bc_w, sizeof(double) * 6 * w.NB);
       // prior: J0^T J0 (row-major n*n), J0^T r0, r0^T r0 in fp64; J0 is column-major (Eigen)
@@ -407,16 +419,18 @@ template <class T> class SolverImpl : public SolverBase {
     // ---- device pointers of the input arena
     Dev<T> &d = dev_;
     std::memset(&d, 0, sizeof d);
-    d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0;
+    d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0; d.Atot = A0;
     d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw; maxK_ = maxK; max_schur_tiles_ = maxSchurTiles;
     d.wins = CTV_D(WinMeta, o_meta);
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
     d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(T, o_imu_u); d.imu_meas = CTV_D(T, o_imu_meas);
     d.v_cauchy = CTV_D(double, o_v_cauchy);
-    d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_rowi = CTV_D(int32_t, o_v_rowi); d.v_rowj = CTV_D(int32_t, o_v_rowj);
-    d.v_ti = CTV_D(int64_t, o_v_ti); d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
-    d.vitems = CTV_D(VisItem, o_vitems); d.vblk = CTV_D(int32_t, o_vblk);
+    d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_anc = CTV_D(int32_t, o_v_anc); d.v_rowj = CTV_D(int32_t, o_v_rowj);
+    d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
+    d.a_win = CTV_D(int32_t, o_a_win); d.a_lm = CTV_D(int32_t, o_a_lm); d.a_row = CTV_D(int32_t, o_a_row); d.a_t = CTV_D(int64_t, o_a_t);
+    d.a_obs = CTV_D(double, o_a_obs);
+    d.vitems = CTV_D(VisItem, o_vitems); d.vblk = CTV_D(int32_t, o_vblk); d.vblk_anc = CTV_D(int32_t, o_vblk_anc);
     d.bc_win = CTV_D(int32_t, o_bc_win); d.bc_i = CTV_D(int32_t, o_bc_i); d.bc_j = CTV_D(int32_t, o_bc_j); d.bc_w = CTV_D(double, o_bc_w);
     d.pJ0 = CTV_D(double, o_pJ0); d.pr0 = CTV_D(double, o_pr0);
     d.pH = CTV_D(double, o_pH); d.pb0 = CTV_D(double, o_pb0); d.pc0 = CTV_D(double, o_pc0); d.p_x0 = CTV_D(double, o_p_x0);
@@ -428,10 +442,17 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(in_.dev, in_.host, in_bytes, hipMemcpyHostToDevice, stream_));
     in_bytes_ = in_bytes;
     any_vis_lds_ = any_vis_glb_ = false;
-    for (const auto &mm : meta_) { if (mm.vis_lds) any_vis_lds_ = true; else if (mm.V > 0) any_vis_glb_ = true; }
+    // (a window whose packed Hessian does not fit in LDS counts as "global" even without visual blocks -- e.g. an IMU-only predict of a
+    // long spline: the store-semantics tail only finishes LDS-resident windows, so such a batch must take the accumulate path)
+    for (const auto &mm : meta_) { if (mm.vis_lds) any_vis_lds_ = true; else any_vis_glb_ = true; }
     all_windows_have_imu_ = !meta_.empty();
     for (const auto &mm : meta_) if (mm.ngrp == 0) all_windows_have_imu_ = false;
     deterministic_ = opt_.deterministic > 0 || (opt_.deterministic < 0 && nw <= 64);
+    // The order-fixed accumulation exists for batches whose every window keeps its packed Hessian in LDS, on the matrix-core kernels.
+    // An explicit request that cannot be honoured is an error; the default (-1) falls back to the accumulate path for such batches.
+    if (opt_.deterministic > 0 && (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_))
+      return fail(CTVIO_ERR_INVALID, "deterministic = 1 needs use_mfma != 0 and every window's packed Hessian in LDS (K <= 24): this batch would "
+                                     "fall back to floating-point atomics");
     maxK_ = maxK;
     // ---- work arena (device only)
     state_doubles_ = (size_t)7 * K0 + 6 * F0 + L0 + nw;
@@ -444,7 +465,8 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t part_stride = ((size_t)6 * maxK * (6 * maxK + 1) / 2 + 2 * (6 * (size_t)maxK + 1) + 7) & ~(size_t)7;
     const int nparts_alloc = store_path() ? vis_parts() : 1;
     const size_t o_pgrad = seg(8 * (size_t)std::max(pv0, 1)), o_Hpart = seg(nparts_alloc > 1 ? 8 * part_stride * nparts_alloc * (size_t)nw : 8);
-    const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vs = seg(4 * 2 * Vt);
+    const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vsj = seg(4 * Vt);
+    const size_t o_arec = seg(8 * (size_t)AREC * At), o_a_s = seg(4 * At);
     // two normal-equation sets (current linearisation / speculative linearisation at the candidate, Lm::cur)
     const size_t o_Hpp = seg(8 * (size_t)H0), o_Hpp1 = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
@@ -465,7 +487,7 @@ template <class T> class SolverImpl : public SolverBase {
     d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
     d.imu_cost = CTV_W(double, o_imu_cost); d.vis_cost = CTV_W(double, o_vis_cost); d.misc_cost = CTV_W(double, o_misc_cost);
     d.pgrad = CTV_W(double, o_pgrad); d.Hpart = CTV_W(double, o_Hpart); d.npart_stride = (int32_t)part_stride;
-    d.Jt = CTV_W(T, o_Jt); d.vs = CTV_W(int32_t, o_vs);
+    d.Jt = CTV_W(T, o_Jt); d.vsj = CTV_W(int32_t, o_vsj); d.arec = CTV_W(double, o_arec); d.a_s = CTV_W(int32_t, o_a_s);
     d.HppS[0] = CTV_W(double, o_Hpp); d.HppS[1] = CTV_W(double, o_Hpp1); d.S = CTV_W(double, o_S);
     d.WS[0] = CTV_W(T, o_W); d.WS[1] = CTV_W(T, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
     d.gS[0] = CTV_W(double, o_g); d.gS[1] = CTV_W(double, o_g1);
@@ -548,18 +570,31 @@ template <class T> class SolverImpl : public SolverBase {
     else hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
     ph_end();
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
-    if (opt_.use_mfma && d.Gtot && d.Vtot && !profiling_ && !std::getenv("CTVIO_SPLIT_LINEARIZE")) {
+    if (merge_linearize()) {
       // one launch for both evaluations (independent work: their latencies overlap on batches smaller than the chip); a profiled
       // solve (and CTVIO_SPLIT_LINEARIZE=1, for rocprofv3 runs) keeps them apart so that each gets its own timing
+      if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, mode);
       launch_linearize_merged(mode);
       return;
     }
+    ph_begin(PH_VIS_LIN);
+    if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, mode);   // the i ends, once per anchor
+    ph_end();
     ph_begin(PH_IMU_LIN);
     if (d.Gtot) launch_imu_linearize(imu_lds, mode);
     ph_end();
     ph_begin(PH_VIS_LIN);
-    if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode);
+    if (d.Vtot) hipLaunchKernelGGL(k_vis_eval, dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode);
     ph_end();
+  }
+  // The merged launch runs the visual body with the IMU body's register allocation (one wave per SIMD): only for batches smaller than
+  // the chip, where the single-wave latencies of the two evaluations overlap instead of adding up.  CTVIO_MERGE_LINEARIZE = 0 / 1 forces
+  // the choice (A/B measurements).
+  bool merge_linearize() const {
+    const Dev<T> &d = dev_;
+    if (!(opt_.use_mfma && d.Gtot && d.Vtot && !profiling_ && !std::getenv("CTVIO_SPLIT_LINEARIZE"))) return false;
+    if (const char *e = std::getenv("CTVIO_MERGE_LINEARIZE")) return e[0] == '1';
+    return d.nwin <= 128;
   }
   void launch_assemble(int mode) {
     const Dev<T> &d = dev_;
@@ -683,7 +718,7 @@ template <class T> class SolverImpl : public SolverBase {
   // assembly variants run).  Two batches with identical totals can differ in these (e.g. the same sum K split differently).
   std::vector<long long> launch_signature() const {
     return {(long long)vis_lds_, (long long)vis_glb_, (long long)any_vis_lds_, (long long)any_vis_glb_, (long long)maxK_, (long long)max_schur_tiles_,
-            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles(), (long long)imu_zero_mode()};
+            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles(), (long long)imu_zero_mode(), (long long)merge_linearize()};
   }
   int ensure_graph() {
     const std::vector<long long> sig = launch_signature();
@@ -868,7 +903,8 @@ template <class T> class SolverImpl : public SolverBase {
     hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 1);
     hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
     if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(T), COST_AT_X);
-    if (d.Vtot) hipLaunchKernelGGL((k_vis_eval<T>), dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
+    if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
+    if (d.Vtot) hipLaunchKernelGGL(k_vis_eval, dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
     hipLaunchKernelGGL((k_misc<T>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0);
     hipLaunchKernelGGL((k_initial_cost<T>), dim3(d.nwin), dim3(64), 0, stream_, d, 1);
     Lm lm;
@@ -1295,33 +1331,49 @@ int32_t ctvio_shard_count(int32_t n, int32_t device, int32_t n_devices) {
 }
 namespace {
 std::mutex g_shard_mu;
-std::vector<ctvio_solver *> g_shard_solvers;   // one per device ordinal, created on first use
+std::vector<ctvio_solver *> g_shard_solvers;   // one per shard, created on first use (and again when the options change)
+std::vector<ctvio_options> g_shard_opts;       // the options each handle was created with
+}
+// The number of shards ctvio_solve_sharded uses: min(requested or all devices, devices present, windows).  With the TEST-ONLY
+// environment switch CTVIO_SHARD_OVERSUBSCRIBE=1 the device count does not clamp it (shard g runs on device g mod #devices), so that
+// the multi-shard path can be exercised on a box with one GPU.
+int32_t ctvio_shards_used(int32_t n_devices, int32_t n) {
+  const int ndev = ctvio_device_count();
+  if (ndev <= 0 || n <= 0) return 0;
+  if (std::getenv("CTVIO_SHARD_OVERSUBSCRIBE") && n_devices > 0) return std::min(n_devices, n);
+  return std::min(n_devices > 0 ? std::min(n_devices, ndev) : ndev, n);
 }
 void ctvio_sharded_release(void) {
   std::lock_guard<std::mutex> lk(g_shard_mu);
-  for (auto *sv : g_shard_solvers) ctvio_destroy(sv);
+  for (auto *sv : g_shard_solvers) if (sv) ctvio_destroy(sv);
   g_shard_solvers.clear();
+  g_shard_opts.clear();
 }
 int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t n, const ctvio_window *wins, int32_t max_iterations,
                             ctvio_summary *out, double *quat, double *pos, double *bias, double *rho, double *ld) {
   if (n <= 0 || !wins) return ctv::fail(CTVIO_ERR_INVALID, "empty batch");
   const int ndev = ctvio_device_count();
   if (ndev <= 0) return ctv::fail(CTVIO_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
-  const int G = std::min(n_devices > 0 ? std::min(n_devices, ndev) : ndev, n);
+  const int G = ctvio_shards_used(n_devices, n);
   std::lock_guard<std::mutex> lk(g_shard_mu);   // one sharded solve at a time per process (the handles are shared)
-  if ((int)g_shard_solvers.size() < G) g_shard_solvers.resize((size_t)G, nullptr);
+  if ((int)g_shard_solvers.size() < G) { g_shard_solvers.resize((size_t)G, nullptr); g_shard_opts.resize((size_t)G); }
   // offsets of every window in the caller's concatenated state arrays
   std::vector<size_t> k0((size_t)n + 1, 0), f0((size_t)n + 1, 0), l0((size_t)n + 1, 0);
   for (int i = 0; i < n; ++i) { k0[i + 1] = k0[i] + (size_t)std::max(wins[i].K, 0); f0[i + 1] = f0[i] + (size_t)std::max(wins[i].F, 0); l0[i + 1] = l0[i] + (size_t)std::max(wins[i].L, 0); }
   std::vector<int> rcs((size_t)G, CTVIO_OK);
   std::vector<std::string> errs((size_t)G);
-  auto work = [&](int g) {
-    auto failed = [&](int rc) { rcs[g] = rc; errs[g] = "device " + std::to_string(g) + ": " + ctvio_last_error(); };   // (thread-local error text)
+  auto work_body = [&](int g) {
+    auto failed = [&](int rc) { rcs[g] = rc; errs[g] = "shard " + std::to_string(g) + ": " + ctvio_last_error(); };   // (thread-local error text)
+    ctvio_options o;
+    if (opt) o = *opt; else ctvio_default_options(&o);
+    o.device = g % ndev;
+    if (g_shard_solvers[g] && std::memcmp(&o, &g_shard_opts[g], sizeof o) != 0) {   // the caller changed the options: a fresh handle
+      ctvio_destroy(g_shard_solvers[g]);
+      g_shard_solvers[g] = nullptr;
+    }
     if (!g_shard_solvers[g]) {
-      ctvio_options o;
-      if (opt) o = *opt; else ctvio_default_options(&o);
-      o.device = g;
       if (const int rc = ctvio_create(&o, &g_shard_solvers[g])) return failed(rc);
+      g_shard_opts[g] = o;
     }
     ctvio_solver *sv = g_shard_solvers[g];
     std::vector<ctvio_window> mine;
@@ -1347,6 +1399,11 @@ int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t
       if (ld) ld[i] = l[j];
       ka += w.K; fa += w.F; la += w.L;
     }
+  };
+  auto work = [&](int g) {   // (an exception escaping a std::thread would terminate the process)
+    try { work_body(g); }
+    catch (const std::exception &e) { rcs[g] = CTVIO_ERR_HIP; errs[g] = "shard " + std::to_string(g) + ": " + e.what(); }
+    catch (...) { rcs[g] = CTVIO_ERR_HIP; errs[g] = "shard " + std::to_string(g) + ": unknown exception"; }
   };
   std::vector<std::thread> th;
   for (int g = 1; g < G; ++g) th.emplace_back(work, g);

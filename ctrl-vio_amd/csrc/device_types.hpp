@@ -14,6 +14,7 @@ struct WinMeta {
   int32_t knot0, bias0, lm0;   // offsets into state arrays (knots, bias states, landmarks)
   int32_t imu0, grp0, ngrp;    // IMU samples (sorted by group) / groups
   int32_t vis0, bc0;           // visual blocks (LANDMARK-major, padded: see Vp) / bias-chain links
+  int32_t anc0, A;             // anchors: distinct (landmark, t_i, row_i, p_i) of the window's visual blocks, landmark-major
   int32_t vitem0, nvitem;      // visual work items (<= CH blocks of one frame pair, listed in Dev::vblk)
   int32_t vis_lds, Vp;         // 1: the packed visual Hessian fits in LDS (k_assemble_vis); Vp: block slots of the window incl. padding
                                // (a multiple of 64; a landmark's blocks are consecutive and never straddle a group of 64)
@@ -40,7 +41,7 @@ struct ImuGroup {
 
 // Per-window Levenberg-Marquardt state (Ceres 1.14 TrustRegionMinimizer variables).
 // sensor-to-IMU extrinsic applied by k_spline_eval when on != 0 (reference ExtrinsicParam::se3)
-constexpr int VT_ROWS = 68;   // rows of a visual tile (Dev::Jt)
+constexpr int VT_ROWS = 40;   // doubles per block record in Dev::Jt (factors.hpp: VB_*)
 struct SensorExt { double q[4]; double p[3]; int on; };
 
 struct Lm {
@@ -92,22 +93,31 @@ template <class T> struct Dev {
   double *imu_cost;      // [Gtot] 1/2 |r|^2 of the group's samples; vis_cost [Vtot / 64] robustified cost of the wave's blocks;
   double *vis_cost;      // misc_cost [nwin] bias chain + prior: summed per window in a fixed order by k_lm_control (no atomics)
   double *misc_cost;
-  // visual factors
-  const int32_t *v_win, *v_lm;
-  const int64_t *v_ti, *v_tj;   // relative to the window's t0
-  const int32_t *v_rowi, *v_rowj;
-  const T *v_obs;        // [4][Vtot] pix, piy, pjx, pjy
+  // visual factors.  Anchors = the i ends: all blocks of a feature share (t_i, row_i, p_i) in the reference (trajectory_manager.cpp:
+  // 367-383); the host finds the distinct ones (any caller-given blocks are handled: a landmark may own several anchors), k_vis_anchor
+  // evaluates each once per linearisation into a record (factors.hpp: AREC doubles), the blocks evaluate only their j end.
+  const int32_t *a_win, *a_lm;  // [Atot] window / landmark (window-local) of the anchor
+  const int64_t *a_t;           // [Atot] t_i relative to the window's t0
+  const int32_t *a_row;         // [Atot] row_i
+  const double *a_obs;          // [2][Atot] p_i
+  double *arec;                 // [Atot][AREC] records of the state being linearised
+  int32_t *a_s;                 // [Atot] first active knot of the anchor end
+  int32_t Atot, pad_at;
+  const int32_t *v_win, *v_lm, *v_anc;   // [Vtot] window (-1: padding slot), landmark, anchor (absolute) of the block slot
+  const int64_t *v_tj;          // relative to the window's t0
+  const int32_t *v_rowj;
+  const T *v_obs;        // [2][Vtot] pjx, pjy
   const double *v_cauchy; // [Vtot] width a of the block's ceres::CauchyLoss(a) (<= 0: no loss): the reference picks it per residual
                          // block (trajectory_estimator.cpp:320-323: 1 when the feature is being marginalised, else 2)
-  T *Jt;                 // robust-corrected visual Jacobian + residual, block-major [Vtot][VT_ROWS]: the assembly gathers the blocks of
-                         // an item (frame-pair order) from the landmark-major block order, 528 contiguous bytes each; a wave of
-                         // k_vis_eval writes the 64 x VT_ROWS entries of its blocks as ONE contiguous 34 KB region (from LDS).
-                         // Row entries: 0-23 rotation columns of the i end (2 col + residual row), 24-47 of the j end, 48/49 inverse
-                         // depth, 50/51 line delay, 52/53 residual, 54-67 the position columns in compact form: P~ (2 x 3), cp0[4],
-                         // cp1[4]  (J~_pos(k, b) = cp0[k] P~[b] / -cp1[k] P~[b])
-  int32_t *vs;           // [2][Vtot] first active knot of the i-end / j-end
+  T *Jt;                 // robust-corrected block records, block-major [Vtot][VT_ROWS] (factors.hpp VB_*: rotation columns of the j end,
+                         // inverse-depth and line-delay columns, residual, A~ (2 x 3) and the j end's blending coefficients -- the i-end
+                         // columns are A~ times the anchor record and are rebuilt by the assembly): the assembly gathers the blocks of an
+                         // item (frame-pair order) from the landmark-major block order, 320 contiguous bytes each; a wave of k_vis_eval
+                         // writes the 64 x VT_ROWS entries of its blocks as ONE contiguous 20 KB region (from LDS).
+  int32_t *vsj;          // [Vtot] first active knot of the j end
   const VisItem *vitems;
   const int32_t *vblk;   // [Vtot] block slots in frame-pair order, window by window (VisItem::start indexes it)
+  const int32_t *vblk_anc; // [Vtot] the anchors (absolute) of those blocks
   int32_t maxL, maxLdw;
   // bias chain
   const int32_t *bc_win, *bc_i, *bc_j;

@@ -444,151 +444,165 @@ template <class T, class SC, bool SMALL = false, class F> CTV_DI void eval_RTp_j
   f(3, pending);
 }
 
-template <class T> struct Calib {
-  Q4<T> q_CI;
-  V3<T> p_CI;
-  T img_w, cauchy_a;
-};
+// ------------------------------------------------------------------------------------------------
+// Visual block (ImageFeatureDelayFactor::Evaluate, image_feature_factor.h:63-269), FACTORED THROUGH THE ANCHOR END.
+//
+// The reprojection residual depends on the pose unknowns only through the 3-vector x_j (the point in camera j):
+//     x_j = R_CI^T (R_Ij^T (p_G - p_Ij) - p_CI),     p_G = R_Ii p_Ii + p_IiinG   (the point in the global frame),
+// so every column of the block's 2 x 50 Jacobian is A (2 x 3) times a 3-vector, A = sw J_v R_CI^T R_Ij^T (:184-197), and the
+// robust corrector (linear in J) turns A into A~ once.  Everything on the anchor side of p_G -- EvaluateRp and its per-knot
+// Jacobians, VelocityBody, p(t_i), v(t_i) (:104-131, 199-216) -- depends on (t_i, row_i, p_i, rho) alone, and the reference gives
+// all blocks of a feature the same (t_i, row_i, p_i) (trajectory_manager.cpp:367-383): it is evaluated ONCE per anchor
+// (vis_anchor_eval -> a record of AREC doubles) instead of once per block (5-6 times per landmark), and a block evaluates only its
+// own j end (vis_block_eval).  Column by column (local order rot_i 12 | pos_i 12 | rot_j 12 | pos_j 12 | rho | ld):
+//     rot_i (k, b)  = A~ GR_k[:, b],   GR_k = -R_Ii hat(p_Ii) J^Rp_k              (record)
+//     pos_i (k, b)  = cp0[k] A~[:, b]                                              (record: cp0)
+//     rot_j (k, b)  = (A~ hat(p_G - p_Ij)) J^RTp_k[:, b]                           (block)
+//     pos_j (k, b)  = -cp1[k] A~[:, b]                                             (block: cp1)
+//     rho           = A~ y,   y = -(1 / rho) R_Ii R_CI x_ci                        (record)
+//     ld            = B~ (R_Ij^T (h - row_j v_j) - row_j Om_j x (R_Ij^T (p_G - p_Ij))),  h = row_i (v_i + R_Ii (Om_i x p_Ii))  (record),
+//                     B~ = corrector(sw J_v R_CI^T), A~ = B~ R_Ij^T
+// The i-end columns are never materialised per block: the assembly rebuilds them from A~ and the record, the rows of W take
+// sum_b (A~^T J~_rho) over the anchor's blocks times the record.
+constexpr int AREC = 50;        // doubles per anchor record
+constexpr int AR_PG = 0;        // [3]  p_G
+constexpr int AR_GR = 3;        // [12][3] GR[c][m] = GR_k(m, b), c = 3 k + b: the three factors of column c are consecutive
+constexpr int AR_CP0 = 39;      // [4]  blending coefficients of the position spline at t_i
+constexpr int AR_Y = 43;        // [3]
+constexpr int AR_H = 46;        // [3]  (entry 49 unused: records are 16-byte multiples)
 
-// Visual block.  Local column order of J (2 x 50): rot_i (12) | pos_i (12) | rot_j (12) | pos_j (12) | rho | ld.
-// Outputs are already robust-corrected (r~ = sqrt(rho') r, J~ = sqrt(rho')(J - alpha/s r r^T J)); returns
-// the block's cost contribution rho(s)/2.  Emit::put(col, j0, j1) receives column `col` of J~ (both rows).
-// SMALL: every knot-pair log of both ends is below 0.5 rad (checked by the caller): series-only exp / Jr, no branches.
-// LOCAL = false: the knots are in the global frame (RrefT unused): the fp64 path needs no local frame.
-template <class T, class Emit, class SC, bool SMALL = false, bool LOCAL = true>
-CTV_DI T visual_eval(const Knots4<T> &ki, const Knots4<T> &kj, const SC &sci, const SC &scj, T ui, T uj, T idt,
-                     const Calib<T> &cal, const M3<T> &RrefT, T pix, T piy, T pjx, T pjy, T rowi, T rowj, T d_inv, T r[2], bool want_jac,
-                     Emit &emit) {
-  const T inv_d = T(1) / d_inv;
-  const V3<T> x_ci = mk<T>(pix * inv_d, piy * inv_d, inv_d);
-  const V3<T> p_Ii = qrot(cal.q_CI, x_ci) + cal.p_CI;
-
-  const Q4<T> S_IitoG = eval_Rp<T, SC, SMALL>(ki.q, sci, ui, (M3<T> *)nullptr, false);     // values only; the Jacobians are streamed below
-  const Q4<T> S_GtoIj = eval_RTp<T, SC, SMALL>(kj.q, scj, uj, (M3<T> *)nullptr, false);
-  T cp0[4], cp1[4];
-  basis<T, false, 0>(ui, T(1), cp0);
-  basis<T, false, 0>(uj, T(1), cp1);
-  V3<T> p_IiinG = mk<T>(0, 0, 0), p_IjinG = mk<T>(0, 0, 0);
+// q0 / p[4]: rotation of the first active knot and the positions of the four active knots of the anchor end (global frame).
+template <bool SMALL, class SC>
+CTV_DI void vis_anchor_eval(const Q4<double> &q0, const V3<double> p[4], const SC &sc, double u, double idt, const Q4<double> &q_CI,
+                            const V3<double> &p_CI, double pix, double piy, double rowi, double d_inv, bool want_jac, double *rec) {
+  const double inv_d = 1.0 / d_inv;
+  const V3<double> c_i = qrot(q_CI, mk<double>(pix * inv_d, piy * inv_d, inv_d));   // R_CI x_ci
+  const V3<double> p_Ii = c_i + p_CI;
+  Q4<double> qk[4];
+  qk[0] = q0;
+  const Q4<double> S_IitoG = eval_Rp<double, SC, SMALL>(qk, sc, u, (M3<double> *)nullptr, false);
+  const M3<double> RIiG = q2R(S_IitoG);
+  double cp0[4];
+  basis<double, false, 0>(u, 1.0, cp0);
+  V3<double> pI = mk<double>(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { p_IiinG = p_IiinG + cp0[i] * ki.p[i]; p_IjinG = p_IjinG + cp1[i] * kj.p[i]; }
-  V3<T> v_i = mk<T>(0, 0, 0), v_j = mk<T>(0, 0, 0);   // spline velocities of both ends (line-delay column): taken here, so the
-  if (want_jac) {                                       // knot positions are dead after this point
-    T dcp0[4], dcp1[4];
-    basis<T, false, 1>(ui, idt, dcp0);
-    basis<T, false, 1>(uj, idt, dcp1);
+  for (int i = 0; i < 4; ++i) pI = pI + cp0[i] * p[i];
+  const V3<double> pG = mul(RIiG, p_Ii) + pI;
+  rec[AR_PG] = pG.x; rec[AR_PG + 1] = pG.y; rec[AR_PG + 2] = pG.z;
+  if (!want_jac) return;
+  double dcp0[4];
+  basis<double, false, 1>(u, idt, dcp0);
+  V3<double> v_i = mk<double>(0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v_i = v_i + dcp0[i] * ki.p[i]; v_j = v_j + dcp1[i] * kj.p[i]; }
-  }
+  for (int i = 0; i < 4; ++i) v_i = v_i + dcp0[i] * p[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rec[AR_CP0 + i] = cp0[i];
+  const V3<double> y = (-inv_d) * mul(RIiG, c_i);
+  rec[AR_Y] = y.x; rec[AR_Y + 1] = y.y; rec[AR_Y + 2] = y.z;
+  const V3<double> Om_i = eval_omega<double, SC, SMALL>(sc, u, idt);
+  const V3<double> h = rowi * (v_i + mul(RIiG, cross(Om_i, p_Ii)));
+  rec[AR_H] = h.x; rec[AR_H + 1] = h.y; rec[AR_H + 2] = h.z;
+  const M3<double> M0 = scale(mul_hat(RIiG, p_Ii), -1.0);     // -R_Ii hat(p_Ii)
+  eval_Rp_jac_stream<double, SC, SMALL>(sc, u, [&](int kk, const M3<double> &Jk) {
+    const M3<double> G = mul(M0, Jk);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int mm = 0; mm < 3; ++mm) rec[AR_GR + 3 * (3 * kk + b) + mm] = G.m[3 * mm + b];
+  });
+}
 
-  const V3<T> p_G = qrot(S_IitoG, p_Ii) + p_IiinG;
-  const Q4<T> S_ItoC = qconj(cal.q_CI);
-  const Q4<T> S_GtoCj = qmul(S_ItoC, S_GtoIj);   // (the extrinsic is user input: Sophus' exact renormalisation)
-  const V3<T> dpg = p_G - p_IjinG;
-  const V3<T> x_j = qrot(S_GtoCj, dpg) - qrot(S_ItoC, cal.p_CI);
-  const T dji = T(1) / x_j.z;
-  const T sw = cal.img_w;
-  const T r0 = sw * (x_j.x * dji - pjx), r1 = sw * (x_j.y * dji - pjy);
+// Entries of a block's record in Dev::Jt (VT_ROWS doubles, robust-corrected): the assembly's input.
+constexpr int VB_JROT = 0;      // [12][2] rotation columns of the j end: entry 2 c + residual row, c = 3 k + b
+constexpr int VB_RHO = 24;      // [2]  inverse-depth column
+constexpr int VB_LD = 26;       // [2]  line-delay column
+constexpr int VB_RES = 28;      // [2]  r~
+constexpr int VB_AT = 30;       // [3][2] A~: entry 30 + 2 m + residual row
+constexpr int VB_CP1 = 36;      // [4]  blending coefficients of the position spline at t_j
 
-  // robust loss (Cauchy): rho(s) = b log(1 + s/b), rho' = 1/(1+s/b), rho'' = -rho'^2/b
-  const T s = r0 * r0 + r1 * r1;
-  T cost, sq = T(1), rs = T(1), alpha_sq = T(0);
-  if (cal.cauchy_a > T(0)) {
-    const T b = cal.cauchy_a * cal.cauchy_a, c = T(1) / b;
-    const T inv = T(1) / (T(1) + s * c);
-    cost = T(0.5) * b * t_log1p(s * c);
-    const T rho1 = inv, rho2 = -c * inv * inv;
-    sq = t_sqrt(rho1);
-    if (s == T(0) || rho2 <= T(0)) { rs = sq; alpha_sq = T(0); }
-    else { const T D = T(1) + T(2) * s * rho2 / rho1; const T al = T(1) - t_sqrt(D); rs = sq / (T(1) - al); alpha_sq = al / s; }
+// q0 / p[4]: the j end's knots.  RCIT = R_CI^T (row major).  Emit receives the block record entry by entry -- put(entry, value) --
+// with the inverse-depth column first (sinks that form J_rho^T J_c need it up front); r[2] = r~; returns the block's cost rho(s)/2.
+template <bool SMALL, class SC, class Emit>
+CTV_DI double vis_block_eval(const double *rec, const Q4<double> &q0, const V3<double> p[4], const SC &sc, double u, double idt,
+                             const M3<double> &RCIT, const V3<double> &p_CI, double sw, double cauchy_a, double pjx, double pjy, double rowj,
+                             double r[2], bool want_jac, Emit &emit) {
+  Q4<double> qk[4];
+  qk[0] = q0;
+  const Q4<double> S_GtoIj = eval_RTp<double, SC, SMALL>(qk, sc, u, (M3<double> *)nullptr, false);
+  double cp1[4];
+  basis<double, false, 0>(u, 1.0, cp1);
+  V3<double> pIj = mk<double>(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pIj = pIj + cp1[i] * p[i];
+  const V3<double> dpg = mk<double>(rec[AR_PG], rec[AR_PG + 1], rec[AR_PG + 2]) - pIj;
+  const V3<double> bj = qrot(S_GtoIj, dpg);             // R_Ij^T (p_G - p_Ij)
+  const V3<double> x_j = mul(RCIT, bj - p_CI);
+  const double dji = 1.0 / x_j.z;
+  const double r0 = sw * (x_j.x * dji - pjx), r1 = sw * (x_j.y * dji - pjy);
+  // robust loss (Cauchy): rho(s) = b log(1 + s/b), rho' = 1/(1+s/b), rho'' = -rho'^2/b; corrector as marginalization_factor.cpp:39-67
+  const double s = r0 * r0 + r1 * r1;
+  double cost, sq = 1.0, rs = 1.0, alpha_sq = 0.0;
+  if (cauchy_a > 0.0) {
+    const double b = cauchy_a * cauchy_a, c = 1.0 / b;
+    const double inv = 1.0 / (1.0 + s * c);
+    cost = 0.5 * b * log1p(s * c);
+    const double rho1 = inv, rho2 = -c * inv * inv;
+    sq = sqrt(rho1);
+    if (s == 0.0 || rho2 <= 0.0) { rs = sq; alpha_sq = 0.0; }
+    else { const double D = 1.0 + 2.0 * s * rho2 / rho1; const double al = 1.0 - sqrt(D); rs = sq / (1.0 - al); alpha_sq = al / s; }
   } else {
-    cost = T(0.5) * s;
+    cost = 0.5 * s;
   }
   r[0] = rs * r0;
   r[1] = rs * r1;
   if (!want_jac) return cost;
-
-  // corrector applied column by column
-  auto out = [&](int col, T j0, T j1) {
-    const T rj = r0 * j0 + r1 * j1;
-    emit.put(col, sq * (j0 - alpha_sq * r0 * rj), sq * (j1 - alpha_sq * r1 * rj));
-  };
-  // J_v (image_feature_factor.h:184-186)
-  const T Jv[6] = {dji, T(0), -dji * dji * x_j.x, T(0), dji, -dji * dji * x_j.y};
-  const M3<T> RGCj = q2R(S_GtoCj), RIiG = q2R(S_IitoG);
-  const M3<T> RGCjRi = mul(RGCj, RIiG);
-  // inverse depth (image_feature_factor.h:239-248) -- emitted first: sinks that form J_rho^T J_c need it up front
+  // B~ = corrector(sw J_v R_CI^T), J_v = [dji 0 -dji^2 x; 0 dji -dji^2 y] (image_feature_factor.h:184-186)
+  double Bt[6], At[6];
   {
-    const V3<T> y = mul(RGCjRi, qrot(cal.q_CI, x_ci));
-    const T f = -inv_d * sw;
-    out(48, f * (Jv[0] * y.x + Jv[2] * y.z), f * (Jv[4] * y.y + Jv[5] * y.z));
-  }
-  {
-    const M3<T> t0 = mul_hat(RGCjRi, p_Ii), t1 = mul_hat(RGCj, dpg);
-    T lhsR0[6], lhsP0[6], lhsR1[6];  // :192-197 (lhsP1 = -lhsP0)
+    const double fx = -dji * dji * x_j.x, fy = -dji * dji * x_j.y;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        T s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          s0 += Jv[3 * a + kx] * t0.m[3 * kx + b]; s1 += Jv[3 * a + kx] * RGCj.m[3 * kx + b]; s2 += Jv[3 * a + kx] * t1.m[3 * kx + b];
-        }
-        lhsR0[3 * a + b] = -s0; lhsP0[3 * a + b] = s1; lhsR1[3 * a + b] = s2;
-      }
-    if constexpr (LOCAL) {  // position columns back to the global frame: J_p = J_p' R_ref^T (see imu_eval)
-      T g6[6];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          g6[3 * a + b] = lhsP0[3 * a] * RrefT.m[b] + lhsP0[3 * a + 1] * RrefT.m[3 + b] + lhsP0[3 * a + 2] * RrefT.m[6 + b];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) lhsP0[i] = g6[i];
+    for (int c = 0; c < 3; ++c) {
+      const double j0 = sw * (dji * RCIT.m[c] + fx * RCIT.m[6 + c]), j1 = sw * (dji * RCIT.m[3 + c] + fy * RCIT.m[6 + c]);
+      const double rj = r0 * j0 + r1 * j1;
+      Bt[c] = sq * (j0 - alpha_sq * r0 * rj);
+      Bt[3 + c] = sq * (j1 - alpha_sq * r1 * rj);
     }
-    // position columns: the 2 x 3 block P~ = corrector(sw * lhsP0) is shared by all eight position knots, column (knot k, axis b)
-    // of the i-end is cp0[k] P~[b], of the j-end -cp1[k] P~[b] (the corrector is linear in J).  Sinks that materialise J~ keep
-    // just P~ and the two sets of blending coefficients (put_pos) instead of the 48 columns.
-    {
-      T Pt[6];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const T j0 = sw * lhsP0[b], j1 = sw * lhsP0[3 + b], rj = r0 * j0 + r1 * j1;
-        Pt[2 * b] = sq * (j0 - alpha_sq * r0 * rj);
-        Pt[2 * b + 1] = sq * (j1 - alpha_sq * r1 * rj);
-      }
-      emit.put_pos(Pt, cp0, cp1);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          emit.put(12 + 3 * kk + b, cp0[kk] * Pt[2 * b], cp0[kk] * Pt[2 * b + 1]);
-          emit.put(36 + 3 * kk + b, -cp1[kk] * Pt[2 * b], -cp1[kk] * Pt[2 * b + 1]);
-        }
-    }
-    // rotation columns, knot by knot as the per-knot partial Jacobians become final (image_feature_factor.h:199-216)
-    auto rot_cols = [&](int col0, const T lhs[6], const M3<T> &Jk) {
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        T a0 = 0, a1 = 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { a0 += lhs[c] * Jk.m[3 * c + b]; a1 += lhs[3 + c] * Jk.m[3 * c + b]; }
-        out(col0 + b, sw * a0, sw * a1);
-      }
-    };
-    eval_Rp_jac_stream<T, SC, SMALL>(sci, ui, [&](int kk, const M3<T> &Jk) { rot_cols(3 * kk, lhsR0, Jk); });
-    eval_RTp_jac_stream<T, SC, SMALL>(kj.q, scj, uj, [&](int kk, const M3<T> &Jk) { rot_cols(24 + 3 * kk, lhsR1, Jk); });
   }
-  // line delay (image_feature_factor.h:251-264)
+  const M3<double> RGIj = q2R(S_GtoIj);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) At[3 * a + c] = Bt[3 * a] * RGIj.m[c] + Bt[3 * a + 1] * RGIj.m[3 + c] + Bt[3 * a + 2] * RGIj.m[6 + c];
+  // inverse depth (image_feature_factor.h:239-248)
+  emit.put(VB_RHO, At[0] * rec[AR_Y] + At[1] * rec[AR_Y + 1] + At[2] * rec[AR_Y + 2]);
+  emit.put(VB_RHO + 1, At[3] * rec[AR_Y] + At[4] * rec[AR_Y + 1] + At[5] * rec[AR_Y + 2]);
+#pragma unroll
+  for (int mm = 0; mm < 3; ++mm) { emit.put(VB_AT + 2 * mm, At[mm]); emit.put(VB_AT + 2 * mm + 1, At[3 + mm]); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) emit.put(VB_CP1 + i, cp1[i]);
+  // line delay (image_feature_factor.h:251-264), in the frame of IMU j
   {
-    const V3<T> Om_i = eval_omega<T, SC, SMALL>(sci, ui, idt), Om_j = eval_omega<T, SC, SMALL>(scj, uj, idt);
-    const M3<T> RGIj = q2R(S_GtoIj);
-    const V3<T> a1 = qrot(S_GtoIj, rowi * v_i - rowj * v_j);
-    const V3<T> a2 = (-rowj) * cross(Om_j, mul(RGIj, dpg));
-    const V3<T> a3 = rowi * mul(RGIj, mul(RIiG, cross(Om_i, p_Ii)));
-    const V3<T> Jx = qrot(S_ItoC, a1 + a2 + a3);
-    out(49, sw * (Jv[0] * Jx.x + Jv[2] * Jx.z), sw * (Jv[4] * Jx.y + Jv[5] * Jx.z));
+    double dcp1[4];
+    basis<double, false, 1>(u, idt, dcp1);
+    V3<double> v_j = mk<double>(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_j = v_j + dcp1[i] * p[i];
+    const V3<double> Om_j = eval_omega<double, SC, SMALL>(sc, u, idt);
+    const V3<double> hv = mk<double>(rec[AR_H], rec[AR_H + 1], rec[AR_H + 2]) - rowj * v_j;
+    const V3<double> Jx = qrot(S_GtoIj, hv) - rowj * cross(Om_j, bj);
+    emit.put(VB_LD, Bt[0] * Jx.x + Bt[1] * Jx.y + Bt[2] * Jx.z);
+    emit.put(VB_LD + 1, Bt[3] * Jx.x + Bt[4] * Jx.y + Bt[5] * Jx.z);
   }
+  // rotation columns of the j end, knot by knot as the per-knot partial Jacobians become final (image_feature_factor.h:199-216):
+  // E = A~ hat(p_G - p_Ij), row by row A~[a] x dpg
+  const V3<double> E0 = cross(mk<double>(At[0], At[1], At[2]), dpg), E1 = cross(mk<double>(At[3], At[4], At[5]), dpg);
+  eval_RTp_jac_stream<double, SC, SMALL>(qk, sc, u, [&](int kk, const M3<double> &Jk) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      emit.put(VB_JROT + 2 * (3 * kk + b), E0.x * Jk.m[b] + E0.y * Jk.m[3 + b] + E0.z * Jk.m[6 + b]);
+      emit.put(VB_JROT + 2 * (3 * kk + b) + 1, E1.x * Jk.m[b] + E1.y * Jk.m[3 + b] + E1.z * Jk.m[6 + b]);
+    }
+  });
   return cost;
 }
 

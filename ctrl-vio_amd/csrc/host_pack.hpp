@@ -76,7 +76,9 @@ struct PackTmp {
   std::vector<int32_t> iorder, iseg;    // IMU: sample order by (segment, bias state); segment of every sample (input order)
   std::vector<int32_t> vord;            // visual blocks: order by (ti, tj, rowi, rowj)  (frame-pair order: the assembly's items)
   std::vector<int32_t> lord, vpos;      // landmark-major slots: lord[slot] = block or -1 (padding), vpos[block] = slot
+  std::vector<int32_t> anc_of, anc_rep; // anchors (distinct i ends), numbered landmark-major: anchor of every block / a block that carries it
   int32_t ngrp = 0, nvitem = 0, Vp = 0; // Vp: slots incl. padding, a multiple of 64
+  int32_t A = 0;                        // number of anchors
   std::string err;
 };
 
@@ -163,27 +165,55 @@ inline void plan_window(const ctvio_window *w, int vch, PackTmp &t) {
     if (fresh) { t.nvitem++; cnt = 0; }
     cnt++;
   }
-  // Evaluation order: landmark-major (frame-pair order inside a landmark), so that the wave of k_vis_eval that evaluates a
-  // landmark's blocks also forms its row of W.  A landmark never straddles a group of 64 slots (padding slots in front of it);
-  // the window's slot count is a multiple of 64 (windows start on a wave boundary).
-  std::vector<int32_t> lcount((size_t)w->L + 1, 0), lstart((size_t)w->L + 1, 0);
-  for (int v = 0; v < V; ++v) lcount[w->v_lm[v]]++;
-  int pos = 0;
-  for (int l = 0; l < w->L; ++l) {
+  // Anchors: the distinct i ends (landmark, t_i, row_i, p_i).  The reference adds every observation of a feature against the
+  // feature's first one (trajectory_manager.cpp:367-383), i.e. one anchor per landmark; the C ABI takes arbitrary blocks, so a
+  // landmark may own several (found by a linear search over the landmark's short list).  Numbered landmark-major.
+  const int L = w->L;
+  std::vector<int32_t> first((size_t)L, -1), next, rep, tmp_anc((size_t)V), acount;
+  auto same_anchor = [&](int a, int b) {
+    return w->v_ti[a] == w->v_ti[b] && w->v_rowi[a] == w->v_rowi[b] && w->v_pi[2 * a] == w->v_pi[2 * b] && w->v_pi[2 * a + 1] == w->v_pi[2 * b + 1];
+  };
+  std::vector<int32_t> lcount((size_t)L + 1, 0);
+  for (int i = 0; i < V; ++i) {
+    const int v = t.vord[i], l = w->v_lm[v];
+    lcount[l]++;
+    int a = first[l], prev = -1;
+    while (a >= 0 && !same_anchor(rep[a], v)) { prev = a; a = next[a]; }
+    if (a < 0) {
+      a = (int)rep.size();
+      rep.push_back(v); next.push_back(-1); acount.push_back(0);
+      if (prev < 0) first[l] = a; else next[prev] = a;
+    }
+    tmp_anc[v] = a;
+    acount[a]++;
+  }
+  // Evaluation order: landmark-major (inside a landmark anchor by anchor, frame-pair order inside an anchor), so that the wave of
+  // k_vis_eval that evaluates a landmark's blocks also forms its row of W.  A landmark never straddles a group of 64 slots (padding
+  // slots in front of it); the window's slot count is a multiple of 64 (windows start on a wave boundary).
+  t.A = (int)rep.size();
+  t.anc_rep.resize((size_t)t.A);
+  std::vector<int32_t> newid((size_t)t.A), astart((size_t)t.A);
+  int pos = 0, na = 0;
+  for (int l = 0; l < L; ++l) {
     const int c = lcount[l];
     if (c > 64) { t.err = "more than 64 observations of one landmark"; return; }
     if ((pos & 63) + c > 64) pos = (pos + 63) & ~63;
-    lstart[l] = pos;
-    pos += c;
+    for (int a = first[l]; a >= 0; a = next[a]) {
+      newid[a] = na; t.anc_rep[na] = rep[a]; astart[na] = pos;
+      pos += acount[a];
+      ++na;
+    }
   }
   t.Vp = (pos + 63) & ~63;
   t.lord.assign((size_t)t.Vp, -1);
   t.vpos.resize(V);
-  for (int i = 0; i < V; ++i) {     // frame-pair order inside a landmark
-    const int v = t.vord[i];
-    const int slot = lstart[w->v_lm[v]]++;
+  t.anc_of.resize(V);
+  for (int i = 0; i < V; ++i) {     // frame-pair order inside an anchor
+    const int v = t.vord[i], a = newid[tmp_anc[v]];
+    const int slot = astart[a]++;
     t.lord[slot] = v;
     t.vpos[v] = slot;
+    t.anc_of[v] = a;
   }
 }
 

@@ -1001,43 +1001,20 @@ template <class T> __global__ __launch_bounds__(256) void k_assemble_imu(Dev<T> 
 }
 
 // ------------------------------------------------------------------------------------------------ visual
-// is local column c (0..49) one of the 24 position columns (i-end 12..23, j-end 36..47)?  Those are not materialised:
-// J~[c] = cp0[k] P~[b] / -cp1[k] P~[b], rebuilt from the 14 numbers of Jp by the assembly kernels.
-__device__ __forceinline__ constexpr bool vis_pos_col(int c) { return (c >= 12 && c < 24) || (c >= 36 && c < 48); }
-// Entry index (0 .. VT_ROWS) of staging row `row` = 2 * column + residual row (< 100) of a materialised (non-position) column
-__device__ __forceinline__ constexpr int vis_trow(int row) { return row < 24 ? row : (row < 72 ? row - 24 : row - 48); }
-// k_vis_eval<LIN> stages the J~ of its 64 blocks in LDS, block-major like the copy in HBM ([64][VT_LD]: this lane's block starts
-// at J[0]; the odd stride spreads the lanes over the banks) and forms the landmark rows from it after the evaluation.
-constexpr int VT_LD = VT_ROWS + 1;
-template <class T> struct VisTileSink {
-  T *J;
-  __device__ __forceinline__ void put(int col, T j0, T j1) {
-    if (!vis_pos_col(col)) { J[vis_trow(2 * col)] = j0; J[vis_trow(2 * col) + 1] = j1; }
-  }
-  __device__ __forceinline__ void put_pos(const T Pt[6], const T cp0[4], const T cp1[4]) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) J[54 + i] = Pt[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { J[60 + i] = cp0[i]; J[64 + i] = cp1[i]; }
-  }
-};
-template <class T> struct VisNullSink {
-  __device__ __forceinline__ void put(int, T, T) {}
-  __device__ __forceinline__ void put_pos(const T *, const T *, const T *) {}
-};
-// J~ entry (staging row = 2 * column + residual row, < 100; 100 / 101 = the residual) of block v from the block-major storage
-template <class T> __device__ __forceinline__ T vis_J_entry(const T *Jt, int row, unsigned v) {
-  const T *J = Jt + (size_t)v * VT_ROWS;
-  if (row >= 100) return J[52 + row - 100];
+// Entry (row = 2 * local column + residual row, < 100; 100 / 101 = the residual) of the robust-corrected 2 x 50 Jacobian of the block
+// in slot v with anchor `anc`, rebuilt from the block record and the anchor record (factors.hpp): the cross-check assembly's input.
+__device__ __forceinline__ double vis_J_entry(const Dev<double> &d, int row, unsigned v, unsigned anc) {
+  const double *J = d.Jt + (size_t)v * VT_ROWS;
+  if (row >= 100) return J[VB_RES + row - 100];
   const int col = row >> 1, rr = row & 1;
-  if (!vis_pos_col(col)) return J[vis_trow(row)];
-  const int c = col < 24 ? col - 12 : col - 36, kk = c / 3, b = c % 3;
-  const T pt = J[54 + 2 * b + rr];
-  return col < 24 ? J[60 + kk] * pt : -J[64 + kk] * pt;
+  if (col >= 48) return J[(col == 48 ? VB_RHO : VB_LD) + rr];
+  const double *rec = d.arec + (size_t)anc * AREC;
+  if (col < 12) return J[VB_AT + rr] * rec[AR_GR + 3 * col] + J[VB_AT + 2 + rr] * rec[AR_GR + 3 * col + 1] + J[VB_AT + 4 + rr] * rec[AR_GR + 3 * col + 2];
+  if (col < 24) { const int c = col - 12; return rec[AR_CP0 + c / 3] * J[VB_AT + 2 * (c % 3) + rr]; }
+  if (col < 36) return J[VB_JROT + 2 * (col - 24) + rr];
+  const int c = col - 36;
+  return -(J[VB_CP1 + c / 3] * J[VB_AT + 2 * (c % 3) + rr]);
 }
-
-// width of block v's Cauchy loss (per residual block, like the reference: trajectory_estimator.cpp:320-323)
-template <class T> __device__ __forceinline__ double vis_cauchy(const Dev<T> &d, const WinMeta &, int v) { return d.v_cauchy[v]; }
 
 // time -> (first active knot, u) in integer ns (reference spline_segment.h:83-85); the line delay is
 // truncated to integer ns exactly as image_feature_factor.h:72.
@@ -1048,24 +1025,68 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
   u = (double)(tau % m.dt_ns) / (double)m.dt_ns;
 }
 
-// One lane per visual block, landmark-major: evaluate r~, J~ (robust-corrected), materialise J~ block-major and form the rows of W,
-// Hll, g_rho of the wave's landmarks into the normal-equation set the mode selects.  The wave's share of the cost goes to
-// Dev::vis_cost (a window's block slots start on a wave boundary: one window per wave).  A window on its last allowed iteration is
-// only costed (residuals, no Jacobians, nothing else written).
-constexpr int VIS_LDS_BYTES = 64 * VT_LD * 8;   // the J~ of a wave's 64 blocks (>= one fp64 row of the largest window: 642 doubles)
-template <class T>
-__device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigned char *smt, int4 *rmeta, int2 *rhg, int vblock) {
-  const int v = vblock * 64 + threadIdx.x;
-  const long long t_entry = d.dbg ? clock64() : 0ll;
-  // the J~ of the wave's 64 blocks ([64][VT_LD]), afterwards reused for the fp64 rows of W of the wave's landmarks
-  constexpr int LDS_BYTES = VIS_LDS_BYTES;
-  T *wcs = reinterpret_cast<T *>(smt);
+// One lane per ANCHOR (the i end shared by a feature's blocks: factors.hpp): the record of the state being linearised.  The usual wave --
+// every knot-pair log of its anchors below 0.5 rad (a ballot) -- takes the series-only evaluation (no branch, no closed-form code on the
+// path), the others the general one; both in the global frame.
+__global__ __launch_bounds__(64) void k_vis_anchor(Dev<double> d, int mode) {
+  const int a = blockIdx.x * 64 + threadIdx.x;
+  if (a >= d.Atot) return;
+  const int w = d.a_win[a];
+  const Lm &lm = d.lm[w];
+  if (!lin_run(lm, mode)) return;
+  const WinMeta &m = d.wins[w];
+  const bool jac = !lin_cost_only(lm, mode, d.prm);
   const bool at_cand = mode == LIN_SPEC;
   const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *rho = at_cand ? d.crho : d.rho, *ldp = at_cand ? d.cld : d.ld;
-  const double *kd = d.lkd;
+  int si;
+  double ui;
+  const int rowi = d.a_row[a];
+  vis_times(m, d.a_t[a], rowi, ldp[w], si, ui);
+  si = max(0, min(si, m.K - 4));   // host validated the worst case; clamp keeps loads in range regardless
+  SegConstLazy<double, double> sc;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+  seg_const_lazy(d.lkd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sc);
+  double dmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dmax = fmax(dmax, dot(sc.d[i], sc.d[i]));
+  const bool small = __ballot(dmax >= 0.25) == 0ull;
+  const double *qi = quat + 4 * (m.knot0 + si), *pi = pos + 3 * (m.knot0 + si);
+  const Q4<double> q0 = qmk<double>(qi[0], qi[1], qi[2], qi[3]);
+  V3<double> p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = mk<double>(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]);
+  const Q4<double> q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
+  const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+  double *rec = reinterpret_cast<double *>(__builtin_assume_aligned(d.arec + (size_t)a * AREC, 16));
+  const double pix = d.a_obs[a], piy = d.a_obs[(size_t)d.Atot + a], d_inv = rho[m.lm0 + d.a_lm[a]];
+  if (small) vis_anchor_eval<true>(q0, p, sc, ui, m.inv_dt, q_CI, p_CI, pix, piy, (double)rowi, d_inv, jac, rec);
+  else vis_anchor_eval<false>(q0, p, sc, ui, m.inv_dt, q_CI, p_CI, pix, piy, (double)rowi, d_inv, jac, rec);
+  d.a_s[a] = si;
+}
+
+// k_vis_eval<LIN> stages the records of its 64 blocks in LDS, block-major like the copy in HBM ([64][VT_LD]: this lane's block starts
+// at J[0]; the odd stride spreads the lanes over the banks) and forms the landmark rows from it after the evaluation.
+constexpr int VT_LD = VT_ROWS + 1;
+struct VisRecSink {
+  double *J;
+  __device__ __forceinline__ void put(int e, double v) { J[e] = v; }
+};
+struct VisNullSink {
+  __device__ __forceinline__ void put(int, double) {}
+};
+
+// One lane per visual block, landmark-major: evaluate the block's own (j) end against its anchor's record -- r~ and the record of J~
+// (robust-corrected), materialised block-major -- and form the rows of W, Hll, g_rho of the wave's landmarks into the normal-equation
+// set the mode selects.  The wave's share of the cost goes to Dev::vis_cost (a window's block slots start on a wave boundary: one window
+// per wave).  A window on its last allowed iteration is only costed (residuals, no Jacobians, nothing else written).
+constexpr int VIS_LDS_BYTES = 64 * VT_LD * 8;   // the records of a wave's 64 blocks, afterwards the fp64 rows of W of the wave's landmarks
+__device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, unsigned char *smt, long long *rowoff, int *rlm, int vblock) {
+  const int v = vblock * 64 + threadIdx.x;
+  constexpr int LDS_BYTES = VIS_LDS_BYTES;
+  double *wcs = reinterpret_cast<double *>(smt);
+  const bool at_cand = mode == LIN_SPEC;
+  const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *ldp = at_cand ? d.cld : d.ld;
   double c = 0.0;
-  int w = -1, ksi = 0, ksj = 0, my_lm = -1, tg = 0;
-  int mP = 0, mldw = 0, mK6 = 0, mlm0 = 0, mu0 = 0, mW0lo = 0, mW0hi = 0;   // the lane's window, for the landmark rows
+  int w = -1, ksj = 0, my_lm = -1, my_anc = -1, tg = 0;
   bool on = false, costed = false;
   if (v < d.Vtot) {
     w = d.v_win[v];
@@ -1075,71 +1096,51 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
       const WinMeta &m = d.wins[w];
       const bool jac = !lin_cost_only(lm, mode, d.prm);
       tg = lin_target(lm, mode);
-      int si, sj;
-      double ui, uj;
-      const double ld = ldp[w];
-      const int rowi = d.v_rowi[v], rowj = d.v_rowj[v];
-      vis_times(m, d.v_ti[v], rowi, ld, si, ui);
-      vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
-      si = max(0, min(si, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
-      sj = max(0, min(sj, m.K - 4));
-      Calib<T> cal;
-      cal.q_CI = qmk<T>((T)m.q_CI[0], (T)m.q_CI[1], (T)m.q_CI[2], (T)m.q_CI[3]);
-      cal.p_CI = mk<T>((T)m.p_CI[0], (T)m.p_CI[1], (T)m.p_CI[2]);
-      cal.img_w = (T)m.img_w;
-      cal.cauchy_a = (T)vis_cauchy(d, m, v);
-      const size_t V = (size_t)d.Vtot;
-      const T d_inv = (T)rho[m.lm0 + d.v_lm[v]];
-      T r[2];
-      SegConstLazy<T, T> sci, scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
-      seg_const_lazy(kd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sci);
-      seg_const_lazy(kd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
-      // The usual wave: every knot-pair log of its blocks' two ends below 0.5 rad -> series-only evaluation (no branch, no closed-form
-      // code on the path) in the GLOBAL frame, positions relative to the anchor end's first knot.  Otherwise (uniform choice: a ballot
-      // over the running lanes) the general form, in the local frame of that knot as the fp32 kernels had it.
+      int sj;
+      double uj;
+      const int rowj = d.v_rowj[v];
+      vis_times(m, d.v_tj[v], rowj, ldp[w], sj, uj);
+      sj = max(0, min(sj, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
+      SegConstLazy<double, double> scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+      seg_const_lazy(d.lkd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
+      // The usual wave: every knot-pair log of its blocks below 0.5 rad -> series-only evaluation (uniform choice: a ballot over the
+      // running lanes); otherwise the general form.  Global frame, absolute positions (fp64).
       double dmax = 0.0;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) dmax = fmax(dmax, fmax((double)dot(sci.d[i], sci.d[i]), (double)dot(scj.d[i], scj.d[i])));
+      for (int i = 0; i < 3; ++i) dmax = fmax(dmax, dot(scj.d[i], scj.d[i]));
       const bool small = __ballot(dmax >= 0.25) == 0ull;
-      Knots4<T> ki, kj;
-      M3<T> RrefT = m3_id<T>();
-      if (jac && small) {
-        const double *qi = quat + 4 * (m.knot0 + si), *qj = quat + 4 * (m.knot0 + sj), *pi = pos + 3 * (m.knot0 + si), *pj = pos + 3 * (m.knot0 + sj);
-        ki.q[0] = qmk<T>((T)qi[0], (T)qi[1], (T)qi[2], (T)qi[3]);   // (only the first knot's rotation is used: the others enter through the pair logs)
-        kj.q[0] = qmk<T>((T)qj[0], (T)qj[1], (T)qj[2], (T)qj[3]);
-        ki.q[1] = ki.q[2] = ki.q[3] = ki.q[0];
-        kj.q[1] = kj.q[2] = kj.q[3] = kj.q[0];
+      const double *qj = quat + 4 * (m.knot0 + sj), *pj = pos + 3 * (m.knot0 + sj);
+      const Q4<double> q0 = qmk<double>(qj[0], qj[1], qj[2], qj[3]);
+      V3<double> p[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ki.p[i] = mk<T>((T)(pi[3 * i] - pi[0]), (T)(pi[3 * i + 1] - pi[1]), (T)(pi[3 * i + 2] - pi[2]));
-          kj.p[i] = mk<T>((T)(pj[3 * i] - pi[0]), (T)(pj[3 * i + 1] - pi[1]), (T)(pj[3 * i + 2] - pi[2]));
-        }
-      } else {
-        LocalFrame<T> lf;
-        lf.init(quat, pos, m.knot0 + si);       // both ends relative to the first active knot of the anchor end
-        lf.load(quat, pos, m.knot0 + si, ki);
-        lf.load(quat, pos, m.knot0 + sj, kj);
-        RrefT = lf.RrefT();
+      for (int i = 0; i < 4; ++i) p[i] = mk<double>(pj[3 * i], pj[3 * i + 1], pj[3 * i + 2]);
+      const int anc = d.v_anc[v];
+      const double *rec = reinterpret_cast<const double *>(__builtin_assume_aligned(d.arec + (size_t)anc * AREC, 16));
+      M3<double> RCIT;
+      {
+        const M3<double> R = q2R(qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]));
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) RCIT.m[3 * a + b] = R.m[3 * b + a];
       }
+      const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+      const double pjx = d.v_obs[v], pjy = d.v_obs[(size_t)d.Vtot + v], ca = d.v_cauchy[v];
+      double r[2];
       if (jac) {
-        VisTileSink<T> sink{wcs + VT_LD * threadIdx.x};
+        VisRecSink sink{wcs + VT_LD * threadIdx.x};
         on = true;
         my_lm = d.v_lm[v];
-        mP = m.P; mldw = m.ldw; mK6 = 6 * m.K; mlm0 = m.lm0; mu0 = m.u0; mW0lo = (int)(m.W0 & 0xffffffffll); mW0hi = (int)(m.W0 >> 32);
-        if (small)
-          c = (double)visual_eval<T, VisTileSink<T>, SegConstLazy<T, T>, true, false>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v],
-                  d.v_obs[V + v], d.v_obs[2 * V + v], d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
-        else
-          c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
-                                     d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, true, sink);
-        sink.J[52] = r[0]; sink.J[53] = r[1];
-        d.vs[v] = si; d.vs[V + v] = sj;
-        ksi = si; ksj = sj;
+        my_anc = anc;
+        if (small) c = vis_block_eval<true>(rec, q0, p, scj, uj, m.inv_dt, RCIT, p_CI, m.img_w, ca, pjx, pjy, (double)rowj, r, true, sink);
+        else c = vis_block_eval<false>(rec, q0, p, scj, uj, m.inv_dt, RCIT, p_CI, m.img_w, ca, pjx, pjy, (double)rowj, r, true, sink);
+        sink.J[VB_RES] = r[0]; sink.J[VB_RES + 1] = r[1];
+        d.vsj[v] = sj;
+        ksj = sj;
       } else {
-        VisNullSink<T> nsink;
+        VisNullSink nsink;
         costed = true;
-        c = (double)visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)m.inv_dt, cal, RrefT, d.v_obs[v], d.v_obs[V + v], d.v_obs[2 * V + v],
-                                   d.v_obs[3 * V + v], (T)rowi, (T)rowj, d_inv, r, false, nsink);
+        c = vis_block_eval<false>(rec, q0, p, scj, uj, m.inv_dt, RCIT, p_CI, m.img_w, ca, pjx, pjy, (double)rowj, r, false, nsink);
       }
     } else {
       w = -1;
@@ -1155,174 +1156,157 @@ __device__ __forceinline__ void vis_eval_body(const Dev<T> &d, int mode, unsigne
       if (lane == 0) d.vis_cost[vblock] = cs;
     }
     if (on_mask == 0) return;                  // (wave-uniform)
-    const int tgw = __builtin_amdgcn_readfirstlane(__shfl(tg, __ffsll((long long)on_mask) - 1));   // normal-equation set of the wave's window
-    T *Wset = d.WS[tgw];
+    // the wave's window (a window's slots start on a wave boundary) and its normal-equation set
+    const int first_on = __ffsll((long long)on_mask) - 1;
+    const int tgw = __builtin_amdgcn_readfirstlane(__shfl(tg, first_on)), wu = __builtin_amdgcn_readfirstlane(__shfl(w, first_on));
+    const WinMeta &mu = d.wins[wu];
+    const int P = mu.P, K6 = 6 * mu.K, ldw = mu.ldw, lm0 = mu.lm0, u0 = mu.u0;
+    const long long W0 = mu.W0;
+    double *Wset = d.WS[tgw];
     double *Hllset = d.HllS[tgw], *gset = d.gS[tgw];
     // One wave per workgroup: LDS hand-overs only need the wave's own LDS operations to have completed.  (__syncthreads() also
     // waits for vmcnt(0), i.e. for the J~ and W stores in flight to be acknowledged -- ~5 us per barrier here, measured.)
 #define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
-    long long *dbg = (d.dbg && vblock == 1000) ? d.dbg + 32 : nullptr;
-    if (dbg && lane == 0) { dbg[-1] = t_entry; dbg[0] = clock64() + (long long)(c * 0); }
     LDS_SYNC();
-    // ---- J~ goes out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs of
-    //      entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
+    // ---- the records go out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs
+    //      of entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
     {
-      T *dst = d.Jt + (size_t)(vblock * 64) * VT_ROWS;
+      double *dst = d.Jt + (size_t)(vblock * 64) * VT_ROWS;
       constexpr int HP = VT_ROWS / 2;            // pairs per block
 #pragma unroll 4
       for (int k = 0; k < HP; ++k) {             // 64 * HP pairs, 64 per store
         const int i = k * 64 + lane, bl = i / HP, r = 2 * (i - bl * HP);
-        VecN<T, 2> pr;
+        VecN<double, 2> pr;
         pr.v[0] = wcs[VT_LD * bl + r];
         pr.v[1] = wcs[VT_LD * bl + r + 1];
-        if ((on_mask >> bl) & 1ull) *reinterpret_cast<VecN<T, 2> *>(dst + (size_t)bl * VT_ROWS + r) = pr;
+        if ((on_mask >> bl) & 1ull) *reinterpret_cast<VecN<double, 2> *>(dst + (size_t)bl * VT_ROWS + r) = pr;
       }
     }
-    if (dbg && lane == 0) dbg[1] = clock64();
-    // ---- this lane's contributions to its landmark's row of W: J_rho^T J_c for the 49 pose columns (slot 48 = line delay),
-    //      Hll, g_rho
-    T wr[51];
+    // ---- this lane's contributions to its landmark's row of W.  With jr = J~_rho (2) and n3 = A~^T jr (3): the columns of the block's own
+    //      (j) end are jr^T J~_rot and -cp1[k] n3; the anchor end's are (sum over the anchor's blocks of n3)^T [GR | cp0 (x) I] -- formed
+    //      once per anchor from the record; line delay, Hll, g_rho ride with that sum.
+    double wj[24], s6[6];
     {
-      const T *Jl = wcs + VT_LD * lane;
-      const T jr0 = Jl[48], jr1 = Jl[49];
+      const double *Jl = wcs + VT_LD * lane;
+      const double jr0 = Jl[VB_RHO], jr1 = Jl[VB_RHO + 1];
 #pragma unroll
-      for (int cc = 0; cc < 12; ++cc) {
-        wr[cc] = jr0 * Jl[2 * cc] + jr1 * Jl[2 * cc + 1];
-        wr[24 + cc] = jr0 * Jl[24 + 2 * cc] + jr1 * Jl[25 + 2 * cc];
+      for (int cc = 0; cc < 12; ++cc) wj[cc] = jr0 * Jl[VB_JROT + 2 * cc] + jr1 * Jl[VB_JROT + 2 * cc + 1];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s6[b] = jr0 * Jl[VB_AT + 2 * b] + jr1 * Jl[VB_AT + 2 * b + 1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double cp1 = Jl[VB_CP1 + k];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) wj[12 + 3 * k + b] = -(cp1 * s6[b]);
       }
-      T qb[3], cp0[4], cp1[4];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) qb[b] = jr0 * Jl[54 + 2 * b] + jr1 * Jl[55 + 2 * b];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { cp0[k] = Jl[60 + k]; cp1[k] = Jl[64 + k]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) { wr[12 + 3 * k + b] = cp0[k] * qb[b]; wr[36 + 3 * k + b] = -(cp1[k] * qb[b]); }
-      wr[48] = jr0 * Jl[50] + jr1 * Jl[51];
-      wr[49] = jr0 * jr0 + jr1 * jr1;
-      wr[50] = jr0 * Jl[52] + jr1 * Jl[53];
+      s6[3] = jr0 * Jl[VB_LD] + jr1 * Jl[VB_LD + 1];
+      s6[4] = jr0 * jr0 + jr1 * jr1;
+      s6[5] = jr0 * Jl[VB_RES] + jr1 * Jl[VB_RES + 1];
     }
-    // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave).  The buffer becomes
-    //      NR fp64 rows (+ Hll, g_rho per row); every lane adds its 51 values into the row of its landmark (LDS atomics: blocks
-    //      of a landmark share the anchor end's knots, the two ends of a block may share knots), NR landmarks per sweep; then the
-    //      knot and line-delay columns of every row, Hll and g_rho are written: W is complete when this kernel ends.
-    if (dbg && lane == 0) dbg[2] = clock64() + (long long)(wr[3] * 0);
-    const int prev_lm = __shfl_up(my_lm, 1), prev_w = __shfl_up(w, 1);
-    const bool head = on && (lane == 0 || prev_lm != my_lm || prev_w != w);
-    const unsigned long long heads = __ballot(head);
+    // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave), anchor by anchor.  The buffer
+    //      becomes NR fp64 rows ([0, K6) knot columns, K6 line delay, K6 + 1 Hll, K6 + 2 g_rho); every lane adds the 24 values of its
+    //      own end into the row of its landmark (LDS atomics: the ends of different blocks may share knots), the head lane of every anchor
+    //      the anchor end's 24 + 3 from the segmented sum; NR landmarks per sweep; then the knot and line-delay columns of every row,
+    //      Hll and g_rho are written: W is complete when this kernel ends.
+    const int prev_lm = __shfl_up(my_lm, 1), prev_anc = __shfl_up(my_anc, 1);
+    const bool head = on && (lane == 0 || prev_lm != my_lm), head_a = on && (lane == 0 || prev_anc != my_anc);
+    const unsigned long long heads = __ballot(head), heads_a = __ballot(head_a);
     const int ord = __popcll(heads & ((2ull << lane) - 1ull)) - 1;     // ordinal of this lane's landmark in the wave
     const int nlm = __popcll(heads);
-    int ldmax = mldw;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ldmax = max(ldmax, __shfl_xor(ldmax, off));
-    ldmax = __builtin_amdgcn_readfirstlane(ldmax) | 1;   // odd row stride: ldw is a multiple of 32 doubles, which would put column g of EVERY row in the same LDS bank
-    // Segmented sums over the lanes of a landmark -- valid when all its blocks share the anchor end (the reference's factors do:
-    // ti and rowi are those of the feature's first observation): same knots, same addresses.  Otherwise every lane adds its own.
-    const int hl = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));       // head lane of this lane's landmark
-    const int hsi = __shfl(ksi, on ? hl : lane);
-    const bool presum = !__any(on && ksi != hsi);                           // (uniform)
-    double wsum[27];
-#pragma unroll
-    for (int cc = 0; cc < 24; ++cc) wsum[cc] = (double)wr[cc];
-    wsum[24] = (double)wr[48]; wsum[25] = (double)wr[49]; wsum[26] = (double)wr[50];
-    int maxlen = on ? lane - hl + 1 : 0;                                               // longest landmark of the wave (uniform)
+    const int ha = 63 - __clzll((long long)(heads_a & ((2ull << lane) - 1ull)));       // head lane of this lane's anchor
+    int maxlen = on ? lane - ha + 1 : 0;                                               // longest anchor of the wave (uniform)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
     maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-    for (int off = 1; presum && off < maxlen; off <<= 1) {
-      const int oo = __shfl_down(on ? ord : -1, off);
-      const bool take = on && (lane + off < 64) && oo == ord;
+    for (int off = 1; off < maxlen; off <<= 1) {     // segmented sums over the lanes of an anchor (an LDS atomic of several lanes on ONE
+      const int oh = __shfl_down(on ? ha : -1, off);  // address costs ~64 cycles per lane)
+      const bool take = on && (lane + off < 64) && oh == ha;
 #pragma unroll
-      for (int cc = 0; cc < 27; ++cc) { const double o = __shfl_down(wsum[cc], off); wsum[cc] += take ? o : 0.0; }
+      for (int cc = 0; cc < 6; ++cc) { const double o = __shfl_down(s6[cc], off); s6[cc] += take ? o : 0.0; }
     }
     double *rows = reinterpret_cast<double *>(smt);
-    const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / (ldmax + 2)));
-    double *hg = rows + (size_t)NR * ldmax;                            // [NR][2] Hll, g_rho
-    // rmeta: per landmark of the wave K6, P, W row offset; rhg: where Hll and g_rho go
-    int KC = mK6;                                                      // compact columns per row: knots + line delay
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) KC = max(KC, __shfl_xor(KC, off));
-    KC = __builtin_amdgcn_readfirstlane(KC) + 1;
-    if (head) {
-      const long long wo = (((long long)mW0hi << 32) | (unsigned int)mW0lo) + (long long)my_lm * mldw;
-      rmeta[ord] = int4{mK6, mP, (int)(wo & 0xffffffffll), (int)(wo >> 32)};
-      rhg[ord] = int2{mlm0 + my_lm, mu0 + mP + my_lm};
-    }
-    LDS_SYNC();   // every lane has read its column of J~
+    const int RS = K6 + 3;                                             // odd row stride (K6 is even)
+    const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / RS));
+    if (head) { rowoff[ord] = W0 + (long long)my_lm * ldw; rlm[ord] = my_lm; }
+    LDS_SYNC();   // every lane has read its record
     for (int c0 = 0; c0 < nlm; c0 += NR) {
       const int nr = min(NR, nlm - c0);
-      for (int i = lane; i < NR * (ldmax + 2); i += 64) rows[i] = 0.0;     // (hg follows the rows)
+      for (int i = lane; i < nr * RS; i += 64) rows[i] = 0.0;
       LDS_SYNC();
       if (on && ord >= c0 && ord < c0 + nr) {
-        double *row = rows + (size_t)(ord - c0) * ldmax;
-        // anchor end, line delay, Hll, g_rho: summed over the landmark's lanes beforehand (wsum), added by the head lane alone --
-        // an LDS atomic of several lanes on ONE address costs ~64 cycles per lane (4-8 lanes per landmark: 2/3 of this phase)
-        if (head || !presum) {
+        double *row = rows + (size_t)(ord - c0) * RS;
+        if (head_a) {
+          const double *rec = d.arec + (size_t)my_anc * AREC;
+          const int ksi = d.a_s[my_anc];
 #pragma unroll
-          for (int cc = 0; cc < 24; ++cc) atomicAdd(&row[vis_col(cc, ksi, ksj, mP)], wsum[cc]);
-          atomicAdd(&row[mP - 1], wsum[24]);
-          atomicAdd(&hg[2 * (ord - c0)], wsum[25]);
-          atomicAdd(&hg[2 * (ord - c0) + 1], wsum[26]);
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              const int cc = 3 * k + b;
+              atomicAdd(&row[6 * (ksi + k) + b], s6[0] * rec[AR_GR + 3 * cc] + s6[1] * rec[AR_GR + 3 * cc + 1] + s6[2] * rec[AR_GR + 3 * cc + 2]);
+              atomicAdd(&row[6 * (ksi + k) + 3 + b], rec[AR_CP0 + k] * s6[b]);
+            }
+          atomicAdd(&row[K6], s6[3]);
+          atomicAdd(&row[K6 + 1], s6[4]);
+          atomicAdd(&row[K6 + 2], s6[5]);
         }
 #pragma unroll
-        for (int cc = 24; cc < 48; ++cc) atomicAdd(&row[vis_col(cc, ksi, ksj, mP)], (double)wr[cc]);
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            atomicAdd(&row[6 * (ksj + k) + b], wj[3 * k + b]);
+            atomicAdd(&row[6 * (ksj + k) + 3 + b], wj[12 + 3 * k + b]);
+          }
       }
       LDS_SYNC();
-      if (dbg && lane == 0) dbg[3 + 2 * (c0 / NR)] = clock64();
       // write-out: the nr rows' knot columns as ONE flat list of 16-byte column pairs (K6 is even, a row starts on a 256-byte boundary),
       // 64 pairs per store instruction -- row by row it took three mostly empty stores per row, and under load a store costs ~100
-      // cycles whatever its width (16 rows: 48 stores; now 18 + 1).  The rows of a wave belong to one window: same K6.
+      // cycles whatever its width.  The rows of a wave belong to one window: same K6.
       {
-        const int npair = (KC - 1) >> 1;                       // column pairs per row
+        const int npair = K6 >> 1;                             // column pairs per row
         const int total = nr * npair;
         int q = lane / npair, cp = lane - q * npair;           // (one division per lane; afterwards incremental)
         for (int it = lane; it < total; it += 64) {
-          const int4 mt = rmeta[c0 + q];
-          T *Wr = Wset + (((long long)mt.w << 32) | (unsigned int)mt.z);
-          const double *row = rows + (size_t)q * ldmax;
-          VecN<T, 2> rv;
-          rv.v[0] = (T)row[2 * cp]; rv.v[1] = (T)row[2 * cp + 1];
-          *reinterpret_cast<VecN<T, 2> *>(Wr + 2 * cp) = rv;
+          double *Wr = Wset + rowoff[c0 + q];
+          const double *row = rows + (size_t)q * RS;
+          VecN<double, 2> rv;
+          rv.v[0] = row[2 * cp]; rv.v[1] = row[2 * cp + 1];
+          *reinterpret_cast<VecN<double, 2> *>(Wr + 2 * cp) = rv;
           cp += 64;
           while (cp >= npair) { cp -= npair; ++q; }
         }
-        if (lane < nr) {                                       // the line-delay column of row `lane`
-          const int4 mt = rmeta[c0 + lane];
-          T *Wr = Wset + (((long long)mt.w << 32) | (unsigned int)mt.z);
-          Wr[mt.y - 1] = (T)rows[(size_t)lane * ldmax + mt.y - 1];
+        if (lane < nr) {                                       // the line-delay column of row `lane`, its Hll and g_rho
+          const double *row = rows + (size_t)lane * RS;
+          const int l = rlm[c0 + lane];
+          Wset[rowoff[c0 + lane] + P - 1] = row[K6];
+          Hllset[lm0 + l] = row[K6 + 1];
+          gset[u0 + P + l] = row[K6 + 2];
         }
       }
-      if (lane < nr) {
-        const int2 hgi = rhg[c0 + lane];                     // x: index into Hll, y: index into g
-        Hllset[hgi.x] = hg[2 * lane];
-        gset[hgi.y] = hg[2 * lane + 1];
-      }
       LDS_SYNC();
-      if (dbg && lane == 0) { dbg[4 + 2 * (c0 / NR)] = clock64(); dbg[10] = nlm * 1000000ll + (long long)(LDS_BYTES / 8); dbg[11] = NR * 1000 + ldmax; }
     }
 #undef LDS_SYNC
   }
 }
 
-template <class T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void k_vis_eval(Dev<T> d, int mode) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_vis_eval(Dev<double> d, int mode) {
   __shared__ __attribute__((aligned(16))) unsigned char smt[VIS_LDS_BYTES];
-  __shared__ int4 rmeta[64];
-  __shared__ int2 rhg[64];
-  vis_eval_body<T>(d, mode, smt, rmeta, rhg, blockIdx.x);
+  __shared__ long long rowoff[64];
+  __shared__ int rlm[64];
+  vis_eval_body(d, mode, smt, rowoff, rlm, blockIdx.x);
 }
 
 // Both evaluations in ONE launch: workgroups [0, Gtot) take an IMU group each, the others a wave of 64 visual block slots.  The two are
 // independent; for a batch smaller than the chip their single-wave latencies (23 us each for one window) overlap instead of adding
 // up, and large batches lose nothing.  The IMU rows use the head of the visual kernel's LDS buffer.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linearize_f64(Dev<double> d, int mode, int general_only, int zero_mode) {
+  static_assert(VIS_LDS_BYTES >= (72 * 33 + 64) * 8, "the IMU rows use the head of the visual body's LDS buffer");
   __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
-  __shared__ int4 rmeta[64];
-  __shared__ int2 rhg[64];
+  __shared__ long long rowoff[64];
+  __shared__ int rlm[64];
   if ((int)blockIdx.x < d.Gtot) {
     if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, zero_mode);
-  } else vis_eval_body<double>(d, mode, smt, rmeta, rhg, blockIdx.x - d.Gtot);
+  } else vis_eval_body(d, mode, smt, rowoff, rlm, blockIdx.x - d.Gtot);
 }
 
 // Visual assembly: gridDim.y workgroups (8 waves each) per window.  The host sorted the visual blocks by
@@ -1385,12 +1369,13 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
     {
       const int c = lane % CH, rr = lane / CH;
       const unsigned blk = (unsigned)d.vblk[v0 + (c < n ? c : 0)];   // slot of the item's block c (landmark-major evaluation order)
+      const unsigned anc = (unsigned)d.vblk_anc[v0 + (c < n ? c : 0)];
       T tmp[NPASS];
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         const int row = i * RPP + rr;
         tmp[i] = T(0);
-        if (row < 102 && c < n) tmp[i] = vis_J_entry<T>(d.Jt, row, blk);
+        if (row < 102 && c < n) tmp[i] = vis_J_entry(d, row, blk, anc);
       }
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
@@ -1398,7 +1383,7 @@ template <class T, int CH, bool LDSH> __global__ __launch_bounds__(512) void k_a
         if (row < 102) Js[row * CHP + c] = tmp[i];
       }
     }
-    if (lane < n) { const int blk = d.vblk[v0 + lane]; ks[lane] = d.vs[blk]; ks[CH + lane] = d.vs[V + blk]; }
+    if (lane < n) { ks[lane] = d.a_s[d.vblk_anc[v0 + lane]]; ks[CH + lane] = d.vsj[d.vblk[v0 + lane]]; }
     __syncthreads();
     
     int start = 0;
@@ -1623,11 +1608,13 @@ template <class T, int CH, bool LDSH, int NW = 8, bool STORE = false> __global__
   typedef typename MfmaAcc<T>::type acc_t;
   constexpr int CHP = CH + 2, RPP = 64 / CH, NT = 64 * NW;
   static_assert(!STORE || LDSH, "the store-semantics tail needs the LDS-resident Hessian");
-  // staged rows per item: 0..95 pose columns (row = 2 * column + residual row), 98/99 line delay, 100/101 residual, 102..115 the
-  // compact position data (P~ 6 rows, cp0 4, cp1 4).  Only 66 of them come from HBM -- the 48 position rows (24..47, 72..95)
-  // are rebuilt in LDS from rows 102..115, the inverse-depth rows 96/97 are not needed here.
-  constexpr int SROWS = 116, NSRC = 66, NPASS = (NSRC + RPP - 1) / RPP, NEXP = 48 / RPP;
-  static_assert(24 % RPP == 0, "source regions must start on a pass boundary");
+  // staged rows per item: 0..95 pose columns (row = 2 * column + residual row), 98/99 line delay, 100/101 residual, 102..107 A~,
+  // 108..111 cp0, 112..115 cp1.  38 of them come from the block records in HBM (rows 48..71 = the j end's rotation columns, 98..107,
+  // 112..115) and 4 from the anchor records (cp0); the anchor end's rotation rows 0..23 are A~ times the anchor's GR (9 record entries
+  // per lane, held in registers), the 48 position rows (24..47, 72..95) are rebuilt in LDS from rows 102..115; the inverse-depth
+  // column is not needed here.
+  static_assert(CH == 8 && F64, "the staging pattern is written for items of 8 blocks");
+  constexpr int SROWS = 116, NEXP = 48 / RPP;
   const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
@@ -1704,7 +1691,7 @@ template <class T, int CH, bool LDSH, int NW = 8, bool STORE = false> __global__
 #pragma unroll
   for (int I = 0; I < 3; ++I) orow[I] = (2 * (16 * I + l15) + rr) * CHP;
   const int ldrow = (98 + rr) * CHP, rrow = (100 + rr) * CHP;
-  T tmp[NPASS];
+  T tj[5], tg9[9], tc0 = T(0);
   int n = 0, v0 = 0, key_i = 0, key_j = 0;
   // the (start, count) of this wave's items: lane r holds item r, read once -- a per-item load of the descriptor would put a
   // full memory round trip in front of every item's J~ request
@@ -1727,31 +1714,37 @@ template <class T, int CH, bool LDSH, int NW = 8, bool STORE = false> __global__
   // The blocks of an item are slots of the landmark-major evaluation order, listed in Dev::vblk: the slot of this lane's block
   // (c = sc) and of the block whose keys it reads (lane) are requested one item ahead, so that the J~ loads of an item do not
   // wait for its slot list.
-  int idn = 0, idkn = 0;
+  int idn = 0, idkn = 0, ian = 0, iakn = 0;
   auto load_ids = [&](int r) {
     int istart, icount;
     item_desc(r, istart, icount);
     idn = d.vblk[istart + (sc < icount ? sc : 0)];
+    ian = d.vblk_anc[istart + (sc < icount ? sc : 0)];
     idkn = d.vblk[istart + (lane < icount ? lane : 0)];
+    iakn = d.vblk_anc[istart + (lane < icount ? lane : 0)];
   };
   auto fetch = [&](int r) {   // request item r of this wave: unconditional loads on clamped addresses, masked when staged
     int istart, icount;
     item_desc(r, istart, icount);
     n = icount;
     v0 = istart;
-    // J~ is block-major ([slot][VT_ROWS]): source row q of this lane in pass i = RPP i + srr: rotation entries (q < 48) sit at
-    // entry q, line delay / residual / compact position data (48 <= q < 66) at entry q + 2 (the inverse-depth entries 48, 49
-    // are skipped); 24 and 48 are multiples of RPP, so the shift is the same for a whole pass.  One 32-bit lane offset, the
-    // pass offset is a constant; the RPP lanes of a block read RPP consecutive entries.
-    const unsigned loff = (unsigned)idn * (unsigned)VT_ROWS + (unsigned)srr;
+    // The block records are block-major ([slot][VT_ROWS]); lane (sc, srr) takes entries srr + 8 i of its block: 0..23 the j end's
+    // rotation columns, 26..33 line delay / residual / A~[0..3], 34..39 A~[4, 5] and cp1 (the inverse-depth entries 24, 25 are
+    // skipped) -- the RPP lanes of a block read RPP consecutive entries.  From the anchor record: the three factors GR[c][0..2] of the
+    // lane's three anchor-end rotation entries e = srr + 8 i (column c = e / 2) and one of the four cp0.
+    const unsigned jb = (unsigned)idn * (unsigned)VT_ROWS + (unsigned)srr;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-      const int q0 = i * RPP;
-      if (q0 + RPP <= NSRC) tmp[i] = d.Jt[loff + (unsigned)(q0 + (q0 >= 48 ? 2 : 0))];
-      else tmp[i] = d.Jt[(unsigned)idn * (unsigned)VT_ROWS + (unsigned)(min(q0 + srr, NSRC - 1) + 2)];   // last, partial pass
-    }
-    key_i = d.vs[idkn];
-    key_j = d.vs[V + idkn];
+    for (int i = 0; i < 3; ++i) tj[i] = d.Jt[jb + (unsigned)(8 * i)];
+    tj[3] = d.Jt[jb + 26u];
+    tj[4] = d.Jt[(unsigned)idn * (unsigned)VT_ROWS + (unsigned)min(34 + srr, VT_ROWS - 1)];
+    const double *rec = d.arec + (size_t)ian * AREC;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int mm = 0; mm < 3; ++mm) tg9[3 * i + mm] = rec[AR_GR + 3 * ((srr + 8 * i) >> 1) + mm];
+    tc0 = rec[AR_CP0 + (srr & 3)];
+    key_i = d.a_s[iakn];
+    key_j = d.vsj[idkn];
     load_ids(r + 1);
   };
   if (nvitem > 0) load_ids(0);
@@ -1824,14 +1817,24 @@ template <class T, int CH, bool LDSH, int NW = 8, bool STORE = false> __global__
   for (int r = 0; r < rounds && nvitem > 0; ++r) {
     // ---- stage the fetched item (LDS operations of one wave are ordered: no barrier), then request the next one
     const int ncur = n;
+    {
+      const bool in = sc < ncur;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-      const int q = i * RPP + srr;
-      const int row = q + (q < 24 ? 0 : q < 48 ? 24 : 50);
-      if (q < NSRC) Js[row * CHP + sc] = (sc < ncur) ? tmp[i] : T(0);
+      for (int i = 0; i < 3; ++i) Js[(48 + srr + 8 * i) * CHP + sc] = in ? tj[i] : T(0);
+      Js[(98 + srr) * CHP + sc] = in ? tj[3] : T(0);                     // rows 98..105: line delay, residual, A~[0..3]
+      if (srr < 2) Js[(106 + srr) * CHP + sc] = in ? tj[4] : T(0);       // A~[4, 5]
+      else if (srr < 6) Js[(110 + srr) * CHP + sc] = in ? tj[4] : T(0);  // cp1 (entries 36..39 -> rows 112..115)
+      if (srr < 4) Js[(108 + srr) * CHP + sc] = in ? tc0 : T(0);         // cp0 (anchor record)
     }
     if (lane < CH) { ks[lane] = key_i; ks[CH + lane] = key_j; }
     __builtin_amdgcn_wave_barrier();
+    // anchor end's rotation rows: entry e = srr + 8 i (= 2 * column + residual row) = A~[rr][0..2] . GR[column][0..2]
+    {
+      const int rr2 = srr & 1;
+      const T a0 = Js[(102 + rr2) * CHP + sc], a1 = Js[(104 + rr2) * CHP + sc], a2 = Js[(106 + rr2) * CHP + sc];   // (zero for sc >= ncur)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Js[(srr + 8 * i) * CHP + sc] = a0 * tg9[3 * i] + a1 * tg9[3 * i + 1] + a2 * tg9[3 * i + 2];
+    }
     // position rows: column 12 + 3 k + b (i end) = cp0[k] P~[b], column 36 + 3 k + b (j end) = -cp1[k] P~[b]
 #pragma unroll
     for (int e = 0; e < NEXP; ++e) {
@@ -3246,37 +3249,34 @@ template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev
   for (int i = tid; i < m.Vp; i += 256) {
     const int v = m.vis0 + i;
     if (d.v_win[v] < 0) continue;   // padding slot
+    // raw residual at the current state: anchor value and block value evaluated here, pair constants straight from the knots
+    // (independent of the tables and of the records the solver keeps)
+    const int a = d.v_anc[v];
     int si, sj;
     double ui, uj;
     const double ld = d.ld[w];
-    const int rowi = d.v_rowi[v], rowj = d.v_rowj[v];
-    vis_times(m, d.v_ti[v], rowi, ld, si, ui);
+    const int rowi = d.a_row[a], rowj = d.v_rowj[v];
+    vis_times(m, d.a_t[a], rowi, ld, si, ui);
     vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
     si = max(0, min(si, m.K - 4)); sj = max(0, min(sj, m.K - 4));
-    Knots4<double> ki, kj;
-    LocalFrame<double> lf;
-    lf.init(d.quat, d.pos, m.knot0 + si);
-    lf.load(d.quat, d.pos, m.knot0 + si, ki);
-    lf.load(d.quat, d.pos, m.knot0 + sj, kj);
+    Knots4<double> gi, gj;
+    const double z3[3] = {0, 0, 0};
+    load_knots<double>(d.quat, d.pos, m.knot0 + si, z3, gi);
+    load_knots<double>(d.quat, d.pos, m.knot0 + sj, z3, gj);
     SegConst<double> sci, scj;
-    {
-      Knots4<double> gi, gj;   // pair constants straight from the (global-frame) knots: independent of the tables
-      const double z3[3] = {0, 0, 0};
-      load_knots<double>(d.quat, d.pos, m.knot0 + si, z3, gi);
-      load_knots<double>(d.quat, d.pos, m.knot0 + sj, z3, gj);
-      seg_const(gi, sci, false);
-      seg_const(gj, scj, false);
-    }
-    Calib<double> cal;
-    cal.q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
-    cal.p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
-    cal.img_w = m.img_w;
-    cal.cauchy_a = -1.0;   // raw residual
-    const size_t V = (size_t)d.Vtot;
-    double r[2];
-    VisNullSink<double> sink;
-    visual_eval<double>(ki, kj, sci, scj, ui, uj, m.inv_dt, cal, lf.RrefT(), (double)d.v_obs[v], (double)d.v_obs[V + v], (double)d.v_obs[2 * V + v],
-                        (double)d.v_obs[3 * V + v], (double)rowi, (double)rowj, d.rho[m.lm0 + d.v_lm[v]], r, false, sink);
+    seg_const(gi, sci, false);
+    seg_const(gj, scj, false);
+    const Q4<double> q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
+    const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+    const M3<double> R = q2R(q_CI);
+    M3<double> RCIT;
+    for (int aa = 0; aa < 3; ++aa) for (int bb = 0; bb < 3; ++bb) RCIT.m[3 * aa + bb] = R.m[3 * bb + aa];
+    double rec[AREC], r[2];
+    vis_anchor_eval<false>(gi.q[0], gi.p, sci, ui, m.inv_dt, q_CI, p_CI, d.a_obs[a], d.a_obs[(size_t)d.Atot + a], (double)rowi,
+                           d.rho[m.lm0 + d.v_lm[v]], false, rec);
+    VisNullSink sink;
+    vis_block_eval<false>(rec, gj.q[0], gj.p, scj, uj, m.inv_dt, RCIT, p_CI, m.img_w, -1.0 /* raw residual */, (double)d.v_obs[v],
+                          (double)d.v_obs[(size_t)d.Vtot + v], (double)rowj, r, false, sink);
     atomicAdd(&sums[12], fabs(r[0]));
     atomicAdd(&sums[13], fabs(r[1]));
   }

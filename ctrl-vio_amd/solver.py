@@ -130,8 +130,11 @@ class Solver:
         locked (option.lock_ab / lock_wb), knots 0..fixed_upto constant.  NB: the reference calls SetFixedIndex(max_bef_idx)
         AFTER its AddIMUMeasurementAnalytic loop, and constancy is decided when a knot is added
         (trajectory_estimator.cpp:134-138), so in the reference as written no knot is constant: pass fixed_upto = -1 for
-        that behaviour, max_bef_idx for what the call order suggests was intended."""
+        that behaviour, max_bef_idx for what the call order suggests was intended.  The per-block Cauchy widths go with the visual
+        blocks; per-knot constancy (knot_const) is a property of the caller's window and is KEPT: a knot the caller holds constant
+        stays constant in the predict as well."""
         p = w.copy()
+        p.v_cauchy = None
         z = lambda a: a[:0]
         p.v_lm, p.v_ti, p.v_tj, p.v_rowi, p.v_rowj, p.v_pi, p.v_pj = z(p.v_lm), z(p.v_ti), z(p.v_tj), z(p.v_rowi), z(p.v_rowj), z(p.v_pi), z(p.v_pj)
         p.bc_i, p.bc_j, p.bc_w = z(p.bc_i), z(p.bc_j), z(p.bc_w)

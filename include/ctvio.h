@@ -64,7 +64,10 @@ typedef struct ctvio_options {
   double min_lm_diagonal, max_lm_diagonal; /* 1e-6, 1e32 */
   int32_t max_consecutive_invalid_steps;   /* 5 */
   int32_t deterministic;        /* 1: order-fixed accumulation everywhere (no floating-point atomics): two runs of the same batch
-                                   are bitwise equal; -1 (default): on for batches of <= 64 windows, off beyond; 0: off */
+                                   are bitwise equal.  It exists for batches whose every window has K <= 24 (packed Hessian in LDS)
+                                   with use_mfma != 0: ctvio_upload / ctvio_set_batch return CTVIO_ERR_INVALID for any other batch
+                                   instead of silently accumulating with atomics.  -1 (default): on for batches of <= 64 windows
+                                   where it applies, the atomic path (run-to-run differences ~1e-13 in the state) otherwise; 0: off */
   int32_t host_threads;         /* host threads that validate / pack a batch (ctvio_set_batch, ctvio_upload); 0 = min(cores, 16) */
   int32_t use_graph;            /* 1 (default): the launch sequence of one LM pass is captured into a hipGraph and replayed */
   int32_t line_search;          /* 1 (default): Ceres' projected Armijo line search of bounds-constrained problems
@@ -223,9 +226,14 @@ int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, cons
 int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t n, const ctvio_window *wins, int32_t max_iterations,
                             ctvio_summary *out, double *quat, double *pos, double *bias, double *rho, double *ld);
 void ctvio_sharded_release(void);
-/* The partition itself (no device needed): owner of window w, and how many of n windows device g gets. */
+/* The partition itself (no device needed): owner of window w, and how many of n windows device g gets -- for G shards.  The G a
+ * call of ctvio_solve_sharded really uses is ctvio_shards_used(n_devices, n) = min(n_devices or all, devices present, n): pass THAT
+ * to ctvio_shard_of / ctvio_shard_count when predicting owners.  Options: a call whose *opt differs from the one a kept handle was
+ * created with gets a fresh handle (tolerances, deterministic, use_mfma, line_search ... take effect immediately).  Failures inside a
+ * shard's host thread (HIP errors, std::bad_alloc) come back as that shard's status; nothing is thrown across the ABI. */
 int32_t ctvio_shard_of(int32_t window_id, int32_t n_devices);
 int32_t ctvio_shard_count(int32_t n, int32_t device, int32_t n_devices);
+int32_t ctvio_shards_used(int32_t n_devices, int32_t n);
 
 /* Kernel timing of the next ctvio_solve calls with HIP events recorded on the solver's stream around every
  * launch group (adds a few microseconds per launch: use a dedicated profiling solve, not the timed one). */

@@ -5,16 +5,16 @@
 #include "../ctrl-vio_amd/csrc/factors.hpp"
 
 using namespace ctv;
+constexpr int VT_ROWS_HOST = 40;   // = device_types.hpp: VT_ROWS (entries of a block record)
 
 namespace {
 template <class T> struct ImuSink {
   T *J;
   void put_col(int col, const T v[6]) { for (int r = 0; r < 6; ++r) J[r * 30 + col] = v[r]; }
 };
-template <class T> struct VisSink {
-  T *J;
-  void put(int col, T j0, T j1) { J[col] = j0; J[50 + col] = j1; }
-  void put_pos(const T *, const T *, const T *) {}
+struct RecSink {
+  double *e;
+  void put(int entry, double v) { e[entry] = v; }
 };
 
 // local frame of the reference knot (q_ref, p_ref): the same preparation the kernels do (LocalFrame in kernels.hpp)
@@ -60,35 +60,48 @@ void imu_eval_t(const double *q, const double *p, double u, double idt, const do
   for (int i = 0; i < 180; ++i) J[i] = JJ[i];
 }
 
-template <class T>
+// The factored visual block (factors.hpp: vis_anchor_eval + vis_block_eval), composed back into the reference's 2 x 50 Jacobian
+// (local column order rot_i 12 | pos_i 12 | rot_j 12 | pos_j 12 | rho | ld) exactly as the kernels consume it: i-end rotation
+// columns = A~ GR, position columns = cp0 / -cp1 times A~.
+template <bool SMALL>
 double visual_eval_t(const double *qi, const double *pi, const double *qj, const double *pj, double ui, double uj,
                      double idt, const double *q_CI, const double *p_CI, double img_w, double cauchy_a, const double *obs,
                      double rowi, double rowj, double d_inv, double *r, double *J) {
-  Knots4<T> ki, kj;
-  HostLocalFrame<T> lf(qi, pi);   // both ends relative to the first knot of the i-end
-  lf.load(qi, pi, ki);
-  lf.load(qj, pj, kj);
-  Calib<T> cal;
-  cal.q_CI = qmk<T>((T)q_CI[0], (T)q_CI[1], (T)q_CI[2], (T)q_CI[3]);
-  cal.p_CI = mk<T>((T)p_CI[0], (T)p_CI[1], (T)p_CI[2]);
-  cal.img_w = (T)img_w;
-  cal.cauchy_a = (T)cauchy_a;
-  T rr[2], JJ[100];
-  for (int i = 0; i < 100; ++i) JJ[i] = 0;
-  VisSink<T> sink{JJ};
-  SegConst<T> sci, scj;   // as on the device: pair constants from the fp64 table (k_knot_prep)
+  SegConst<double> sci, scj;   // as on the device: pair constants from the fp64 table (k_knot_prep)
   {
-    double dt[9]; T jt[27];
-    for (int i = 0; i < 3; ++i) knot_pair_const<T>(qi + 4 * i, qi + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    double dt[9], jt[27];
+    for (int i = 0; i < 3; ++i) knot_pair_const<double>(qi + 4 * i, qi + 4 * i + 4, dt + 3 * i, jt + 9 * i);
     seg_const_load(dt, jt, sci, true);
-    for (int i = 0; i < 3; ++i) knot_pair_const<T>(qj + 4 * i, qj + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    for (int i = 0; i < 3; ++i) knot_pair_const<double>(qj + 4 * i, qj + 4 * i + 4, dt + 3 * i, jt + 9 * i);
     seg_const_load(dt, jt, scj, true);
   }
-  T cost = visual_eval<T>(ki, kj, sci, scj, (T)ui, (T)uj, (T)idt, cal, lf.RrefT(), (T)obs[0], (T)obs[1], (T)obs[2], (T)obs[3], (T)rowi, (T)rowj,
-                          (T)d_inv, rr, true, sink);
-  r[0] = rr[0]; r[1] = rr[1];
-  for (int i = 0; i < 100; ++i) J[i] = JJ[i];
-  return (double)cost;
+  V3<double> Pi[4], Pj[4];
+  for (int i = 0; i < 4; ++i) { Pi[i] = mk<double>(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]); Pj[i] = mk<double>(pj[3 * i], pj[3 * i + 1], pj[3 * i + 2]); }
+  const Q4<double> qci = qmk<double>(q_CI[0], q_CI[1], q_CI[2], q_CI[3]);
+  const V3<double> pci = mk<double>(p_CI[0], p_CI[1], p_CI[2]);
+  double rec[AREC];
+  vis_anchor_eval<SMALL>(qmk<double>(qi[0], qi[1], qi[2], qi[3]), Pi, sci, ui, idt, qci, pci, obs[0], obs[1], rowi, d_inv, true, rec);
+  const M3<double> R = q2R(qci);
+  M3<double> RCIT;
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) RCIT.m[3 * a + b] = R.m[3 * b + a];
+  double blk[VT_ROWS_HOST];
+  for (int i = 0; i < VT_ROWS_HOST; ++i) blk[i] = 0;
+  RecSink sink{blk};
+  const double cost = vis_block_eval<SMALL>(rec, qmk<double>(qj[0], qj[1], qj[2], qj[3]), Pj, scj, uj, idt, RCIT, pci, img_w, cauchy_a, obs[2], obs[3],
+                                            rowj, r, true, sink);
+  for (int rr = 0; rr < 2; ++rr) {
+    double *Jr = J + 50 * rr;
+    const double At[3] = {blk[VB_AT + rr], blk[VB_AT + 2 + rr], blk[VB_AT + 4 + rr]};
+    for (int c = 0; c < 12; ++c) {
+      Jr[c] = At[0] * rec[AR_GR + 3 * c] + At[1] * rec[AR_GR + 3 * c + 1] + At[2] * rec[AR_GR + 3 * c + 2];
+      Jr[24 + c] = blk[VB_JROT + 2 * c + rr];
+    }
+    for (int k = 0; k < 4; ++k)
+      for (int b = 0; b < 3; ++b) { Jr[12 + 3 * k + b] = rec[AR_CP0 + k] * At[b]; Jr[36 + 3 * k + b] = -blk[VB_CP1 + k] * At[b]; }
+    Jr[48] = blk[VB_RHO + rr];
+    Jr[49] = blk[VB_LD + rr];
+  }
+  return cost;
 }
 }  // namespace
 
@@ -98,11 +111,11 @@ void hm_imu_eval(int fp32, const double *q, const double *p, double u, double id
   if (fp32) imu_eval_t<float>(q, p, u, idt, g, bias, gyro, acc, w, r, J);
   else imu_eval_t<double>(q, p, u, idt, g, bias, gyro, acc, w, r, J);
 }
-double hm_visual_eval(int fp32, const double *qi, const double *pi, const double *qj, const double *pj, double ui, double uj,
+double hm_visual_eval(int small_angle, const double *qi, const double *pi, const double *qj, const double *pj, double ui, double uj,
                       double idt, const double *q_CI, const double *p_CI, double img_w, double cauchy_a, const double *obs,
                       double rowi, double rowj, double d_inv, double *r, double *J) {
-  if (fp32) return visual_eval_t<float>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
-  return visual_eval_t<double>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
+  if (small_angle) return visual_eval_t<true>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
+  return visual_eval_t<false>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
 }
 void hm_so3(int fp32, const double *phi, double *exp_q, double *Jr, double *JrInv, double *log_of_exp) {
   if (fp32) {

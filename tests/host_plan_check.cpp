@@ -5,13 +5,15 @@
 #include "../ctrl-vio_amd/csrc/host_pack.hpp"
 
 extern "C" {
-// in: V blocks (landmark, ti, tj, rowi, rowj), L landmarks, items of <= vch blocks.  out: Vp, lord[Vp_cap], vpos[V], vord[V], nvitem.
+// in: V blocks (landmark, ti, tj, rowi, rowj, pi), L landmarks, items of <= vch blocks.  out: Vp, lord[Vp_cap], vpos[V], vord[V], nvitem,
+// the number of anchors, anc_of[V] (anchor of every block) and anc_rep[V] (first A entries: a block carrying each anchor).
 // returns 0, or 1 when the plan is rejected (err_out gets the message).
-int hp_plan(int V, int L, const int32_t *v_lm, const int64_t *v_ti, const int64_t *v_tj, const int32_t *v_rowi, const int32_t *v_rowj, int vch,
-            int Vp_cap, int32_t *Vp, int32_t *lord, int32_t *vpos, int32_t *vord, int32_t *nvitem, char *err_out, int err_cap) {
+int hp_plan(int V, int L, const int32_t *v_lm, const int64_t *v_ti, const int64_t *v_tj, const int32_t *v_rowi, const int32_t *v_rowj,
+            const double *v_pi, int vch, int Vp_cap, int32_t *Vp, int32_t *lord, int32_t *vpos, int32_t *vord, int32_t *nvitem, int32_t *A,
+            int32_t *anc_of, int32_t *anc_rep, char *err_out, int err_cap) {
   ctvio_window w{};
   w.V = V; w.L = L; w.M = 0;
-  w.v_lm = v_lm; w.v_ti = v_ti; w.v_tj = v_tj; w.v_rowi = v_rowi; w.v_rowj = v_rowj;
+  w.v_lm = v_lm; w.v_ti = v_ti; w.v_tj = v_tj; w.v_rowi = v_rowi; w.v_rowj = v_rowj; w.v_pi = v_pi;
   w.dt_ns = 1; w.t0_ns = 0;
   ctv::PackTmp t;
   ctv::plan_window(&w, vch, t);
@@ -19,7 +21,9 @@ int hp_plan(int V, int L, const int32_t *v_lm, const int64_t *v_ti, const int64_
   *Vp = t.Vp; *nvitem = t.nvitem;
   if (t.Vp > Vp_cap) return 2;
   for (int i = 0; i < t.Vp; ++i) lord[i] = t.lord[i];
-  for (int i = 0; i < V; ++i) { vpos[i] = t.vpos[i]; vord[i] = t.vord[i]; }
+  for (int i = 0; i < V; ++i) { vpos[i] = t.vpos[i]; vord[i] = t.vord[i]; anc_of[i] = t.anc_of[i]; }
+  *A = t.A;
+  for (int a = 0; a < t.A; ++a) anc_rep[a] = t.anc_rep[a];
   return 0;
 }
 }

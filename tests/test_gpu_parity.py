@@ -493,6 +493,33 @@ def test_imu_only_window_without_landmarks(cv, oracle, prec):
     assert cv.rel_state_error(wg, wo)["state"] < (1e-6 if prec == "fp64" else 5e-2)
 
 
+def test_mixed_batch_tiny_window_and_imu_only_long_spline_deterministic(cv, oracle):
+    """A window whose packed Hessian does not fit in LDS (K >= 25) and that has NO visual blocks -- the IMU-only predict of a long
+    spline -- batched with an LDS-resident window, deterministic mode on: the store-semantics tail only finishes LDS-resident windows,
+    so the batch must take the accumulate path; both windows against the oracle (round-3 advisor finding: the IMU-only window's
+    normal equations were left unwritten)."""
+    tiny = cv.synth.make_window("tiny", seed=11)
+    big = cv.synth.make_window("config1", seed=1200, F=10, dt_ns=40_000_000, with_prior=False)    # K = 27
+    assert big.K >= 25
+    pred = cv.Solver.predict_window(big, fixed_upto=-1)
+    assert pred.V == 0
+    ref = []
+    for w0 in (tiny, pred):
+        wo = w0.copy()
+        ref.append((wo, oracle.OracleWindow(wo).solve(8)))
+    with cv.Solver() as s:               # (default: the deterministic mode for batches of <= 64 windows where it applies)
+        ws = [tiny.copy(), pred.copy()]
+        s.set_windows(ws)
+        sms = s.solve(8)
+    with cv.Solver(deterministic=1) as s:   # an explicit request that cannot be honoured is refused, not silently dropped
+        with pytest.raises(cv.capi.CtvioError):
+            s.set_windows([tiny.copy(), pred.copy()])
+    for wg, sm, (wo, sm_o) in zip(ws, sms, ref):
+        assert sm["iterations"] == sm_o.iterations
+        assert sm["final_cost"] == pytest.approx(sm_o.final_cost, rel=1e-8)
+        assert cv.rel_state_error(wg, wo)["state"] < 1e-6
+
+
 def test_imu_only_predict_named_entry(cv, oracle):
     """Solver.predict = the reference's InitTrajectory (trajectory_manager.cpp:288-315): IMU factors only, biases locked, knots
     up to the fixed index constant, Solve(8) -- on a config-2-sized window, product precision and the mixed mode."""

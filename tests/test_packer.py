@@ -114,3 +114,18 @@ def test_native_tumrs_window_shape(cv):
     assert per.max() <= 150 and per.max() >= 120
     n_obs = np.bincount(w.v_lm, minlength=w.L) + 1
     assert n_obs.min() >= 2 and n_obs.max() >= 10
+
+
+def test_predict_window_handles_the_optional_fields(cv):
+    """Solver.predict_window (InitTrajectory's factor set) on a window that carries per-block Cauchy widths and per-knot constancy:
+    the widths go with the visual blocks, the constancy mask stays (no GPU needed: this is host-side packing)."""
+    w = cv.synth.make_window("tiny", seed=5)
+    w.v_cauchy = np.full(w.V, 1.0)
+    kc = np.zeros(w.K, np.uint8); kc[3] = 1
+    w.knot_const = kc
+    w.normalize()
+    p = cv.Solver.predict_window(w, fixed_upto=1)
+    assert p.V == 0 and p.v_cauchy is None and p.NB == 0 and p.pn == 0
+    assert p.lock_bg and p.lock_ba and p.fixed_upto == 1
+    assert p.knot_const is not None and p.knot_const.tolist() == kc.tolist()
+    assert p.M == w.M and p.K == w.K
