@@ -16,11 +16,15 @@ barrier, the max-over-ranks time and the all-gather of the per-window result rec
 
 Extra objects on the JSON line:
   roofline       dominant kernel of a profiled solve of one handle (HIP events on the solver's stream, other handles idle):
-                 achieved = algorithmic bytes (or flops, when the kernel's intensity is beyond the ridge) per launch
-                 (DESIGN.md section 4) / average launch duration, against 8 TB/s HBM (78.6 TFLOP/s fp64);
-                 roofline_kernels: the same line for every named kernel; roofline_mfma: the Schur SYRK.
+                 achieved = algorithmic bytes or flops per launch / average launch duration, against 8 TB/s HBM
+                 or 78.6 TFLOP/s fp64 -- whichever roof the kernel is closer to; both fractions, the PMC traffic and the issue counters
+                 of the committed rocprofv3 passes ride along; roofline_kernels: the same line for every named kernel; roofline_mfma:
+                 the Schur SYRK (also under config5 for K = 64).
   parity         max relative state error of the timed path against the fp64 CPU oracle on a sample of the windows
-  cpu_baseline   the oracle (a port of the reference's Ceres path: oracle/ctvo.c) on 1 host core, the same sample.
+  cpu_baseline   the oracle (a port of the reference's Ceres path: oracle/ctvo.c) on 1 host core, the same sample;
+                 cpu_baseline_all_cores: one window per thread on every host core (configs[3]).
+  small_batches  8 and 64 windows per launch (configs[3] as written: 64 windows over 8 GPUs); config3.spline_eval: the batched per-row
+                 trajectory query (7040 row times per window) with its HBM roofline.
 """
 import argparse
 import importlib
@@ -41,12 +45,30 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}   # v_mfma_f32_32x32x2_f32 (gui
 
 
 def kernel_of_phase(precision):
-    return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_eval<double>",
+    return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_anchor + k_vis_eval",
             "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_tiles"}
+
+
+# rocprofv3 names of the kernels behind a launch group (counter tables: profiles/pmc_traffic.json, profiles/pmc_issue.json)
+PMC_KERNELS = {"k_imu_linearize": ["k_imu_linearize_f64"], "k_vis_eval": ["k_vis_anchor", "k_vis_eval"], "k_assemble_vis": ["k_assemble_vis_mfma"],
+               "k_schur_mfma": ["k_schur_window_f64"], "k_cholesky_solve": ["k_cholesky_tiles"]}
+# fp64 instruction counts of the visual evaluation bodies, read off the ISA (tools/vis_isa_count.sh): per block 714 fp64 VALU instructions
+# = 972 flop (+ 24 + 6 + 72 of the landmark-row contributions), per anchor 813 = 1190 flop
+VIS_BLOCK_FLOP, VIS_ANCHOR_FLOP = 972 + 2 * (24 + 6) + 2 * 72 // 4, 1190
 
 
 def imu_groups(w):
     return len({(int((t - w.t0_ns) // w.dt_ns), int(b)) for t, b in zip(w.imu_t, w.imu_bias)})
+
+
+def vis_anchors(w):
+    """distinct i ends (landmark, t_i, row_i, p_i) of the window's visual blocks: one record each (csrc/host_pack.hpp)"""
+    return len({(int(l), int(t), int(r), float(p[0]), float(p[1])) for l, t, r, p in zip(w.v_lm, w.v_ti, w.v_rowi, w.v_pi)})
+
+
+def workload_label(w, config, iters):
+    return (f"{config}: {w.F - 1} KF / {w.L} landmarks / {w.M} IMU sliding window (K = {w.K} knots, {w.V} reprojection blocks), "
+            f"<= {iters} LM iterations (Ceres 1.14 trust region + projected line search)")
 
 
 def algorithmic_bytes(w, phase, fp_bytes):
@@ -54,16 +76,19 @@ def algorithmic_bytes(w, phase, fp_bytes):
     linearisation scalar (8 in the product path)."""
     K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
     G = imu_groups(w)
+    A = vis_anchors(w)
     if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
         return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
-    # a visual block's J~ is stored compactly: 2 r + 52 J (rotation, inverse depth, line delay) + 14 (P~, blending coefficients)
-    if phase == "k_vis_eval":        # what HBM must move: per block its own inputs (2 times, 2 rows, 4 observations, landmark / window index,
-        # loss width: 72 B -- the knots are shared by the window's blocks and come out of cache: counted once per window) + (r, compact
-        # J~) out; the rows of W (knot + line-delay columns), Hll, g_rho
-        return V * (72 + 68 * fp_bytes) + K * 7 * 8 + L * (8 + (6 * K + 1) * fp_bytes + 16)
-    if phase == "k_assemble_vis":    # compact J~ and r~ read once (the depth column is not needed) + keys + slot list + packed fp64 Hessian flushed once
+    # A block's record is 40 doubles (rotation columns of its own end 24, inverse depth 2, line delay 2, residual 2, A~ 6, cp1 4); an
+    # anchor's record 50 (p_G 3, GR 36, cp0 4, y 3, h 3).
+    if phase == "k_vis_eval":        # anchors: inputs (t, row, obs, indices: 36 B) in, record out and in again once (the blocks read it);
+        # blocks: own inputs (t, row, 2 obs, 3 indices, loss width: 48 B), record out; the knots are shared by the window's blocks and come
+        # out of cache: counted once per window; the rows of W (knot + line-delay columns), Hll, g_rho
+        return A * (36 + 2 * 50 * 8) + V * (48 + 40 * fp_bytes) + K * 7 * 8 + L * (8 + (6 * K + 1) * fp_bytes + 16)
+    if phase == "k_assemble_vis":    # block records read once (38 of the 40 entries: the depth column is not needed) + keys + slot lists, GR
+        # and cp0 of every anchor once (40 doubles), the packed fp64 Hessian flushed once
         K6 = 6 * K   # + the knot x knot part (24 x 24) of every IMU group tile, added into the same LDS Hessian
-        return V * (66 * fp_bytes + 12) + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
+        return V * (38 * fp_bytes + 16) + A * 40 * 8 + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
     if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
         return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
     if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written
@@ -79,8 +104,8 @@ def algorithmic_flops(w, phase):
         # is w^2 sum lamA_k lamA_k' I3 (10 products per sample); 3 gyro rows x 16 columns -- + ~1.9 k for the evaluation in its staged
         # form (csrc/factors.hpp: 632 FMAs + 623 multiplies / adds per sample, counted in the ISA)
         return M * (2 * (3 * (28 * 29 // 2 - 12 * 13 // 2) + 10) + 2 * 3 * (16 * 17 // 2) + 1900)
-    if phase == "k_vis_eval":        # ~3 k per block for r, J~ (two SO(3) spline poses and their Jacobians)
-        return V * 3000
+    if phase == "k_vis_eval":        # counted in the ISA (tools/vis_isa_count.sh): one spline end per block, one per anchor
+        return V * VIS_BLOCK_FLOP + vis_anchors(w) * VIS_ANCHOR_FLOP
     if phase == "k_assemble_vis":    # 48 x 48 lower triangle + line-delay and residual columns, 2 rows per block
         return V * 2 * 2 * (48 * 49 // 2 + 2 * 49)
     if phase == "k_cholesky_solve":
@@ -96,8 +121,9 @@ def structural_schur_flops(w):
     return (6 * w.K + 1) * (6 * w.K + 2) * w.L
 
 
-def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device, with_oracle):
-    """Device-resident rate of another BASELINE config on one handle, plus the state error of nseed distinct windows against the oracle."""
+def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device, with_oracle, profile=False):
+    """Device-resident rate of another BASELINE config on one handle, plus the state error of nseed distinct windows against the oracle.
+    profile: one more solve with HIP events around every launch group -> phase times and the Schur SYRK's MFMA roofline for this shape."""
     import ctypes as C
     import numpy as np
     uniq = [cv.synth.make_window(config, seed=1000 + i) for i in range(max(nuniq, nseed))]
@@ -116,6 +142,25 @@ def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device
         dt = time.perf_counter() - t0
         out["solves_per_s"] = nwin * steps / dt
         out["ms_per_launch"] = 1e3 * dt / steps
+        if profile:
+            sv.set_profiling(True)
+            sv.restore_state()
+            sv.solve_raw(iters)
+            sv.set_profiling(False)
+            torch.cuda.synchronize()
+            ms, n = sv.last_timing()
+            names = cv.Solver.PHASES
+            out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}
+            pk = MFMA_PEAK_TFLOPS["fp64"]
+            fls = sum(structural_schur_flops(w) for w in wl)
+            fl = sum(w.P * (w.P + 1) * w.L for w in wl)
+            avg = 1e-3 * ms[4] / max(int(n[4]), 1)
+            out["roofline_mfma"] = {"kernel": "k_schur_window_f64 (K = %d, P = %d)" % (wl[0].K, wl[0].P), "bound": "mfma", "achieved": fls / avg / 1e12,
+                                    "peak": pk, "unit": "TFLOP/s", "frac": fls / avg / 1e12 / pk, "avg_launch_us": 1e6 * avg,
+                                    "flops_per_launch": fls, "flop_count": "structural: (6K + 1)(6K + 2) L", "nominal_flops_per_launch": fl,
+                                    "nominal_frac": fl / avg / 1e12 / pk, "windows_per_launch": nwin}
+            chol = 1e-3 * ms[5] / max(int(n[5]), 1)
+            out["cholesky_us_per_launch"] = 1e6 * chol
         if with_oracle:
             import pyctvo
             batch = [uniq[i].copy() for i in range(nseed)]
@@ -130,6 +175,86 @@ def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device
             out["max_rel_state_err"] = float(max(errs))
             out["parity_windows"] = nseed
     return out
+
+
+def small_batch(cv, lib, torch, C, np, uniq, nwin, iters, device):
+    """ONE launch of nwin windows (BASELINE configs[3] as written: 64 windows over 8 GPUs = 8 per GPU): end to end and device resident."""
+    with cv.Solver(device=device, host_threads=min(nwin, 8)) as sb:
+        keep = []
+        arr = (cv.capi.CWindow * nwin)()
+        wl = [uniq[i % len(uniq)] for i in range(nwin)]
+        for j, w in enumerate(wl):
+            arr[j] = cv.capi.to_cwindow(w, keep)
+        K = sum(w.K for w in wl); F = sum(w.F for w in wl); L = sum(w.L for w in wl)
+        o = (np.zeros((K, 4)), np.zeros((K, 3)), np.zeros((F, 6)), np.zeros(max(L, 1)), np.zeros(nwin))
+
+        def one():
+            cv.capi.check(lib.ctvio_set_batch(sb._h, nwin, C.cast(arr, C.c_void_p)))
+            cv.capi.check(lib.ctvio_solve(sb._h, iters, None))
+            cv.capi.check(lib.ctvio_get_batch_state(sb._h, *[cv.capi._p(a) for a in o]))
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            one()
+        torch.cuda.synchronize()
+        e2e = (time.perf_counter() - t0) / 20
+        cv.capi.check(lib.ctvio_set_batch(sb._h, nwin, C.cast(arr, C.c_void_p)))
+        sb.snapshot_state()
+        sb.solve_raw(iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            sb.restore_state()
+            sb.solve_raw(iters)
+        torch.cuda.synchronize()
+        res = (time.perf_counter() - t0) / 20
+    return {"windows": nwin, "end_to_end_ms": 1e3 * e2e, "device_resident_ms": 1e3 * res, "end_to_end_solves_per_s": nwin / e2e,
+            "device_resident_solves_per_s": nwin / res}
+
+
+def row_queries(cv, torch, np, nwin, device):
+    """pose + velocity + angular velocity at every rolling-shutter row time of every frame -- 11 frames x 640 rows
+    = 7040 queries per window -- for a batch of config-3 windows in ONE launch (ctvio_spline_eval_batch).  Algorithmic HBM bytes per row:
+    12 in (window id + time) + 104 out (13 doubles); the knots come out of cache."""
+    uniq = [cv.synth.make_window("config3", seed=1000 + i) for i in range(8)]
+    wl = [uniq[i % 8].copy() for i in range(nwin)]
+    F, rows = wl[0].F, 640
+    frame_t = np.arange(F, dtype=np.int64) * 100_000_000
+    per = (frame_t[:, None] + (np.arange(rows, dtype=np.int64)[None, :] * int(3.0e-5 * 1e9))).ravel()     # t_f + row * line delay
+    win = np.repeat(np.arange(nwin, dtype=np.int32), per.size)
+    t = np.tile(per, nwin) + np.repeat(np.array([w.t0_ns for w in wl], np.int64), per.size)
+    n = int(t.size)
+    with cv.Solver(device=device) as sq:
+        sq.set_windows(wl)
+        sq.spline_eval_batch(win, t)                      # warm-up (scratch arenas grow once)
+        kms, wall = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            _, ms = sq.spline_eval_batch(win, t)
+            wall.append(time.perf_counter() - t0); kms.append(ms)
+    k = 1e-3 * min(kms)
+    nb = 116.0 * n
+    return {"windows": nwin, "rows_per_window": int(per.size), "rows": n, "kernel_us": 1e6 * k, "rows_per_s_kernel": n / k,
+            "rows_per_s_end_to_end": n / min(wall), "algorithmic_bytes_per_row": 116,
+            "roofline": {"kernel": "k_spline_eval (batch)", "bound": "hbm", "achieved": nb / k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": nb / k / 1e9 / HBM_PEAK_GBS, "traffic": None},
+            "note": "end to end includes the H2D copy of 12 B and the D2H copy of 104 B per row through pinned staging and the host-side scatter"}
+
+
+def cpu_all_cores(config, iters, seed0, n):
+    """the second CPU baseline -- all host cores, one window per process (oracle/all_cores.py in a fresh interpreter: the
+    workers are forked without a HIP runtime).  NB pool.map hands chunk i to whichever worker is free: the windows a worker prepared
+    are the ones it solves only when chunks and workers pair up, so every worker prepares on demand."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "all_cores.py"), config, str(iters), str(seed0), str(n)],
+                       capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        return {"error": p.stderr[-500:]}
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    return {"value": r["solves"] / r["seconds"], "unit": "solves/s", "cores": r["processes"], "kind": "port",
+            "sample": f"{r['solves']} solves of {config} windows (seeds {seed0}..{seed0 + n - 1}), fp64 C oracle (oracle/ctvo.c), one window per "
+                      f"process on {r['processes']} processes of a {r['host_cores']}-core host, {r['seconds']:.1f} s"}
 
 
 def respawn_under_torchrun(args):
@@ -169,12 +294,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # rank -> device.  One rank per GPU is the product layout (RCCL over xGMI).  When there are more ranks than visible devices (the
+    # multi-rank path exercised on a one-GPU box: tests/test_gpu_multirank.py) ranks share devices and the collectives run over gloo on
+    # host tensors -- RCCL cannot put two ranks on one device.
+    ndev = max(torch.cuda.device_count(), 1)
+    shared_device = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     dist = None
+    coll_device = torch.device("cpu") if shared_device else torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     cv = importlib.import_module("ctrl-vio_amd")
     import ctypes as C
 
@@ -247,7 +382,7 @@ def main():
         t = time.perf_counter() - t0
         barrier()
         if dist is not None:
-            tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([t], device=coll_device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         return t
@@ -265,13 +400,13 @@ def main():
     t_total = timed(args.steps, resident_headline)
     n_solved = args.windows * world * args.steps
     fp_bytes = 8 if args.precision == "fp64" else 4
+    w_lab = uniq[0]
     out = {
-        "metric": "sliding-window solves/sec (10 KF, 200 lm, 2000 IMU)", "value": n_solved / t_total, "unit": "solves/s",
+        "metric": "sliding-window solves/sec (%d KF, %d lm, %d IMU)" % (w_lab.F - 1, w_lab.L, w_lab.M), "value": n_solved / t_total, "unit": "solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_total / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: 10 KF / 200 landmarks / 2000 IMU sliding window, <= {args.iters} LM iterations "
-                               f"(Ceres 1.14 trust region + projected line search)",
+        "config": {"workload": workload_label(w_lab, args.config, args.iters),
                    "timed_region": "device-resident solve only" if resident_headline else
                                    "end to end per batch: validate + pack (host threads) + H2D + LM solve + D2H of every state",
                    "windows_per_gpu_per_step": args.windows, "distinct_windows_per_gpu": nuniq, "streams_per_gpu": nstream, "concurrent_solves_per_gpu": nslots,
@@ -294,7 +429,7 @@ def main():
         cv.capi.check(lib.ctvio_solve(solvers[si]._h, args.iters, C.cast(sm, C.c_void_p)))
         sms_all += [s.as_dict() for s in sm]
     rec_local = cv.sharding.make_records(my_ids, sms_all)
-    rec = cv.sharding.gather_records(rec_local, args.windows * world, device=torch.device("cuda", local)) if dist is not None else None
+    rec = cv.sharding.gather_records(rec_local, args.windows * world, device=coll_device) if dist is not None else None
     if rec is not None:
         ids = rec[:, 0]
         assert not np.isnan(ids).any() and sorted(ids.astype(int).tolist()) == list(range(args.windows * world)), "RCCL gather lost a window"
@@ -303,7 +438,9 @@ def main():
         out["solve_summary"] = {"windows": int(src.shape[0]), "iterations_mean": float(np.mean(src[:, 1])),
                                 "terminations": sorted({cv.capi.TERMINATION.get(int(t), "?") for t in src[:, 2]}),
                                 "line_search_reduced_steps": int(sum(s["num_line_search_reduced"] for s in sms_all)),
-                                "gathered_with": "RCCL all_gather (GPU tensors)" if rec is not None else "single rank"}
+                                "gathered_with": ("single rank" if rec is None else "gloo all_gather (ranks share a device)" if shared_device
+                                                  else "RCCL all_gather (GPU tensors)"),
+                                "window_ids_gathered_once": bool(rec is None or sorted(rec[:, 0].astype(int).tolist()) == list(range(args.windows * world)))}
         # ---- roofline: one more device-resident solve of handle 0 with HIP events around every launch group on its stream;
         #      the other handles are idle, so a duration is the kernel's own (two streams sharing the chip stretch both)
         solver = solvers[0]
@@ -317,13 +454,14 @@ def main():
         wl0 = keeps[0][1]
         w_ref = uniq[0]
         pk = MFMA_PEAK_TFLOPS["fp64" if args.precision == "fp64" else "fp32"]
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        pmc = {}
-        if os.path.exists(tfile):
+        def load_json(name):
+            f = os.path.join(ROOT, "profiles", name)
             try:
-                pmc = json.load(open(tfile))
+                return json.load(open(f)) if os.path.exists(f) else {}
             except Exception:
-                pmc = {}
+                return {}
+        pmc = load_json("pmc_traffic.json")      # per-kernel FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 passes
+        issue = load_json("pmc_issue.json")      # per-kernel SQ issue counters of the committed pass
 
         def kernel_line(i):
             """roofline entry of launch group i: HBM-bound unless its algorithmic intensity is beyond the ridge (peak flops / peak bytes)"""
@@ -331,14 +469,31 @@ def main():
             nf = sum(algorithmic_flops(w, names[i]) for w in wl0)
             avg_s = 1e-3 * ms[i] / max(int(n[i]), 1)
             kname = kmap.get(names[i], names[i])
-            traffic = pmc.get(kname, {}).get(str(per[0]), {}).get("traffic_bytes")
-            compute = nf / max(nb, 1) > pk * 1e12 / (HBM_PEAK_GBS * 1e9)
+            tparts = [pmc.get(k, {}).get(str(per[0]), {}).get("traffic_bytes") for k in PMC_KERNELS.get(names[i], [])]
+            traffic = sum(tparts) if tparts and all(t is not None for t in tparts) else None
+            # Which roof?  Both fractions are computed; the label follows the LARGER one (the resource the kernel is closer to), and the
+            # issue counters of the committed rocprofv3 pass (profiles/pmc_issue.json: tools/profile_round4.sh) ride along -- a kernel at a
+            # quarter of either roof is bound by neither, and `limiter` says by what instead.
+            hbm_frac = nb / avg_s / 1e9 / HBM_PEAK_GBS
+            fl_frac = nf / avg_s / 1e12 / pk
+            compute = fl_frac > hbm_frac
             ach = nf / avg_s / 1e12 if compute else nb / avg_s / 1e9
             peak = pk if compute else HBM_PEAK_GBS
-            return {"kernel": kname, "bound": "mfma" if compute else "hbm", "achieved": ach, "peak": peak,
+            line = {"kernel": kname, "bound": "mfma" if compute else "hbm", "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s" if compute else "GB/s", "frac": ach / peak, "traffic": traffic, "avg_launch_us": 1e6 * avg_s,
                     "launches": int(n[i]), "windows_per_launch": per[0], "algorithmic_bytes_per_launch": nb,
-                    "algorithmic_flops_per_launch": nf, "share_of_profiled_solve": float(ms[i] / max(sum(ms[:7]), 1e-12))}
+                    "algorithmic_flops_per_launch": nf, "hbm_frac": hbm_frac, "fp64_frac": fl_frac,
+                    "share_of_profiled_solve": float(ms[i] / max(sum(ms[:7]), 1e-12))}
+            iss = [issue.get(k) for k in PMC_KERNELS.get(names[i], [])]
+            if iss and all(x is not None for x in iss):
+                tot = lambda key: sum(x.get(key, 0.0) for x in iss)
+                wc = max(tot("SQ_WAVE_CYCLES"), 1.0)
+                line["issue"] = {"valu_active_share_of_wave_cycles": tot("SQ_ACTIVE_INST_VALU") / wc, "parked_share": tot("SQ_WAIT_ANY") / wc,
+                                 "issue_stall_share": tot("SQ_WAIT_INST_ANY") / wc, "valu_instructions": tot("SQ_INSTS_VALU"),
+                                 "mfma_busy_cycles": tot("SQ_VALU_MFMA_BUSY_CYCLES"), "source": "profiles/pmc_issue.json (rocprofv3 --pmc, 2048 windows per launch)"}
+                line["limiter"] = ("fp64 issue" if line["issue"]["valu_active_share_of_wave_cycles"] > 0.5 else
+                                   "latency: waves parked on memory / LDS / barriers" if line["issue"]["parked_share"] > 0.5 else "mixed issue / latency")
+            return line
 
         dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
         out["roofline"] = kernel_line(dom)
@@ -398,9 +553,12 @@ def main():
                     det[name + "_ms_per_64_windows"] = 1e3 * (time.perf_counter() - t0) / 10
             det["cost_ratio"] = det["deterministic_ms_per_64_windows"] / det["throughput_ms_per_64_windows"]
             out["deterministic_mode"] = det
+            # ---- BASELINE configs[3] as written is 64 windows over 8 GPUs = 8 per GPU: launch-latency territory, reported beside the headline
+            out["small_batches"] = [small_batch(cv, lib, torch, C, np, uniq, nb_, args.iters, local) for nb_ in (8, 64)]
             ora = not args.no_cpu_baseline
             out["config3"] = side_config(cv, lib, torch, "config3", 1024, 16, args.iters, 2, 8, local, ora)
-            out["config5"] = side_config(cv, lib, torch, "config5", 128, 8, args.iters, 2, 8, local, ora)
+            out["config3"]["spline_eval"] = row_queries(cv, torch, np, 256, local)
+            out["config5"] = side_config(cv, lib, torch, "config5", 128, 8, args.iters, 2, 8, local, ora, profile=True)
             out["tumrs"] = side_config(cv, lib, torch, "tumrs", 2048, 16, args.iters, 2, 8, local, ora)
             wt = cv.synth.make_window("tumrs", seed=1000)
             out["tumrs"]["imu_lane_utilisation"] = wt.M / (64.0 * imu_groups(wt))   # one 64-lane pass per (segment, bias) group
@@ -439,6 +597,9 @@ def main():
                 k0 += w.K; f0 += w.F; l0 += w.L
             out["parity"] = {"max_rel_state_err": float(max(errs)), "median_rel_state_err": float(np.median(errs)), "windows": len(errs),
                              "tolerance": 1e-4, "reference": "fp64 C oracle, same Ceres settings", "pass": bool(max(errs) <= 1e-4)}
+            if not args.quick:   # configs[3]: 64 windows, one per thread, all host cores
+                ncore = os.cpu_count() or 1
+                out["cpu_baseline_all_cores"] = cpu_all_cores(args.config, args.iters, 1000, max(64, min(4 * ncore, 1024)))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()   # rank 0 prints after its extra measurements; nobody tears the communicator down under it

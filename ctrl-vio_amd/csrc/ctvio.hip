@@ -101,6 +101,8 @@ struct SolverBase {
   virtual int lm_step(int id, double mu, double *delta, double *mc) = 0;
   virtual int spline_eval(int id, int n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3,
                           const double *q_SI = nullptr, const double *p_SI = nullptr) = 0;
+  virtual int spline_eval_batch(int64_t n, const int32_t *win, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3,
+                                double *kernel_ms) = 0;
   virtual int gauge_restore(int n, const int32_t *ids, const int32_t *knot, const double *q0, const double *t0) = 0;
   virtual int marginalize(int id, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
   virtual int marginalize_batch(const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0) = 0;
@@ -577,13 +579,11 @@ template <class T> class SolverImpl : public SolverBase {
       launch_linearize_merged(mode);
       return;
     }
-    ph_begin(PH_VIS_LIN);
-    if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, mode);   // the i ends, once per anchor
-    ph_end();
     ph_begin(PH_IMU_LIN);
     if (d.Gtot) launch_imu_linearize(imu_lds, mode);
     ph_end();
-    ph_begin(PH_VIS_LIN);
+    ph_begin(PH_VIS_LIN);   // (one timed group: the anchors' records, then the blocks)
+    if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, mode);   // the i ends, once per anchor
     if (d.Vtot) hipLaunchKernelGGL(k_vis_eval, dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode);
     ph_end();
   }
@@ -786,7 +786,7 @@ template <class T> class SolverImpl : public SolverBase {
       std::fprintf(stderr, "\n");
       std::fprintf(stderr, "[ctvio] cholesky clock64 deltas:");
       for (int i = 1; i < 24; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
-      std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> wave 1000, clock64 deltas (evaluation | J~ copy-out | landmark contributions | per sweep: scatter, rows out):");
+      std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> wave 1000, clock64 deltas (evaluation | contributions + segmented sums | record copy-out | per sweep: scatter, rows out):");
       for (int i = 32; i < 40; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, " | landmarks %lld, rows per sweep %lld", st[42] / 1000000, st[43] / 1000);
       std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | per item of rounds 0, 1: staged, run products.., scatter | rounds | imu tiles | H flush | g flush):");
@@ -1116,11 +1116,53 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, stream_));
     double *dp = reinterpret_cast<double *>(ds + o_out), *dv = dp + (pose7 ? (size_t)7 * n : 0), *dw = dv + (vel3 ? (size_t)3 * n : 0),
            *da = dw + (omega3 ? (size_t)3 * n : 0);
-    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, n, reinterpret_cast<const long long *>(ds),
+    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, (const int32_t *)nullptr, n, reinterpret_cast<const long long *>(ds),
                        pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr, reinterpret_cast<int *>(ds + o_err), ext);
     HIPCHK(hipMemcpyAsync(hs + o_err, ds + o_err, 16 + nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    const int err = *reinterpret_cast<int *>(hs + o_err);
+    const double *ho = reinterpret_cast<const double *>(hs + o_out);
+    if (pose7) { std::memcpy(pose7, ho, sizeof(double) * 7 * n); ho += (size_t)7 * n; }
+    if (vel3) { std::memcpy(vel3, ho, sizeof(double) * 3 * n); ho += (size_t)3 * n; }
+    if (omega3) { std::memcpy(omega3, ho, sizeof(double) * 3 * n); ho += (size_t)3 * n; }
+    if (acc3) std::memcpy(acc3, ho, sizeof(double) * 3 * n);
+    if (err) return fail(CTVIO_ERR_INVALID, "query time outside the spline");
+    return CTVIO_OK;
+  }
+  // Queries of any windows of the batch in ONE launch (query i: window win[i], absolute time t_ns[i]).
+  int spline_eval_batch(int64_t n64, const int32_t *win, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3,
+                        double *kernel_ms) override {
+    if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
+    if (n64 < 0 || n64 > (int64_t)1 << 30 || (n64 && (!t_ns || !win))) return fail(CTVIO_ERR_INVALID, "bad arguments");
+    const int n = (int)n64;
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (n == 0) return CTVIO_OK;
+    // grow-only scratch (pinned host mirror): [t_rel n x i64 | window n x i32 | err | pose 7n | vel 3n | omega 3n | acc 3n]
+    const size_t o_win = sizeof(long long) * (size_t)n, o_err = (o_win + sizeof(int32_t) * (size_t)n + 15) & ~(size_t)15, o_out = o_err + 16;
+    const size_t nd = (size_t)n * ((pose7 ? 7 : 0) + (vel3 ? 3 : 0) + (omega3 ? 3 : 0) + (acc3 ? 3 : 0));
+    if (const int rc = call_scratch(o_out + nd * sizeof(double))) return rc;
+    char *hs = call_host_, *ds = call_dev_.p;
+    long long *rel = reinterpret_cast<long long *>(hs);
+    int32_t *hw = reinterpret_cast<int32_t *>(hs + o_win);
+    for (int i = 0; i < n; ++i) {
+      if (win[i] < 0 || win[i] >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "query " + std::to_string(i) + ": window id out of range");
+      hw[i] = win[i];
+      rel[i] = (long long)(t_ns[i] - t0_[win[i]]);
+    }
+    *reinterpret_cast<int *>(hs + o_err) = 0;
+    HIPCHK(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, stream_));
+    double *dp = reinterpret_cast<double *>(ds + o_out), *dv = dp + (pose7 ? (size_t)7 * n : 0), *dw = dv + (vel3 ? (size_t)3 * n : 0),
+           *da = dw + (omega3 ? (size_t)3 * n : 0);
+    if (kernel_ms) HIPCHK(hipEventRecord(ev_[10], stream_));
+    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, 0, reinterpret_cast<const int32_t *>(ds + o_win), n,
+                       reinterpret_cast<const long long *>(ds), pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr,
+                       reinterpret_cast<int *>(ds + o_err), SensorExt{});
+    if (kernel_ms) HIPCHK(hipEventRecord(ev_[11], stream_));
+    HIPCHK(hipMemcpyAsync(hs + o_err, ds + o_err, 16 + nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipGetLastError());
+    if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev_[10], ev_[11])); *kernel_ms = ms; }
     const int err = *reinterpret_cast<int *>(hs + o_err);
     const double *ho = reinterpret_cast<const double *>(hs + o_out);
     if (pose7) { std::memcpy(pose7, ho, sizeof(double) * 7 * n); ho += (size_t)7 * n; }
@@ -1140,7 +1182,7 @@ template <class T> class SolverImpl : public SolverBase {
  private:
   ctvio_options opt_;
   hipStream_t stream_ = nullptr;
-  hipEvent_t ev_[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool uploaded_ = false, profiling_ = false, profiling_requested_ = false;
   double timing_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int32_t ph_n_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_iters_ = 0;
@@ -1317,6 +1359,10 @@ int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, cons
 }
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3, double *omega3, double *acc3) {
   CHK_S; return s->impl->spline_eval(id, n, t_ns, pose7, vel3, omega3, acc3);
+}
+int32_t ctvio_spline_eval_batch(ctvio_solver *s, int64_t n, const int32_t *win, const int64_t *t_ns, double *pose7, double *vel3, double *omega3,
+                                double *acc3, double *kernel_ms) {
+  CHK_S; return s->impl->spline_eval_batch(n, win, t_ns, pose7, vel3, omega3, acc3, kernel_ms);
 }
 int32_t ctvio_sensor_pose(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, const double *q_SI, const double *p_SI, double *pose7) {
   CHK_S;

@@ -522,15 +522,25 @@ constexpr int VB_CP1 = 36;      // [4]  blending coefficients of the position sp
 
 // q0 / p[4]: the j end's knots.  RCIT = R_CI^T (row major).  Emit receives the block record entry by entry -- put(entry, value) --
 // with the inverse-depth column first (sinks that form J_rho^T J_c need it up front); r[2] = r~; returns the block's cost rho(s)/2.
+// The j end's rotation spline is walked ONCE: A_i = exp(c_{i+1} d_i) serves EvaluateRTp's chain S_{i+1} = S_i A_i
+// (so3_spline_view.h:208-276), VelocityBody's conjugates (:356-411) and the Jacobian recursion, and the per-knot partial Jacobians
+// J_i = H_{i-1} JrI_{i-1} - H_i JrI_i^T, H_i = c_{i+1} R(S_i) Jr(-c_{i+1} d_i) are never formed: the rotation columns need only
+// E J_i with E = A~ hat(p_G - p_Ij) (2 x 3), so the recursion runs on the 2 x 3 products E H_i (a third of the multiplications).
 template <bool SMALL, class SC, class Emit>
 CTV_DI double vis_block_eval(const double *rec, const Q4<double> &q0, const V3<double> p[4], const SC &sc, double u, double idt,
                              const M3<double> &RCIT, const V3<double> &p_CI, double sw, double cauchy_a, double pjx, double pjy, double rowj,
                              double r[2], bool want_jac, Emit &emit) {
-  Q4<double> qk[4];
-  qk[0] = q0;
-  const Q4<double> S_GtoIj = eval_RTp<double, SC, SMALL>(qk, sc, u, (M3<double> *)nullptr, false);
-  double cp1[4];
+  double c[4], cp1[4];
+  basis<double, true, 0>(u, 1.0, c);
   basis<double, false, 0>(u, 1.0, cp1);
+  Q4<double> A[3], S[4];
+  S[0] = q0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    A[i] = so3_exp_sel<SMALL>(c[i + 1] * sc.d[i]);
+    S[i + 1] = qmul_unit(S[i], A[i]);
+  }
+  const Q4<double> S_GtoIj = qconj(S[3]);
   V3<double> pIj = mk<double>(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) pIj = pIj + cp1[i] * p[i];
@@ -543,10 +553,10 @@ CTV_DI double vis_block_eval(const double *rec, const Q4<double> &q0, const V3<d
   const double s = r0 * r0 + r1 * r1;
   double cost, sq = 1.0, rs = 1.0, alpha_sq = 0.0;
   if (cauchy_a > 0.0) {
-    const double b = cauchy_a * cauchy_a, c = 1.0 / b;
-    const double inv = 1.0 / (1.0 + s * c);
-    cost = 0.5 * b * log1p(s * c);
-    const double rho1 = inv, rho2 = -c * inv * inv;
+    const double b = cauchy_a * cauchy_a, cc = 1.0 / b;
+    const double inv = 1.0 / (1.0 + s * cc);
+    cost = 0.5 * b * log1p(s * cc);
+    const double rho1 = inv, rho2 = -cc * inv * inv;
     sq = sqrt(rho1);
     if (s == 0.0 || rho2 <= 0.0) { rs = sq; alpha_sq = 0.0; }
     else { const double D = 1.0 + 2.0 * s * rho2 / rho1; const double al = 1.0 - sqrt(D); rs = sq / (1.0 - al); alpha_sq = al / s; }
@@ -561,18 +571,18 @@ CTV_DI double vis_block_eval(const double *rec, const Q4<double> &q0, const V3<d
   {
     const double fx = -dji * dji * x_j.x, fy = -dji * dji * x_j.y;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double j0 = sw * (dji * RCIT.m[c] + fx * RCIT.m[6 + c]), j1 = sw * (dji * RCIT.m[3 + c] + fy * RCIT.m[6 + c]);
+    for (int k = 0; k < 3; ++k) {
+      const double j0 = sw * (dji * RCIT.m[k] + fx * RCIT.m[6 + k]), j1 = sw * (dji * RCIT.m[3 + k] + fy * RCIT.m[6 + k]);
       const double rj = r0 * j0 + r1 * j1;
-      Bt[c] = sq * (j0 - alpha_sq * r0 * rj);
-      Bt[3 + c] = sq * (j1 - alpha_sq * r1 * rj);
+      Bt[k] = sq * (j0 - alpha_sq * r0 * rj);
+      Bt[3 + k] = sq * (j1 - alpha_sq * r1 * rj);
     }
   }
   const M3<double> RGIj = q2R(S_GtoIj);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) At[3 * a + c] = Bt[3 * a] * RGIj.m[c] + Bt[3 * a + 1] * RGIj.m[3 + c] + Bt[3 * a + 2] * RGIj.m[6 + c];
+    for (int k = 0; k < 3; ++k) At[3 * a + k] = Bt[3 * a] * RGIj.m[k] + Bt[3 * a + 1] * RGIj.m[3 + k] + Bt[3 * a + 2] * RGIj.m[6 + k];
   // inverse depth (image_feature_factor.h:239-248)
   emit.put(VB_RHO, At[0] * rec[AR_Y] + At[1] * rec[AR_Y + 1] + At[2] * rec[AR_Y + 2]);
   emit.put(VB_RHO + 1, At[3] * rec[AR_Y] + At[4] * rec[AR_Y + 1] + At[5] * rec[AR_Y + 2]);
@@ -582,27 +592,63 @@ CTV_DI double vis_block_eval(const double *rec, const Q4<double> &q0, const V3<d
   for (int i = 0; i < 4; ++i) emit.put(VB_CP1 + i, cp1[i]);
   // line delay (image_feature_factor.h:251-264), in the frame of IMU j
   {
-    double dcp1[4];
+    double dc[4], dcp1[4];
+    basis<double, true, 1>(u, idt, dc);
     basis<double, false, 1>(u, idt, dcp1);
     V3<double> v_j = mk<double>(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v_j = v_j + dcp1[i] * p[i];
-    const V3<double> Om_j = eval_omega<double, SC, SMALL>(sc, u, idt);
+    V3<double> Om_j = dc[1] * sc.d[0];                  // VelocityBody: conj(A_i) = exp(-c_{i+1} d_i)
+#pragma unroll
+    for (int i = 1; i < 3; ++i) Om_j = qrot(qconj(A[i]), Om_j) + dc[i + 1] * sc.d[i];
     const V3<double> hv = mk<double>(rec[AR_H], rec[AR_H + 1], rec[AR_H + 2]) - rowj * v_j;
     const V3<double> Jx = qrot(S_GtoIj, hv) - rowj * cross(Om_j, bj);
     emit.put(VB_LD, Bt[0] * Jx.x + Bt[1] * Jx.y + Bt[2] * Jx.z);
     emit.put(VB_LD + 1, Bt[3] * Jx.x + Bt[4] * Jx.y + Bt[5] * Jx.z);
   }
-  // rotation columns of the j end, knot by knot as the per-knot partial Jacobians become final (image_feature_factor.h:199-216):
-  // E = A~ hat(p_G - p_Ij), row by row A~[a] x dpg
-  const V3<double> E0 = cross(mk<double>(At[0], At[1], At[2]), dpg), E1 = cross(mk<double>(At[3], At[4], At[5]), dpg);
-  eval_RTp_jac_stream<double, SC, SMALL>(qk, sc, u, [&](int kk, const M3<double> &Jk) {
+  // rotation columns of the j end (image_feature_factor.h:199-216): E = A~ hat(p_G - p_Ij), row by row A~[a] x dpg;
+  // knots come out 0, 1, 2, 3
+  {
+    const V3<double> E0 = cross(mk<double>(At[0], At[1], At[2]), dpg), E1 = cross(mk<double>(At[3], At[4], At[5]), dpg);
+    const double E[6] = {E0.x, E0.y, E0.z, E1.x, E1.y, E1.z};
+    auto mul23 = [](const double X[6], const M3<double> &M, double Y[6]) {          // Y = X M
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      emit.put(VB_JROT + 2 * (3 * kk + b), E0.x * Jk.m[b] + E0.y * Jk.m[3 + b] + E0.z * Jk.m[6 + b]);
-      emit.put(VB_JROT + 2 * (3 * kk + b) + 1, E1.x * Jk.m[b] + E1.y * Jk.m[3 + b] + E1.z * Jk.m[6 + b]);
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Y[3 * a + k] = X[3 * a] * M.m[k] + X[3 * a + 1] * M.m[3 + k] + X[3 * a + 2] * M.m[6 + k];
+    };
+    auto mul23T = [](const double X[6], const M3<double> &M, double Y[6]) {         // Y = X M^T
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Y[3 * a + k] = X[3 * a] * M.m[3 * k] + X[3 * a + 1] * M.m[3 * k + 1] + X[3 * a + 2] * M.m[3 * k + 2];
+    };
+    double Ep[6];                                       // E times the pending term of the recursion
+    mul23(E, q2R(S[0]), Ep);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double ER[6], EH[6], t6[6];
+      if (i == 0) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ER[e] = Ep[e];
+      } else {
+        mul23(E, q2R(S[i]), ER);
+      }
+      mul23(ER, so3_Jr_sel<SMALL>((-c[i + 1]) * sc.d[i]), EH);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) EH[e] *= c[i + 1];
+      const M3<double> JrIi = sc.jri(i);
+      mul23T(EH, JrIi, t6);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        emit.put(VB_JROT + 2 * (3 * i + b), Ep[b] - t6[b]);
+        emit.put(VB_JROT + 2 * (3 * i + b) + 1, Ep[3 + b] - t6[3 + b]);
+      }
+      mul23(EH, JrIi, Ep);
     }
-  });
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { emit.put(VB_JROT + 2 * (9 + b), Ep[b]); emit.put(VB_JROT + 2 * (9 + b) + 1, Ep[3 + b]); }
+  }
   return cost;
 }
 

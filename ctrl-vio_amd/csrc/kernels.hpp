@@ -691,6 +691,15 @@ __device__ __forceinline__ void imu_chain_accel(const double *A, int q4, int l15
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0));
 }
 
+// The fast body's groups: every knot-pair log below 0.5 rad, isotropic accelerometer weights.  Asked in two places (the fast body about its
+// own group, k_imu_linearize_rest about every group of its window) that must agree to the bit: the operations are spelled out (no
+// contraction choices left to the compiler).
+__device__ __forceinline__ bool imu_fast_pred(const double kd[9], const double *imu_w) {
+  double mx = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) mx = fmax(mx, __fma_rn(kd[3 * i + 2], kd[3 * i + 2], __fma_rn(kd[3 * i + 1], kd[3 * i + 1], __dmul_rn(kd[3 * i], kd[3 * i]))));
+  return mx < 0.25 && imu_w[3] == imu_w[4] && imu_w[3] == imu_w[5];
+}
 // ---- The product path's body for the usual group (imu_group_fast: knot-pair logs below 0.5 rad, isotropic accelerometer weights).
 // Same wave-per-group scheme and row streaming as the general body above, with
 //   * the evaluation in stages (factors.hpp, staged form): values, gyro Jacobians -> three row phases, accelerometer Jacobians -> three row
@@ -753,6 +762,12 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   if (!lin_run(d.lm[w], mode)) return;
   const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
   const WinMeta &m = d.wins[w];
+  // is this group the fast body's?  (imu_group_fast, decided HERE from the pair logs already in registers and the window record already on
+  // its way: asked up front by the kernel it was a dependent chain group -> window -> pair table in front of everything else)
+  {
+    const double kd9[9] = {sc.d[0].x, sc.d[0].y, sc.d[0].z, sc.d[1].x, sc.d[1].y, sc.d[1].z, sc.d[2].x, sc.d[2].y, sc.d[2].z};
+    if (!imu_fast_pred(kd9, m.imu_w)) return;   // (uniform) left to k_imu_linearize_rest
+  }
   long long *dbg = (d.dbg && gidx == 5000 && jac) ? d.dbg + 64 : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of lane 0 at the phase boundaries
   int dbi = 0;
 #define CTV_ISTAMP(x) do { if (dbg && lane == 0 && dbi < 16) dbg[dbi++] = clock64() + (long long)((x) * 0.0); } while (0)
@@ -923,12 +938,9 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
 // reference's: one scalar per sensor) -- any other weighting takes the general body as well.
 __device__ __forceinline__ bool imu_group_fast(const Dev<double> &d, int gidx) {
   const ImuGroup grp = d.groups[gidx];
-  const WinMeta &m = d.wins[grp.win];
-  const double *kd = d.lkd + 3 * (m.knot0 + grp.s);
-  double mx = 0.0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) mx = fmax(mx, kd[3 * i] * kd[3 * i] + kd[3 * i + 1] * kd[3 * i + 1] + kd[3 * i + 2] * kd[3 * i + 2]);
-  return mx < 0.25 && m.imu_w[3] == m.imu_w[4] && m.imu_w[3] == m.imu_w[5];
+  const double *kd = d.lkd + 3 * grp.kabs;
+  const double kd9[9] = {kd[0], kd[1], kd[2], kd[3], kd[4], kd[5], kd[6], kd[7], kd[8]};
+  return imu_fast_pred(kd9, d.wins[grp.win].imu_w);
 }
 // The groups the fast body leaves out are picked up by k_imu_linearize_rest (one wave per WINDOW: its lanes look at the window's groups,
 // the wave then takes the flagged ones in turn -- 12 us per launch when there is nothing to do, which is the rule): the two bodies in
@@ -936,7 +948,7 @@ __device__ __forceinline__ bool imu_group_fast(const Dev<double> &d, int gidx) {
 // (general_only: every group through the general body -- ctvio_options.use_mfma = 2 / CTVIO_IMU_GENERAL=1, the tests' way into it)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode, int general_only, int zero_mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x, zero_mode);
+  if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x, zero_mode);   // (returns at once when the group is not its own)
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev<double> d, int mode, int general_only, int zero_mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
@@ -1028,12 +1040,19 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 // One lane per ANCHOR (the i end shared by a feature's blocks: factors.hpp): the record of the state being linearised.  The usual wave --
 // every knot-pair log of its anchors below 0.5 rad (a ballot) -- takes the series-only evaluation (no branch, no closed-form code on the
 // path), the others the general one; both in the global frame.
+constexpr int AREC_LD = AREC + 1;   // odd LDS stride of the staged records
 __global__ __launch_bounds__(64) void k_vis_anchor(Dev<double> d, int mode) {
+  // the records of the wave's 64 anchors are staged in LDS and written as ONE contiguous region with 16-byte stores (a lane writing
+  // its own 400-byte record entry by entry costs 50 scattered partial-line stores: 229 MB of write traffic for 164 MB of records)
+  __shared__ __attribute__((aligned(16))) double srec[64 * AREC_LD];
   const int a = blockIdx.x * 64 + threadIdx.x;
-  if (a >= d.Atot) return;
+  bool run = false;
+  if (a < d.Atot) run = lin_run(d.lm[d.a_win[a]], mode);
+  const unsigned long long run_mask = __ballot(run);
+  if (run_mask == 0) return;                   // (wave-uniform)
+  if (run) {
   const int w = d.a_win[a];
   const Lm &lm = d.lm[w];
-  if (!lin_run(lm, mode)) return;
   const WinMeta &m = d.wins[w];
   const bool jac = !lin_cost_only(lm, mode, d.prm);
   const bool at_cand = mode == LIN_SPEC;
@@ -1056,11 +1075,29 @@ __global__ __launch_bounds__(64) void k_vis_anchor(Dev<double> d, int mode) {
   for (int i = 0; i < 4; ++i) p[i] = mk<double>(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]);
   const Q4<double> q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
   const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
-  double *rec = reinterpret_cast<double *>(__builtin_assume_aligned(d.arec + (size_t)a * AREC, 16));
+  double *rec = srec + AREC_LD * threadIdx.x;
+  if (!jac)                                    // (a costed record carries p_G alone; the rest goes out as zeros, not as stale LDS)
+    for (int e = 0; e < AREC; ++e) rec[e] = 0.0;
   const double pix = d.a_obs[a], piy = d.a_obs[(size_t)d.Atot + a], d_inv = rho[m.lm0 + d.a_lm[a]];
   if (small) vis_anchor_eval<true>(q0, p, sc, ui, m.inv_dt, q_CI, p_CI, pix, piy, (double)rowi, d_inv, jac, rec);
   else vis_anchor_eval<false>(q0, p, sc, ui, m.inv_dt, q_CI, p_CI, pix, piy, (double)rowi, d_inv, jac, rec);
   d.a_s[a] = si;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);          // (one wave per workgroup: the wave's own LDS writes have completed)
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int lane = threadIdx.x;
+    double *dst = d.arec + (size_t)(blockIdx.x * 64) * AREC;
+    constexpr int HP = AREC / 2;                 // pairs per record
+#pragma unroll 5
+    for (int k = 0; k < HP; ++k) {               // 64 * HP pairs, 64 per store (cost-only records carry p_G alone: the rest is never read)
+      const int i = k * 64 + lane, bl = i / HP, r = 2 * (i - bl * HP);
+      VecN<double, 2> pr;
+      pr.v[0] = srec[AREC_LD * bl + r];
+      pr.v[1] = srec[AREC_LD * bl + r + 1];
+      if ((run_mask >> bl) & 1ull) *reinterpret_cast<VecN<double, 2> *>(dst + (size_t)bl * AREC + r) = pr;
+    }
+  }
 }
 
 // k_vis_eval<LIN> stages the records of its 64 blocks in LDS, block-major like the copy in HBM ([64][VT_LD]: this lane's block starts
@@ -1081,6 +1118,7 @@ struct VisNullSink {
 constexpr int VIS_LDS_BYTES = 64 * VT_LD * 8;   // the records of a wave's 64 blocks, afterwards the fp64 rows of W of the wave's landmarks
 __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, unsigned char *smt, long long *rowoff, int *rlm, int vblock) {
   const int v = vblock * 64 + threadIdx.x;
+  const long long t_entry = d.dbg ? clock64() : 0ll;
   constexpr int LDS_BYTES = VIS_LDS_BYTES;
   double *wcs = reinterpret_cast<double *>(smt);
   const bool at_cand = mode == LIN_SPEC;
@@ -1167,21 +1205,9 @@ __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, un
     // One wave per workgroup: LDS hand-overs only need the wave's own LDS operations to have completed.  (__syncthreads() also
     // waits for vmcnt(0), i.e. for the J~ and W stores in flight to be acknowledged -- ~5 us per barrier here, measured.)
 #define LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
+    long long *dbg = (d.dbg && vblock == 1000) ? d.dbg + 32 : nullptr;   // (profiling aid: clock stamps of one wave)
+    if (dbg && lane == 0) { dbg[-1] = t_entry; dbg[0] = clock64() + (long long)(c * 0); }
     LDS_SYNC();
-    // ---- the records go out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs
-    //      of entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
-    {
-      double *dst = d.Jt + (size_t)(vblock * 64) * VT_ROWS;
-      constexpr int HP = VT_ROWS / 2;            // pairs per block
-#pragma unroll 4
-      for (int k = 0; k < HP; ++k) {             // 64 * HP pairs, 64 per store
-        const int i = k * 64 + lane, bl = i / HP, r = 2 * (i - bl * HP);
-        VecN<double, 2> pr;
-        pr.v[0] = wcs[VT_LD * bl + r];
-        pr.v[1] = wcs[VT_LD * bl + r + 1];
-        if ((on_mask >> bl) & 1ull) *reinterpret_cast<VecN<double, 2> *>(dst + (size_t)bl * VT_ROWS + r) = pr;
-      }
-    }
     // ---- this lane's contributions to its landmark's row of W.  With jr = J~_rho (2) and n3 = A~^T jr (3): the columns of the block's own
     //      (j) end are jr^T J~_rot and -cp1[k] n3; the anchor end's are (sum over the anchor's blocks of n3)^T [GR | cp0 (x) I] -- formed
     //      once per anchor from the record; line delay, Hll, g_rho ride with that sum.
@@ -1203,11 +1229,17 @@ __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, un
       s6[4] = jr0 * jr0 + jr1 * jr1;
       s6[5] = jr0 * Jl[VB_RES] + jr1 * Jl[VB_RES + 1];
     }
-    // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave), anchor by anchor.  The buffer
-    //      becomes NR fp64 rows ([0, K6) knot columns, K6 line delay, K6 + 1 Hll, K6 + 2 g_rho); every lane adds the 24 values of its
-    //      own end into the row of its landmark (LDS atomics: the ends of different blocks may share knots), the head lane of every anchor
-    //      the anchor end's 24 + 3 from the segmented sum; NR landmarks per sweep; then the knot and line-delay columns of every row,
-    //      Hll and g_rho are written: W is complete when this kernel ends.
+    // the anchor record's GR and cp0 again (every lane asks for its own anchor's: same lines as during the evaluation; only the head
+    // lane of an anchor uses them) -- requested here, consumed after the copy-out below, which hides the round trip
+    double hg[40];
+    int ksi;
+    {
+      const double *rec = reinterpret_cast<const double *>(__builtin_assume_aligned(d.arec + (size_t)max(my_anc, 0) * AREC, 16));
+#pragma unroll
+      for (int e = 0; e < 40; ++e) hg[e] = rec[AR_GR + e];     // GR[12][3], cp0[4]: entries 3 .. 42
+      ksi = d.a_s[max(my_anc, 0)];
+    }
+    // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave), anchor by anchor.
     const int prev_lm = __shfl_up(my_lm, 1), prev_anc = __shfl_up(my_anc, 1);
     const bool head = on && (lane == 0 || prev_lm != my_lm), head_a = on && (lane == 0 || prev_anc != my_anc);
     const unsigned long long heads = __ballot(head), heads_a = __ballot(head_a);
@@ -1224,27 +1256,54 @@ __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, un
 #pragma unroll
       for (int cc = 0; cc < 6; ++cc) { const double o = __shfl_down(s6[cc], off); s6[cc] += take ? o : 0.0; }
     }
+    if (dbg && lane == 0) dbg[1] = clock64() + (long long)(s6[0] * 0);
+    // ---- the records go out block-major: the 64 x VT_ROWS entries of the wave's blocks are one contiguous region, written as pairs
+    //      of entries (16 bytes per lane, 1 KiB per store: under load a store costs ~100 cycles whatever its width, measured)
+    {
+      double *dst = d.Jt + (size_t)(vblock * 64) * VT_ROWS;
+      constexpr int HP = VT_ROWS / 2;            // pairs per block
+#pragma unroll 4
+      for (int k = 0; k < HP; ++k) {             // 64 * HP pairs, 64 per store
+        const int i = k * 64 + lane, bl = i / HP, r = 2 * (i - bl * HP);
+        VecN<double, 2> pr;
+        pr.v[0] = wcs[VT_LD * bl + r];
+        pr.v[1] = wcs[VT_LD * bl + r + 1];
+        if ((on_mask >> bl) & 1ull) *reinterpret_cast<VecN<double, 2> *>(dst + (size_t)bl * VT_ROWS + r) = pr;
+      }
+    }
+    if (dbg && lane == 0) dbg[2] = clock64();
+    // the anchor end's 24 columns from the segmented sum (used by the head lane of the anchor)
+    double wi[24];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int cc = 3 * k + b;
+        wi[cc] = s6[0] * hg[3 * cc] + s6[1] * hg[3 * cc + 1] + s6[2] * hg[3 * cc + 2];
+        wi[12 + cc] = hg[36 + k] * s6[b];
+      }
+    // The buffer becomes NR fp64 rows ([0, K6) knot columns, K6 line delay, K6 + 1 Hll, K6 + 2 g_rho); every lane adds the 24 values of
+    // its own end into the row of its landmark (LDS atomics: the ends of different blocks may share knots), the head lane of every
+    // anchor the anchor end's 24 + 3; NR landmarks per sweep; then the knot and line-delay columns of every row, Hll and g_rho are
+    // written: W is complete when this kernel ends.
     double *rows = reinterpret_cast<double *>(smt);
     const int RS = K6 + 3;                                             // odd row stride (K6 is even)
     const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / RS));
     if (head) { rowoff[ord] = W0 + (long long)my_lm * ldw; rlm[ord] = my_lm; }
-    LDS_SYNC();   // every lane has read its record
+    LDS_SYNC();   // every lane has read its record, the copy-out has read them all
     for (int c0 = 0; c0 < nlm; c0 += NR) {
       const int nr = min(NR, nlm - c0);
-      for (int i = lane; i < nr * RS; i += 64) rows[i] = 0.0;
+      for (int i = 2 * lane; i < nr * RS; i += 128) *reinterpret_cast<VecN<double, 2> *>(rows + i) = VecN<double, 2>{{0.0, 0.0}};   // (NR RS + 1 doubles fit)
       LDS_SYNC();
       if (on && ord >= c0 && ord < c0 + nr) {
         double *row = rows + (size_t)(ord - c0) * RS;
         if (head_a) {
-          const double *rec = d.arec + (size_t)my_anc * AREC;
-          const int ksi = d.a_s[my_anc];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-              const int cc = 3 * k + b;
-              atomicAdd(&row[6 * (ksi + k) + b], s6[0] * rec[AR_GR + 3 * cc] + s6[1] * rec[AR_GR + 3 * cc + 1] + s6[2] * rec[AR_GR + 3 * cc + 2]);
-              atomicAdd(&row[6 * (ksi + k) + 3 + b], rec[AR_CP0 + k] * s6[b]);
+              atomicAdd(&row[6 * (ksi + k) + b], wi[3 * k + b]);
+              atomicAdd(&row[6 * (ksi + k) + 3 + b], wi[12 + 3 * k + b]);
             }
           atomicAdd(&row[K6], s6[3]);
           atomicAdd(&row[K6 + 1], s6[4]);
@@ -1259,6 +1318,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, un
           }
       }
       LDS_SYNC();
+      if (dbg && lane == 0) dbg[3 + 2 * (c0 / NR)] = clock64();
       // write-out: the nr rows' knot columns as ONE flat list of 16-byte column pairs (K6 is even, a row starts on a 256-byte boundary),
       // 64 pairs per store instruction -- row by row it took three mostly empty stores per row, and under load a store costs ~100
       // cycles whatever its width.  The rows of a wave belong to one window: same K6.
@@ -1284,6 +1344,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, un
         }
       }
       LDS_SYNC();
+      if (dbg && lane == 0) { dbg[4 + 2 * (c0 / NR)] = clock64(); dbg[10] = nlm * 1000000ll; dbg[11] = NR * 1000; }
     }
 #undef LDS_SYNC
   }
@@ -1305,7 +1366,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   __shared__ long long rowoff[64];
   __shared__ int rlm[64];
   if ((int)blockIdx.x < d.Gtot) {
-    if (!general_only && imu_group_fast(d, blockIdx.x)) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, zero_mode);
+    if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, zero_mode);
   } else vis_eval_body(d, mode, smt, rowoff, rlm, blockIdx.x - d.Gtot);
 }
 
@@ -1861,19 +1922,26 @@ template <class T, int CH, bool LDSH, int NW = 8, bool STORE = false> __global__
       // 4 K-steps (8 blocks) per trip: the operand reads first, then the products -- one LDS latency per trip
       for (int v8 = start; v8 < end; v8 += 8) {
         T a[4][3], ldv[4], rv[4];
+        // (the usual item is one run that ends with the item: the columns past it were staged as zeros, nothing to mask)
+        const bool nomask = end == ncur && v8 + 8 <= CH;     // uniform
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int blk = v8 + 2 * s + bsel;
-          const bool in = blk < end;
           const int bc = min(blk, CH + 1);   // a valid LDS address even when past the run (value discarded)
 #pragma unroll
           for (int I = 0; I < 3; ++I) a[s][I] = Js[orow[I] + bc];
           ldv[s] = Js[ldrow + bc];
           rv[s] = Js[rrow + bc];
+        }
+        if (!nomask) {
 #pragma unroll
-          for (int I = 0; I < 3; ++I) a[s][I] = in ? a[s][I] : T(0);
-          ldv[s] = in ? ldv[s] : T(0);
-          rv[s] = in ? rv[s] : T(0);
+          for (int s = 0; s < 4; ++s) {
+            const bool in = v8 + 2 * s + bsel < end;
+#pragma unroll
+            for (int I = 0; I < 3; ++I) a[s][I] = in ? a[s][I] : T(0);
+            ldv[s] = in ? ldv[s] : T(0);
+            rv[s] = in ? rv[s] : T(0);
+          }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -2797,6 +2865,11 @@ template <int J> __device__ __forceinline__ void chol16_from(double (&v)[16], do
 }
 __device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
 
+// (A BLOCKED diagonal tile -- the 16 pivots in four blocks of four, at most three broadcast-and-FMA per pivot inside a block and the block's
+//  rank-4 update of the later columns, for the tile and for the inverse in the making, as two v_mfma_f64_16x16x4 -- was built and measured in
+//  round 4: 8.7 k cycles per tile against 8.3 k, the factorisation unchanged at 84 us.  The tile's time is not its row updates but the
+//  sixteen sequential pivots: readlane -> class test -> v_rsq_f64 -> two Newton steps -> scale -> readlane is ~300 dependent cycles each,
+//  211 of them per factorisation, whatever happens between them.  Not kept.)
 template <class T, int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_tiles(Dev<T> d) {
   constexpr int NT = 64 * NW, TS = 16 * 17;    // a 16 x 16 block in LDS: row stride 17
   const int w = blockIdx.x;
@@ -3308,11 +3381,13 @@ template <class T> __global__ __launch_bounds__(256) void k_residual_summary(Dev
 
 // ------------------------------------------------------------------------------------------------ trajectory query
 // Se3Spline::poseNs / transVelWorld / rotVelBody / transAccelWorld (se3_spline.h:361-399), fp64, one lane per query.
+// win_ids == nullptr: every query belongs to window w; otherwise query i belongs to window win_ids[i] (one launch for a whole batch).
 template <class T>
-__global__ void k_spline_eval(Dev<T> d, int w, int n, const long long *t_rel, double *pose7, double *vel3, double *omega3, double *acc3,
-                              int *err, SensorExt ext) {
+__global__ void k_spline_eval(Dev<T> d, int w, const int32_t *win_ids, int n, const long long *t_rel, double *pose7, double *vel3, double *omega3,
+                              double *acc3, int *err, SensorExt ext) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (win_ids) w = win_ids[i];
   const WinMeta &m = d.wins[w];
   const long long st = t_rel[i];
   const int s = (int)(st / m.dt_ns);

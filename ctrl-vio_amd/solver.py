@@ -246,6 +246,19 @@ class Solver:
         capi.check(self._lib.ctvio_spline_eval(self._h, wid, n, capi._p(t), capi._p(pose), capi._p(vel), capi._p(om), capi._p(acc)))
         return pose, vel, om, acc
 
+    def spline_eval_batch(self, win, t_ns, want=("pose", "vel", "omega")):
+        """Queries of any windows of the batch in one launch (ctvio_spline_eval_batch): query i = (window win[i], absolute time
+        t_ns[i]).  Returns (dict of the requested outputs, device milliseconds of the evaluation kernel alone)."""
+        t = np.ascontiguousarray(t_ns, np.int64); wi = np.ascontiguousarray(win, np.int32)
+        n = int(t.shape[0])
+        out = {"pose": np.zeros((n, 7)) if "pose" in want else None, "vel": np.zeros((n, 3)) if "vel" in want else None,
+               "omega": np.zeros((n, 3)) if "omega" in want else None, "acc": np.zeros((n, 3)) if "acc" in want else None}
+        ms = C.c_double()
+        ptr = lambda a: capi._p(a) if a is not None else None
+        capi.check(self._lib.ctvio_spline_eval_batch(self._h, C.c_int64(n), capi._p(wi), capi._p(t), ptr(out["pose"]), ptr(out["vel"]),
+                                                     ptr(out["omega"]), ptr(out["acc"]), C.cast(C.byref(ms), C.c_void_p)))
+        return {k: v for k, v in out.items() if v is not None}, float(ms.value)
+
     def sensor_pose(self, wid: int, t_ns, q_SI, p_SI):
         """Trajectory::GetSensorPose (reference src/spline/trajectory.cpp:39-56): poseNs(t) * T_StoI, evaluated on the device.
         q_SI = (x,y,z,w).  Returns (n,7) = (p, q)."""

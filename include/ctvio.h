@@ -185,6 +185,15 @@ int32_t ctvio_lm_step(ctvio_solver *s, int32_t id, double mu, double *delta, dou
 int32_t ctvio_spline_eval(ctvio_solver *s, int32_t id, int32_t n, const int64_t *t_ns, double *pose7, double *vel3,
                           double *omega3, double *acc3);
 
+/* The same queries for ANY windows of the batch in ONE launch (the per-row poses of rolling-shutter frames,
+ * 11 x 640 row times per window, for a whole batch): query i belongs to window win[i] (0 .. ctvio_num_windows - 1) at absolute time
+ * t_ns[i]; outputs in query order, laid out as in ctvio_spline_eval, any may be NULL.  Reference consumers: Se3Spline::poseNs /
+ * transVelWorld / rotVelBody (se3_spline.h:361-399), Trajectory::GetSensorPose (trajectory.cpp:39-56) called once per time.
+ * kernel_ms (may be NULL) receives the device time of the evaluation kernel alone (HIP events on the solver's stream); the call itself
+ * also pays for the H2D copy of the queries and the D2H copy of the results. */
+int32_t ctvio_spline_eval_batch(ctvio_solver *s, int64_t n, const int32_t *win, const int64_t *t_ns, double *pose7, double *vel3,
+                                double *omega3, double *acc3, double *kernel_ms);
+
 /* Sensor pose on the device: Trajectory::GetSensorPose (src/spline/trajectory.cpp:39-56; used for the camera by
  * visual_odometry.cpp:197-221): pose_S_to_G(t) = poseNs(t) * T_StoI with T_StoI = (q_SI = (x,y,z,w), p_SI).  pose7 as above.
  * A query outside [minTimeNs, maxTimeNs) is an error (the reference asserts). */

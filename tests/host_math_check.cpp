@@ -106,10 +106,9 @@ double visual_eval_t(const double *qi, const double *pi, const double *qj, const
 }  // namespace
 
 extern "C" {
-void hm_imu_eval(int fp32, const double *q, const double *p, double u, double idt, const double *g, const double *bias,
+void hm_imu_eval(const double *q, const double *p, double u, double idt, const double *g, const double *bias,
                  const double *gyro, const double *acc, const double *w, double *r, double *J) {
-  if (fp32) imu_eval_t<float>(q, p, u, idt, g, bias, gyro, acc, w, r, J);
-  else imu_eval_t<double>(q, p, u, idt, g, bias, gyro, acc, w, r, J);
+  imu_eval_t<double>(q, p, u, idt, g, bias, gyro, acc, w, r, J);
 }
 double hm_visual_eval(int small_angle, const double *qi, const double *pi, const double *qj, const double *pj, double ui, double uj,
                       double idt, const double *q_CI, const double *p_CI, double img_w, double cauchy_a, const double *obs,
@@ -117,23 +116,13 @@ double hm_visual_eval(int small_angle, const double *qi, const double *pi, const
   if (small_angle) return visual_eval_t<true>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
   return visual_eval_t<false>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
 }
-void hm_so3(int fp32, const double *phi, double *exp_q, double *Jr, double *JrInv, double *log_of_exp) {
-  if (fp32) {
-    V3<float> v = mk<float>((float)phi[0], (float)phi[1], (float)phi[2]);
-    Q4<float> q = so3_exp(v);
-    exp_q[0] = q.x; exp_q[1] = q.y; exp_q[2] = q.z; exp_q[3] = q.w;
-    M3<float> a = so3_Jr(v), b = so3_Jr_inv(v);
-    for (int i = 0; i < 9; ++i) { Jr[i] = a.m[i]; JrInv[i] = b.m[i]; }
-    V3<float> l = so3_log(q);
-    log_of_exp[0] = l.x; log_of_exp[1] = l.y; log_of_exp[2] = l.z;
-  } else {
-    V3<double> v = mk<double>(phi[0], phi[1], phi[2]);
-    Q4<double> q = so3_exp(v);
-    exp_q[0] = q.x; exp_q[1] = q.y; exp_q[2] = q.z; exp_q[3] = q.w;
-    M3<double> a = so3_Jr(v), b = so3_Jr_inv(v);
-    for (int i = 0; i < 9; ++i) { Jr[i] = a.m[i]; JrInv[i] = b.m[i]; }
-    V3<double> l = so3_log(q);
-    log_of_exp[0] = l.x; log_of_exp[1] = l.y; log_of_exp[2] = l.z;
-  }
+void hm_so3(const double *phi, double *exp_q, double *Jr, double *JrInv, double *log_of_exp) {
+  V3<double> v = mk<double>(phi[0], phi[1], phi[2]);
+  Q4<double> q = so3_exp(v);
+  exp_q[0] = q.x; exp_q[1] = q.y; exp_q[2] = q.z; exp_q[3] = q.w;
+  M3<double> a = so3_Jr(v), b = so3_Jr_inv(v);
+  for (int i = 0; i < 9; ++i) { Jr[i] = a.m[i]; JrInv[i] = b.m[i]; }
+  V3<double> l = so3_log(q);
+  log_of_exp[0] = l.x; log_of_exp[1] = l.y; log_of_exp[2] = l.z;
 }
 }

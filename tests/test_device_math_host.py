@@ -1,6 +1,5 @@
 """CPU: the device math headers (ctrl-vio_amd/csrc/so3.hpp, factors.hpp) compiled with g++ for the test
-only (tests/host_math_check.cpp) and compared block by block with the fp64 oracle.  fp64 instantiation
-must agree to rounding; the fp32 instantiation (what the product kernels run) to the stated tolerances."""
+only (tests/host_math_check.cpp) and compared block by block with the fp64 oracle (fp64 like the kernels: agreement to rounding)."""
 import ctypes as C
 import os
 import subprocess
@@ -32,13 +31,13 @@ def _d(x):
     return C.c_double(float(x))
 
 
-def _imu(hm, w, m, fp32):
+def _imu(hm, w, m):
     st = int(w.imu_t[m]) - w.t0_ns
     s, u = st // w.dt_ns, (st % w.dt_ns) / w.dt_ns
     q = np.ascontiguousarray(w.quat[s:s + 4]); p = np.ascontiguousarray(w.pos[s:s + 4])
     r = np.zeros(6); J = np.zeros((6, 30))
     b = np.ascontiguousarray(w.bias[w.imu_bias[m]])
-    hm.hm_imu_eval(int(fp32), _p(q), _p(p), _d(u), _d(1e9 / w.dt_ns), _p(w.gravity), _p(b),
+    hm.hm_imu_eval(_p(q), _p(p), _d(u), _d(1e9 / w.dt_ns), _p(w.gravity), _p(b),
                    _p(np.ascontiguousarray(w.imu_gyro[m])), _p(np.ascontiguousarray(w.imu_acc[m])), _p(w.imu_w), _p(r), _p(J))
     return r, J
 
@@ -64,15 +63,15 @@ def _corrected(w, r, J):
     return np.sqrt(rho1) * r, np.sqrt(rho1) * J, 0.5 * b2 * np.log1p(s / b2)
 
 
-@pytest.mark.parametrize("fp32,rtol", [(0, 1e-11), (1, 3e-5)])
-def test_imu_block_matches_oracle(cv, oracle, hm, fp32, rtol):
+def test_imu_block_matches_oracle(cv, oracle, hm):
+    rtol = 1e-11
     w = cv.synth.make_window("config1", seed=1003)
     o = oracle.OracleWindow(w)
     for m in range(0, w.M, 37):
         r0, J0, _ = o.imu_block(m)
-        r, J = _imu(hm, w, m, fp32)
+        r, J = _imu(hm, w, m)
         # whitened residuals are O(1e2) at the initial guess; compare on the scale of the block
-        assert np.abs(r - r0).max() <= rtol * max(np.abs(r0).max(), 1.0) * (20 if fp32 else 1)
+        assert np.abs(r - r0).max() <= rtol * max(np.abs(r0).max(), 1.0)
         assert np.abs(J - J0).max() <= rtol * np.abs(J0).max()
 
 
@@ -94,13 +93,13 @@ def test_visual_block_matches_oracle(cv, oracle, hm, small):
         assert cost == pytest.approx(cost0, rel=1e-10, abs=1e-12)
 
 
-@pytest.mark.parametrize("fp32,tol", [(0, 1e-13), (1, 2e-6)])
-def test_lie_primitives(oracle, hm, fp32, tol):
+def test_lie_primitives(oracle, hm):
+    tol = 1e-13
     rng = np.random.default_rng(5)
     for scale in (1e-7, 1e-4, 1e-2, 0.3, 0.99, 1.01, 2.5):
         phi = rng.normal(size=3); phi *= scale / np.linalg.norm(phi)
         q = np.zeros(4); Jr = np.zeros((3, 3)); Ji = np.zeros((3, 3)); lg = np.zeros(3)
-        hm.hm_so3(int(fp32), _p(phi), _p(q), _p(Jr), _p(Ji), _p(lg))
+        hm.hm_so3(_p(phi), _p(q), _p(Jr), _p(Ji), _p(lg))
         np.testing.assert_allclose(q, oracle.so3_exp(phi), atol=tol)
         np.testing.assert_allclose(Jr, oracle.so3_Jr(phi), atol=tol * 2)
         np.testing.assert_allclose(Ji, oracle.so3_Jr_inv(phi), atol=tol * 4)

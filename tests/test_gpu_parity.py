@@ -231,6 +231,36 @@ def test_spline_eval(cv, oracle, win_cfg1):
             s.spline_eval(0, np.array([w.max_time_ns()], np.int64))
 
 
+def test_spline_eval_batch_all_windows_one_launch(cv, oracle):
+    """ctvio_spline_eval_batch: queries of ANY windows of the batch in one launch (per-row poses of
+    rolling-shutter frames for a whole batch) -- a ragged batch (different K, dt, t0), interleaved window ids, against the oracle's
+    spline evaluation window by window and against the one-window entry; an out-of-range time or window id is an error."""
+    ws = [cv.synth.make_window("tiny", seed=21), cv.synth.make_window("config1", seed=1004), cv.synth.make_window("config3", seed=1005)]
+    ws[1].t0_ns = 1_000_000_007                       # (absolute times: every window has its own t0)
+    ws[1].imu_t = ws[1].imu_t + 1_000_000_007; ws[1].v_ti = ws[1].v_ti + 1_000_000_007; ws[1].v_tj = ws[1].v_tj + 1_000_000_007
+    rng = np.random.default_rng(4)
+    win = rng.integers(0, len(ws), 4000).astype(np.int32)
+    t = np.array([rng.integers(ws[i].t0_ns, ws[i].max_time_ns()) for i in win], np.int64)
+    with cv.Solver() as s:
+        s.set_windows([w.copy() for w in ws])
+        out, ms = s.spline_eval_batch(win, t, want=("pose", "vel", "omega", "acc"))
+        assert ms > 0.0
+        for i, w in enumerate(ws):
+            sel = np.flatnonzero(win == i)
+            ref = oracle.OracleWindow(w.copy()).spline_eval(t[sel])        # pose, vel, omega, acc
+            one = s.spline_eval(i, t[sel])
+            for k, key in enumerate(("pose", "vel", "omega", "acc")):
+                np.testing.assert_allclose(out[key][sel], ref[k], rtol=1e-12, atol=1e-11)
+                np.testing.assert_array_equal(out[key][sel], one[k])          # the same kernel body: bitwise
+        only, _ = s.spline_eval_batch(win[:10], t[:10], want=("omega",))
+        assert set(only) == {"omega"}
+        np.testing.assert_array_equal(only["omega"], out["omega"][:10])
+        with pytest.raises(cv.capi.CtvioError):
+            s.spline_eval_batch(np.array([0], np.int32), np.array([ws[0].max_time_ns()], np.int64))
+        with pytest.raises(cv.capi.CtvioError):
+            s.spline_eval_batch(np.array([3], np.int32), np.array([ws[0].t0_ns], np.int64))
+
+
 def test_sensor_pose(cv, oracle, win_cfg1):
     """ctvio_sensor_pose = Trajectory::GetSensorPose (trajectory.cpp:39-56): pose_I_to_G(t) * T_StoI, against the oracle's
     poseNs composed with the reference's camera extrinsic on the host (numpy, fp64)."""
@@ -571,6 +601,32 @@ def test_golden_edge_fixtures_through_the_hip_path(cv, oracle, golden_dir, name,
         assert dn[np.ix_(mask, mask)].max() < 2e-5 and dn[ld].max() < 1e-4
         gs = np.abs(d["g"]).max()
         assert np.abs(gg - d["g"])[mask].max() / gs < 1e-5 and abs(gg[ld] - d["g"][ld]) / abs(d["g"][ld]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["fd_config2_seed1000.npz", "fd_config3_seed1001.npz"])
+def test_bench_size_fd_fixtures_through_the_hip_path(cv, golden_dir, name):
+    """The device's normal equations at the BENCHMARKED sizes (config 2 = the headline shape, config 3 = rolling-shutter stress) straight
+    against the finite-difference fixtures of the independent NumPy restatement (make_golden.py bench_fd) -- not via the oracle;
+    tolerances = the finite-difference accuracy of the fixtures (tests/test_oracle_golden.py uses the same)."""
+    d = np.load(os.path.join(golden_dir, name))
+    w = cv.Window.from_dict(d, "w_")
+    P = w.P
+    with cv.Solver() as s:
+        s.set_windows([w.copy()])
+        Hg, Wg, Hllg, gg, costg = s.linearize(0)
+    assert costg == pytest.approx(float(d["cost"]), rel=1e-10)
+    scp = np.sqrt(np.maximum(np.diag(d["Hpp"]), 1e-30)); scl = np.sqrt(np.maximum(d["Hll"], 1e-30))
+    ld = P - 1
+    mask = np.ones(P, bool); mask[ld] = False
+    Hs = np.tril(Hg) + np.tril(Hg, -1).T                                  # (the device fills the lower triangle)
+    dpp = np.abs(Hs - d["Hpp"]) / np.outer(scp, scp)
+    dw = np.abs(Wg - d["W"]) / np.outer(scp, scl)
+    assert dpp[np.ix_(mask, mask)].max() < 2e-5 and dpp[ld].max() < 1e-4
+    assert dw[mask].max() < 2e-5 and dw[ld].max() < 1e-4
+    assert np.abs(Hllg / d["Hll"] - 1).max() < 2e-5
+    gs = np.abs(d["g"]).max()
+    gm = np.ones(w.N, bool); gm[ld] = False
+    assert np.abs(gg - d["g"])[gm].max() / gs < 1e-5 and abs(gg[ld] - d["g"][ld]) / abs(d["g"][ld]) < 1e-4
 
 
 def test_config5_large_window_vs_oracle(cv, oracle):

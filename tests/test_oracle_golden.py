@@ -168,3 +168,27 @@ def test_per_block_cauchy_and_knot_mask_in_the_oracle(cv, oracle):
     oracle.OracleWindow(wn).solve(15)
     assert np.array_equal(wn.quat[[1, 4]], q0[[1, 4]]) and np.array_equal(wn.pos[[1, 4]], p0[[1, 4]])
     assert np.abs(wn.quat[[0, 2, 3]] - q0[[0, 2, 3]]).max() > 0
+
+
+@pytest.mark.parametrize("name", ["fd_config2_seed1000.npz", "fd_config3_seed1001.npz"])
+def test_dense_normal_equations_at_the_benchmarked_sizes(cv, oracle, golden_dir, name):
+    """The same comparison at the sizes bench.py measures -- a config-2 window (10 KF / 200 landmarks / 2000 IMU, the headline) and a
+    config-3 window (300 landmarks, rolling-shutter stress): the oracle's analytic H = [Hpp W; W^T diag(Hll)], g and cost against the
+    finite-difference fixture of the independent NumPy restatement (tests/golden/make_golden.py bench_fd)."""
+    w, d = _load(cv, golden_dir, name)
+    H, g, cost = oracle.OracleWindow(w).build_normal()
+    P = w.P
+    assert cost == pytest.approx(float(d["cost"]), rel=1e-10)
+    off = H[P:, P:] - np.diag(np.diag(H[P:, P:]))
+    assert np.abs(off).max() == 0.0                                       # landmarks do not couple
+    scp = np.sqrt(np.maximum(np.diag(d["Hpp"]), 1e-30)); scl = np.sqrt(np.maximum(d["Hll"], 1e-30))
+    ld = P - 1
+    mask = np.ones(P, bool); mask[ld] = False
+    dpp = np.abs(H[:P, :P] - d["Hpp"]) / np.outer(scp, scp)
+    dw = np.abs(H[:P, P:] - d["W"]) / np.outer(scp, scl)
+    assert dpp[np.ix_(mask, mask)].max() < 2e-5 and dpp[ld].max() < 1e-4
+    assert dw[mask].max() < 2e-5 and dw[ld].max() < 1e-4
+    assert np.abs(np.diag(H)[P:] / d["Hll"] - 1).max() < 2e-5
+    gs = np.abs(d["g"]).max()
+    gm = np.ones(w.N, bool); gm[ld] = False
+    assert np.abs(g - d["g"])[gm].max() / gs < 1e-5 and abs(g[ld] - d["g"][ld]) / abs(d["g"][ld]) < 1e-4
