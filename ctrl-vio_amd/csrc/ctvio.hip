@@ -666,6 +666,7 @@ template <class T> class SolverImpl : public SolverBase {
     if (!opt_.use_mfma || store_path() || !all_windows_have_imu_ || std::getenv("CTVIO_ZERO_KERNEL")) return 0;
     return vis_parts() == 1 ? 1 : 2;
   }
+  static int imu_walk_waves() { static const int n = std::getenv("CTVIO_IMU_WAVES") ? std::max(1, std::atoi(std::getenv("CTVIO_IMU_WAVES"))) : 2048; return n; }
   int imu_general_only() const { static const int env = std::getenv("CTVIO_IMU_GENERAL") ? 1 : 0; return (env || opt_.use_mfma == 2) ? 1 : 0; }
   void launch_linearize_merged(int mode);
   void launch_assemble_vis_lds(int parts, int mode);
@@ -1227,7 +1228,8 @@ template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) 
   const Dev<double> &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
   if (opt_.use_mfma) {
-    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(d.Gtot), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
+    // (at most 2048 waves -- two rounds of one wave per SIMD -- each walking its share of the groups with the next group's data in flight)
+    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(std::min(d.Gtot, imu_walk_waves())), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
     hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
   }
   else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);

@@ -1,14 +1,13 @@
-// factors.hpp -- per-residual-block device evaluation (residual + analytic Jacobian), templated on
-// the scalar.  Knots are addressed by global index: the 4 active control points of an evaluation at
-// time t are knots s..s+3 with s = (t - t0)/dt, so the reference's SplineMeta / parameter-pointer
-// bookkeeping (src/spline/spline_segment.h:131-191, trajectory_estimator.cpp:114-141) disappears.
+// factors.hpp -- per-residual-block device evaluation (residual + analytic Jacobian), fp64.  Knots are addressed by global index:
+// the 4 active control points of an evaluation at time t are knots s..s+3 with s = (t - t0)/dt, so the reference's SplineMeta /
+// parameter-pointer bookkeeping (src/spline/spline_segment.h:131-191, trajectory_estimator.cpp:114-141) disappears.
 //
-//   imu_eval     SplitSpineView::Evaluate (split_spline_view.h:67-214) fused with
-//                IMUFactor::Evaluate (trajectory_value_factor.h:141-248)
-//   visual_eval  ImageFeatureDelayFactor::Evaluate (image_feature_factor.h:63-269) with
-//                So3SplineView::EvaluateRp/EvaluateRTp/VelocityBody (so3_spline_view.h:136-276,356-411),
-//                RdSplineView::evaluate (rd_spline_view.h:63-94) and ceres::CauchyLoss + Corrector
-//                (restated in the reference at marginalization_factor.cpp:39-67)
+//   imu_eval*                         SplitSpineView::Evaluate (split_spline_view.h:67-214) fused with IMUFactor::Evaluate
+//                                     (trajectory_value_factor.h:141-248): general form and the product kernel's staged form
+//   vis_anchor_eval / vis_block_eval  ImageFeatureDelayFactor::Evaluate (image_feature_factor.h:63-269) with So3SplineView::EvaluateRp /
+//                                     EvaluateRTp / VelocityBody (so3_spline_view.h:136-276,356-411), RdSplineView::evaluate
+//                                     (rd_spline_view.h:63-94) and ceres::CauchyLoss + Corrector (restated in the reference at
+//                                     marginalization_factor.cpp:39-67), factored through the anchor end
 #pragma once
 #include "so3.hpp"
 
@@ -26,10 +25,10 @@ template <class T> struct SegConst {
   CTV_DI M3<T> jri(int i) const { return JrI[i]; }
 };
 // The same with Jr^-1(d_i) left in the per-window table (k_knot_prep) and fetched where it is used: the 27 values per knot
-// group are not held in registers across the whole block evaluation (fp64: 54 VGPRs per spline end).
-template <class T, class TJ> struct SegConstLazy {
+// group are not held in registers across the whole block evaluation (54 VGPRs per spline end).
+template <class T> struct SegConstLazy {
   V3<T> d[3];
-  const TJ *tab;   // [3][9]
+  const T *tab;   // [3][9]
   CTV_DI M3<T> jri(int i) const {
     M3<T> J;
 #pragma unroll
@@ -44,7 +43,7 @@ template <class T> struct SegConstS {
   M3<T> JrI[3];
   CTV_DI const M3<T> &jri(int i) const { return JrI[i]; }
 };
-template <class T, class TJ> CTV_DI void seg_const_lazy(const double *kd, const TJ *kjri, SegConstLazy<T, TJ> &sc) {
+template <class T> CTV_DI void seg_const_lazy(const double *kd, const T *kjri, SegConstLazy<T> &sc) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) sc.d[i] = mk<T>((T)kd[3 * i], (T)kd[3 * i + 1], (T)kd[3 * i + 2]);
   sc.tab = kjri;
@@ -57,10 +56,9 @@ template <class T> CTV_DI void seg_const(const Knots4<T> &k, SegConst<T> &sc, bo
   }
 }
 
-// The same from the per-window tables k_knot_prep fills once per state (d of every consecutive knot pair in fp64,
-// Jr^-1(d) in T): the per-pair quantities do not depend on the residual block, so they are hoisted out of the
-// per-block evaluation (the reference recomputes them inside every factor, so3_spline_view.h:160-166).
-// One table entry: d = log(q_a^-1 q_b) in fp64 and Jr^-1(d) evaluated in TJ from the rounded d.
+// The same from the per-window tables k_knot_prep fills once per state (d of every consecutive knot pair and Jr^-1(d)): the per-pair
+// quantities do not depend on the residual block, so they are hoisted out of the per-block evaluation (the reference recomputes
+// them inside every factor, so3_spline_view.h:160-166).  One table entry: d = log(q_a^-1 q_b) and Jr^-1(d).
 template <class TJ> CTV_DI void knot_pair_const(const double *qa, const double *qb, double *d3, TJ *jri9) {
   const V3<double> dd = so3_log(qmul(qconj(qmk<double>(qa[0], qa[1], qa[2], qa[3])), qmk<double>(qb[0], qb[1], qb[2], qb[3])));
   d3[0] = dd.x; d3[1] = dd.y; d3[2] = dd.z;
@@ -86,10 +84,10 @@ template <class T, class TJ> CTV_DI void seg_const_load(const double *kd, const 
 // Sink::put_col(col, v[6]) receives every column of J (all 6 rows, structural zeros included);
 // r[6] is returned whitened.
 //
-// Local frame (fp32 accuracy): the caller passes the knots expressed relative to a reference knot,
+// Local frame (general form only): the caller passes the knots expressed relative to a reference knot,
 // q'_k = q_ref^-1 q_k, p'_k = R_ref^T (p_k - p_ref), and gravity as R_ref^T g.  Residuals are invariant under this
 // change of gauge and right-perturbation rotation Jacobians are unchanged; only the position Jacobians need
-// J_p = J_p' R_ref^T (RrefT).  Rotations near identity keep ~10x more significant digits in fp32.
+// J_p = J_p' R_ref^T (RrefT).  (The staged form of the product kernel works in the global frame.)
 // Jacobian of one IMU block in factored form: the 6 x 30 matrix is w .* [Jw | 0 | I3 | 0 ; Ja | lamA (x) Rinv_g | 0 | I3]
 // (trajectory_value_factor.h:198-245).  Consumers read it column by column (imu_emit_cols) or row by row (imu_row_*).
 template <class T> struct ImuJac {

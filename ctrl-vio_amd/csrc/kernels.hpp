@@ -39,6 +39,14 @@ __device__ __forceinline__ bool lin_cost_only(const Lm &lm, int mode, const LmPa
 }
 __device__ __forceinline__ int lin_target(const Lm &lm, int mode) { return mode == LIN_SPEC ? 1 - lm.cur : lm.cur; }
 
+// a lane's double as a wave-uniform value (two v_readlane_b32)
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // local column -> unknown index maps
 __device__ __forceinline__ int imu_col(int c, int s, int K, int bias) {
   if (c < 12) return 6 * (s + c / 3) + c % 3;
@@ -536,7 +544,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev<double> &d, int
   lf.init(s_quat, s_pos, m.knot0 + grp.s);
   lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
   const M3<double> RrefT = lf.RrefT();
-  SegConstLazy<double, double> sc;   // Jr^-1 of the three knot pairs: fetched from the table where it is used
+  SegConstLazy<double> sc;   // Jr^-1 of the three knot pairs: fetched from the table where it is used
   seg_const_lazy(d.lkd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc);
   double bias[6], wgt[6];
   const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
@@ -710,63 +718,75 @@ __device__ __forceinline__ bool imu_fast_pred(const double kd[9], const double *
 //   * the next pass's measurements requested before the current pass is evaluated.
 // (fp64 MFMA and fp64 VALU instructions share one datapath on gfx950 -- tools/mfma_valu_overlap.hip: one wave's MFMAs and FMAs add up,
 //  two waves on a SIMD do not overlap them either -- so the kernel's time is the SUM of its vector and matrix work: both are cut here.)
-__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [72][33] + 64 */, int gidx, int zero_mode) {
-  const ImuGroup grp = d.groups[gidx];
-  const int w = grp.win;
-  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
+// A wave WALKS its groups g0, g0 + stride, ... (k_imu_linearize_f64: 2048 waves for the whole batch) and everything the NEXT group's
+// record locates -- pair logs and Jr^-1, first knot's rotation, knot positions, bias, gravity, weights, 1 / dt, the window's LM flags, one
+// element per lane -- is requested while the CURRENT group is evaluated, and the record after that is on its way as well; the next group's
+// first 64 samples are requested by the current group's last pass.  A group's own prologue (three dependent round trips group -> window ->
+// data at one wave per SIMD: ~10 k of a group's 55 k cycles, measured) shrinks to a few dozen v_readlane.
+struct ImuPre { double pc, kq; int fl; };
+__device__ __forceinline__ void imu_prefetch(const Dev<double> &d, int mode, const ImuGroup &g, int lane, ImuPre &o) {
   const bool at_cand = mode == LIN_SPEC;
   const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
-  auto uni = [](double x) {   // a wave-uniform value the compiler cannot prove uniform -> scalar registers
-    const long long b = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-  };
-  // ---- everything the group record alone locates is requested first (clock stamps: the prologue was 10 k of a group's 55 k cycles, three
-  //      dependent round trips group -> window -> data; the window's record and LM state now travel in parallel with the data)
-  const int k0g = grp.kabs;
+  const WinMeta &m = d.wins[g.win];
+  const Lm &lm = d.lm[g.win];
+  const double *kd = d.lkd + 3 * g.kabs, *kj = d.kjri + 9 * g.kabs;
+  const double *q = s_quat + 4 * g.kabs, *pp = s_pos + 3 * g.kabs, *bp = s_bias + 6 * g.babs;
+  // pc: lanes 0..8 the pair logs, 9..35 Jr^-1 (row major per pair)
+  o.pc = *(lane < 9 ? kd + lane : kj + (min(lane, 35) - 9));
+  // kq: 0..3 q_0 | 4..15 the four knot positions | 21..23 gravity | 24..29 bias | 30..35 weights | 36 1 / dt   (unconditional loads on valid addresses)
+  const double *src = lane < 4 ? q + lane : lane < 16 ? pp + (lane - 4) : lane < 21 ? q : lane < 24 ? m.gravity + (lane - 21)
+                      : lane < 30 ? bp + (lane - 24) : lane < 36 ? m.imu_w + (lane - 30) : &m.inv_dt;
+  o.kq = *src;
+  // fl: lanes 0..3 the window's LM flags (not written by any linearisation kernel)
+  const int32_t *fp = lane == 0 ? &lm.status : lane == 1 ? &lm.step_valid : lane == 2 ? &lm.iter : &lm.ls_active;
+  o.fl = *fp;
+}
+__device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int mode, double *A /* LDS [72][33] + 64 */, int g0, int stride, int zero_mode) {
+  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const size_t Mt = (size_t)d.Mtot;
-  const int base = grp.iabs;
+  int gidx = g0;
+  ImuGroup grp = d.groups[gidx];
+  ImuPre cur;
+  imu_prefetch(d, mode, grp, lane, cur);                 // (the walk's first group: its round trips are exposed once)
   double gyn[3], acn[3], un;   // the next pass's measurements, in flight while the current pass is evaluated
   {
-    const int idx = base + min(lane, grp.count - 1);
+    const int idx = grp.iabs + min(lane, grp.count - 1);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
     un = d.imu_u[idx];
   }
-  double gcv = 0.0;   // this lane's entry of the LDS constants (below)
-  {
-    const double *q = s_quat + 4 * k0g, *p = s_pos + 3 * k0g, *bp = s_bias + 6 * grp.babs;
-    const M3<double> R0 = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
-    if (lane < 12) gcv = p[lane] - p[lane % 3];
-    else if (lane < 21) {   // R_0^T, row major (a select chain: no dynamically indexed register array)
-      const int e = lane - 12, src = 3 * (e % 3) + e / 3;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) gcv = src == i ? R0.m[i] : gcv;
-    }
-    else if (lane >= 24 && lane < 30) gcv = bp[lane - 24];
-  }
+  bool has_next = gidx + stride < d.Gtot;
+  ImuGroup grpn = d.groups[has_next ? gidx + stride : gidx];
+  for (;;) {
+  // ---- the group after the next one's record and the next one's constants: on their way during this group
+  const bool has_next2 = has_next && gidx + 2 * stride < d.Gtot;
+  const ImuGroup grpn2 = d.groups[has_next2 ? gidx + 2 * stride : gidx];
+  ImuPre nxt;
+  imu_prefetch(d, mode, grpn, lane, nxt);
+  bool nmeas = false;          // the next group's first pass has been requested (by this group's last pass)
+  do {
+  const int w = grp.win;
+  const int base = grp.iabs;
   // the group's constants: knot-pair logs and Jr^-1 (used a dozen times per pass) in scalar registers, the rest (used once or twice per
   // pass) in LDS behind the row buffer -- [0..11] knot positions relative to knot 0, [12..20] R_0^T, [21..23] gravity, [24..29] bias,
   // [30..35] weights.  (All of them in scalar registers overflow the SGPR file: 250 v_readlane per pass to fetch them back.)
   SegConstS<double> sc;
-  {
-    const double *kd = d.lkd + 3 * k0g, *kj = d.kjri + 9 * k0g;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      sc.d[i] = mk<double>(uni(kd[3 * i]), uni(kd[3 * i + 1]), uni(kd[3 * i + 2]));
+  for (int i = 0; i < 3; ++i) {
+    sc.d[i] = mk<double>(readlane_d(cur.pc, 3 * i), readlane_d(cur.pc, 3 * i + 1), readlane_d(cur.pc, 3 * i + 2));
 #pragma unroll
-      for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = uni(kj[9 * i + e]);
-    }
+    for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = readlane_d(cur.pc, 9 + 9 * i + e);
   }
-  // ---- the window: LM state and record
-  if (!lin_run(d.lm[w], mode)) return;
-  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);   // (uniform) the last allowed iteration only costs its candidate
-  const WinMeta &m = d.wins[w];
-  // is this group the fast body's?  (imu_group_fast, decided HERE from the pair logs already in registers and the window record already on
-  // its way: asked up front by the kernel it was a dependent chain group -> window -> pair table in front of everything else)
+  // ---- the window: LM state
+  const int f_status = __builtin_amdgcn_readlane(cur.fl, 0), f_valid = __builtin_amdgcn_readlane(cur.fl, 1), f_iter = __builtin_amdgcn_readlane(cur.fl, 2),
+            f_ls = __builtin_amdgcn_readlane(cur.fl, 3);
+  if (!(f_status == 0 && (mode != LIN_SPEC || f_valid != 0))) break;                                   // lin_run
+  const bool jac = !(mode == COST_AT_X || (mode == LIN_SPEC && f_iter >= d.prm.max_iters && f_ls == 0));   // lin_cost_only: (uniform) the last allowed iteration only costs its candidate
+  // is this group the fast body's?  (imu_group_fast, decided HERE from the pair logs and the weights already in registers)
   {
     const double kd9[9] = {sc.d[0].x, sc.d[0].y, sc.d[0].z, sc.d[1].x, sc.d[1].y, sc.d[1].z, sc.d[2].x, sc.d[2].y, sc.d[2].z};
-    if (!imu_fast_pred(kd9, m.imu_w)) return;   // (uniform) left to k_imu_linearize_rest
+    const double w6[6] = {0.0, 0.0, 0.0, readlane_d(cur.kq, 33), readlane_d(cur.kq, 34), readlane_d(cur.kq, 35)};
+    if (!imu_fast_pred(kd9, w6)) break;   // (uniform) left to k_imu_linearize_rest
   }
   long long *dbg = (d.dbg && gidx == 5000 && jac) ? d.dbg + 64 : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of lane 0 at the phase boundaries
   int dbi = 0;
@@ -774,14 +794,21 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   CTV_ISTAMP(0.0);
   double *gc = A + 72 * 33;   // (8 spare rows behind the 64: the chains' last prefetch)
   {
-    if (lane >= 21 && lane < 24) gcv = m.gravity[lane - 21];
-    else if (lane >= 30 && lane < 36) gcv = m.imu_w[lane - 30];
+    double gcv = cur.kq;      // lanes 21..35: gravity, bias, weights as requested
+    const M3<double> R0 = q2R(qmk<double>(readlane_d(cur.kq, 0), readlane_d(cur.kq, 1), readlane_d(cur.kq, 2), readlane_d(cur.kq, 3)));
+    const double pk = __shfl(cur.kq, 4 + min(lane, 11)), p0 = __shfl(cur.kq, 4 + min(lane, 11) % 3);
+    if (lane < 12) gcv = pk - p0;
+    else if (lane < 21) {   // R_0^T, row major (a select chain: no dynamically indexed register array)
+      const int e = lane - 12, src = 3 * (e % 3) + e / 3;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gcv = src == i ? R0.m[i] : gcv;
+    }
     __builtin_amdgcn_wave_barrier();
     if (lane < 36) gc[lane] = gcv;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
-  const double idt = m.inv_dt;
+  const double idt = readlane_d(cur.kq, 36);
   double csum = 0.0;
   if (!jac) {   // residuals only
     for (int c0 = 0; c0 < grp.count; c0 += 64) {
@@ -800,7 +827,7 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
     if (lane == 0) d.imu_cost[gidx] = csum;
-    return;
+    break;
   }
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   double spp[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -813,7 +840,10 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
     for (int i = 0; i < 3; ++i) { gy[i] = gyn[i]; ac[i] = acn[i]; }
     const double u = un;
     {
-      const int idx = base + min(c0 + 64 + lane, grp.count - 1);   // (clamped: the last pass re-reads a valid sample and drops it)
+      // the next pass's samples -- after the group's last pass the NEXT GROUP's first ones (without one, a valid sample that is dropped)
+      const bool last = c0 + 64 >= grp.count;
+      const int idx = (last && has_next) ? grpn.iabs + min(lane, grpn.count - 1) : base + min(c0 + 64 + lane, grp.count - 1);
+      nmeas = last;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
       un = d.imu_u[idx];
@@ -929,6 +959,21 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev<double> &d, int
   imu_zero_share(d, mode, grp, gidx, zero_mode);
   CTV_ISTAMP(0.0);
 #undef CTV_ISTAMP
+  } while (false);
+  // ---- on to the wave's next group
+  if (!has_next) break;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();          // (the tile copy-out has read the LDS buffer before the next group writes its constants)
+  if (!nmeas) {                             // this group left early: the next one's first pass has not been asked for yet
+    const int idx = grpn.iabs + min(lane, grpn.count - 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gyn[i] = d.imu_meas[(size_t)i * Mt + idx]; acn[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
+    un = d.imu_u[idx];
+  }
+  gidx += stride;
+  grp = grpn; grpn = grpn2; cur = nxt;
+  has_next = has_next2;
+  }
 }
 
 // One wave per SIMD: the evaluation needs ~430 fp64-pair registers; with a 512-register budget the overflow lives in AGPRs.
@@ -948,7 +993,7 @@ __device__ __forceinline__ bool imu_group_fast(const Dev<double> &d, int gidx) {
 // (general_only: every group through the general body -- ctvio_options.use_mfma = 2 / CTVIO_IMU_GENERAL=1, the tests' way into it)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_f64(Dev<double> d, int mode, int general_only, int zero_mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x, zero_mode);   // (returns at once when the group is not its own)
+  if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x, gridDim.x, zero_mode);   // (skips the groups that are not its own)
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev<double> d, int mode, int general_only, int zero_mode) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
@@ -1062,7 +1107,7 @@ __global__ __launch_bounds__(64) void k_vis_anchor(Dev<double> d, int mode) {
   const int rowi = d.a_row[a];
   vis_times(m, d.a_t[a], rowi, ldp[w], si, ui);
   si = max(0, min(si, m.K - 4));   // host validated the worst case; clamp keeps loads in range regardless
-  SegConstLazy<double, double> sc;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+  SegConstLazy<double> sc;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
   seg_const_lazy(d.lkd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sc);
   double dmax = 0.0;
 #pragma unroll
@@ -1139,7 +1184,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev<double> &d, int mode, un
       const int rowj = d.v_rowj[v];
       vis_times(m, d.v_tj[v], rowj, ldp[w], sj, uj);
       sj = max(0, min(sj, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
-      SegConstLazy<double, double> scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+      SegConstLazy<double> scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
       seg_const_lazy(d.lkd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
       // The usual wave: every knot-pair log of its blocks below 0.5 rad -> series-only evaluation (uniform choice: a ballot over the
       // running lanes); otherwise the general form.  Global frame, absolute positions (fp64).
@@ -1366,7 +1411,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   __shared__ long long rowoff[64];
   __shared__ int rlm[64];
   if ((int)blockIdx.x < d.Gtot) {
-    if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, zero_mode);
+    if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, d.Gtot, zero_mode);   // (one group per wave here)
   } else vis_eval_body(d, mode, smt, rowoff, rlm, blockIdx.x - d.Gtot);
 }
 
@@ -2516,13 +2561,6 @@ template <class T> __global__ __launch_bounds__(256) void k_rhs(Dev<T> d) {
     const double s = part[0][li] + part[1][li] + part[2][li] + part[3][li];
     d.rhs[m.p0 + i] = d.active[m.u0 + i] ? s - d.gS[d.lm[w].cur][m.u0 + i] : 0.0;
   }
-}
-
-__device__ __forceinline__ double readlane_d(double x, int lane) {
-  const long long b = __double_as_longlong(x);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // Dense fp64 Cholesky of the P x P reduced system + solve, one workgroup (4 waves) per window, right-looking with

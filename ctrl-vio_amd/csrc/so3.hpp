@@ -1,13 +1,15 @@
-// so3.hpp -- device-side SO(3) / small fixed-size algebra for gfx950, templated on the scalar.
+// so3.hpp -- device-side SO(3) / small fixed-size algebra for gfx950 (fp64: the small vector / matrix types are templates, every
+// instantiation is double).
 //
 // Conventions follow the reference (quaternion storage x,y,z,w; right perturbation R*exp(d)):
 //   exp/log          src/sophus_lib/so3.hpp:534-569 / 220-262
 //   Jr / Jr^-1       src/utils/sophus_utils.hpp:166-199 / 210-242
 //   q*q renormalise  src/sophus_lib/so3.hpp:338-355
-// T = double reproduces the reference's branches and thresholds (eps 1e-10).  T = float keeps the
-// same functions but evaluates the cancellation-prone coefficients ((1-cos)/t^2, (t-sin)/t^3,
-// 1/t^2-(1+cos)/(2 t sin)) by half-angle identities / Taylor series below |t| < 1, because the
-// reference's closed forms lose all fp32 digits at the ~1e-2 rad knot-to-knot rotations seen here.
+// The same FUNCTIONS as the reference's, not the same branches: below |phi| = 0.5 rad (every knot-to-knot rotation of a usable
+// spline) exp, Jr and Jr^-1 are evaluated by their Taylor series (truncation below 1e-17: the closed forms (1 - cos t) / t^2,
+// (t - sin t) / t^3, 1 / t^2 - (1 + cos t) / (2 t sin t) lose ~1e-16 / t^2 to cancellation there and need sqrt / sin / cos), above it
+// by the reference's closed forms; log keeps the reference's atan form and its 1e-10 thresholds.  tests/test_properties.py checks the
+// identities and the continuity at the switch on this very header compiled for the host.
 #pragma once
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -107,21 +109,7 @@ template <class T> CTV_DI M3<T> q2R(Q4<T> q) {
   return R;
 }
 
-// ---- transcendental wrappers
-CTV_DI float t_sin(float x) { return sinf(x); }
-CTV_DI double t_sin(double x) { return sin(x); }
-CTV_DI float t_cos(float x) { return cosf(x); }
-CTV_DI double t_cos(double x) { return cos(x); }
-CTV_DI float t_atan(float x) { return atanf(x); }
-CTV_DI double t_atan(double x) { return atan(x); }
-CTV_DI float t_sqrt(float x) { return sqrtf(x); }
-CTV_DI double t_sqrt(double x) { return sqrt(x); }
-CTV_DI float t_log1p(float x) { return log1pf(x); }
-CTV_DI double t_log1p(double x) { return log1p(x); }
-CTV_DI float t_abs(float x) { return fabsf(x); }
-CTV_DI double t_abs(double x) { return fabs(x); }
-
-// ---- exp: so3.hpp:534-569 (series branch below eps; fp32 switches to the series earlier)
+// ---- exp: so3.hpp:534-569
 CTV_DI Q4<double> so3_exp(V3<double> w) {
   const double th2 = dot(w, w);
   double im, re;
@@ -140,22 +128,6 @@ CTV_DI Q4<double> so3_exp(V3<double> w) {
   }
   return qmk<double>(im * w.x, im * w.y, im * w.z, re);
 }
-CTV_DI Q4<float> so3_exp(V3<float> w) {
-  const float th2 = dot(w, w);
-  float im, re;
-  if (th2 < 0.25f) {
-    // |theta| < 0.5 (always the case for lambda * d between neighbouring knots): Taylor series in h^2 = (theta/2)^2,
-    // truncation < 3e-19 -- no range reduction, ~10 FMAs instead of sinf + cosf
-    const float h2 = 0.25f * th2;
-    im = 0.5f * (1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f + h2 * (1.0f / 362880.0f)))));
-    re = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f + h2 * (1.0f / 40320.0f))));
-  } else {
-    const float th = sqrtf(th2);
-    im = sinf(0.5f * th) / th;
-    re = cosf(0.5f * th);
-  }
-  return qmk<float>(im * w.x, im * w.y, im * w.z, re);
-}
 
 // ---- log: so3.hpp:220-262 (atan form)
 CTV_DI V3<double> so3_log(Q4<double> q) {
@@ -165,20 +137,6 @@ CTV_DI V3<double> so3_log(Q4<double> q) {
   else if (fabs(w) < 1e-10) f = (w > 0 ? 3.14159265358979323846 : -3.14159265358979323846) / n;
   else f = 2.0 * atan(n / w) / n;
   return mk<double>(f * q.x, f * q.y, f * q.z);
-}
-CTV_DI V3<float> so3_log(Q4<float> q) {
-  const float n2 = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
-  float f;
-  if (n2 < 0.04f * w * w) {              // |log| < ~0.4 rad: atan(x)/x = 1 - x^2/3 + x^4/5 - ... (x = n/w), truncation < 3e-10
-    const float x2 = n2 / (w * w);
-    f = (2.0f / w) * (1.0f + x2 * (-1.0f / 3.0f + x2 * (0.2f + x2 * (-1.0f / 7.0f + x2 * (1.0f / 9.0f + x2 * (-1.0f / 11.0f))))));
-  } else if (fabsf(w) < 1e-5f) {
-    f = (w > 0 ? 3.14159265f : -3.14159265f) / sqrtf(n2);
-  } else {
-    const float n = sqrtf(n2);
-    f = 2.0f * atanf(n / w) / n;
-  }
-  return mk<float>(f * q.x, f * q.y, f * q.z);
 }
 
 // ---- Jr: I - a*hat + b*hat^2,  a = (1-cos t)/t^2, b = (t - sin t)/t^3   (sophus_utils.hpp:166-199)
@@ -191,17 +149,6 @@ CTV_DI void jr_coeffs(double n2, double &a, double &b) {
     b = 1.0 / 6.0 + n2 * (-1.0 / 120.0 + n2 * (1.0 / 5040.0 + n2 * (-1.0 / 362880.0 + n2 * (1.0 / 39916800.0 + n2 * (-1.0 / 6227020800.0 +
         n2 * (1.0 / 1307674368000.0 + n2 * (-1.0 / 355687428096000.0)))))));
   } else { const double n = sqrt(n2); a = (1 - cos(n)) / n2; b = (n - sin(n)) / (n2 * n); }
-}
-CTV_DI void jr_coeffs(float n2, float &a, float &b) {
-  if (n2 < 1.0f) {
-    // a = 1/2 - t^2/24 + t^4/720 - t^6/40320 + t^8/3628800 ; b = 1/6 - t^2/120 + t^4/5040 - t^6/362880 + t^8/39916800
-    a = 0.5f + n2 * (-1.0f / 24.0f + n2 * (1.0f / 720.0f + n2 * (-1.0f / 40320.0f + n2 * (1.0f / 3628800.0f))));
-    b = 1.0f / 6.0f + n2 * (-1.0f / 120.0f + n2 * (1.0f / 5040.0f + n2 * (-1.0f / 362880.0f + n2 * (1.0f / 39916800.0f))));
-  } else {
-    const float n = sqrtf(n2), sh = sinf(0.5f * n);
-    a = 2.0f * sh * sh / n2;
-    b = (n - sinf(n)) / (n2 * n);
-  }
 }
 // (hat^2 = phi phi^T - |phi|^2 I written out: 19 operations instead of a 3 x 3 product and 18 more)
 template <class T> CTV_DI M3<T> so3_Jr(V3<T> phi) {
@@ -250,15 +197,14 @@ CTV_DI Q4<double> qmul_unit(Q4<double> a, Q4<double> b) {
   o.x *= s; o.y *= s; o.z *= s; o.w *= s;
   return o;
 }
-CTV_DI Q4<float> qmul_unit(Q4<float> a, Q4<float> b) { return qmul(a, b); }
 
 // compile-time choice between the two (SMALL: the caller has bounded |phi| < 0.5)
 template <bool SMALL, class T> CTV_DI Q4<T> so3_exp_sel(V3<T> w) {
-  if constexpr (SMALL && sizeof(T) == 8) return so3_exp_small(w);
+  if constexpr (SMALL) return so3_exp_small(w);
   else return so3_exp(w);
 }
 template <bool SMALL, class T> CTV_DI M3<T> so3_Jr_sel(V3<T> phi) {
-  if constexpr (SMALL && sizeof(T) == 8) return so3_Jr_small(phi);
+  if constexpr (SMALL) return so3_Jr_small(phi);
   else return so3_Jr(phi);
 }
 
@@ -269,12 +215,6 @@ CTV_DI double jrinv_coeff(double n2) {
            n2 * (691.0 / 1307674368000.0 + n2 * (1.0 / 74724249600.0 + n2 * (3617.0 / 10670622842880000.0)))))));
   const double n = sqrt(n2);
   return 1.0 / n2 - (1 + cos(n)) / (2 * n * sin(n));
-}
-CTV_DI float jrinv_coeff(float n2) {
-  if (n2 < 1.0f)  // 1/12 + t^2/720 + t^4/30240 + t^6/1209600 + t^8/47900160
-    return 1.0f / 12.0f + n2 * (1.0f / 720.0f + n2 * (1.0f / 30240.0f + n2 * (1.0f / 1209600.0f + n2 * (1.0f / 47900160.0f))));
-  const float n = sqrtf(n2);
-  return 1.0f / n2 - (1 + cosf(n)) / (2 * n * sinf(n));
 }
 template <class T> CTV_DI M3<T> so3_Jr_inv(V3<T> phi) {
   const T c = jrinv_coeff(dot(phi, phi));

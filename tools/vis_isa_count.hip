@@ -5,7 +5,7 @@ using namespace ctv;
 struct Sink { double *J; __device__ void put(int e, double v) { J[e] = v; } };
 extern "C" __global__ void isa_vis_block_small(const double *rec, const double *kn, const double *kd, const double *kj, const double *cal, double *out) {
   const int i = threadIdx.x;
-  SegConstLazy<double, double> sc;
+  SegConstLazy<double> sc;
   seg_const_lazy(kd + 3 * i, kj + 9 * i, sc);
   V3<double> p[4];
   for (int k = 0; k < 4; ++k) p[k] = mk<double>(kn[64 * (4 + 3 * k) + i], kn[64 * (5 + 3 * k) + i], kn[64 * (6 + 3 * k) + i]);
@@ -19,7 +19,7 @@ extern "C" __global__ void isa_vis_block_small(const double *rec, const double *
 }
 extern "C" __global__ void isa_vis_anchor_small(const double *kn, const double *kd, const double *kj, const double *cal, double *rec) {
   const int i = threadIdx.x;
-  SegConstLazy<double, double> sc;
+  SegConstLazy<double> sc;
   seg_const_lazy(kd + 3 * i, kj + 9 * i, sc);
   V3<double> p[4];
   for (int k = 0; k < 4; ++k) p[k] = mk<double>(kn[64 * (4 + 3 * k) + i], kn[64 * (5 + 3 * k) + i], kn[64 * (6 + 3 * k) + i]);
