@@ -114,11 +114,11 @@ struct SolverBase {
   virtual void *stream() = 0;
 };
 
-template <class T> class SolverImpl : public SolverBase {
+class SolverImpl : public SolverBase {
  public:
   // visual blocks per work item (k_assemble_vis*): eight per-wave staging areas [116][VCH + 2] must fit beside the fp64 LDS Hessian
   static constexpr int VCH = 8;
-  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 116 * (VCH + 2) * sizeof(T) + (size_t)8 * 2 * VCH * sizeof(int); }
+  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 116 * (VCH + 2) * sizeof(double) + (size_t)8 * 2 * VCH * sizeof(int); }
   explicit SolverImpl(const ctvio_options &o) : opt_(o) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -134,16 +134,16 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipStreamCreate(&stream_));
     for (auto &e : ev_) HIPCHK(hipEventCreate(&e));
     // kernels that need more than 64 KiB of dynamic LDS
-    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<T, 16, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<T, 8, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<T, VCH, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<16, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<8, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -260,9 +260,9 @@ template <class T> class SolverImpl : public SolverBase {
     const size_t o_state = seg(sizeof(double) * ((size_t)7 * K0 + 6 * F0 + L0 + nw));   // quat | pos | bias | rho | ld, contiguous
     const size_t o_knot_win = seg(4 * (size_t)K0), o_bias_win = seg(4 * (size_t)F0), o_lm_win = seg(4 * (size_t)L0);
     const size_t o_groups = seg(sizeof(ImuGroup) * (size_t)G0), o_imu_grp = seg(4 * Mt);
-    const size_t o_imu_u = seg(sizeof(T) * Mt), o_imu_meas = seg(sizeof(T) * 6 * Mt);
+    const size_t o_imu_u = seg(sizeof(double) * Mt), o_imu_meas = seg(sizeof(double) * 6 * Mt);
     const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_anc = seg(4 * Vt), o_v_rowj = seg(4 * Vt);
-    const size_t o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(T) * 2 * Vt);
+    const size_t o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(double) * 2 * Vt);
     const size_t o_v_cauchy = seg(8 * Vt);
     const size_t o_a_win = seg(4 * At), o_a_lm = seg(4 * At), o_a_row = seg(4 * At), o_a_t = seg(8 * At), o_a_obs = seg(8 * 2 * At);
     const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_vblk = seg(4 * Vt), o_vblk_anc = seg(4 * Vt);
@@ -285,7 +285,7 @@ template <class T> class SolverImpl : public SolverBase {
     int32_t *h_knot_win = CTV_H(int32_t, o_knot_win), *h_bias_win = CTV_H(int32_t, o_bias_win), *h_lm_win = CTV_H(int32_t, o_lm_win);
     ImuGroup *h_groups = CTV_H(ImuGroup, o_groups);
     int32_t *h_imu_grp = CTV_H(int32_t, o_imu_grp);
-    T *h_imu_u = CTV_H(T, o_imu_u), *h_imu_meas = CTV_H(T, o_imu_meas), *h_v_obs = CTV_H(T, o_v_obs);
+    double *h_imu_u = CTV_H(double, o_imu_u), *h_imu_meas = CTV_H(double, o_imu_meas), *h_v_obs = CTV_H(double, o_v_obs);
     double *h_v_cauchy = CTV_H(double, o_v_cauchy);
     int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_anc = CTV_H(int32_t, o_v_anc), *h_v_rowj = CTV_H(int32_t, o_v_rowj);
     int64_t *h_v_tj = CTV_H(int64_t, o_v_tj);
@@ -325,10 +325,10 @@ template <class T> class SolverImpl : public SolverBase {
         h_imu_grp[e] = g;
         const int64_t st = w.imu_t[src] - w.t0_ns;
         const double uu = (double)(st % w.dt_ns) / (double)w.dt_ns;
-        h_imu_u[e] = (T)uu;
+        h_imu_u[e] = (double)uu;
         for (int c = 0; c < 3; ++c) {
-          h_imu_meas[(size_t)c * Mt + e] = (T)w.imu_gyro[3 * src + c];
-          h_imu_meas[(size_t)(3 + c) * Mt + e] = (T)w.imu_acc[3 * src + c];
+          h_imu_meas[(size_t)c * Mt + e] = (double)w.imu_gyro[3 * src + c];
+          h_imu_meas[(size_t)(3 + c) * Mt + e] = (double)w.imu_acc[3 * src + c];
         }
       }
       // anchors (the i ends, landmark-major) and visual blocks: evaluation slots in landmark-major order (padding slots: window -1,
@@ -344,13 +344,13 @@ template <class T> class SolverImpl : public SolverBase {
         const size_t e = (size_t)m.vis0 + i;
         if (v < 0) {
           h_v_win[e] = -1; h_v_lm[e] = 0; h_v_anc[e] = m.anc0; h_v_tj[e] = 0; h_v_rowj[e] = 0; h_v_cauchy[e] = 0.0;
-          for (int c = 0; c < 2; ++c) h_v_obs[(size_t)c * Vt + e] = T(0);
+          for (int c = 0; c < 2; ++c) h_v_obs[(size_t)c * Vt + e] = 0.0;
           continue;
         }
         h_v_win[e] = wi; h_v_lm[e] = w.v_lm[v]; h_v_anc[e] = m.anc0 + t.anc_of[v];
         h_v_tj[e] = w.v_tj[v] - w.t0_ns;
         h_v_rowj[e] = w.v_rowj[v];
-        h_v_obs[e] = (T)w.v_pj[2 * v]; h_v_obs[Vt + e] = (T)w.v_pj[2 * v + 1];
+        h_v_obs[e] = (double)w.v_pj[2 * v]; h_v_obs[Vt + e] = (double)w.v_pj[2 * v + 1];
         h_v_cauchy[e] = w.v_cauchy ? w.v_cauchy[v] : w.cauchy_a;
       }
       // the assembly's items: <= VCH blocks of one frame pair, frame-pair order, as lists of slots (vblk)
@@ -419,17 +419,17 @@ template <class T> class SolverImpl : public SolverBase {
       }
     });
     // ---- device pointers of the input arena
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     std::memset(&d, 0, sizeof d);
     d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0; d.Atot = A0;
     d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw; maxK_ = maxK; max_schur_tiles_ = maxSchurTiles;
     d.wins = CTV_D(WinMeta, o_meta);
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
-    d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(T, o_imu_u); d.imu_meas = CTV_D(T, o_imu_meas);
+    d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(double, o_imu_u); d.imu_meas = CTV_D(double, o_imu_meas);
     d.v_cauchy = CTV_D(double, o_v_cauchy);
     d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_anc = CTV_D(int32_t, o_v_anc); d.v_rowj = CTV_D(int32_t, o_v_rowj);
-    d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(T, o_v_obs);
+    d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(double, o_v_obs);
     d.a_win = CTV_D(int32_t, o_a_win); d.a_lm = CTV_D(int32_t, o_a_lm); d.a_row = CTV_D(int32_t, o_a_row); d.a_t = CTV_D(int64_t, o_a_t);
     d.a_obs = CTV_D(double, o_a_obs);
     d.vitems = CTV_D(VisItem, o_vitems); d.vblk = CTV_D(int32_t, o_vblk); d.vblk_anc = CTV_D(int32_t, o_vblk_anc);
@@ -460,19 +460,19 @@ template <class T> class SolverImpl : public SolverBase {
     state_doubles_ = (size_t)7 * K0 + 6 * F0 + L0 + nw;
     off = 0;
     const size_t o_cstate = seg(8 * state_doubles_), o_snap = seg(8 * state_doubles_);
-    const size_t o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(T) * 9 * (size_t)K0);
-    const size_t o_tiles = seg(sizeof(T) * 1024 * (size_t)G0);
+    const size_t o_lkd = seg(8 * 3 * (size_t)K0), o_kjri = seg(sizeof(double) * 9 * (size_t)K0);
+    const size_t o_tiles = seg(sizeof(double) * 1024 * (size_t)G0);
     const size_t o_imu_cost = seg(8 * (size_t)std::max(G0, 1)), o_vis_cost = seg(8 * ((Vt + 63) / 64)), o_misc_cost = seg(8 * (size_t)nw);
     // packed partial Hessians of the multi-part store-semantics assembly (knot triangle + line-delay row + gradient per part)
     const size_t part_stride = ((size_t)6 * maxK * (6 * maxK + 1) / 2 + 2 * (6 * (size_t)maxK + 1) + 7) & ~(size_t)7;
     const int nparts_alloc = store_path() ? vis_parts() : 1;
     const size_t o_pgrad = seg(8 * (size_t)std::max(pv0, 1)), o_Hpart = seg(nparts_alloc > 1 ? 8 * part_stride * nparts_alloc * (size_t)nw : 8);
-    const size_t o_Jt = seg(sizeof(T) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vsj = seg(4 * Vt);
+    const size_t o_Jt = seg(sizeof(double) * VT_ROWS * 64 * ((Vt + 63) / 64)), o_vsj = seg(4 * Vt);
     const size_t o_arec = seg(8 * (size_t)AREC * At), o_a_s = seg(4 * At);
     // two normal-equation sets (current linearisation / speculative linearisation at the candidate, Lm::cur)
     const size_t o_Hpp = seg(8 * (size_t)H0), o_Hpp1 = seg(8 * (size_t)H0), o_S = seg(8 * (size_t)H0);
     const size_t o_zero0 = off;   // ---- zeroed at every upload from here ...
-    const size_t o_W = seg(sizeof(T) * (size_t)W0), o_W1 = seg(sizeof(T) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_Hll1 = seg(8 * (size_t)L0),
+    const size_t o_W = seg(sizeof(double) * (size_t)W0), o_W1 = seg(sizeof(double) * (size_t)W0), o_Hll = seg(8 * (size_t)L0), o_Hll1 = seg(8 * (size_t)L0),
                  o_g = seg(8 * (size_t)U0), o_g1 = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
                  o_cscale = seg(8 * (size_t)U0), o_lm = seg(sizeof(Lm) * (size_t)nw), o_nact = seg(16), o_dbg = seg(8 * 128);
     const size_t o_zero1 = off;   // ---- ... to here
@@ -486,12 +486,12 @@ template <class T> class SolverImpl : public SolverBase {
 #define CTV_W(type, o) reinterpret_cast<type *>(wb + (o))
     d.cquat = CTV_W(double, o_cstate); d.cpos = d.cquat + (size_t)4 * K0; d.cbias = d.cpos + (size_t)3 * K0; d.crho = d.cbias + (size_t)6 * F0; d.cld = d.crho + L0;
     snap_ = CTV_W(double, o_snap);
-    d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(T, o_kjri); d.imu_tiles = CTV_W(T, o_tiles);
+    d.lkd = CTV_W(double, o_lkd); d.kjri = CTV_W(double, o_kjri); d.imu_tiles = CTV_W(double, o_tiles);
     d.imu_cost = CTV_W(double, o_imu_cost); d.vis_cost = CTV_W(double, o_vis_cost); d.misc_cost = CTV_W(double, o_misc_cost);
     d.pgrad = CTV_W(double, o_pgrad); d.Hpart = CTV_W(double, o_Hpart); d.npart_stride = (int32_t)part_stride;
-    d.Jt = CTV_W(T, o_Jt); d.vsj = CTV_W(int32_t, o_vsj); d.arec = CTV_W(double, o_arec); d.a_s = CTV_W(int32_t, o_a_s);
+    d.Jt = CTV_W(double, o_Jt); d.vsj = CTV_W(int32_t, o_vsj); d.arec = CTV_W(double, o_arec); d.a_s = CTV_W(int32_t, o_a_s);
     d.HppS[0] = CTV_W(double, o_Hpp); d.HppS[1] = CTV_W(double, o_Hpp1); d.S = CTV_W(double, o_S);
-    d.WS[0] = CTV_W(T, o_W); d.WS[1] = CTV_W(T, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
+    d.WS[0] = CTV_W(double, o_W); d.WS[1] = CTV_W(double, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
     d.gS[0] = CTV_W(double, o_g); d.gS[1] = CTV_W(double, o_g1);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
     d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;
@@ -564,14 +564,14 @@ template <class T> class SolverImpl : public SolverBase {
   // Linearisation of every window the mode selects (kernels.hpp: LIN_AT_X / LIN_SPEC / COST_AT_X) into its normal-equation set;
   // the cost partials of the evaluated state come out on the way.
   void launch_linearize(int mode) {
-    const Dev<T> &d = dev_;
+    const Dev &d = dev_;
     const int nw = d.nwin;
     constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
-    if (!store_path()) { if (!imu_zero_mode()) hipLaunchKernelGGL((k_zero_normal<T>), dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode); }
-    else hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
+    if (!store_path()) { if (!imu_zero_mode()) hipLaunchKernelGGL(k_zero_normal, dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode); }
+    else hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
     ph_end();
-    const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(T);
+    const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(double);
     if (merge_linearize()) {
       // one launch for both evaluations (independent work: their latencies overlap on batches smaller than the chip); a profiled
       // solve (and CTVIO_SPLIT_LINEARIZE=1, for rocprofv3 runs) keeps them apart so that each gets its own timing
@@ -591,25 +591,25 @@ template <class T> class SolverImpl : public SolverBase {
   // the chip, where the single-wave latencies of the two evaluations overlap instead of adding up.  CTVIO_MERGE_LINEARIZE = 0 / 1 forces
   // the choice (A/B measurements).
   bool merge_linearize() const {
-    const Dev<T> &d = dev_;
+    const Dev &d = dev_;
     if (!(opt_.use_mfma && d.Gtot && d.Vtot && !profiling_ && !std::getenv("CTVIO_SPLIT_LINEARIZE"))) return false;
     if (const char *e = std::getenv("CTVIO_MERGE_LINEARIZE")) return e[0] == '1';
     return d.nwin <= 128;
   }
   void launch_assemble(int mode) {
-    const Dev<T> &d = dev_;
+    const Dev &d = dev_;
     const int nw = d.nwin;
     const int parts = vis_parts();   // few windows: split each window's items over several workgroups to fill the chip
     if (store_path()) {
       // every entry of Hpp / g is written once, completely, with a plain store: no zeroing pass, no k_assemble_imu, no atomics
       ph_begin(PH_ASM_VIS);
       launch_assemble_vis_store(parts, mode);
-      if (parts > 1) hipLaunchKernelGGL((k_reduce_finalize<T>), dim3(deterministic_ ? 48 : 24, nw), dim3(256), 0, stream_, d, mode, parts);
-      else hipLaunchKernelGGL((k_bias_rows<T>), dim3(8, nw), dim3(256), 0, stream_, d, mode);
+      if (parts > 1) hipLaunchKernelGGL(k_reduce_finalize, dim3(deterministic_ ? 48 : 24, nw), dim3(256), 0, stream_, d, mode, parts);
+      else hipLaunchKernelGGL(k_bias_rows, dim3(8, nw), dim3(256), 0, stream_, d, mode);
       ph_end();
       if (mode != LIN_SPEC) {   // (the candidate's gradient norm: k_pass_end)
         ph_begin(PH_ASM_REST);
-        hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
+        hipLaunchKernelGGL(k_post_linearize, dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
         ph_end();
       }
       return;
@@ -619,22 +619,22 @@ template <class T> class SolverImpl : public SolverBase {
     if (any_vis_glb_) launch_assemble_vis_glb(parts, mode);
     ph_end();
     ph_begin(PH_ASM_REST);
-    if (d.Gtot) hipLaunchKernelGGL((k_assemble_imu<T>), dim3(nw), dim3(256), 0, stream_, d, mode);
-    hipLaunchKernelGGL((k_misc<T>), dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0);
-    if (mode != LIN_SPEC) hipLaunchKernelGGL((k_post_linearize<T>), dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
+    if (d.Gtot) hipLaunchKernelGGL(k_assemble_imu, dim3(nw), dim3(256), 0, stream_, d, mode);
+    hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0);
+    if (mode != LIN_SPEC) hipLaunchKernelGGL(k_post_linearize, dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();
   }
   // Trust-region step of every window that starts a new iteration (damping, Schur complement, Cholesky, back-substitution), then the
   // candidate x (+) alpha delta of every window with a valid step (also those inside the line search: new alpha, same delta).
   void launch_step() {
-    const Dev<T> &d = dev_;
+    const Dev &d = dev_;
     const int nw = d.nwin;
     ph_begin(PH_SCHUR);
     launch_schur();
     ph_end();
     if (!schur_makes_rhs()) {
       ph_begin(PH_REST);
-      hipLaunchKernelGGL((k_rhs<T>), dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
+      hipLaunchKernelGGL(k_rhs, dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
       ph_end();
     }
     ph_begin(PH_CHOL);
@@ -644,16 +644,18 @@ template <class T> class SolverImpl : public SolverBase {
     if (chol_tiles()) {
       const int ntr = d.maxP / 16 + 1;
       const size_t lds = (size_t)(2 * ntr * 272 + 32 * ntr + 4) * sizeof(double);   // panel + inverses + vectors
-      if (chol_tiles() == 2) hipLaunchKernelGGL((k_cholesky_tiles<T, 8, 14>), dim3(nw), dim3(512), lds, stream_, d);   // (A/B variant: 8 waves x 14 tiles)
-      else hipLaunchKernelGGL((k_cholesky_tiles<T, 16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
+      if (chol_tiles() == 2) hipLaunchKernelGGL((k_cholesky_tiles<8, 14>), dim3(nw), dim3(512), lds, stream_, d);   // (A/B variant: 8 waves x 14 tiles)
+      else hipLaunchKernelGGL((k_cholesky_tiles<16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
     }
-    else if (nw <= 192) hipLaunchKernelGGL((k_cholesky_solve<T, 8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
-    else hipLaunchKernelGGL((k_cholesky_solve<T, 4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
+    else if (nw <= 192) hipLaunchKernelGGL((k_cholesky_solve<8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
+    else hipLaunchKernelGGL((k_cholesky_solve<4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
     // (fewer windows than CUs: 16 waves per window shorten the landmark back-substitution from 7 trips to 2)
-    if (nw <= 192) hipLaunchKernelGGL((k_step_finish<T, 16>), dim3(nw), dim3(1024), (size_t)d.maxP * sizeof(double), stream_, d);
-    else hipLaunchKernelGGL((k_step_finish<T, 4>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
+    // (fewer windows than CUs: 8 waves per window shorten the landmark back-substitution; 16 waves -- a 128-register cap -- spilled 18
+    //  registers to scratch and were measured slower: 3.15 vs 3.09 ms per single-window solve)
+    if (nw <= 192) hipLaunchKernelGGL((k_step_finish<8>), dim3(nw), dim3(512), (size_t)d.maxP * sizeof(double), stream_, d);
+    else hipLaunchKernelGGL((k_step_finish<4>), dim3(nw), dim3(256), (size_t)d.maxP * sizeof(double), stream_, d);
     ph_end();
   }
   void launch_schur();
@@ -672,9 +674,9 @@ template <class T> class SolverImpl : public SolverBase {
   void launch_assemble_vis_lds(int parts, int mode);
   void launch_assemble_vis_glb(int parts, int mode);
   void launch_assemble_vis_store(int parts, int mode) {
-    const Dev<T> &d = dev_;
-    if (deterministic_) hipLaunchKernelGGL((k_assemble_vis_mfma<T, VCH, true, 1, true>), dim3(d.nwin, parts), dim3(64), vis_lds_, stream_, d, mode);
-    else hipLaunchKernelGGL((k_assemble_vis_mfma<T, VCH, true, 8, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
+    const Dev &d = dev_;
+    if (deterministic_) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true, 1, true>), dim3(d.nwin, parts), dim3(64), vis_lds_, stream_, d, mode);
+    else hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true, 8, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
   }
   bool schur_makes_rhs() const { return schur_rhs_done_; }
   // CTVIO_CHOL_TILES = 0 / 1 / 2 forces the choice (A/B measurements: panel kernel / 16 waves x 7 tiles / 8 waves x 14 tiles)
@@ -692,26 +694,26 @@ template <class T> class SolverImpl : public SolverBase {
   // by-product; k_pass_end accepts / rejects / continues the search, swaps the sets on acceptance and starts the next iteration
   // (continuation tests, LM diagonal).  The launch list is fixed: kernels skip windows that are not in the matching phase.
   void launch_pass() {
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     launch_step();
     launch_linearize(LIN_SPEC);
     launch_assemble(LIN_SPEC);
     ph_begin(PH_REST);
     // (windows that start another pass count themselves in k_pass_end; the counter was cleared by k_step_finish)
-    hipLaunchKernelGGL((k_pass_end<T>), dim3(nw), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL(k_pass_end, dim3(nw), dim3(256), 0, stream_, d);
     ph_end();
   }
   // The first linearisation of a solve (and of the diagnostic entries): knot-pair constants, normal equations and cost of the
   // current state in set 0, Jacobi scaling.
   void launch_initial(double mu, int keep_scale) {
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
-    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, mu, keep_scale);
-    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL(k_lm_init, dim3(wb), dim3(64), 0, stream_, d, mu, keep_scale);
+    hipLaunchKernelGGL(k_knot_prep, dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
     launch_linearize(LIN_AT_X);
     launch_assemble(LIN_AT_X);
-    hipLaunchKernelGGL((k_initial_cost<T>), dim3(nw), dim3(64), 0, stream_, d, 0);
+    hipLaunchKernelGGL(k_initial_cost, dim3(nw), dim3(64), 0, stream_, d, 0);
   }
   // The pass as a hipGraph (captured once per batch shape: the kernel arguments are the Dev struct, so equal shapes in the
   // grow-only arenas give identical graphs), replayed instead of ~25 launches.
@@ -740,7 +742,7 @@ template <class T> class SolverImpl : public SolverBase {
   int solve(int max_iters, ctvio_summary *out) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (max_iters < 0) return fail(CTVIO_ERR_INVALID, "max_iterations < 0");
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     set_params(max_iters);
     profiling_ = profiling_requested_;
@@ -750,7 +752,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipEventRecord(ev_[8], stream_));
     launch_initial(opt_.initial_radius, 0);
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
-    hipLaunchKernelGGL((k_begin_iter<T>), dim3(nw), dim3(256), 0, stream_, d);   // the first iteration; later ones start in k_pass_end
+    hipLaunchKernelGGL(k_begin_iter, dim3(nw), dim3(256), 0, stream_, d);   // the first iteration; later ones start in k_pass_end
     // max_iters passes finish every window that never enters the line search; the host looks at the "windows that start another
     // pass" counter every check_every passes and keeps launching while any is left
     const int check = std::max(1, opt_.check_every);
@@ -841,7 +843,7 @@ template <class T> class SolverImpl : public SolverBase {
   // every window's state in one device-to-host copy (concatenated in window order, like the device arrays)
   int get_batch_state(double *quat, double *pos, double *bias, double *rho, double *ld) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
-    const Dev<T> &d = dev_;
+    const Dev &d = dev_;
     if (state_doubles_ > state_host_cap_) {
       if (state_host_) (void)hipHostFree(state_host_);
       state_host_cap_ = state_doubles_ + state_doubles_ / 8;
@@ -865,7 +867,7 @@ template <class T> class SolverImpl : public SolverBase {
   int linearize(int id, double *Hpp, double *W, double *Hll, double *g, double *cost) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     set_params(1);
     launch_initial(opt_.initial_radius, 0);
@@ -875,10 +877,10 @@ template <class T> class SolverImpl : public SolverBase {
       HIPCHK(hipMemcpy2DAsync(Hpp, sizeof(double) * (size_t)P, d.HppS[0] + m.H0, sizeof(double) * (size_t)m.ldh, sizeof(double) * (size_t)P, (size_t)P,
                               hipMemcpyDeviceToHost, stream_));
     }
-    std::vector<T> Wh;
+    std::vector<double> Wh;
     if (W && m.L) {
       Wh.resize((size_t)m.Lpad * m.ldw);
-      HIPCHK(hipMemcpyAsync(Wh.data(), d.WS[0] + m.W0, sizeof(T) * Wh.size(), hipMemcpyDeviceToHost, stream_));
+      HIPCHK(hipMemcpyAsync(Wh.data(), d.WS[0] + m.W0, sizeof(double) * Wh.size(), hipMemcpyDeviceToHost, stream_));
     }
     if (Hll && m.L) HIPCHK(hipMemcpyAsync(Hll, d.HllS[0] + m.lm0, sizeof(double) * m.L, hipMemcpyDeviceToHost, stream_));
     if (g) HIPCHK(hipMemcpyAsync(g, d.gS[0] + m.u0, sizeof(double) * m.N, hipMemcpyDeviceToHost, stream_));
@@ -898,16 +900,16 @@ template <class T> class SolverImpl : public SolverBase {
   int cost(int id, double *cost) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int wb = nblk(d.nwin, 64);
     set_params(1);
-    hipLaunchKernelGGL((k_lm_init<T>), dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 1);
-    hipLaunchKernelGGL((k_knot_prep<T>), dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
-    if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(T), COST_AT_X);
+    hipLaunchKernelGGL(k_lm_init, dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 1);
+    hipLaunchKernelGGL(k_knot_prep, dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
+    if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(double), COST_AT_X);
     if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
     if (d.Vtot) hipLaunchKernelGGL(k_vis_eval, dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
-    hipLaunchKernelGGL((k_misc<T>), dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0);
-    hipLaunchKernelGGL((k_initial_cost<T>), dim3(d.nwin), dim3(64), 0, stream_, d, 1);
+    hipLaunchKernelGGL(k_misc, dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0);
+    hipLaunchKernelGGL(k_initial_cost, dim3(d.nwin), dim3(64), 0, stream_, d, 1);
     Lm lm;
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -918,12 +920,12 @@ template <class T> class SolverImpl : public SolverBase {
   int lm_step(int id, double mu, double *delta, double *mc) override {
     if (!uploaded_) return fail(CTVIO_ERR_STATE, "ctvio_upload not called");
     if (id < 0 || id >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int wb = nblk(d.nwin, 64);
     set_params(1);
     launch_initial(mu, 0);
     HIPCHK(hipMemsetAsync(d.n_active, 0, sizeof(int32_t), stream_));
-    hipLaunchKernelGGL((k_begin_iter<T>), dim3(d.nwin), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL(k_begin_iter, dim3(d.nwin), dim3(256), 0, stream_, d);
     launch_step();
     const WinMeta &m = meta_[id];
     Lm lm;
@@ -941,7 +943,7 @@ template <class T> class SolverImpl : public SolverBase {
   int marg_device(const int8_t *role_all, int only, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0, bool *too_large,
                   int *stalled = nullptr) {
     if (stalled) *stalled = -1;
-    Dev<T> &d = dev_;
+    Dev &d = dev_;
     const int nw = d.nwin, wb = nblk(nw, 64);
     *too_large = false;
     std::vector<MargMeta> metas((size_t)nw);
@@ -978,8 +980,8 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(mg_scr_.alloc(scr));
     HIPCHK(mg_out_.alloc(outd));
     constexpr size_t lds = ((size_t)MARG_MAXD * (MARG_MAXD + 1) / 2 + 4 * MARG_MAXD + 512) * sizeof(double) + 2 * MARG_MAXD * sizeof(int);
-    if (!marg_attr_set_) { HIPCHK(hipFuncSetAttribute((const void *)k_marginalize<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); marg_attr_set_ = true; }
-    hipLaunchKernelGGL((k_marginalize<T>), dim3(nw), dim3(256), lds, stream_, d, mg_meta_.p, mg_idx_.p, mg_scr_.p, mg_out_.p, eps);
+    if (!marg_attr_set_) { HIPCHK(hipFuncSetAttribute((const void *)k_marginalize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); marg_attr_set_ = true; }
+    hipLaunchKernelGGL(k_marginalize, dim3(nw), dim3(256), lds, stream_, d, mg_meta_.p, mg_idx_.p, mg_scr_.p, mg_out_.p, eps);
     std::vector<double> outh(std::max<size_t>(outd, 1));
     HIPCHK(hipMemcpyAsync(outh.data(), mg_out_.p, sizeof(double) * std::max<size_t>(outd, 1), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipMemcpyAsync(metas.data(), mg_meta_.p, sizeof(MargMeta) * nw, hipMemcpyDeviceToHost, stream_));
@@ -1063,7 +1065,7 @@ template <class T> class SolverImpl : public SolverBase {
     const int n = 14 + m.pn;
     DBuf<double> out;
     HIPCHK(out.alloc(n));
-    hipLaunchKernelGGL((k_residual_summary<T>), dim3(1), dim3(256), (size_t)(14 + 2 * m.pn) * sizeof(double), stream_, dev_, id, out.p);
+    hipLaunchKernelGGL(k_residual_summary, dim3(1), dim3(256), (size_t)(14 + 2 * m.pn) * sizeof(double), stream_, dev_, id, out.p);
     HIPCHK(hipMemcpyAsync(sums, out.p, sizeof(double) * n, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
@@ -1087,7 +1089,7 @@ template <class T> class SolverImpl : public SolverBase {
     std::memcpy(hs, ids, sizeof(int32_t) * n); std::memcpy(hs + sizeof(int32_t) * n, knot, sizeof(int32_t) * n);
     std::memcpy(hs + ioff, q0, sizeof(double) * 4 * n); std::memcpy(hs + ioff + sizeof(double) * 4 * n, t0, sizeof(double) * 3 * n);
     HIPCHK(hipMemcpyAsync(ds, hs, nbytes, hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL((k_gauge_restore<T>), dim3(n), dim3(64), 0, stream_, dev_, n, reinterpret_cast<const int32_t *>(ds),
+    hipLaunchKernelGGL(k_gauge_restore, dim3(n), dim3(64), 0, stream_, dev_, n, reinterpret_cast<const int32_t *>(ds),
                        reinterpret_cast<const int32_t *>(ds) + n, reinterpret_cast<const double *>(ds + ioff), reinterpret_cast<const double *>(ds + ioff) + 4 * (size_t)n);
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
@@ -1117,7 +1119,7 @@ template <class T> class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, stream_));
     double *dp = reinterpret_cast<double *>(ds + o_out), *dv = dp + (pose7 ? (size_t)7 * n : 0), *dw = dv + (vel3 ? (size_t)3 * n : 0),
            *da = dw + (omega3 ? (size_t)3 * n : 0);
-    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, (const int32_t *)nullptr, n, reinterpret_cast<const long long *>(ds),
+    hipLaunchKernelGGL(k_spline_eval, dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, id, (const int32_t *)nullptr, n, reinterpret_cast<const long long *>(ds),
                        pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr, reinterpret_cast<int *>(ds + o_err), ext);
     HIPCHK(hipMemcpyAsync(hs + o_err, ds + o_err, 16 + nd * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -1156,7 +1158,7 @@ template <class T> class SolverImpl : public SolverBase {
     double *dp = reinterpret_cast<double *>(ds + o_out), *dv = dp + (pose7 ? (size_t)7 * n : 0), *dw = dv + (vel3 ? (size_t)3 * n : 0),
            *da = dw + (omega3 ? (size_t)3 * n : 0);
     if (kernel_ms) HIPCHK(hipEventRecord(ev_[10], stream_));
-    hipLaunchKernelGGL((k_spline_eval<T>), dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, 0, reinterpret_cast<const int32_t *>(ds + o_win), n,
+    hipLaunchKernelGGL(k_spline_eval, dim3(nblk(n, 256)), dim3(256), 0, stream_, dev_, 0, reinterpret_cast<const int32_t *>(ds + o_win), n,
                        reinterpret_cast<const long long *>(ds), pose7 ? dp : nullptr, vel3 ? dv : nullptr, omega3 ? dw : nullptr, acc3 ? da : nullptr,
                        reinterpret_cast<int *>(ds + o_err), SensorExt{});
     if (kernel_ms) HIPCHK(hipEventRecord(ev_[11], stream_));
@@ -1193,7 +1195,7 @@ template <class T> class SolverImpl : public SolverBase {
   std::vector<std::unique_ptr<HostWindow>> own_;   // windows recorded by ctvio_add_window (owning copies)
   std::vector<WinMeta> meta_;
   std::vector<int64_t> t0_;
-  Dev<T> dev_;
+  Dev dev_;
   int Mtot_ = 0, Vtot_ = 0;
   size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0, in_bytes_ = 0, state_doubles_ = 0;
   Arena in_, work_;          // uploaded inputs (pinned mirror) / device-only work buffers
@@ -1216,7 +1218,7 @@ template <class T> class SolverImpl : public SolverBase {
   double *snap_ = nullptr;   // state snapshot (inside work_)
   Lm *lm_host_ = nullptr; size_t lm_host_cap_ = 0;
   hipGraphExec_t graph_exec_ = nullptr;   // one LM pass (launch_pass) as a graph, valid while dev_ == graph_dev_
-  Dev<T> graph_dev_;
+  Dev graph_dev_;
   std::vector<long long> graph_sig_;
   bool deterministic_ = false;   // order-fixed accumulation for this batch (ctvio_options.deterministic)
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
@@ -1224,34 +1226,34 @@ template <class T> class SolverImpl : public SolverBase {
   int maxK_ = 0, max_schur_tiles_ = 0;
 };
 
-template <> void SolverImpl<double>::launch_imu_linearize(size_t lds, int mode) {
-  const Dev<double> &d = dev_;
+void SolverImpl::launch_imu_linearize(size_t lds, int mode) {
+  const Dev &d = dev_;
   // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
   if (opt_.use_mfma) {
     // (at most 2048 waves -- two rounds of one wave per SIMD -- each walking its share of the groups with the next group's data in flight)
     hipLaunchKernelGGL(k_imu_linearize_f64, dim3(std::min(d.Gtot, imu_walk_waves())), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
     hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
   }
-  else hipLaunchKernelGGL((k_imu_linearize<double, 32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
+  else hipLaunchKernelGGL((k_imu_linearize<32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
 }
-template <> void SolverImpl<double>::launch_linearize_merged(int mode) {
-  const Dev<double> &d = dev_;
+void SolverImpl::launch_linearize_merged(int mode) {
+  const Dev &d = dev_;
   hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode, imu_general_only(), imu_zero_mode());
   hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
 }
-template <> void SolverImpl<double>::launch_assemble_vis_lds(int parts, int mode) {
-  const Dev<double> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
-  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
+void SolverImpl::launch_assemble_vis_lds(int parts, int mode) {
+  const Dev &d = dev_;
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
+  else hipLaunchKernelGGL((k_assemble_vis<VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
 }
 // windows whose packed Hessian does not fit in LDS (K > 25): run products on the MFMA units, added to Hpp with global atomics
-template <> void SolverImpl<double>::launch_assemble_vis_glb(int parts, int mode) {
-  const Dev<double> &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
-  else hipLaunchKernelGGL((k_assemble_vis<double, VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
+void SolverImpl::launch_assemble_vis_glb(int parts, int mode) {
+  const Dev &d = dev_;
+  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
+  else hipLaunchKernelGGL((k_assemble_vis<VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
 }
-template <> void SolverImpl<double>::launch_schur() {
-  const Dev<double> &d = dev_;
+void SolverImpl::launch_schur() {
+  const Dev &d = dev_;
   schur_rhs_done_ = false;
   if (opt_.use_mfma) {   // fp64 matrix cores
     const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
@@ -1271,7 +1273,7 @@ template <> void SolverImpl<double>::launch_schur() {
       schur_rhs_done_ = true;
     }
   } else {
-    hipLaunchKernelGGL((k_schur_generic<double>), dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
+    hipLaunchKernelGGL(k_schur_generic, dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
   }
 }
 
@@ -1318,7 +1320,7 @@ int32_t ctvio_create(const ctvio_options *opt, ctvio_solver **out) {
   std::unique_ptr<ctvio_solver> s(new ctvio_solver);
   int rc;
   if (o.precision != CTVIO_FP64) return ctv::fail(CTVIO_ERR_INVALID, "precision: only CTVIO_FP64 exists (the mixed fp32 mode was removed: it missed the 1e-4 contract)");
-  { auto *p = new ctv::SolverImpl<double>(o); s->impl.reset(p); rc = p->init(); }
+  { auto *p = new ctv::SolverImpl(o); s->impl.reset(p); rc = p->init(); }
   if (rc != CTVIO_OK) return rc;
   *out = s.release();
   return CTVIO_OK;

@@ -72,8 +72,8 @@ struct LmParams {
   int32_t max_invalid, max_iters;
 };
 
-// Device pointers of one batch.  T = scalar of the linearisation kernels: double (the reference's arithmetic) is the only instantiation.
-template <class T> struct Dev {
+// Device pointers of one batch (all arithmetic is fp64, like the reference's).
+struct Dev {
   int32_t nwin, Ktot, Ftot, Ltot, Mtot, Gtot, Vtot, NBtot, Utot, maxN, maxP, maxPn;
   const WinMeta *wins;
   // state, fp64 master copies: current and candidate
@@ -83,13 +83,13 @@ template <class T> struct Dev {
   // per consecutive knot pair (k, k+1) of the state about to be linearised (the initial state: k_knot_prep; every candidate:
   // k_step_finish): d = log(R_k^-1 R_k+1) and Jr^-1(d) -- shared by all residual blocks of the window
   double *lkd;           // [Ktot][3]
-  T *kjri;               // [Ktot][9]
+  double *kjri;               // [Ktot][9]
   // IMU factors (sorted by group)
   const ImuGroup *groups;
   const int32_t *imu_grp;
-  const T *imu_u;        // [Mtot] normalised time in the segment
-  const T *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
-  T *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
+  const double *imu_u;        // [Mtot] normalised time in the segment
+  const double *imu_meas;     // [6][Mtot] gyro xyz, accel xyz
+  double *imu_tiles;          // [Gtot][32*32]  A^T A of the group, A = [J | r] (6n x 31)
   double *imu_cost;      // [Gtot] 1/2 |r|^2 of the group's samples; vis_cost [Vtot / 64] robustified cost of the wave's blocks;
   double *vis_cost;      // misc_cost [nwin] bias chain + prior: summed per window in a fixed order by k_lm_control (no atomics)
   double *misc_cost;
@@ -106,10 +106,10 @@ template <class T> struct Dev {
   const int32_t *v_win, *v_lm, *v_anc;   // [Vtot] window (-1: padding slot), landmark, anchor (absolute) of the block slot
   const int64_t *v_tj;          // relative to the window's t0
   const int32_t *v_rowj;
-  const T *v_obs;        // [2][Vtot] pjx, pjy
+  const double *v_obs;        // [2][Vtot] pjx, pjy
   const double *v_cauchy; // [Vtot] width a of the block's ceres::CauchyLoss(a) (<= 0: no loss): the reference picks it per residual
                          // block (trajectory_estimator.cpp:320-323: 1 when the feature is being marginalised, else 2)
-  T *Jt;                 // robust-corrected block records, block-major [Vtot][VT_ROWS] (factors.hpp VB_*: rotation columns of the j end,
+  double *Jt;                 // robust-corrected block records, block-major [Vtot][VT_ROWS] (factors.hpp VB_*: rotation columns of the j end,
                          // inverse-depth and line-delay columns, residual, A~ (2 x 3) and the j end's blending coefficients -- the i-end
                          // columns are A~ times the anchor record and are rebuilt by the assembly): the assembly gathers the blocks of an
                          // item (frame-pair order) from the landmark-major block order, 320 contiguous bytes each; a wave of k_vis_eval
@@ -136,7 +136,7 @@ template <class T> struct Dev {
   const double *p_x0;
   // normal equations, two sets (Lm::cur): linearisation at the current state / speculative linearisation at the candidate
   double *HppS[2];       // [sum P*ldh] lower triangle used
-  T *WS[2];              // Hpl^T, landmark-major
+  double *WS[2];              // Hpl^T, landmark-major
   double *HllS[2], *gS[2];   // [Ltot], [Utot]
   double *S, *rhs;       // Schur complement (lower) and its right-hand side [sum P]
   double *chol_inv;      // [nwin][chol_nblk][32][32] inverses of the diagonal blocks of the Cholesky factor (row-major)

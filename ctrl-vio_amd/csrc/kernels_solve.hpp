@@ -1,0 +1,1011 @@
+// kernels_solve.hpp -- The step: begin_iteration / k_begin_iter, Schur complement (k_schur_window_f64, k_schur_tile_f64, k_schur_generic + k_rhs), Cholesky
+// (k_cholesky_tiles register-resident, k_cholesky_solve panel kernel), k_step_finish (back-substitution, candidate, its pair table).
+// Part of kernels.hpp (included from there, in order; not a stand-alone header).
+#pragma once
+
+namespace ctv {
+
+// ------------------------------------------------------------------------------------------------ Schur + solve
+// Start of an iteration, by the threads of one workgroup.  Thread 0: FinalizeIterationAndCheckIfMinimizerCanContinue (windows inside
+// the line search only report that they are still running).  Then, for the windows that start an iteration: the LM diagonal
+// D^2 = clamp(diag(J^T J), min, max) / mu on the Jacobi-scaled system (Ceres LevenbergMarquardtStrategy::ComputeStep), expressed for
+// the unscaled system: dd_j = clamp(c_j^2 H_jj) / (mu c_j^2), and 1 / (Hll + dd) of the landmarks.
+__device__ __forceinline__ void begin_iteration(const Dev &d, int w, int *s_go) {
+  Lm &lm = d.lm[w];
+  if (threadIdx.x == 0) {
+    int go = 0;
+    if (!lm.status) {
+      if (lm.ls_active) atomicAdd(d.n_active, 1);   // inside the line search: no new LM iteration
+      else if (lm.iter >= d.prm.max_iters) lm.status = 1 + 0;
+      else if (lm.last_ok && __longlong_as_double((long long)lm.gmax_bits) <= d.prm.gtol) lm.status = 1 + 1;
+      else if (lm.mu <= d.prm.min_radius) lm.status = 1 + 4;
+      else {
+        lm.iter += 1;
+        lm.accept = 0; lm.step_valid = 0; lm.chol_fail = 0; lm.alpha = 1.0;
+        atomicAdd(d.n_active, 1);
+        go = 1;
+      }
+    }
+    *s_go = go;
+  }
+  __syncthreads();
+  if (!*s_go) return;
+  const WinMeta &m = d.wins[w];
+  const double mu = lm.mu;
+  const double *Hd = d.HppS[lm.cur] + m.H0, *Hl = d.HllS[lm.cur] + m.lm0;
+  for (int j = threadIdx.x; j < m.N; j += blockDim.x) {
+    const bool act = d.active[m.u0 + j] != 0;
+    const double c = d.cscale[m.u0 + j];
+    const double h = (j < m.P) ? Hd[(long long)j * m.ldh + j] : Hl[j - m.P];
+    const double sc = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
+    const double dd = act ? sc / (mu * c * c) : 0.0;
+    d.dd[m.u0 + j] = dd;
+    if (j >= m.P) d.dinv[m.lm0 + j - m.P] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
+  }
+}
+// The first iteration of a solve (every later one starts at the end of the previous pass: k_pass_end).
+__global__ __launch_bounds__(256) void k_begin_iter(Dev d) {
+  __shared__ int s_go;
+  begin_iteration(d, blockIdx.x, &s_go);
+}
+
+__device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> (bi >= bj), row-major over the lower triangle
+  bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  bj = t - bi * (bi + 1) / 2;
+}
+
+// fp64 product path, large batches: the window kernel on the fp64 matrix cores.  One workgroup (8 waves) per window; W is read
+// from HBM once, staged through LDS in double-buffered chunks of 16 landmarks (masked by the active flags, g_rho appended as
+// column P so that the tile row holding index P also produces the reduced right-hand side: no k_rhs pass).  Output tiles are
+// 16 x 16 (v_mfma_f64_16x16x4_f64, K = 4 landmarks per instruction); tile t of the lower triangle belongs to wave t % 8, which
+// keeps its <= NTQ accumulators in registers over the whole landmark loop; tiles over bias-only columns have no products.
+// NPRE = compact chunk elements per thread (16 (6K + 2) / 512 rounded up); NTQ = ceil(tiles with products / 8).
+template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2) void k_schur_window_f64(Dev d) {
+  const int w = blockIdx.x;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int nt = ldw >> 4, ntile = nt * (nt + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double smd64[];
+  double *Wb = smd64;                    // [2][16][ldw]
+  double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)
+  double *dch = acts + ldw;              // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
+  int *tlist = reinterpret_cast<int *>(dch + 32);   // [8 NTQ] tiles with products (bi << 8 | bj), any order
+  int &tcount = tlist[8 * NTQ];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
+  const double *Wp = d.WS[d.lm[w].cur] + m.W0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
+  for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0 : 0.0;
+  if (tid == 0) tcount = 0;
+  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P - 1 (plus the rhs row P): a tile has products
+  // when its row tile and its column tile both hold such a column.  Those tiles (55 of 105 at K = 24) are listed and dealt to
+  // the waves; the others only need the epilogue (S = Hpp + D).
+  auto nz_row = [&](int b) { return (16 * b < K6) || (P >= 16 * b && P - 1 < 16 * b + 16); };
+  auto nz_col = [&](int b) { return (16 * b < K6) || (P - 1 >= 16 * b && P - 1 < 16 * b + 16); };
+  __syncthreads();   // tcount
+  for (int t = tid; t < ntile; t += 512) {
+    int ti, tj;
+    tile_decode(t, ti, tj);
+    if (nz_row(ti) && nz_col(tj)) { const int pos = atomicAdd(&tcount, 1); if (pos < 8 * NTQ) tlist[pos] = (ti << 8) | tj; }
+  }
+  // Only the knot columns [0, 6K), the line-delay column P - 1 and the appended g_rho column P are fetched and staged (NC
+  // compact columns per landmark); every other column of the two LDS buffers is zeroed once and stays zero.
+  const int nchunk = (L + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
+  for (int e = tid; e < 2 * nel; e += 512) Wb[e] = 0.0;
+  double pre[NPRE];
+  double pre_d = 0.0;
+  int pre_lc[NPRE];     // chunk row << 16 | window column of this thread's elements (the same for every chunk)
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int e = min(tid + 512 * k, nelc - 1), cc = e % NC;
+    pre_lc[k] = ((e / NC) << 16) | (cc < K6 ? cc : P - 1 + (cc - K6));
+  }
+  auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int l = min(16 * ch + (pre_lc[k] >> 16), L - 1), c = pre_lc[k] & 0xffff;
+      pre[k] = (c == P) ? gl[l] : Wp[(long long)l * ldw + c];
+    }
+    if (tid < 16) pre_d = dinv[min(16 * ch + tid, L - 1)];
+  };
+  auto stash = [&](int ch, int buf) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int lr = pre_lc[k] >> 16, c = pre_lc[k] & 0xffff;
+      const bool lv = 16 * ch + lr < L;
+      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0;
+    }
+    if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
+  };
+  __syncthreads();   // acts, zeroed buffers, tile list
+  const int nact = min(tcount, 8 * NTQ);
+  // this wave's tiles: slot q holds list entry wave + 8 q; slots past the end repeat the wave's first tile (products computed,
+  // result dropped) so that the tile loop below has no branches and the operand reads of a tile overlap the previous products
+  int tij[NTQ];
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) tij[q] = __builtin_amdgcn_readfirstlane(tlist[(wave + 8 * q < nact) ? wave + 8 * q : min(wave, max(nact - 1, 0))]);   // SGPRs
+  f64x4 acc[NTQ];
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  if (nchunk > 0) { fetch(0); stash(0, 0); }
+  __syncthreads();
+  for (int ch = 0; ch < nchunk && nact > 0; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) fetch(ch + 1);
+    const double *B = Wb + buf * nel + q4 * ldw + l15;
+    double dl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
+#pragma unroll
+    for (int q = 0; q < NTQ; ++q) {
+      double a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[s] = B[4 * s * ldw + 16 * (tij[q] >> 8)];
+        b[s] = B[4 * s * ldw + 16 * (tij[q] & 255)];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
+    }
+    if (ch + 1 < nchunk) stash(ch + 1, buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
+  const double *H = d.HppS[d.lm[w].cur] + m.H0;
+  auto write_tile = [&](int ti, int tj, const f64x4 &av) {
+    const int jj = 16 * tj + l15, jc = min(jj, P - 1);
+    const bool act_j = d.active[u0 + jc] != 0;
+    const double dd_j = d.dd[u0 + jc], g_j = d.gS[d.lm[w].cur][u0 + jc];
+    double hv[4];
+    unsigned char act_i[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ic = min(16 * ti + q4 + 4 * r, P - 1);
+      act_i[r] = d.active[u0 + ic];
+      hv[r] = H[(long long)ic * ldh + min(jc, ic)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = 16 * ti + q4 + 4 * r;
+      if (ii < P && jj <= ii) {
+        const bool on = act_i[r] && act_j;
+        S[(long long)ii * ldh + jj] = on ? hv[r] - av[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+      } else if (ii == P && jj < P) {
+        rhs[jj] = act_j ? av[r] - g_j : 0.0;
+      }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) {
+    if (wave + 8 * q >= nact) continue;
+    write_tile(tij[q] >> 8, tij[q] & 255, acc[q]);
+  }
+  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  for (int t = wave; t < ntile; t += 8) {     // tiles without products
+    int ti, tj;
+    tile_decode(t, ti, tj);
+    if (nz_row(ti) && nz_col(tj)) continue;
+    write_tile(ti, tj, zero4);
+  }
+}
+
+// fp64 path: the same SYRK on the fp64 matrix cores, one wave per 16 x 16 tile of the lower triangle
+// (v_mfma_f64_16x16x4_f64: A operand lane l = X[k = l/16][i = l%16], B operand lane l = Y[k = l/16][j = l%16],
+// D register r of lane l = D[(l/16) + 4r][l%16]; measured with tools/mfma_f64_layout.hip).  Operands straight from W,
+// 16 landmarks (4 products) per trip with all loads of a trip in flight; the reduced rhs is left to k_rhs.
+__global__ __launch_bounds__(64) void k_schur_tile_f64(Dev d, int ntile_max) {
+  // XCD-aware tile -> workgroup map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles of one
+  // window get ids that are congruent mod 8: they all run on one XCD and the window's W (re-read by every tile) comes out of
+  // that L2 instead of being fetched 8 times over the fabric.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int w = (slot / ntile_max) * 8 + xcd, tile = slot % ntile_max;
+  if (w >= d.nwin) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int nt = P / 16 + 1;   // tile rows up to index P: the rhs rides along as row P (g_rho on the A side), so the tile row that
+  if (tile >= nt * (nt + 1) / 2) return;   // holds it also produces W^T diag(dinv) g_rho -- no separate k_rhs pass
+  int bi, bj;
+  tile_decode(tile, bi, bj);
+  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
+  const int i = min(16 * bi + l15, ldw - 1), j = min(16 * bj + l15, ldw - 1);
+  const bool rhs_lane = 16 * bi + l15 == P;
+  const double ai = (16 * bi + l15 < P && d.active[u0 + min(i, P - 1)]) ? 1.0 : 0.0;
+  const double aj = (16 * bj + l15 < P && d.active[u0 + min(j, P - 1)]) ? 1.0 : 0.0;
+  const double *Wp = d.WS[d.lm[w].cur] + m.W0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
+  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
+  const bool nz_i = (16 * bi < K6) || (P >= 16 * bi && P - 1 < 16 * bi + 16);
+  const bool nz_j = (16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16);
+  const int lend = (nz_i && nz_j) ? L : 0;   // L == 0: the loop (and its clamped row L - 1) is skipped
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int l0 = 0; l0 < lend; l0 += 16) {
+    double wa[4], wb[4], dv[4], gv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {   // unconditional loads on clamped rows, masked below
+      const int lc = min(l0 + 4 * s + q4, L - 1);
+      wa[s] = Wp[(long long)lc * ldw + i];
+      wb[s] = Wp[(long long)lc * ldw + j];
+      dv[s] = dinv[lc];
+      gv[s] = gl[lc];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wa[s] = rhs_lane ? gv[s] : wa[s] * ai;   // (unconditional loads, selected afterwards)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool lv = l0 + 4 * s + q4 < L;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], lv ? wb[s] * aj * dv[s] : 0.0, acc, 0, 0, 0);
+    }
+  }
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
+  const double *H = d.HppS[d.lm[w].cur] + m.H0;
+  const int jj = 16 * bj + l15, jc = min(jj, P - 1);
+  const bool act_j = d.active[u0 + jc] != 0;
+  const double dd_j = d.dd[u0 + jc], g_j = d.gS[d.lm[w].cur][u0 + jc];
+  double hv[4];
+  unsigned char act_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ic = min(16 * bi + q4 + 4 * r, P - 1);
+    act_i[r] = d.active[u0 + ic];
+    hv[r] = H[(long long)ic * ldh + min(jc, ic)];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ii = 16 * bi + q4 + 4 * r;
+    if (ii < P && jj <= ii) {
+      const bool on = act_i[r] && act_j;
+      S[(long long)ii * ldh + jj] = on ? hv[r] - acc[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+    } else if (ii == P && jj < P) {
+      rhs[jj] = act_j ? acc[r] - g_j : 0.0;   // reduced right-hand side: -g_p + W^T diag(dinv) g_rho
+    }
+  }
+}
+
+__global__ void k_schur_generic(Dev d) {
+  const int w = blockIdx.y;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)m.P * m.P) return;
+  const int ii = (int)(e / m.P), jj = (int)(e % m.P);
+  if (jj > ii) return;
+  const bool on = d.active[m.u0 + ii] && d.active[m.u0 + jj];
+  double val;
+  if (on) {
+    const double *Wp = d.WS[d.lm[w].cur] + m.W0;
+    double acc = 0.0;
+    for (int l = 0; l < m.L; ++l) acc += (double)Wp[(long long)l * m.ldw + ii] * (double)Wp[(long long)l * m.ldw + jj] * d.dinv[m.lm0 + l];
+    val = d.HppS[d.lm[w].cur][m.H0 + (long long)ii * m.ldh + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
+  } else {
+    val = (ii == jj) ? 1.0 : 0.0;
+  }
+  d.S[m.H0 + (long long)ii * m.ldh + jj] = val;
+}
+
+// rhs_p = -g_p + W^T diag(dinv) g_l.  256 threads = 64 unknowns x 4 landmark slices (coalesced over the unknowns).
+__global__ __launch_bounds__(256) void k_rhs(Dev d) {
+  const int w = blockIdx.y;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
+  const WinMeta &m = d.wins[w];
+  __shared__ double part[4][64];
+  const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + li;
+  double v = 0.0;
+  if (i < m.P && d.active[m.u0 + i]) {
+    const double *Wp = d.WS[d.lm[w].cur] + m.W0 + i;
+    const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + m.u0 + m.P;
+    for (int l = sl; l < m.L; l += 4) v += (double)Wp[(long long)l * m.ldw] * (dinv[l] * gl[l]);
+  }
+  part[sl][li] = v;
+  __syncthreads();
+  if (sl == 0 && i < m.P) {
+    const double s = part[0][li] + part[1][li] + part[2][li] + part[3][li];
+    d.rhs[m.p0 + i] = d.active[m.u0 + i] ? s - d.gS[d.lm[w].cur][m.u0 + i] : 0.0;
+  }
+}
+
+// Dense fp64 Cholesky of the P x P reduced system + solve, one workgroup (4 waves) per window, right-looking with
+// 32-column panels, the matrix products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   1. wave 0 factors the 32 x 32 diagonal block, one row per lane in registers, with v_readlane broadcasts (no LDS,
+//      no barriers inside the 32 pivot steps) and forms L11^-1 in the same sweep (lane = column of the inverse).
+//      Meanwhile waves 1-3 stage the panel rows A21 (and the rhs row) into LDS, k-major.
+//   2. L21 = A21 L11^-T as an MFMA product, in place in the LDS panel (a 16-row tile is owned by one wave);
+//   3. trailing update A22 -= L21 L21^T: one 16 x 16 tile per wave at a time, 8 MFMAs, read-modify-write of S.
+// The right-hand side rides along as an extra matrix row (Cholesky of [S b; b^T .]), so y = L^-1 b needs no
+// separate forward substitution; only the block back-substitution L^T x = y remains.  Result in delta[0..P).
+// MFMA register layout (measured, tools/mfma_f64_layout.hip): A operand lane l = A[l%16][l/16], B operand lane l =
+// B[l/16][l%16], D register r of lane l = D[(l/16) + 4r][l%16].
+
+// Diagonal block of k_cholesky_solve: factorisation fused with the inversion, on ONE register array.  Lanes 0-31 hold the rows
+// of the block (v[c] = A[lane][c]), lanes 32-63 the columns of X = L11^-1 in the making (v[c] = X[c][lane - 32], identity at the
+// start).  The rank-1 update of pivot J, a_c -= a_J s with s = L[C][J] = v[J] of lane C, is also the substitution step
+// x_c -= x_J s of the inverse: one v_readlane pair and ONE v_fma per (J, C) serve both halves of the wave.
+// One update as an asm block so that the broadcast value lives for exactly these instructions (left to the compiler, every
+// broadcast was spilled and reloaded).
+template <int C> __device__ __forceinline__ void chol_bcast_update(double &vc, double vj, int vj_lo, int vj_hi) {
+  asm("v_readlane_b32 s96, %2, %4\n\tv_readlane_b32 s97, %3, %4\n\ts_nop 1\n\t"
+      "v_fma_f64 %0, -%1, s[96:97], %0"
+      : "+v"(vc)
+      : "v"(vj), "v"(vj_lo), "v"(vj_hi), "n"(C)
+      : "s96", "s97");
+}
+// The same for the first column after the pivot, whose result feeds the next pivot's v_readlane straight away: gfx950 needs a
+// wait state between a VALU write of a VGPR and a v_readlane of it (and between the compiler's scaling of v[J] and the first
+// v_readlane here); the hazard recogniser cannot see into an asm block, so the s_nops are spelled out.
+template <int C> __device__ __forceinline__ void chol_bcast_update_first(double &vc, double vj, int vj_lo, int vj_hi) {
+  asm("s_nop 1\n\tv_readlane_b32 s96, %2, %4\n\tv_readlane_b32 s97, %3, %4\n\ts_nop 1\n\t"
+      "v_fma_f64 %0, -%1, s[96:97], %0\n\ts_nop 1"
+      : "+v"(vc)
+      : "v"(vj), "v"(vj_lo), "v"(vj_hi), "n"(C)
+      : "s96", "s97");
+}
+// 1 / sqrt(p) of the pivot: hardware estimate + two Newton steps (short dependent chain instead of sqrt + divide)
+__device__ __forceinline__ double chol_pivot_rsqrt(double pj, int &bad) {
+  const bool ok = (pj > 0.0) && isfinite(pj);
+  if (!ok) bad = 1;
+  const double ps = ok ? pj : 1.0;
+  double di = __builtin_amdgcn_rsq(ps);
+  const double hp = 0.5 * ps;
+  di = di * (1.5 - hp * di * di);
+  di = di * (1.5 - hp * di * di);
+  return di;
+}
+// Four columns at once, each broadcast in its own SGPR pair: with a single pair every update waited for the previous FMA to
+// release it (~42 cycles per update, measured: 25 k cycles per 32 x 32 block); here the eight v_readlane run ahead of the
+// four FMAs, which also puts the two wait states gfx950 wants between a VALU write of an SGPR and its VALU read in between.
+template <int C> __device__ __forceinline__ void chol_bcast_update4(double &v0, double &v1, double &v2, double &v3, double vj, int vj_lo, int vj_hi) {
+  asm("v_readlane_b32 s92, %5, %7\n\tv_readlane_b32 s93, %6, %7\n\t"
+      "v_readlane_b32 s94, %5, %8\n\tv_readlane_b32 s95, %6, %8\n\t"
+      "v_readlane_b32 s96, %5, %9\n\tv_readlane_b32 s97, %6, %9\n\t"
+      "v_readlane_b32 s98, %5, %10\n\tv_readlane_b32 s99, %6, %10\n\t"
+      "v_fma_f64 %0, -%4, s[92:93], %0\n\tv_fma_f64 %1, -%4, s[94:95], %1\n\t"
+      "v_fma_f64 %2, -%4, s[96:97], %2\n\tv_fma_f64 %3, -%4, s[98:99], %3"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)
+      : "v"(vj), "v"(vj_lo), "v"(vj_hi), "n"(C), "n"(C + 1), "n"(C + 2), "n"(C + 3)
+      : "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+}
+// columns C .. 31 of pivot J
+template <int J, int C> __device__ __forceinline__ void chol_row_updates(double (&v)[32], int lo, int hi) {
+  if constexpr (C + 3 <= 31) {
+    chol_bcast_update4<C>(v[C], v[C + 1], v[C + 2], v[C + 3], v[J], lo, hi);
+    chol_row_updates<J, C + 4>(v, lo, hi);
+  } else if constexpr (C <= 31) {
+    chol_bcast_update<C>(v[C], v[J], lo, hi);
+    chol_row_updates<J, C + 1>(v, lo, hi);
+  }
+}
+// Pivot J with its 1 / sqrt already known (di): scale column J, update column J + 1 first, start the NEXT pivot's reciprocal
+// square root from it (its dependent chain of ~10 fp64 operations then overlaps the remaining updates), update the rest.
+template <int J> __device__ __forceinline__ double chol_diag_step(double (&v)[32], double di, int &bad) {
+  v[J] *= di;   // lanes < 32: lane J sqrt(p_J), lanes > J L[i][J]; lanes >= 32: X[J][.], final (every k < J has been eliminated)
+  const int lo = __double2loint(v[J]), hi = __double2hiint(v[J]);
+  double di_next = 0.0;
+  if constexpr (J < 31) {
+    chol_bcast_update_first<J + 1>(v[J + 1], v[J], lo, hi);
+    di_next = chol_pivot_rsqrt(readlane_d(v[J + 1], J + 1), bad);
+    if constexpr (J < 30) chol_row_updates<J, J + 2>(v, lo, hi);
+  }
+  return di_next;
+}
+template <int J> __device__ __forceinline__ void chol_diag_from(double (&v)[32], double di, int &bad) {
+  const double dn = chol_diag_step<J>(v, di, bad);
+  if constexpr (J < 31) chol_diag_from<J + 1>(v, dn, bad);
+}
+__device__ __forceinline__ void chol_diag_all(double (&v)[32], int &bad) {
+  chol_diag_from<0>(v, chol_pivot_rsqrt(readlane_d(v[0], 0), bad), bad);
+}
+// NW waves per window: 4 for large batches (two windows share a CU), 8 when there are fewer windows than CUs (the parallel
+// phases -- L21, trailing update, staging -- go twice as fast; the diagonal blocks hide behind the trailing updates).
+template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev d) {
+  constexpr int NT = 64 * NW;
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status || lm.ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  extern __shared__ __attribute__((aligned(16))) double smc[];
+  double *Lb = smc;                 // [32][34] NEXT diagonal block (row-major), deposited by the trailing update of the current panel
+  double *LiT = Lb + 32 * 34;       // [32][34] L11^-1 transposed: LiT[k][j] = Linv[j][k]
+  double *dinvs = LiT + 32 * 34;    // [32] 1 / L_jj
+  double *yb = dinvs + 32;          // [32]
+  int &s_fail = *reinterpret_cast<int *>(yb + 32);
+  int &s_trip = reinterpret_cast<int *>(yb + 32)[1];   // next unclaimed tile of the trailing update
+  double *LpT = yb + 34;            // [32][RS] panel (+ rhs row) k-major: LpT[k][r]
+  double *S = d.S + m.H0;
+  double *y = d.rhs + m.p0;         // augmented row; becomes L^-1 rhs
+  double *x = d.delta + m.u0;
+  if (tid == 0) s_fail = 0;
+  for (int e = tid; e < 32 * 32; e += NT) {   // first diagonal block -> LDS (rows / columns clamped; masked when read)
+    const int r = e >> 5, c = e & 31;
+    Lb[r * 34 + c] = S[(long long)min(r, P - 1) * ldh + min(c, P - 1)];
+  }
+  __syncthreads();
+  long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
+  const int q4 = lane >> 4, l15 = lane & 15;
+  // ---- diagonal block at column jb (one wave): lanes 0-31 the rows (lanes >= nb of the last, partial block carry identity
+  //      rows), lanes 32-63 the columns of the inverse (identity).  The block is in LDS (Lb): the first one staged above, the
+  //      later ones left there by the trailing update.  Result: LiT (LDS) and chol_inv (HBM, for the back-substitution); L11
+  //      itself is not written back, nothing reads it.
+  auto diag_block = [&](int jb) {
+    const int nb = min(32, P - jb);
+    double v[32];
+#pragma unroll
+    for (int c = 0; c < 32; c += 2) {
+      const VecN<double, 2> v2 = *reinterpret_cast<const VecN<double, 2> *>(Lb + (lane & 31) * 34 + c);
+      v[c] = v2.v[0]; v[c + 1] = v2.v[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const bool in = lane < nb && c < nb && c <= lane;
+      v[c] = in ? v[c] : ((c == (lane & 31)) ? 1.0 : 0.0);
+    }
+    int bad = 0;
+    chol_diag_all(v, bad);
+    if (lane >= 32) {
+      const int col = lane - 32;
+      double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + (jb >> 5)) * 1024;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        LiT[col * 34 + i] = v[i];   // LiT[k = col][j = i] = Linv[i][col]
+        gi[i * 32 + col] = v[i];    // row-major Linv[i][col]
+      }
+    }
+    if (lane == 0 && bad) s_fail = 1;
+  };
+  for (int jb = 0; jb < P; jb += 32) {
+    const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0, ntr = nt + 1;  // ntr: trailing rows incl. the rhs row
+    const int RS = (ntr + 15) & ~15, ntile = RS >> 4;
+    // ---- panel rows (and the rhs row) into the LDS panel, LpT[k][r].  First panel: wave 0 factors the diagonal block
+    //      meanwhile; the later diagonal blocks were factored during the previous trailing update (look-ahead, below).
+    {
+      const int first = jb == 0 ? 64 : 0, nthr = NT - first;
+      if (jb == 0 && wave == 0) diag_block(0);
+      for (int r = tid - first; r >= 0 && r < RS; r += nthr) {
+        const double *src = (r < nt) ? S + (long long)(r0 + r) * ldh + jb : y + jb;
+        double tmp[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tmp[k] = src[min(k, nb - 1)];   // unconditional: 32 loads in flight
+        const bool live = r < ntr;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) LpT[k * RS + r] = (live && k < nb) ? tmp[k] : 0.0;
+      }
+    }
+    if (tid == 0) s_trip = 4;   // wave 0 starts with tiles 0-3 (they hold the next diagonal block)
+    // LDS-only barrier: what the next phase reads (LiT, LpT) is in LDS; wave 0's global stores of the block inverse may
+    // stay in flight (a full __syncthreads would wait for them; they are read after later full barriers only)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    CTV_STAMP();
+    // ---- L21 = A21 L11^-T, in place: Linv is lower triangular, so output columns 0..15 need k < 16 only
+    for (int tr = wave; tr < ntile; tr += NW) {
+      f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+      const double *pa = LpT + 16 * tr + l15;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = 4 * kk + q4;
+        const double av = pa[k * RS];
+        if (kk < 4) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LiT[k * 34 + l15], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, LiT[k * 34 + 16 + l15], c1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tr + q4 + 4 * r;
+        LpT[l15 * RS + row] = c0[r];
+        LpT[(16 + l15) * RS + row] = c1[r];
+        if (row < ntr) {
+          double *dst = (row < nt) ? S + (long long)(r0 + row) * ldh + jb : y + jb;
+          if (l15 < nb) dst[l15] = c0[r];
+          if (16 + l15 < nb) dst[16 + l15] = c1[r];
+        }
+      }
+    }
+    __syncthreads();
+    CTV_STAMP();
+    // ---- trailing update A22 -= L21 L21^T on the lower triangle (16 x 16 tiles) and the rhs row.  Trips of 4 consecutive
+    //      tiles are claimed from an LDS counter.  Wave 0 takes tiles 0-3 first -- (0,0), (1,0), (1,1) are the next diagonal
+    //      block, left in Lb -- then factors that block (LOOK-AHEAD: 21 k cycles on one wave that used to sit between the
+    //      panels with three waves idle) while the other waves work through the rest, then joins them.
+    const int ntt = nt > 0 ? ntile * (ntile + 1) / 2 : 0;   // last panel: nothing left to update
+    // (requesting the next trip's S values before the current products was tried: no gain, it is bandwidth not latency)
+    bool first_trip = wave == 0;
+    while (true) {   // 4 tiles per trip: 16 loads in flight, 32 MFMAs, 16 stores
+      int tb;
+      if (first_trip) tb = 0;
+      else tb = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(&s_trip, 4) : 0);
+      if (tb >= ntt) break;
+      double sv[4][4];
+      int ti4[4], tj4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        tile_decode(min(tb + u, ntt - 1), ti4[u], tj4[u]);
+        const int col = 16 * tj4[u] + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti4[u] + q4 + 4 * r;
+          const double *src = (row < nt) ? S + (long long)(r0 + row) * ldh + r0 : y + r0;
+          sv[u][r] = src[min(col, nt - 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f64x4 c = {0.0, 0.0, 0.0, 0.0};
+        const double *pa = LpT + 16 * ti4[u] + l15, *pb = LpT + 16 * tj4[u] + l15;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = 4 * kk + q4;
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k * RS], pb[k * RS], c, 0, 0, 0);
+        }
+        const int col = 16 * tj4[u] + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti4[u] + q4 + 4 * r;
+          if (tb + u < ntt && col < nt && ((row < nt && col <= row) || row == nt)) {
+            double *dst = (row < nt) ? S + (long long)(r0 + row) * ldh + r0 : y + r0;
+            const double nv = sv[u][r] - c[r];
+            dst[col] = nv;
+            if (row < 32 && row < nt) Lb[row * 34 + col] = nv;   // tiles (0,0), (1,0), (1,1): the next diagonal block
+          }
+        }
+      }
+      if (first_trip) {
+        first_trip = false;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's Lb writes
+        diag_block(r0);
+      }
+    }
+    __syncthreads();
+    CTV_STAMP();
+  }
+  // ---- block back-substitution L^T x = y with the stored block inverses: x_b = Linv_b^T t_b, then t_j -= L[b][j]^T x_b
+  //      for the rows above.  x lives in LDS; per block the loads of Linv_b (wave 0) and of the panel rows (everyone) do
+  //      not depend on x and are issued together, before the block solve.
+  double *xs = LpT;   // the panel is no longer needed
+  for (int i = tid; i < P; i += NT) xs[i] = y[i];
+  __syncthreads();
+  const int nblk = (P + 31) / 32;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int jb = 32 * b, nb = min(32, P - jb);
+    double lv[32];   // column j of the panel rows of this block: L[jb + ii][j]
+    const bool upd = tid < jb;
+    {
+      const int j = min(tid, max(jb - 1, 0));
+#pragma unroll
+      for (int ii = 0; ii < 32; ++ii) lv[ii] = S[(long long)(jb + min(ii, nb - 1)) * ldh + j];
+    }
+    if (wave == 0) {
+      const double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + b) * 1024;
+      double li[32];
+      const int l31 = lane & 31;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) li[i] = gi[i * 32 + l31];
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc += li[i] * ((i < nb) ? xs[jb + i] : 0.0);   // Linv is lower triangular: rows i >= lane
+      __builtin_amdgcn_wave_barrier();
+      if (lane < nb) { xs[jb + lane] = acc; yb[lane] = acc; }
+    }
+    __syncthreads();
+    if (upd) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 32; ++ii) sacc += lv[ii] * ((ii < nb) ? yb[ii] : 0.0);
+      xs[tid] -= sacc;
+    }
+    for (int j = tid + NT; j < jb; j += NT) {   // P > NT + 32: remaining rows
+      double sacc = 0.0;
+      for (int ii = 0; ii < nb; ++ii) sacc += S[(long long)(jb + ii) * ldh + j] * yb[ii];
+      xs[j] -= sacc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < P; i += NT) x[i] = xs[i];
+  CTV_STAMP();
+  if (tid == 0) lm.chol_fail = s_fail;
+#undef CTV_STAMP
+}
+
+// ---- Register-resident tile Cholesky (windows with P <= 223): the whole lower triangle of the reduced system lives in the
+// VGPRs of ONE workgroup as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (tile t = i (i + 1) / 2 + j, i >= j,
+// belongs to wave t % NW, slot t / NW: 105 tiles at P = 211 -> 7 slots x 4 registers per lane on 16 waves).  S is read from HBM
+// exactly once and never written back; the right-hand side rides along as row P (so y = L^-1 b falls out of the factorisation).
+// Per 16-column panel k:
+//   A. the owner of the diagonal tile moves it through LDS into row-per-lane form and factors it with 16 v_readlane pivots
+//      (lanes 0-15 the rows, lanes 16-31 the columns of the inverse: the fused scheme of k_cholesky_solve), leaves L_kk^-1 in LDS;
+//   C. the owners of the tiles below it form L_ik = A_ik L_kk^-T (4 MFMAs; the accumulator -> operand transposition goes through
+//      the tile's slice of the LDS panel) and publish L_ik there;
+//   E. every owner of a trailing tile (i, j), j > k, subtracts L_ik L_jk^T (4 MFMAs, operands from the LDS panel).
+// Back-substitution L^T x = y runs over the tiles still in registers: x_b = L_bb^-T t_b, then t_j -= L_bj^T x_b by the single
+// owner of tile (b, j) -- no atomics anywhere, the summation order is fixed (bitwise reproducible).
+// Pivots with index >= P (the rhs row, padding rows) are forced to 1 and never flagged.
+template <int J, int C> __device__ __forceinline__ void chol16_row_updates(double (&v)[16], int lo, int hi) {
+  if constexpr (C + 3 <= 15) {
+    chol_bcast_update4<C>(v[C], v[C + 1], v[C + 2], v[C + 3], v[J], lo, hi);
+    chol16_row_updates<J, C + 4>(v, lo, hi);
+  } else if constexpr (C <= 15) {
+    chol_bcast_update<C>(v[C], v[J], lo, hi);
+    chol16_row_updates<J, C + 1>(v, lo, hi);
+  }
+}
+template <int J> __device__ __forceinline__ void chol16_from(double (&v)[16], double di, int nreal, int &bad) {
+  v[J] *= di;
+  const int lo = __double2loint(v[J]), hi = __double2hiint(v[J]);
+  if constexpr (J < 15) {
+    chol_bcast_update_first<J + 1>(v[J + 1], v[J], lo, hi);
+    double di_next = 1.0;
+    if (J + 1 < nreal) di_next = chol_pivot_rsqrt(readlane_d(v[J + 1], J + 1), bad);   // (uniform branch; without it -- the 16 pivots as one
+    // basic block, so that the scheduler may put the row updates of pivot J into the bubbles of pivot J + 1's rsq / Newton chain -- the
+    // diagonal tile took 8.2 k cycles instead of 7.6 k: measured, not kept)
+    if constexpr (J < 14) chol16_row_updates<J, J + 2>(v, lo, hi);
+    chol16_from<J + 1>(v, di_next, nreal, bad);
+  }
+}
+__device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
+
+// (A BLOCKED diagonal tile -- the 16 pivots in four blocks of four, at most three broadcast-and-FMA per pivot inside a block and the block's
+//  rank-4 update of the later columns, for the tile and for the inverse in the making, as two v_mfma_f64_16x16x4 -- was built and measured in
+//  round 4: 8.7 k cycles per tile against 8.3 k, the factorisation unchanged at 84 us.  The tile's time is not its row updates but the
+//  sixteen sequential pivots: readlane -> class test -> v_rsq_f64 -> two Newton steps -> scale -> readlane is ~300 dependent cycles each,
+//  211 of them per factorisation, whatever happens between them.  Not kept.)
+template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_tiles(Dev d) {
+  constexpr int NT = 64 * NW, TS = 16 * 17;    // a 16 x 16 block in LDS: row stride 17
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status || lm.ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, ldh = m.ldh, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int NTR = P / 16 + 1, ntiles = NTR * (NTR + 1) / 2, ip = P / 16, rp = P % 16;   // the rhs row P sits in tile row ip, local row rp
+  extern __shared__ __attribute__((aligned(16))) double smt[];
+  double *Li = smt;                    // [NTR][TS] inverses of the diagonal blocks, Li[b][j * 17 + k] = Linv_b[j][k]
+  double *Pn = Li + NTR * TS;          // [NTR][TS] panel: Pn[i][m * 17 + c] = L_ik[m][c] of the current panel
+  double *tv = Pn + NTR * TS;          // [16 NTR] y, then the running right-hand side of the back-substitution
+  double *xs = tv + 16 * NTR;          // [16 NTR] solution
+  int &s_fail = *reinterpret_cast<int *>(xs + 16 * NTR);
+  const double *S = d.S + m.H0, *y = d.rhs + m.p0;
+  if (tid == 0) s_fail = 0;
+  for (int i = tid; i < 16 * NTR; i += NT) tv[i] = 0.0;
+  // ---- this wave's tiles (SGPRs) and their contents
+  int ti[NS], tj[NS];
+  f64x4 acc[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int t = wave + NW * q;
+    int a, b;
+    tile_decode(min(t, ntiles - 1), a, b);
+    ti[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? a : -1);
+    tj[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? b : 1 << 20);   // (never equal to a panel, never a trailing tile: ti < tj)
+    // unconditional loads on clamped addresses straight into the tile registers; fixed up below
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rc = min(16 * a + q4 + 4 * r, P - 1);
+      acc[q][r] = S[(long long)rc * ldh + min(16 * b + l15, rc)];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    if (ti[q] < 0) continue;
+    const int col = 16 * tj[q] + l15;
+    if (ti[q] == tj[q]) {             // diagonal tile: the upper half is not stored in S
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = (col <= 16 * ti[q] + q4 + 4 * r) ? acc[q][r] : 0.0;
+    }
+    if (ti[q] == ip) {                // tile row of the rhs row P; identity beyond it
+      const double yv = y[min(col, P - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ip + q4 + 4 * r;
+        acc[q][r] = row < P ? acc[q][r] : (row == P ? (col < P ? yv : 0.0) : (row == col ? 1.0 : 0.0));
+      }
+    }
+  }
+  __syncthreads();
+  long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of thread 0 at the phase boundaries
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
+  for (int k = 0; k < NTR; ++k) {
+    // ---- A. diagonal tile (k, k)
+    const int td = k * (k + 1) / 2 + k, od = td % NW, sd = td / NW;
+    if (wave == od) {
+      double *Dg = Li + k * TS;
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (q == sd) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Dg[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double v[16];
+      int opaque0;   // a zero the compiler cannot see through: without it the 16 identity columns below are hoisted out of the panel
+      asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));   // loop as loop invariants and, for lack of registers, kept in scratch
+      const int lz = l15 + opaque0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double a = Dg[l15 * 17 + c];
+        v[c] = lane < 16 ? (c <= lz ? a : 0.0) : (c == lz ? 1.0 : 0.0);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();      // every lane has read its row before the block is overwritten with the inverse
+      const int nreal = P - 16 * k;         // pivots below this are real; the rhs row and the padding rows are not factored
+      int bad = 0;
+      double di0 = 1.0;
+      if (nreal > 0) di0 = chol_pivot_rsqrt(readlane_d(v[0], 0), bad);
+      chol16_from<0>(v, di0, nreal, bad);
+      if (lane >= 16 && lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Dg[i * 17 + l15] = v[i];   // Linv[i][column l15]
+      }
+      if (k == ip && lane == rp) {          // the part of y inside the last diagonal tile: L[P][16 ip + c], c < rp
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < rp) tv[16 * ip + c] = v[c];
+      }
+      if (lane == 0 && bad) s_fail = 1;
+    }
+    if (k < 4) CTV_STAMP();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    if (k < 4) CTV_STAMP();
+    // ---- C. L_ik = A_ik L_kk^-T for the tiles below the diagonal one
+    const double *Lk = Li + k * TS;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (tj[q] != k || ti[q] <= k) continue;   // (uniform)
+      double *blk = Pn + ti[q] * TS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double a[4], b[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { a[s4] = blk[l15 * 17 + 4 * s4 + q4]; b[s4] = Lk[l15 * 17 + 4 * s4 + q4]; }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();          // operands are in registers before the slice is overwritten
+      f64x4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], c, 0, 0, 0);
+      acc[q] = c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = c[r];
+      if (ti[q] == ip && q4 == (rp & 3)) tv[16 * k + l15] = f64x4_get(c, rp >> 2);   // y: row P of L
+    }
+    if (k < 4) CTV_STAMP();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    if (k < 4) CTV_STAMP();
+    // ---- E. trailing tiles (i, j), j > k: A_ij -= L_ik L_jk^T
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (ti[q] < 0 || tj[q] <= k || tj[q] >= (1 << 20)) continue;   // (uniform)
+      const double *pa = Pn + ti[q] * TS + l15 * 17 + q4, *pb = Pn + tj[q] * TS + l15 * 17 + q4;
+      double a[4], b[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { a[s4] = -pa[4 * s4]; b[s4] = pb[4 * s4]; }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
+    }
+    // (K-step outermost, so that consecutive MFMAs go to different tiles, was measured slower: 5.7 k cycles for the first panel's
+    //  updates either way, and the diagonal tiles waited longer.  LOOK-AHEAD -- the owner of tile (k + 1, k + 1) updates that tile
+    //  first and factors it while the other waves do their updates, the LDS panel double buffered, its own remaining updates
+    //  deferred to the next panel -- was built and measured slower too: 1.63 vs 1.30 ms per 16 single-window factorisations,
+    //  13.5 vs 10.6 ms per 2048-window solve.  The pivot chain takes ~12 k cycles instead of ~7 k when the other 15 waves are
+    //  busy on the same SIMDs / LDS, s_setprio 3 does not change that, and step C grows by the pending updates.)
+    // (the next panel's step C overwrites the LDS panel only after the barrier that follows its step A)
+    if (k < 4) CTV_STAMP();
+  }
+  CTV_STAMP();
+  __syncthreads();
+  CTV_STAMP();
+  // ---- back-substitution L^T x = y over the tiles in registers
+  for (int b = NTR - 1; b >= 0; --b) {
+    if (wave == (b % NW)) {   // x_b[j] = sum_k Linv[k][j] t[k]: lane (q4, j = l15) sums k = 4 q4 .. 4 q4 + 3, two shuffles add the quarters
+      const double *Lb = Li + b * TS;
+      double xa = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) xa += Lb[(4 * q4 + kk) * 17 + l15] * tv[16 * b + 4 * q4 + kk];
+      xa += __shfl_xor(xa, 16);
+      xa += __shfl_xor(xa, 32);
+      if (q4 == 0) xs[16 * b + l15] = xa;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (ti[q] != b || tj[q] >= b) continue;   // tiles (b, j), j < b: t_j -= L_bj^T x_b
+      double part = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part += acc[q][r] * xs[16 * b + q4 + 4 * r];
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      if (q4 == 0) tv[16 * tj[q] + l15] -= part;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+  }
+  CTV_STAMP();
+  double *x = d.delta + m.u0;
+  for (int i = tid; i < P; i += NT) x[i] = xs[i];
+  if (tid == 0) lm.chol_fail = s_fail;
+#undef CTV_STAMP
+}
+
+// (Fusing this kernel into k_cholesky_tiles -- same workgroup, the pose step straight from LDS -- was built and measured: no gain for
+//  one window (3.09 vs 3.05 ms per solve) and slower for 2048 (15.4 vs 13.6 ms for the two phases): the fused kernel spills, and
+//  the landmark back-substitution wants more workgroups per CU than the tile kernel's registers allow.  Kept apart.)
+// delta_l = dinv_l (-g_l - W_l . delta_p), one wave per landmark (coalesced over the row of W);
+// model_cost_change = 1/2 delta^T (D^2 delta - g)  (equals Ceres' -(J y)^T (r + J y / 2) when
+// (H + D^2) delta = -g);  then ComputeTrustRegionStep validity / HandleInvalidStep.
+// Then, in the same workgroup (one per window): the candidate x (+) alpha delta of this pass (Plus: q <- q exp(d),
+// ceres_local_param.h:137-145; additive elsewhere; the line delay projected on its box, trajectory_estimator.cpp:316-317), |step|^2 and
+// |x|^2 of the reduced program (fixed-order block reductions, no atomics) and the knot-pair constants of the candidate for the
+// linearisation that follows.  Windows inside the line search skip the solve part: their step is the same, only alpha changed.
+template <int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev d) {
+  constexpr int NT = 64 * NWV;
+  const int w = blockIdx.x;
+  // the pass's "windows that start another pass" counter (k_pass_end adds to it, several launches later): cleared here instead of by a
+  // memset node of its own
+  if (w == 0 && threadIdx.x == 0) *d.n_active = 0;
+  Lm &lm = d.lm[w];
+  if (lm.status) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, N = m.N, u0 = m.u0, lm0 = m.lm0, ldw = m.ldw;
+  extern __shared__ __attribute__((aligned(16))) double xs[];   // [P] pose step
+  __shared__ double red[NWV], red_gd[NWV], red_dm[NWV];
+  __shared__ int bad, s_go;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (lm.ls_active) {
+    if (tid == 0) s_go = lm.step_valid;
+  } else {
+  double *x = d.delta + u0;
+  const double *g = d.gS[d.lm[w].cur] + u0, *dd = d.dd + u0;
+  const double *Wp = d.WS[d.lm[w].cur] + m.W0;
+  for (int i = tid; i < P; i += NT) xs[i] = x[i];
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  // delta_rho_l = -(g_l + W_l . delta_p) / (Hll_l + D_l): a wave takes 8 rows of W per pass, 32 loads per lane in flight
+  for (int l0 = 8 * wave; l0 < L; l0 += 8 * NWV) {
+    double acc8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
+    // the row this lane will finish (see the reduction below): its g, 1/(Hll + D) and active flag travel with the W loads
+    const int lrow = min(l0 + (lane >> 3), L - 1);
+    const double g_l = g[P + lrow], dinv_l = d.dinv[lm0 + lrow];
+    const bool act_l = d.active[u0 + P + lrow] != 0;
+    // W is non-zero in the knot columns [0, 6K) and the line-delay column P - 1 only: NCB compact columns
+    const int K6 = 6 * m.K, NCB = K6 + 1;
+    for (int i0 = 0; i0 < NCB; i0 += 256) {
+      double wv[8][4];
+      int col[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int cc = min(i0 + lane + 64 * k, NCB - 1); col[k] = cc < K6 ? cc : P - 1; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // clamped, unconditional loads (a predicated load compiles to branch + load + s_waitcnt: one round trip EACH);
+          // out-of-range columns are masked through xi below, out-of-range rows are never written
+          const int l = min(l0 + u, L - 1);
+          wv[u][k] = Wp[(long long)l * ldw + col[k]];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double xi = (i0 + lane + 64 * k < NCB) ? xs[col[k]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc8[u] += (double)wv[u][k] * xi;
+      }
+    }
+    // 8 row sums over 64 lanes with 10 shuffles: each butterfly step halves the rows a lane carries (bit 5 of the lane
+    // picks rows 0-3 / 4-7, bit 4 the pair, bit 3 the row), then three plain steps; row u = lane >> 3 ends up in lane 8u
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    double v4[4], v2[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v4[q] = (b5 ? acc8[4 + q] : acc8[q]) + __shfl_xor(b5 ? acc8[q] : acc8[4 + q], 32);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v2[q] = (b4 ? v4[2 + q] : v4[q]) + __shfl_xor(b4 ? v4[q] : v4[2 + q], 16);
+    double v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+    v1 += __shfl_xor(v1, 4);
+    v1 += __shfl_xor(v1, 2);
+    v1 += __shfl_xor(v1, 1);
+    if ((lane & 7) == 0 && l0 + (lane >> 3) < L) x[P + l0 + (lane >> 3)] = act_l ? (-g_l - v1) * dinv_l : 0.0;
+  }
+  __syncthreads();
+  double mc = 0.0, gd = 0.0, dm = 0.0;   // model change; g . delta and |delta|_inf for the projected line search
+  for (int j = tid; j < N; j += NT) {
+    const double dj = x[j];
+    if (!isfinite(dj)) bad = 1;
+    if (d.active[u0 + j]) { mc += 0.5 * dj * (dd[j] * dj - g[j]); gd += g[j] * dj; dm = fmax(dm, fabs(dj)); }
+  }
+  for (int off = 32; off > 0; off >>= 1) { mc += __shfl_down(mc, off); gd += __shfl_down(gd, off); dm = fmax(dm, __shfl_down(dm, off)); }
+  if (lane == 0) { red[wave] = mc; red_gd[wave] = gd; red_dm[wave] = dm; }
+  __syncthreads();
+  if (tid == 0) {
+    double mc_t = 0.0, gd_t = 0.0, dm_t = 0.0;
+    for (int q = 0; q < NWV; ++q) { mc_t += red[q]; gd_t += red_gd[q]; dm_t = fmax(dm_t, red_dm[q]); }   // fixed order
+    lm.model_change = mc_t;
+    lm.ls_gd0 = gd_t;
+    lm.ls_dmax = dm_t;
+    const bool valid = !lm.chol_fail && !bad && (mc_t > 0.0);
+    if (valid) { lm.step_valid = 1; lm.invalid = 0; }
+    else {
+      lm.step_valid = 0;
+      if (++lm.invalid >= d.prm.max_invalid) lm.status = 1 + 5;
+      else { lm.mu /= lm.nu; lm.nu *= 2.0; lm.last_ok = 0; lm.nunsucc += 1; }
+    }
+    s_go = valid ? 1 : 0;
+  }
+  }   // (solve part)
+  __syncthreads();
+  if (!s_go) return;
+  // ---- candidate = Plus(x, alpha delta)
+  {
+    const double al = lm.alpha;   // 1, or the trial step size of the projected line search
+    const double *dl = d.delta + u0;
+    const uint8_t *act = d.active + u0;
+    double step2 = 0.0, x2 = 0.0;
+    const int nst = m.K + m.F + L + 1;
+    for (int t = tid; t < nst; t += NT) {
+      if (t < m.K) {
+        const int gk = m.knot0 + t;
+        const bool ar = act[6 * t] != 0, ap = act[6 * t + 3] != 0;
+        const Q4<double> q0 = qmk<double>(d.quat[4 * gk], d.quat[4 * gk + 1], d.quat[4 * gk + 2], d.quat[4 * gk + 3]);
+        Q4<double> q1 = q0;
+        if (ar) q1 = qmul(q0, so3_exp(mk<double>(al * dl[6 * t], al * dl[6 * t + 1], al * dl[6 * t + 2])));
+        d.cquat[4 * gk] = q1.x; d.cquat[4 * gk + 1] = q1.y; d.cquat[4 * gk + 2] = q1.z; d.cquat[4 * gk + 3] = q1.w;
+        if (ar) {
+          step2 += (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) + (q1.z - q0.z) * (q1.z - q0.z) + (q1.w - q0.w) * (q1.w - q0.w);
+          x2 += q1.x * q1.x + q1.y * q1.y + q1.z * q1.z + q1.w * q1.w;
+        }
+        for (int c = 0; c < 3; ++c) {
+          const double p0 = d.pos[3 * gk + c], p1 = ap ? p0 + al * dl[6 * t + 3 + c] : p0;
+          d.cpos[3 * gk + c] = p1;
+          if (ap) { step2 += (p1 - p0) * (p1 - p0); x2 += p1 * p1; }
+        }
+      } else if (t < m.K + m.F) {
+        const int f = t - m.K, gf = m.bias0 + f, u = 6 * m.K + 6 * f;
+        for (int c = 0; c < 6; ++c) {
+          const bool a = act[u + c] != 0;
+          const double b0 = d.bias[6 * gf + c], b1 = a ? b0 + al * dl[u + c] : b0;
+          d.cbias[6 * gf + c] = b1;
+          if (a) { step2 += (b1 - b0) * (b1 - b0); x2 += b1 * b1; }
+        }
+      } else if (t < m.K + m.F + L) {
+        const int l = t - m.K - m.F;
+        const bool a = act[P + l] != 0;
+        const double r0 = d.rho[lm0 + l], r1 = a ? r0 + al * dl[P + l] : r0;
+        d.crho[lm0 + l] = r1;
+        if (a) { step2 += (r1 - r0) * (r1 - r0); x2 += r1 * r1; }
+      } else {
+        const bool a = act[P - 1] != 0;
+        const double l0 = d.ld[w];
+        double l1 = a ? l0 + al * dl[P - 1] : l0;
+        if (a && !m.fix_ld) l1 = fmin(fmax(l1, m.ld_lo), m.ld_hi);
+        d.cld[w] = l1;
+        if (a) { step2 += (l1 - l0) * (l1 - l0); x2 += l1 * l1; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { step2 += __shfl_xor(step2, off); x2 += __shfl_xor(x2, off); }
+    __syncthreads();   // (red / red_gd of the solve part have been consumed)
+    if (lane == 0) { red[wave] = step2; red_gd[wave] = x2; }
+    __syncthreads();   // also: the candidate knots are visible to the whole workgroup
+    if (tid == 0) {
+      double s2 = 0.0, x2t = 0.0;
+      for (int q = 0; q < NWV; ++q) { s2 += red[q]; x2t += red_gd[q]; }   // fixed order
+      lm.step2 = s2;
+      lm.cand_xnorm2 = x2t;
+    }
+  }
+  // ---- knot-pair constants of the candidate (shared by all residual blocks of the linearisation that follows)
+  for (int t = tid; t < m.K - 1; t += NT) {
+    const int gk = m.knot0 + t;
+    knot_pair_const<double>(d.cquat + 4 * gk, d.cquat + 4 * gk + 4, d.lkd + 3 * gk, d.kjri + 9 * gk);
+  }
+}
+
+}  // namespace ctv

@@ -141,7 +141,7 @@ __device__ inline void jacobi_replay(double *slab, int nd, int r0, int nr, const
   }
 }
 
-template <class T> __global__ __launch_bounds__(256) void k_marginalize(Dev<T> d, MargMeta *metas, const int32_t *iscr, double *scr, double *out, double eps) {
+__global__ __launch_bounds__(256) void k_marginalize(Dev d, MargMeta *metas, const int32_t *iscr, double *scr, double *out, double eps) {
   const int w = blockIdx.x, tid = threadIdx.x;
   MargMeta &mm = metas[w];
   const WinMeta &wm = d.wins[w];
@@ -163,7 +163,7 @@ template <class T> __global__ __launch_bounds__(256) void k_marginalize(Dev<T> d
   // ---- dense symmetric A (N x N) from the structured normal equations: [Hpp W^T; W diag(Hll)]
   {
     const double *H = d.HppS[cset] + wm.H0;
-    const T *Wp = d.WS[cset] + wm.W0;
+    const double *Wp = d.WS[cset] + wm.W0;
     for (long long e = tid; e < (long long)N * N; e += 256) {
       const int i = (int)(e / N), j = (int)(e % N);
       double v;
