@@ -721,7 +721,8 @@ class SolverImpl : public SolverBase {
   // assembly variants run).  Two batches with identical totals can differ in these (e.g. the same sum K split differently).
   std::vector<long long> launch_signature() const {
     return {(long long)vis_lds_, (long long)vis_glb_, (long long)any_vis_lds_, (long long)any_vis_glb_, (long long)maxK_, (long long)max_schur_tiles_,
-            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles(), (long long)imu_zero_mode(), (long long)merge_linearize()};
+            (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles(), (long long)imu_zero_mode(), (long long)merge_linearize(), (long long)dev_.nwin,
+            (long long)(std::getenv("CTVIO_SCHUR_TILE2") ? std::atoi(std::getenv("CTVIO_SCHUR_TILE2")) : -1)};
   }
   int ensure_graph() {
     const std::vector<long long> sig = launch_signature();
@@ -1269,7 +1270,14 @@ void SolverImpl::launch_schur() {
       schur_rhs_done_ = true;
     } else {
       const int nt2 = d.maxP / 16 + 1, ntile2 = nt2 * (nt2 + 1) / 2;   // tile rows up to index P (the rhs row)
-      hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile2);
+      const int nb2 = (nt2 + 1) / 2, nblk2 = nb2 * (nb2 + 1) / 2;      // 32 x 32 blocks of the lower triangle
+      // enough tiles to fill the chip several times over (config 5: 666 per window): one wave per 2 x 2 tiles, half the operand loads
+      // per product; otherwise one wave per tile (more waves in flight).  CTVIO_SCHUR_TILE2 = 0 / 1 forces the choice (A/B).
+      const char *e2 = std::getenv("CTVIO_SCHUR_TILE2");
+      const int force2 = e2 ? std::atoi(e2) : -1;
+      const bool tile2 = force2 >= 0 ? force2 != 0 : (long long)d.nwin * ntile2 >= 16384;
+      if (tile2) hipLaunchKernelGGL(k_schur_tile2_f64, dim3(nblk2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nblk2);
+      else hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile2);
       schur_rhs_done_ = true;
     }
   } else {

@@ -264,6 +264,93 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev d, int ntile_max) {
   }
 }
 
+// The same with 2 x 2 REGISTER BLOCKING: a wave owns the four tiles (2 Bi + a, 2 Bj + b) of a 32 x 32 block of the lower triangle and
+// feeds four MFMAs from four operand loads per K-step (the one-tile form: two loads per MFMA).  With operands straight from W the
+// one-tile kernel is bound by L2 bandwidth once there are enough waves to fill the chip (config 5, P = 571: 666 tiles x 128 windows, every
+// tile wave re-reading 2 x 16 columns of its window's 4.9 MB W: 0.19 of the fp64 matrix peak); half the loads per product.  For batches
+// whose tile count fills the chip; a single small window keeps the one-tile form (more waves in flight, shorter latency).
+__global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;     // (XCD-aware map as above: a window's blocks share one L2)
+  const int w = (slot / nblk_max) * 8 + xcd, blk = slot % nblk_max;
+  if (w >= d.nwin) return;
+  if (d.lm[w].status || d.lm[w].ls_active) return;
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int nt = P / 16 + 1, nb = (nt + 1) / 2;   // tile rows up to index P (the rhs row rides along as row P); 32-row blocks
+  if (blk >= nb * (nb + 1) / 2) return;
+  int Bi, Bj;
+  tile_decode(blk, Bi, Bj);
+  const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
+  const int cur = d.lm[w].cur;
+  const double *Wp = d.WS[cur] + m.W0;
+  const double *dinv = d.dinv + m.lm0, *gl = d.gS[cur] + u0 + P;
+  int ci[2], cj[2];
+  bool rhs_lane[2], nz_i[2], nz_j[2];
+  double ai[2], aj[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int bi = 2 * Bi + a, bj = 2 * Bj + a;
+    ci[a] = min(16 * bi + l15, ldw - 1); cj[a] = min(16 * bj + l15, ldw - 1);
+    rhs_lane[a] = 16 * bi + l15 == P;
+    ai[a] = (16 * bi + l15 < P && d.active[u0 + min(ci[a], P - 1)]) ? 1.0 : 0.0;
+    aj[a] = (16 * bj + l15 < P && d.active[u0 + min(cj[a], P - 1)]) ? 1.0 : 0.0;
+    // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1
+    nz_i[a] = bi < nt && ((16 * bi < K6) || (P >= 16 * bi && P - 1 < 16 * bi + 16));
+    nz_j[a] = bj < nt && ((16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16));
+  }
+  const int lend = ((nz_i[0] || nz_i[1]) && (nz_j[0] || nz_j[1])) ? L : 0;   // (uniform)
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int l0 = 0; l0 < lend; l0 += 16) {
+    double wa[2][4], wb[2][4], dv[4], gv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {   // unconditional loads on clamped rows, masked below
+      const int lc = min(l0 + 4 * s + q4, L - 1);
+      const double *row = Wp + (long long)lc * ldw;
+      wa[0][s] = row[ci[0]]; wa[1][s] = row[ci[1]];
+      wb[0][s] = row[cj[0]]; wb[1][s] = row[cj[1]];
+      dv[s] = dinv[lc];
+      gv[s] = gl[lc];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool lv = l0 + 4 * s + q4 < L;
+      const double dvs = lv ? dv[s] : 0.0;
+      const double a0 = rhs_lane[0] ? gv[s] : wa[0][s] * ai[0], a1 = rhs_lane[1] ? gv[s] : wa[1][s] * ai[1];
+      const double b0 = wb[0][s] * aj[0] * dvs, b1 = wb[1][s] * aj[1] * dvs;
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      if (Bi != Bj) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);   // (uniform; on the diagonal block this tile is above the diagonal)
+    }
+  }
+  double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
+  const double *H = d.HppS[cur] + m.H0, *gp = d.gS[cur] + u0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int bi = 2 * Bi + a, bj = 2 * Bj + b;
+      if (bi >= nt || bj > bi) continue;   // (uniform)
+      const int jj = 16 * bj + l15, jc = min(jj, P - 1);
+      const bool act_j = d.active[u0 + jc] != 0;
+      const double dd_j = d.dd[u0 + jc], g_j = gp[jc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * bi + q4 + 4 * r, ic = min(ii, P - 1);
+        if (ii < P && jj <= ii) {
+          const bool on = d.active[u0 + ic] && act_j;
+          S[(long long)ii * ldh + jj] = on ? H[(long long)ic * ldh + min(jc, ic)] - acc[a][b][r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+        } else if (ii == P && jj < P) {
+          rhs[jj] = act_j ? acc[a][b][r] - g_j : 0.0;   // reduced right-hand side: -g_p + W^T diag(dinv) g_rho
+        }
+      }
+    }
+}
+
 __global__ void k_schur_generic(Dev d) {
   const int w = blockIdx.y;
   if (d.lm[w].status || d.lm[w].ls_active) return;

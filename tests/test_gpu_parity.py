@@ -645,6 +645,32 @@ def test_config5_large_window_vs_oracle(cv, oracle):
         assert cv.rel_state_error(batch[i], refs[i])["state"] < 1e-6, i
 
 
+def test_blocked_tile_schur_kernel_matches_the_one_tile_kernel(cv, oracle):
+    """k_schur_tile2_f64 (one wave per 2 x 2 tiles: batches whose tile count fills the chip, e.g. config 5 x 128) against k_schur_tile_f64
+    (one wave per tile) on the same windows -- forced through the A/B switch, since 3 windows would not select it -- and against the
+    oracle: a config-5 window (P = 571: odd number of tile rows, rhs row in the last block) and two config-1 windows with K = 27."""
+    ws = [cv.synth.make_window("config5", seed=1011)] + [cv.synth.make_window("config1", seed=1200 + i, F=10, dt_ns=40_000_000) for i in (0, 2)]
+    res = {}
+    for force in ("0", "1"):
+        os.environ["CTVIO_SCHUR_TILE2"] = force
+        try:
+            with cv.Solver() as s:
+                batch = [w.copy() for w in ws]
+                s.set_windows(batch)
+                res[force] = (batch, s.solve(15))
+        finally:
+            del os.environ["CTVIO_SCHUR_TILE2"]
+    for i, w in enumerate(ws):
+        a, b = res["0"][1][i], res["1"][1][i]
+        assert (a["iterations"], a["num_successful"], a["num_unsuccessful"]) == (b["iterations"], b["num_successful"], b["num_unsuccessful"])
+        assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-10)
+        assert cv.rel_state_error(res["1"][0][i], res["0"][0][i])["state"] < 1e-7
+        ref = w.copy()
+        so = oracle.OracleWindow(ref).solve(15)
+        assert b["iterations"] == so.iterations and b["final_cost"] == pytest.approx(so.final_cost, rel=1e-9)
+        assert cv.rel_state_error(res["1"][0][i], ref)["state"] < 1e-6
+
+
 def test_deterministic_mode_is_bitwise_reproducible(cv):
     """ctvio_options.deterministic (default: on for batches of <= 64 windows): order-fixed accumulation everywhere -- cost and step
     reductions in fixed trees, the visual assembly in one-wave parts whose packed partial Hessians are summed in part order, bias rows /
