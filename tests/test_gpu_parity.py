@@ -41,6 +41,51 @@ def test_linearize_matches_oracle(cv, oracle, win_cfg1, prec, tol):
     assert np.abs((gg - g) / sc).max() < tol * np.abs(g / sc).max()
 
 
+def test_several_anchors_per_landmark_and_large_rotation_visual(cv, oracle, win_cfg1):
+    """The C ABI takes arbitrary blocks: a landmark whose blocks do NOT share the i end (different t_i / row_i / p_i) owns several
+    anchors (host_pack.hpp finds the distinct ones, k_vis_anchor writes a record for each, the rows of W sum over them), and a window
+    with knot-to-knot rotations above 0.5 rad takes the general (closed-form) bodies of both visual kernels.  Dense normal equations
+    and a full solve against the oracle, which evaluates every block on its own."""
+    rng = np.random.default_rng(17)
+    w = win_cfg1.copy()
+    # every third block gets its own i end: another row, a shifted observation, and for some an i time one frame later (kept before t_j)
+    odd = np.arange(w.V) % 3 == 1
+    w.v_rowi = np.where(odd, rng.integers(0, 1024, w.V), w.v_rowi).astype(w.v_rowi.dtype)
+    w.v_pi = w.v_pi + odd[:, None] * rng.normal(0.0, 0.01, (w.V, 2))
+    later = odd & (w.v_tj - w.v_ti >= 200_000_000) & (rng.random(w.V) < 0.5)
+    w.v_ti = np.where(later, w.v_ti + 100_000_000, w.v_ti).astype(w.v_ti.dtype)
+    w.normalize()
+    big = w.copy()                                    # the same blocks on a spline with 0.7 rad between knots 5 / 6 and 11 / 12
+    for k in (6, 12):
+        c, sn = np.cos(0.35), np.sin(0.35)
+        dq = np.array([sn * 0.6, sn * 0.0, sn * 0.8, c])
+        for j in range(k, big.K):
+            x1, y1, z1, w1 = big.quat[j]; x2, y2, z2, w2 = dq
+            big.quat[j] = [w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2,
+                           w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2]
+    big.normalize()
+    for win, tol in ((w, 1e-10), (big, 1e-9)):
+        H, g, cost = oracle.OracleWindow(win.copy()).build_normal()
+        P = win.P
+        sc = _scaled(H)
+        with cv.Solver() as s:
+            s.set_windows([win.copy()])
+            Hg, Wg, Hllg, gg, costg = s.linearize(0)
+        assert costg == pytest.approx(cost, rel=1e-12)
+        assert np.abs((Hg - H[:P, :P]) / np.outer(sc[:P], sc[:P])).max() < tol
+        assert np.abs((Wg - H[:P, P:]) / np.outer(sc[:P], sc[P:])).max() < tol
+        assert np.abs(Hllg / np.diag(H)[P:] - 1).max() < tol
+        assert np.abs((gg - g) / sc).max() < tol * np.abs(g / sc).max()
+    ref = w.copy()
+    so = oracle.OracleWindow(ref).solve(15)
+    with cv.Solver() as s:
+        wg = w.copy()
+        s.set_windows([wg])
+        sm = s.solve(15)[0]
+    assert sm["iterations"] == so.iterations and sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9)
+    assert cv.rel_state_error(wg, ref)["state"] < 1e-6
+
+
 @pytest.mark.parametrize("case", ["general_body", "anisotropic_accel", "large_rotation"])
 def test_imu_linearize_general_body(cv, oracle, win_cfg1, case):
     """k_imu_linearize_f64 specialises the usual IMU group (knot-pair rotations < 0.5 rad, isotropic accelerometer weights); the others go
@@ -740,7 +785,8 @@ def test_per_block_cauchy_and_non_prefix_constant_knots(cv, oracle):
     np.testing.assert_array_equal(wg.pos[[0, 1, 5, 9]], w0.pos[[0, 1, 5, 9]])
 
 
-@pytest.mark.parametrize("name", ["lm_tiny_seed7", "lm_tiny_rs_seed3020", "lm_tiny_rs_seed3028", "lm_config1_seed1001"])
+@pytest.mark.parametrize("name", ["lm_tiny_seed7", "lm_tiny_rs_seed3020", "lm_tiny_rs_seed3028", "lm_config1_seed1001",
+                                  "lm_config2_seed1002", "lm_config3_seed1003"])
 def test_hip_path_reproduces_the_independent_lm_history(cv, golden_dir, name):
     """The device-resident LM (trust region + projected Armijo line search, speculative linearisation) against the committed
     per-iteration fixtures of the independent NumPy restatement of Ceres 1.14's loop (oracle/np_ceres.py, FD Jacobians): the same

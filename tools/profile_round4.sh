@@ -19,8 +19,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/ktw1 -o kt -- python $R/bench.py --no-cpu-baseline --quick --streams 1 --windows 1 --steps 20 --warmup 2 --device-resident-only > /dev/null 2>&1
 cd $R; python tools/prof_summary.py stats $(find $O/ktw1 -name "*.db") > $O/kernel_stats_single_window.txt; head -20 $O/kernel_stats_single_window.txt
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/ktc5 -o kt -- env CTVIO_SPLIT_LINEARIZE=1 python $R/bench.py --config config5 --windows 128 --unique 8 --no-cpu-baseline --quick --streams 1 --steps 2 --warmup 1 --device-resident-only > $O/bench_config5_x128.json 2>/dev/null
-cd $R; python tools/prof_summary.py stats $(find $O/ktc5 -name "*.db") > $O/kernel_stats_config5_x128.txt; head -20 $O/kernel_stats_config5_x128.txt
+rocprofv3 --kernel-trace --stats -d $O/ktc5 -o kt -- env CTVIO_SPLIT_LINEARIZE=1 python $R/bench.py --config config5 --windows 512 --unique 8 --no-cpu-baseline --quick --streams 1 --steps 2 --warmup 1 --device-resident-only > $O/bench_config5_x512.json 2>/dev/null
+cd $R; python tools/prof_summary.py stats $(find $O/ktc5 -name "*.db") > $O/kernel_stats_config5_x512.txt; head -20 $O/kernel_stats_config5_x512.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --quick --steps 3 --warmup 1 > $O/kt_bench.json 2> $O/kt.err
 cd $R; python tools/prof_summary.py stats $(find $O/kt -name "*.db") > $O/kernel_stats_default_4x2048.txt
