@@ -738,7 +738,10 @@ __device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r ==
 //  rank-4 update of the later columns, for the tile and for the inverse in the making, as two v_mfma_f64_16x16x4 -- was built and measured in
 //  round 4: 8.7 k cycles per tile against 8.3 k, the factorisation unchanged at 84 us.  The tile's time is not its row updates but the
 //  sixteen sequential pivots: readlane -> class test -> v_rsq_f64 -> two Newton steps -> scale -> readlane is ~300 dependent cycles each,
-//  211 of them per factorisation, whatever happens between them.  Not kept.)
+//  211 of them per factorisation, whatever happens between them.  Not kept.  Nor was the second attempt: columns left unscaled while they are
+//  used, so that the next pivot waits for a reciprocal (v_rcp_f64 + one third-order correction) instead of v_rsq_f64 + two Newton steps,
+//  with the square root computed beside it -- 9.0 k cycles per tile against 8.3 k.  A lone wave issues in order: work "beside" the chain is
+//  work in front of it, and the extra v_readfirstlane / multiplies cost more than the shorter dependence saved.)
 template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_tiles(Dev d) {
   constexpr int NT = 64 * NW, TS = 16 * 17;    // a 16 x 16 block in LDS: row stride 17
   const int w = blockIdx.x;
