@@ -577,6 +577,26 @@ def main():
             t8 = timed(3, False)
             out["host_share_of_an_8_rank_run"] = {"pack_threads_per_stream": ht8, "end_to_end_solves_per_s": args.windows * 3 / t8,
                                                   "end_to_end_over_device_resident": args.windows * 3 / t8 / out["device_resident_solves_per_s"]}
+            # ---- the host side alone: validate + pack (host threads) + one H2D copy per handle, no solve -- what the packer sustains
+            def pack_only(si, reps):
+                for _ in range(reps):
+                    cv.capi.check(lib.ctvio_set_batch(solvers[si]._h, per[si], C.cast(cbatches[si], C.c_void_p)))
+            th = [threading.Thread(target=pack_only, args=(si, 1)) for si in range(nstream)]
+            for t in th: t.start()
+            for t in th: t.join()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=pack_only, args=(si, 4)) for si in range(nstream)]
+            for t in th: t.start()
+            for t in th: t.join()
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - t0
+            wbytes = sum(getattr(w_lab, a).nbytes for a in ("quat", "pos", "bias", "rho", "imu_t", "imu_gyro", "imu_acc", "imu_bias", "v_lm", "v_ti", "v_tj",
+                                                             "v_rowi", "v_rowj", "v_pi", "v_pj", "bc_i", "bc_j", "bc_w", "pJ0", "pr0"))
+            out["host_pack_only"] = {"handles": nstream, "pack_threads_per_handle": ht8, "windows_per_s": args.windows * 4 / tp,
+                                     "caller_bytes_per_window": int(wbytes), "caller_GB_per_s": args.windows * 4 * wbytes / tp / 1e9,
+                                     "over_device_resident_rate": args.windows * 4 / tp / out["device_resident_solves_per_s"],
+                                     "usable_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
         out["parity"] = None
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the scaling runs must not wait on a CPU loop
