@@ -569,7 +569,7 @@ class SolverImpl : public SolverBase {
     constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
     if (!store_path()) { if (!imu_zero_mode()) hipLaunchKernelGGL(k_zero_normal, dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode); }
-    else hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1);   // prior gradient + cost share
+    else hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1, 0);   // prior gradient + cost share
     ph_end();
     const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(double);
     if (merge_linearize()) {
@@ -619,8 +619,8 @@ class SolverImpl : public SolverBase {
     if (any_vis_glb_) launch_assemble_vis_glb(parts, mode);
     ph_end();
     ph_begin(PH_ASM_REST);
-    if (d.Gtot) hipLaunchKernelGGL(k_assemble_imu, dim3(nw), dim3(256), 0, stream_, d, mode);
-    hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0);
+    // (the IMU tiles' bias rows, the bias chain and the prior in ONE launch: k_misc with assemble_imu_window in front)
+    hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0, d.Gtot ? 1 : 0);
     if (mode != LIN_SPEC) hipLaunchKernelGGL(k_post_linearize, dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();
   }
@@ -909,7 +909,7 @@ class SolverImpl : public SolverBase {
     if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(double), COST_AT_X);
     if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
     if (d.Vtot) hipLaunchKernelGGL(k_vis_eval, dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
-    hipLaunchKernelGGL(k_misc, dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0);
+    hipLaunchKernelGGL(k_misc, dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0, 0);
     hipLaunchKernelGGL(k_initial_cost, dim3(d.nwin), dim3(64), 0, stream_, d, 1);
     Lm lm;
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));

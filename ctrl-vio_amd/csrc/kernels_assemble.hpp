@@ -720,8 +720,10 @@ __device__ __forceinline__ const double *prior_block_ptr(const WinMeta &m, int k
 // Adds to Hpp / g of the set the mode selects (not on a cost-only pass) and stores the window's cost share (Dev::misc_cost).
 // store != 0 (store-semantics assembly tail): nothing is added here -- the prior's gradient J0^T r0 + (J0^T J0) dx goes to Dev::pgrad,
 // and the assembly looks the prior and the chain up when it writes each entry.
-__global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store) {
+// with_imu != 0: the window's IMU group tiles are scattered first (assemble_imu_window: the accumulate path's k_assemble_imu, fused).
+__global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int with_imu) {
   const int w = blockIdx.x;
+  if (with_imu) assemble_imu_window(d, mode, w);
   const Lm &lm = d.lm[w];
   if (!lin_run(lm, mode)) return;
   const bool LIN = !lin_cost_only(lm, mode, d.prm) && !store;

@@ -1,5 +1,5 @@
 // kernels_imu.hpp -- IMU linearisation: k_imu_linearize_f64 (the product path's walk over groups, fast body), the general body / k_imu_linearize_rest,
-// k_imu_linearize<CHUNK> (vector-ALU cross-check), k_assemble_imu.
+// k_imu_linearize<CHUNK> (vector-ALU cross-check), assemble_imu_window (the bias rows of the group tiles: run by k_misc).
 // Part of kernels.hpp (included from there, in order; not a stand-alone header).
 #pragma once
 
@@ -621,8 +621,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.
 // One workgroup per WINDOW walking its groups (one per group was 43 k workgroups of 195 useful threads: dispatch-bound).
-__global__ __launch_bounds__(256) void k_assemble_imu(Dev d, int mode) {
-  const int w = blockIdx.x;
+// (a device function: k_misc runs it in front of the bias chain and the prior -- the two were separate launches of the same shape, one
+//  256-thread workgroup per window, each a chain of dependent loads followed by atomics)
+__device__ __forceinline__ void assemble_imu_window(const Dev &d, int mode, int w) {
   if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
   const int K = m.K, ldh = m.ldh, tg = lin_target(d.lm[w], mode);
