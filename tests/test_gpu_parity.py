@@ -486,6 +486,48 @@ def test_ragged_batch_equals_single(cv):
         assert cv.rel_state_error(batch[i], w1)["state"] < 1e-7
 
 
+def test_random_factor_structures_match_oracle(cv, oracle):
+    """Randomised structure, one ragged batch: random subsets of the visual blocks (landmarks left with one block or none, frame pairs
+    thinned out), blocks with their own i end (several anchors per landmark), blocks reordered, free / fixed line delay at random
+    values, locked biases, constant knots in the middle, no prior -- every window's dense normal equations and cost from the device
+    against the oracle's, which knows nothing of anchors, slots or items."""
+    rng = np.random.default_rng(2024)
+    ws = []
+    for i in range(14):
+        w = cv.synth.make_window("tiny" if i % 3 else "config1", seed=500 + i, with_prior=bool(i % 2))
+        keep = rng.random(w.V) < rng.uniform(0.3, 1.0)
+        if i == 5:
+            keep[:] = False                                    # no visual blocks at all (landmarks stay, unobserved)
+        own = rng.random(w.V) < (0.25 if i % 4 == 1 else 0.0)  # blocks with an i end of their own
+        w.v_rowi = np.where(own, rng.integers(0, 1024, w.V), w.v_rowi).astype(w.v_rowi.dtype)
+        w.v_pi = w.v_pi + own[:, None] * rng.normal(0.0, 0.01, (w.V, 2))
+        order = rng.permutation(np.flatnonzero(keep))          # the caller's order is arbitrary
+        for name in ("v_lm", "v_ti", "v_tj", "v_rowi", "v_rowj", "v_pi", "v_pj"):
+            setattr(w, name, np.ascontiguousarray(getattr(w, name)[order]))
+        w.ld = float(rng.uniform(0.0, 3.5e-5))
+        w.fix_ld = bool(i % 5 == 0)
+        w.lock_bg = bool(i % 7 == 3); w.lock_ba = bool(i % 7 == 4)
+        if i % 6 == 2:
+            kc = np.zeros(w.K, np.uint8); kc[rng.integers(2, w.K - 2, 2)] = 1
+            w.knot_const = kc
+        w.normalize()
+        ws.append(w)
+    with cv.Solver() as s:
+        s.set_windows([w.copy() for w in ws])
+        for i, w in enumerate(ws):
+            H, g, cost = oracle.OracleWindow(w.copy()).build_normal()
+            P = w.P
+            sc = np.sqrt(np.maximum(np.diag(H), 1e-30))
+            Hg, Wg, Hllg, gg, costg = s.linearize(i)
+            assert costg == pytest.approx(cost, rel=1e-12), i
+            assert np.abs((Hg - H[:P, :P]) / np.outer(sc[:P], sc[:P])).max() < 1e-10, i
+            if w.L:
+                assert np.abs((Wg - H[:P, P:]) / np.outer(sc[:P], sc[P:])).max() < 1e-10, i
+                obs = np.diag(H)[P:] > 0
+                assert np.abs(Hllg[obs] / np.diag(H)[P:][obs] - 1).max() < 1e-10 if obs.any() else True, i
+            assert np.abs((gg - g) / np.maximum(sc, 1e-12)).max() < 1e-10 * max(np.abs(g / np.maximum(sc, 1e-12)).max(), 1.0), i
+
+
 def test_edge_cases(cv, oracle):
     """IMU-only predict with fixed knots and locked biases (reference InitTrajectory, trajectory_manager.cpp:288-315),
     no prior, fixed line delay, a landmark without observations."""
