@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -1391,6 +1393,42 @@ namespace {
 std::mutex g_shard_mu;
 std::vector<ctvio_solver *> g_shard_solvers;   // one per shard, created on first use (and again when the options change)
 std::vector<ctvio_options> g_shard_opts;       // the options each handle was created with
+// One persistent host thread per shard (shard 0 runs on the caller's thread): a call posts its per-shard job and waits -- no thread is
+// created or joined per call.  The threads live until ctvio_sharded_release.
+struct ShardWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, quit = false;
+  ~ShardWorker() { stop(); }   // (a process that never calls ctvio_sharded_release: the idle thread is told to quit and joined at exit)
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return has_job || quit; });
+        if (quit) return;
+        f = std::move(job);
+        has_job = false;
+      }
+      f();
+      { std::lock_guard<std::mutex> lk(mu); done = true; }
+      cv.notify_all();
+    }
+  }
+  void post(std::function<void()> f) {
+    { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has_job = true; done = false; }
+    cv.notify_all();
+  }
+  void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); }
+  void stop() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+std::vector<std::unique_ptr<ShardWorker>> g_shard_workers;   // [g - 1] for shard g >= 1
 }
 // The number of shards ctvio_solve_sharded uses: min(requested or all devices, devices present, windows).  With the TEST-ONLY
 // environment switch CTVIO_SHARD_OVERSUBSCRIBE=1 the device count does not clamp it (shard g runs on device g mod #devices), so that
@@ -1403,6 +1441,8 @@ int32_t ctvio_shards_used(int32_t n_devices, int32_t n) {
 }
 void ctvio_sharded_release(void) {
   std::lock_guard<std::mutex> lk(g_shard_mu);
+  for (auto &wk : g_shard_workers) wk->stop();
+  g_shard_workers.clear();
   for (auto *sv : g_shard_solvers) if (sv) ctvio_destroy(sv);
   g_shard_solvers.clear();
   g_shard_opts.clear();
@@ -1463,10 +1503,14 @@ int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t
     catch (const std::exception &e) { rcs[g] = CTVIO_ERR_HIP; errs[g] = "shard " + std::to_string(g) + ": " + e.what(); }
     catch (...) { rcs[g] = CTVIO_ERR_HIP; errs[g] = "shard " + std::to_string(g) + ": unknown exception"; }
   };
-  std::vector<std::thread> th;
-  for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+  while ((int)g_shard_workers.size() < G - 1) {
+    g_shard_workers.emplace_back(new ShardWorker());
+    ShardWorker *wk = g_shard_workers.back().get();
+    wk->th = std::thread([wk] { wk->loop(); });
+  }
+  for (int g = 1; g < G; ++g) g_shard_workers[g - 1]->post([&work, g] { work(g); });
   work(0);
-  for (auto &t : th) t.join();
+  for (int g = 1; g < G; ++g) g_shard_workers[g - 1]->wait();
   for (int g = 0; g < G; ++g) if (rcs[g] != CTVIO_OK) return ctv::fail(rcs[g], errs[g]);
   return CTVIO_OK;
 }

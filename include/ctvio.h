@@ -230,8 +230,9 @@ int32_t ctvio_gauge_restore(ctvio_solver *s, int32_t n, const int32_t *ids, cons
  * ctvio_solve_sharded: ctvio_set_batch + ctvio_solve + ctvio_get_batch_state of the n windows spread over n_devices devices
  * (0: all visible ones; device ordinals 0 .. n_devices - 1; opt->device is ignored).  out (n summaries) and the state arrays are in
  * the caller's WINDOW order, laid out like ctvio_get_batch_state (quat: sum K x 4, pos: sum K x 3, bias: sum F x 6, rho: sum L,
- * ld: n); any of them may be NULL.  The per-device handles are created on first use and kept for the next call (grow-only
- * arenas); ctvio_sharded_release frees them.  Python ranks use torch.distributed + ctrl-vio_amd/sharding.py for the same rule. */
+ * ld: n); any of them may be NULL.  The per-device handles and one persistent host thread per shard are created on first use and kept
+ * for the next call (grow-only arenas, no thread creation per call); ctvio_sharded_release frees them.  One sharded solve at a time
+ * per process (concurrent callers serialise on a mutex: use one solver handle per thread for concurrent batches).  Python ranks use torch.distributed + ctrl-vio_amd/sharding.py for the same rule. */
 int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t n, const ctvio_window *wins, int32_t max_iterations,
                             ctvio_summary *out, double *quat, double *pos, double *bias, double *rho, double *ld);
 void ctvio_sharded_release(void);

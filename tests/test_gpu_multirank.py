@@ -80,3 +80,26 @@ def test_sharded_entry_two_shards_on_one_device(cv):
             k0 += w.K; f0 += w.F; l0 += w.L
     # a different initial radius gives different iterates: the option change really took effect
     assert any(a["final_cost"] != c["final_cost"] or a["iterations"] != c["iterations"] for a, c in zip(res[1e4][5], res[1e1][5]))
+
+
+def test_process_exit_without_sharded_release(cv):
+    """The sharded entry keeps one idle host thread per shard alive between calls; a process that exits WITHOUT ctvio_sharded_release must
+    still exit cleanly (the workers are told to quit and joined by their destructors)."""
+    code = r'''
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.environ["CTV_ROOT"])
+import numpy as np
+cv = importlib.import_module("ctrl-vio_amd")
+lib = cv.capi.load_library()
+ws = [cv.synth.make_window("tiny", seed=310 + i) for i in range(4)]
+keep = []; arr = (cv.capi.CWindow * 4)()
+for i, w in enumerate(ws): arr[i] = cv.capi.to_cwindow(w, keep)
+opt = cv.capi.Options(); lib.ctvio_default_options(C.byref(opt))
+sm = (cv.capi.Summary * 4)()
+cv.capi.check(lib.ctvio_solve_sharded(C.byref(opt), 2, 4, C.cast(arr, C.c_void_p), 5, C.cast(sm, C.c_void_p), None, None, None, None, None))
+assert all(s.as_dict()["iterations"] > 0 for s in sm)
+print("SHARDED_EXIT_OK")
+'''
+    env = dict(os.environ, CTV_ROOT=ROOT, CTVIO_SHARD_OVERSUBSCRIBE="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "SHARDED_EXIT_OK" in p.stdout, (p.returncode, p.stderr[-2000:])
