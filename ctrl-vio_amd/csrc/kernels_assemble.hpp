@@ -53,7 +53,7 @@ template <int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_v
     rowa[a] = ca < 48 ? 2 * ca : (ca == 48 ? 98 : (ca == 49 ? 100 : -1));
     rowb[a] = cb < 48 ? 2 * cb : (cb == 48 ? 98 : (cb == 49 ? 100 : -1));
   }
-  long long *dbg = (d.dbg && w == 0 && part == 0) ? d.dbg + 48 : nullptr;
+  long long *dbg = (d.dbg && w == (d.nwin > 1000 ? 1000 : 0) && part == 0) ? d.dbg + 48 : nullptr;
   int dbi = 0;
 #define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 15) dbg[dbi++] = clock64(); } while (0)
   if (dbg && tid == 0) dbg[dbi++] = t_begin;
@@ -368,7 +368,7 @@ template <int CH, bool LDSH, int NW = 8, bool STORE = false> __global__ __launch
   double *Hg = d.HppS[tgset] + m.H0;
   const int q4 = lane >> 4, l15 = lane & 15, bsel = q4 >> 1, rr = q4 & 1;   // MFMA k index = 2 * (block of the pair) + residual row
   const int sc = lane % CH, srr = lane / CH;                               // staging: column (block) and row parity of this lane
-  long long *dbg = (d.dbg && w == 0 && part == 0) ? d.dbg + 48 : nullptr;
+  long long *dbg = (d.dbg && w == (d.nwin > 1000 ? 1000 : 0) && part == 0) ? d.dbg + 48 : nullptr;
   int dbi = 0;
 #define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 15) dbg[dbi++] = clock64(); } while (0)
   if (dbg && tid == 0) dbg[dbi++] = t_begin;
