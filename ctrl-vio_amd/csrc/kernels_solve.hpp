@@ -732,6 +732,61 @@ template <int J> __device__ __forceinline__ void chol16_from(double (&v)[16], do
     chol16_from<J + 1>(v, di_next, nreal, bad);
   }
 }
+// ---- The same diagonal tile with the broadcasts done by the data-parallel path of the fp64 ALU (v_fmac_f64_dpp row_newbcast:C: every lane of
+// a 16-lane row reads lane C of ITS row; gfx90a+ allows exactly this DPP control on 64-bit operations) -- ONE instruction per column update instead
+// of two v_readlane and an FMA.  A lone wave issues one vector instruction per ~5.3 clocks whether or not it depends on the one before
+// (tools/fp64_latency_probe.hip), so the tile's time is its instruction count and nothing else.  Even rows of the wave (lanes 0-15, 32-47) hold
+// the rows of the tile, odd rows (16-31, 48-63) the columns of the inverse; the odd rows need the multipliers L[C][J] of the EVEN row beside them,
+// which v_permlane16_swap_b32 (gfx950) copies across once per pivot (m).  1 / sqrt(p) = v_rsq_f64 + one third-order step (2^-23 -> below 2^-60).
+// A pivot that is not positive and finite turns everything after it into NaN (no select on the way): the last diagonal entry tells.
+template <int C> __device__ __forceinline__ void chol_dpp_update(double &vc, double m, double vj) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(vc) : "v"(m), "v"(vj), "n"(C));
+}
+template <int C> __device__ __forceinline__ void chol_dpp_update4(double &v0, double &v1, double &v2, double &v3, double m, double vj) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, -%4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, -%4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, -%4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)
+      : "v"(m), "v"(vj), "n"(C), "n"(C + 1), "n"(C + 2), "n"(C + 3));
+}
+template <int J, int C> __device__ __forceinline__ void chol16_dpp_rest(double (&v)[16], double m) {
+  if constexpr (C + 3 <= 15) {
+    chol_dpp_update4<C>(v[C], v[C + 1], v[C + 2], v[C + 3], m, v[J]);
+    chol16_dpp_rest<J, C + 4>(v, m);
+  } else if constexpr (C <= 15) {
+    chol_dpp_update<C>(v[C], m, v[J]);
+    chol16_dpp_rest<J, C + 1>(v, m);
+  }
+}
+__device__ __forceinline__ double chol_pivot_rsqrt3(double p) {
+  const double y = __builtin_amdgcn_rsq(p);
+  const double e = __builtin_fma(-(p * y), y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+// FULL: all sixteen pivots are unknowns of the window (every tile but the last); otherwise pivots >= nreal are forced to 1
+template <int J, bool FULL> __device__ __forceinline__ void chol16_dpp_from(double (&v)[16], double d, int nreal) {
+  v[J] *= d;
+  if constexpr (J < 15) {
+    const unsigned lo = (unsigned)__double2loint(v[J]), hi = (unsigned)__double2hiint(v[J]);
+    const auto slo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0]: odd rows <- the even rows beside them
+    const auto shi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double m = __hiloint2double((int)shi[0], (int)slo[0]);
+    chol_dpp_update<J + 1>(v[J + 1], m, v[J]);
+    double dn = chol_pivot_rsqrt3(readlane_d(v[J + 1], J + 1));
+    if constexpr (!FULL) dn = (J + 1 < nreal) ? dn : 1.0;
+    if constexpr (J < 14) chol16_dpp_rest<J, J + 2>(v, m);
+    chol16_dpp_from<J + 1, FULL>(v, dn, nreal);
+  }
+}
+__device__ __forceinline__ void chol16_dpp(double (&v)[16], int nreal, int &bad) {
+  const double d0 = chol_pivot_rsqrt3(readlane_d(v[0], 0));
+  if (nreal >= 16) chol16_dpp_from<0, true>(v, d0, nreal);
+  else chol16_dpp_from<0, false>(v, nreal > 0 ? d0 : 1.0, nreal);
+  const double last = readlane_d(v[15], 15);   // every column after a bad pivot is NaN (0 x NaN included), so is this one
+  if (!(last - last == 0.0)) bad = 1;
+}
+
 __device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
 
 // (A BLOCKED diagonal tile -- the 16 pivots in four blocks of four, at most three broadcast-and-FMA per pivot inside a block and the block's
@@ -752,7 +807,8 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   const int q4 = lane >> 4, l15 = lane & 15;
   const int NTR = P / 16 + 1, ntiles = NTR * (NTR + 1) / 2, ip = P / 16, rp = P % 16;   // the rhs row P sits in tile row ip, local row rp
   extern __shared__ __attribute__((aligned(16))) double smt[];
-  double *Li = smt;                    // [NTR][TS] inverses of the diagonal blocks, Li[b][j * 17 + k] = Linv_b[j][k]
+  double *Id = smt;                    // [TS] a 16 x 16 identity: the diagonal tile's inverse lanes start from it
+  double *Li = Id + TS;                // [NTR][TS] inverses of the diagonal blocks, Li[b][j * 17 + k] = Linv_b[j][k]
   double *Pn = Li + NTR * TS;          // [NTR][TS] panel: Pn[i][m * 17 + c] = L_ik[m][c] of the current panel
   double *tv = Pn + NTR * TS;          // [16 NTR] y, then the running right-hand side of the back-substitution
   double *xs = tv + 16 * NTR;          // [16 NTR] solution
@@ -760,6 +816,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   const double *S = d.S + m.H0, *y = d.rhs + m.p0;
   if (tid == 0) s_fail = 0;
   for (int i = tid; i < 16 * NTR; i += NT) tv[i] = 0.0;
+  for (int i = tid; i < TS; i += NT) Id[i] = (i / 17 == i % 17) ? 1.0 : 0.0;
   // ---- this wave's tiles (SGPRs) and their contents
   int ti[NS], tj[NS];
   f64x4 acc[NS];
@@ -800,6 +857,9 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 #define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
   CTV_STAMP();
   for (int k = 0; k < NTR; ++k) {
+    int opq;   // (a zero the compiler cannot see through: the per-slot LDS addresses of steps C and E are recomputed each panel -- one add each --
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opq));   // instead of being kept as 14 loop-invariant registers, which no longer fit beside the tile)
+    double *Pnk = Pn + opq;
     // ---- A. diagonal tile (k, k)
     const int td = k * (k + 1) / 2 + k, od = td % NW, sd = td / NW;
     if (wave == od) {
@@ -815,19 +875,17 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
       double v[16];
       int opaque0;   // a zero the compiler cannot see through: without it the 16 identity columns below are hoisted out of the panel
       asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));   // loop as loop invariants and, for lack of registers, kept in scratch
-      const int lz = l15 + opaque0;
+      // even rows of the wave: the tile's rows (whole rows: the factorisation never reads the upper half); odd rows: the identity, from LDS as
+      // well.  (With selects -- lane < 16 ? (c <= lane ? a : 0) : (c == lane) -- the compiler sank each of the 16 LDS reads into its own branch
+      // with its own s_waitcnt: 2.2 k clocks per tile for the load alone, tools/chol16_probe.hip.)
+      const double *src = ((lane & 16) ? Id : Dg) + (l15 + opaque0) * 17;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const double a = Dg[l15 * 17 + c];
-        v[c] = lane < 16 ? (c <= lz ? a : 0.0) : (c == lz ? 1.0 : 0.0);
-      }
+      for (int c = 0; c < 16; ++c) v[c] = src[c];
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();      // every lane has read its row before the block is overwritten with the inverse
       const int nreal = P - 16 * k;         // pivots below this are real; the rhs row and the padding rows are not factored
       int bad = 0;
-      double di0 = 1.0;
-      if (nreal > 0) di0 = chol_pivot_rsqrt(readlane_d(v[0], 0), bad);
-      chol16_from<0>(v, di0, nreal, bad);
+      chol16_dpp(v, nreal, bad);
       if (lane >= 16 && lane < 32) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) Dg[i * 17 + l15] = v[i];   // Linv[i][column l15]
@@ -847,7 +905,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       if (tj[q] != k || ti[q] <= k) continue;   // (uniform)
-      double *blk = Pn + ti[q] * TS;
+      double *blk = Pnk + ti[q] * TS;
 #pragma unroll
       for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = acc[q][r];
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -873,7 +931,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       if (ti[q] < 0 || tj[q] <= k || tj[q] >= (1 << 20)) continue;   // (uniform)
-      const double *pa = Pn + ti[q] * TS + l15 * 17 + q4, *pb = Pn + tj[q] * TS + l15 * 17 + q4;
+      const double *pa = Pnk + ti[q] * TS + l15 * 17 + q4, *pb = Pnk + tj[q] * TS + l15 * 17 + q4;
       double a[4], b[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) { a[s4] = -pa[4 * s4]; b[s4] = pb[4 * s4]; }
