@@ -795,6 +795,8 @@ class SolverImpl : public SolverBase {
       std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> wave 1000, clock64 deltas (evaluation | contributions + segmented sums | record copy-out | per sweep: scatter, rows out):");
       for (int i = 32; i < 40; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, " | landmarks %lld, rows per sweep %lld", st[42] / 1000000, st[43] / 1000);
+      std::fprintf(stderr, "\n[ctvio] schur_window clock64 deltas (prologue + first chunk staged | chunks 0-2: products, stash, barrier | rest of the loop | product tiles out | other tiles out):");
+      for (int i = 97; i < 128 && st[i] != 0; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | per item of rounds 0, 1: staged, run products.., scatter | rounds | imu tiles | H flush | g flush):");
       for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n");
@@ -1260,7 +1262,7 @@ void SolverImpl::launch_schur() {
   schur_rhs_done_ = false;
   if (opt_.use_mfma) {   // fp64 matrix cores
     const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
-    const size_t lds = ((size_t)2 * 16 * d.maxLdw + d.maxLdw + 32 + 64) * sizeof(double);   // + the list of tiles with products
+    const size_t lds = ((size_t)2 * 16 * d.maxLdw + 3 * d.maxLdw + 32 + 64) * sizeof(double);   // + column vectors + the list of tiles with products
     // large batches: one workgroup per window, W staged through LDS once, reduced rhs produced on the way; small batches: one
     // wave per 16 x 16 tile (shorter latency, W re-read per tile), k_rhs forms the reduced right-hand side
     const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");

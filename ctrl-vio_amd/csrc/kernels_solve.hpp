@@ -69,14 +69,19 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   const int nt = ldw >> 4, ntile = nt * (nt + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double smd64[];
   double *Wb = smd64;                    // [2][16][ldw]
-  double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)
-  double *dch = acts + ldw;              // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
+  double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)      } per-column vectors of the epilogue, staged once: no global
+  double *ddv = acts + ldw;              // [ldw] D of the column            } round trip per tile there (the activity of a STAGED column
+  double *gv = ddv + ldw;                // [ldw] gradient                   } travels in pre_lc)
+  double *dch = gv + ldw;                // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
   int *tlist = reinterpret_cast<int *>(dch + 32);   // [8 NTQ] tiles with products (bi << 8 | bj), any order
   int &tcount = tlist[8 * NTQ];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
   const double *Wp = d.WS[d.lm[w].cur] + m.W0;
   const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
-  for (int c = tid; c < ldw; c += 512) acts[c] = (c < P && d.active[u0 + min(c, P - 1)]) ? 1.0 : 0.0;
+  for (int c = tid; c < ldw; c += 512) {
+    const int cc = min(c, P - 1);
+    acts[c] = (c < P && d.active[u0 + cc]) ? 1.0 : 0.0; ddv[c] = d.dd[u0 + cc]; gv[c] = d.gS[d.lm[w].cur][u0 + cc];
+  }
   if (tid == 0) tcount = 0;
   // W is non-zero only in the knot columns [0, 6K) and the line-delay column P - 1 (plus the rhs row P): a tile has products
   // when its row tile and its column tile both hold such a column.  Those tiles (55 of 105 at K = 24) are listed and dealt to
@@ -97,14 +102,16 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   double pre_d = 0.0;
   int pre_lc[NPRE];     // chunk row << 16 | window column of this thread's elements (the same for every chunk)
 #pragma unroll
-  for (int k = 0; k < NPRE; ++k) {
-    const int e = min(tid + 512 * k, nelc - 1), cc = e % NC;
-    pre_lc[k] = ((e / NC) << 16) | (cc < K6 ? cc : P - 1 + (cc - K6));
+  for (int k = 0; k < NPRE; ++k) {   // bit 30: the element is stored as it is (active column, or g_rho); otherwise as zero.  (As a factor read
+    // from LDS at every stash -- acts[c] -- the compiler gave each element its own branch, ds_read and s_waitcnt: five serial round trips per chunk.)
+    const int e = min(tid + 512 * k, nelc - 1), cc = e % NC, c = cc < K6 ? cc : P - 1 + (cc - K6);
+    const bool keep = tid + 512 * k < nelc && (c == P || d.active[u0 + min(c, P - 1)] != 0);
+    pre_lc[k] = ((e / NC) << 16) | c | (keep ? 1 << 30 : 0);
   }
   auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int l = min(16 * ch + (pre_lc[k] >> 16), L - 1), c = pre_lc[k] & 0xffff;
+      const int l = min(16 * ch + ((pre_lc[k] >> 16) & 0xff), L - 1), c = pre_lc[k] & 0xffff;
       pre[k] = (c == P) ? gl[l] : Wp[(long long)l * ldw + c];
     }
     if (tid < 16) pre_d = dinv[min(16 * ch + tid, L - 1)];
@@ -112,14 +119,18 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   auto stash = [&](int ch, int buf) {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int lr = pre_lc[k] >> 16, c = pre_lc[k] & 0xffff;
-      const bool lv = 16 * ch + lr < L;
-      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? ((c == P) ? pre[k] : pre[k] * acts[c]) : 0.0;
+      const int lr = (pre_lc[k] >> 16) & 0xff, c = pre_lc[k] & 0xffff;
+      const bool lv = 16 * ch + lr < L && (pre_lc[k] >> 30) != 0;
+      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? pre[k] : 0.0;
     }
     if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
   };
-  __syncthreads();   // acts, zeroed buffers, tile list
+  __syncthreads();   // zeroed buffers, tile list
   const int nact = min(tcount, 8 * NTQ);
+  long long *dbg = (d.dbg && w == (d.nwin > 1000 ? 1000 : 0)) ? d.dbg + 96 : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of thread 0 at the phase boundaries
+  int dbi = 0;
+#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
+  CTV_STAMP();
   // this wave's tiles: slot q holds list entry wave + 8 q; slots past the end repeat the wave's first tile (products computed,
   // result dropped) so that the tile loop below has no branches and the operand reads of a tile overlap the previous products
   int tij[NTQ];
@@ -130,6 +141,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
   if (nchunk > 0) { fetch(0); stash(0, 0); }
   __syncthreads();
+  CTV_STAMP();
   for (int ch = 0; ch < nchunk && nact > 0; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) fetch(ch + 1);
@@ -137,6 +149,9 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     double dl[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
+    // The eight operand reads of a tile are issued together, and the scheduler may not move anything across the fences: left to itself it
+    // issued every ds_read right before the v_mfma that consumes it -- 28 serial LDS round trips per chunk and wave (5.5 k - 13 k clocks
+    // against 0.9 k of matrix-core time).  One round trip per tile is hidden by the other three waves of the SIMD.
 #pragma unroll
     for (int q = 0; q < NTQ; ++q) {
       double a[4], b[4];
@@ -145,32 +160,46 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
         a[s] = B[4 * s * ldw + 16 * (tij[q] >> 8)];
         b[s] = B[4 * s * ldw + 16 * (tij[q] & 255)];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (ch < 3) CTV_STAMP();
     if (ch + 1 < nchunk) stash(ch + 1, buf ^ 1);
+    if (ch < 3) CTV_STAMP();
     __syncthreads();
+    if (ch < 3) CTV_STAMP();
   }
+  CTV_STAMP();
   // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
   double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
   const double *H = d.HppS[d.lm[w].cur] + m.H0;
-  auto write_tile = [&](int ti, int tj, const f64x4 &av) {
-    const int jj = 16 * tj + l15, jc = min(jj, P - 1);
-    const bool act_j = d.active[u0 + jc] != 0;
-    const double dd_j = d.dd[u0 + jc], g_j = d.gS[d.lm[w].cur][u0 + jc];
-    double hv[4];
-    unsigned char act_i[4];
+  // The Hpp entries of two (product tiles) or four tiles are requested together (every tile used to be a global round trip of its own, 13 in a row per wave:
+  // 40 % of the kernel); the per-column vectors come from LDS, read before any branch (pin) so that they are not sunk into one.
+  auto pin = [](double &x) { asm volatile("" : "+v"(x)); };
+  auto load_h = [&](int ti, int tj, double (&hv)[4]) {
+    const int jc = min(16 * tj + l15, P - 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ic = min(16 * ti + q4 + 4 * r, P - 1);
-      act_i[r] = d.active[u0 + ic];
       hv[r] = H[(long long)ic * ldh + min(jc, ic)];
     }
+  };
+  auto store_tile = [&](int ti, int tj, const f64x4 &av, const double (&hv)[4]) {
+    const int jj = 16 * tj + l15, jc = min(jj, P - 1);
+    double a_j = acts[jc], dd_j = ddv[jc], g_j = gv[jc], a_i[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a_i[r] = acts[min(16 * ti + q4 + 4 * r, P - 1)];
+    pin(a_j); pin(dd_j); pin(g_j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pin(a_i[r]);
+    const bool act_j = a_j != 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ii = 16 * ti + q4 + 4 * r;
       if (ii < P && jj <= ii) {
-        const bool on = act_i[r] && act_j;
+        const bool on = a_i[r] != 0.0 && act_j;
         S[(long long)ii * ldh + jj] = on ? hv[r] - av[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
       } else if (ii == P && jj < P) {
         rhs[jj] = act_j ? av[r] - g_j : 0.0;
@@ -178,17 +207,48 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     }
   };
 #pragma unroll
-  for (int q = 0; q < NTQ; ++q) {
-    if (wave + 8 * q >= nact) continue;
-    write_tile(tij[q] >> 8, tij[q] & 255, acc[q]);
+  for (int g = 0; g < NTQ; g += 2) {   // (two tiles at a time: the accumulators are still alive)
+    double hv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (g + u < NTQ) load_h(tij[g + u < NTQ ? g + u : 0] >> 8, tij[g + u < NTQ ? g + u : 0] & 255, hv[u]);   // (slots past the end repeat a valid tile)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (g + u < NTQ && wave + 8 * (g + u) < nact) store_tile(tij[g + u < NTQ ? g + u : 0] >> 8, tij[g + u < NTQ ? g + u : 0] & 255, acc[g + u < NTQ ? g + u : 0], hv[u]);
   }
+  CTV_STAMP();
   const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  for (int t = wave; t < ntile; t += 8) {     // tiles without products
-    int ti, tj;
-    tile_decode(t, ti, tj);
-    if (nz_row(ti) && nz_col(tj)) continue;
-    write_tile(ti, tj, zero4);
+  auto next_plain = [&](int t) {   // the next tile without products of this wave at or after t (wave-uniform)
+    for (; t < ntile; t += 8) {
+      int ti, tj;
+      tile_decode(t, ti, tj);
+      if (!(nz_row(ti) && nz_col(tj))) break;
+    }
+    return t;
+  };
+  for (int tp = next_plain(wave); tp < ntile;) {
+    int tl[4];
+    double hv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      tl[u] = tp;
+      if (tp < ntile) {
+        int ti, tj;
+        tile_decode(tp, ti, tj);
+        load_h(ti, tj, hv[u]);
+        tp = next_plain(tp + 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tl[u] < ntile) {
+        int ti, tj;
+        tile_decode(tl[u], ti, tj);
+        store_tile(ti, tj, zero4, hv[u]);
+      }
   }
+  CTV_STAMP();
+#undef CTV_STAMP
 }
 
 // fp64 path: the same SYRK on the fp64 matrix cores, one wave per 16 x 16 tile of the lower triangle
