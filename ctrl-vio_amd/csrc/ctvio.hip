@@ -645,7 +645,7 @@ class SolverImpl : public SolverBase {
     // 223 unknowns: the panel kernel, with 8 waves when there are fewer windows than CUs
     if (chol_tiles()) {
       const int ntr = d.maxP / 16 + 1;
-      const size_t lds = (size_t)(272 + 2 * ntr * 272 + 32 * ntr + 4) * sizeof(double);   // identity + panel + inverses + vectors
+      const size_t lds = (size_t)(272 + 2 * ntr * 272 + 32 * ntr + 4 + 512) * sizeof(double);   // identity + panel + inverses + vectors + parked tiles
       if (chol_tiles() == 2) hipLaunchKernelGGL((k_cholesky_tiles<8, 14>), dim3(nw), dim3(512), lds, stream_, d);   // (A/B variant: 8 waves x 14 tiles)
       else hipLaunchKernelGGL((k_cholesky_tiles<16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
     }
@@ -1260,6 +1260,7 @@ void SolverImpl::launch_assemble_vis_glb(int parts, int mode) {
 void SolverImpl::launch_schur() {
   const Dev &d = dev_;
   schur_rhs_done_ = false;
+  dev_.schur_plain_in_H = 0;
   if (opt_.use_mfma) {   // fp64 matrix cores
     const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
     const size_t lds = ((size_t)2 * 16 * d.maxLdw + 3 * d.maxLdw + 32 + 64) * sizeof(double);   // + column vectors + the list of tiles with products
@@ -1268,6 +1269,7 @@ void SolverImpl::launch_schur() {
     const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
     const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
     if (!small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224) {
+      dev_.schur_plain_in_H = (chol_tiles() != 0 && !std::getenv("CTVIO_SCHUR_COPY_PLAIN")) ? 1 : 0;   // (d is dev_: the Cholesky launch sees it too)
       if (16 * nc <= 5 * 512 && max_schur_tiles_ <= 56) hipLaunchKernelGGL((k_schur_window_f64<5, 7>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);

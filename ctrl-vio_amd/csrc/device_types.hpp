@@ -75,6 +75,7 @@ struct LmParams {
 // Device pointers of one batch (all arithmetic is fp64, like the reference's).
 struct Dev {
   int32_t nwin, Ktot, Ftot, Ltot, Mtot, Gtot, Vtot, NBtot, Utot, maxN, maxP, maxPn;
+  int32_t schur_plain_in_H;   // k_schur_window_f64 left the 16 x 16 tiles without Schur products unwritten: k_cholesky_tiles forms them from Hpp + D itself
   const WinMeta *wins;
   // state, fp64 master copies: current and candidate
   double *quat, *pos, *bias, *rho, *ld;

@@ -101,12 +101,12 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   double pre[NPRE];
   double pre_d = 0.0;
   int pre_lc[NPRE];     // chunk row << 16 | window column of this thread's elements (the same for every chunk)
+  double keep[NPRE];    // (read together, after the barrier below)
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) {   // bit 30: the element is stored as it is (active column, or g_rho); otherwise as zero.  (As a factor read
     // from LDS at every stash -- acts[c] -- the compiler gave each element its own branch, ds_read and s_waitcnt: five serial round trips per chunk.)
     const int e = min(tid + 512 * k, nelc - 1), cc = e % NC, c = cc < K6 ? cc : P - 1 + (cc - K6);
-    const bool keep = tid + 512 * k < nelc && (c == P || d.active[u0 + min(c, P - 1)] != 0);
-    pre_lc[k] = ((e / NC) << 16) | c | (keep ? 1 << 30 : 0);
+    pre_lc[k] = ((e / NC) << 16) | c | ((tid + 512 * k < nelc && c == P) ? 1 << 30 : 0);
   }
   auto fetch = [&](int ch) {     // unconditional loads on clamped rows; masked when stored
 #pragma unroll
@@ -125,7 +125,11 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     }
     if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
   };
-  __syncthreads();   // zeroed buffers, tile list
+  __syncthreads();   // zeroed buffers, tile list, column vectors
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) keep[k] = acts[min(pre_lc[k] & 0xffff, ldw - 1)];
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) pre_lc[k] |= (tid + 512 * k < nelc && keep[k] != 0.0) ? 1 << 30 : 0;
   const int nact = min(tcount, 8 * NTQ);
   long long *dbg = (d.dbg && w == (d.nwin > 1000 ? 1000 : 0)) ? d.dbg + 96 : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of thread 0 at the phase boundaries
   int dbi = 0;
@@ -136,9 +140,22 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   int tij[NTQ];
 #pragma unroll
   for (int q = 0; q < NTQ; ++q) tij[q] = __builtin_amdgcn_readfirstlane(tlist[(wave + 8 * q < nact) ? wave + 8 * q : min(wave, max(nact - 1, 0))]);   // SGPRs
+  // The accumulators start at -Hpp (rows beyond the unknowns -- the rhs row -- at 0): the tile's Hpp entries arrive with the first chunk of W
+  // instead of costing the epilogue a global round trip per tile, and S = -(acc) + D needs no second operand there.
+  const double *H = d.HppS[d.lm[w].cur] + m.H0;
   f64x4 acc[NTQ];
+  int opq;   // (a zero the compiler cannot see through: otherwise the row / column indices computed here are kept -- spilled -- for the epilogue)
+  asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
 #pragma unroll
-  for (int q = 0; q < NTQ; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < NTQ; ++q) {
+    const int tq = tij[q] + opq, jc = min(16 * (tq & 255) + l15, P - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = 16 * (tq >> 8) + q4 + 4 * r, ic = min(ii, P - 1);
+      const double h = H[(unsigned)(ic * ldh + min(jc, ic))];   // (32-bit offset from a uniform base: one address register per load)
+      acc[q][r] = ii < P ? -h : 0.0;
+    }
+  }
   if (nchunk > 0) { fetch(0); stash(0, 0); }
   __syncthreads();
   CTV_STAMP();
@@ -172,21 +189,12 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     if (ch < 3) CTV_STAMP();
   }
   CTV_STAMP();
-  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.
+  // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.  The per-column vectors
+  // come from LDS, read before any branch (pin) so that the compiler does not sink each read into a branch of its own.
   double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
-  const double *H = d.HppS[d.lm[w].cur] + m.H0;
-  // The Hpp entries of two (product tiles) or four tiles are requested together (every tile used to be a global round trip of its own, 13 in a row per wave:
-  // 40 % of the kernel); the per-column vectors come from LDS, read before any branch (pin) so that they are not sunk into one.
   auto pin = [](double &x) { asm volatile("" : "+v"(x)); };
-  auto load_h = [&](int ti, int tj, double (&hv)[4]) {
-    const int jc = min(16 * tj + l15, P - 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ic = min(16 * ti + q4 + 4 * r, P - 1);
-      hv[r] = H[(long long)ic * ldh + min(jc, ic)];
-    }
-  };
-  auto store_tile = [&](int ti, int tj, const f64x4 &av, const double (&hv)[4]) {
+  // hs[r] = the tile's entry without the damping: -acc of a product tile, Hpp of a plain one; bs[r] = its rhs-row entry before -g
+  auto store_tile = [&](int ti, int tj, const double (&hs)[4], const double (&bs)[4]) {
     const int jj = 16 * tj + l15, jc = min(jj, P - 1);
     double a_j = acts[jc], dd_j = ddv[jc], g_j = gv[jc], a_i[4];
 #pragma unroll
@@ -200,24 +208,23 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
       const int ii = 16 * ti + q4 + 4 * r;
       if (ii < P && jj <= ii) {
         const bool on = a_i[r] != 0.0 && act_j;
-        S[(long long)ii * ldh + jj] = on ? hv[r] - av[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+        S[(long long)ii * ldh + jj] = on ? hs[r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
       } else if (ii == P && jj < P) {
-        rhs[jj] = act_j ? av[r] - g_j : 0.0;
+        rhs[jj] = act_j ? bs[r] - g_j : 0.0;
       }
     }
   };
 #pragma unroll
-  for (int g = 0; g < NTQ; g += 2) {   // (two tiles at a time: the accumulators are still alive)
-    double hv[2][4];
+  for (int q = 0; q < NTQ; ++q) {
+    if (wave + 8 * q >= nact) continue;
+    double hs[4], bs[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (g + u < NTQ) load_h(tij[g + u < NTQ ? g + u : 0] >> 8, tij[g + u < NTQ ? g + u : 0] & 255, hv[u]);   // (slots past the end repeat a valid tile)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (g + u < NTQ && wave + 8 * (g + u) < nact) store_tile(tij[g + u < NTQ ? g + u : 0] >> 8, tij[g + u < NTQ ? g + u : 0] & 255, acc[g + u < NTQ ? g + u : 0], hv[u]);
+    for (int r = 0; r < 4; ++r) { hs[r] = -acc[q][r]; bs[r] = acc[q][r]; }
+    store_tile(tij[q] >> 8, tij[q] & 255, hs, bs);
   }
   CTV_STAMP();
-  const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  // tiles without products (S = Hpp + D): this wave's list first (scalar), then the Hpp entries of four tiles requested together -- every tile used
+  // to be a global round trip of its own
   auto next_plain = [&](int t) {   // the next tile without products of this wave at or after t (wave-uniform)
     for (; t < ntile; t += 8) {
       int ti, tj;
@@ -226,26 +233,31 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     }
     return t;
   };
+  if (d.schur_plain_in_H) {   // the Cholesky kernel reads Hpp itself (half of this kernel's Hpp reads and S writes were copies); only the
+    for (int c = tid; c < P; c += 512)   // rhs entries of the columns that no product tile covers are left to do
+      if (!nz_col(c >> 4)) rhs[c] = acts[c] != 0.0 ? -gv[c] : 0.0;
+  } else
   for (int tp = next_plain(wave); tp < ntile;) {
-    int tl[4];
-    double hv[4][4];
+    int pi[4], pj[4];   // (-1: none)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      tl[u] = tp;
-      if (tp < ntile) {
-        int ti, tj;
-        tile_decode(tp, ti, tj);
-        load_h(ti, tj, hv[u]);
-        tp = next_plain(tp + 8);
+      pi[u] = -1; pj[u] = 0;
+      if (tp < ntile) { tile_decode(tp, pi[u], pj[u]); tp = next_plain(tp + 8); }
+    }
+    double hv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // unconditional loads (a missing tile repeats tile (0, 0))
+      const int ti = max(pi[u], 0), jc = min(16 * pj[u] + l15, P - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ic = min(16 * ti + q4 + 4 * r, P - 1);
+        hv[u][r] = H[(unsigned)(ic * ldh + min(jc, ic))];
       }
     }
+    const double zero[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (tl[u] < ntile) {
-        int ti, tj;
-        tile_decode(tl[u], ti, tj);
-        store_tile(ti, tj, zero4, hv[u]);
-      }
+      if (pi[u] >= 0) store_tile(pi[u], pj[u], hv[u], zero);
   }
   CTV_STAMP();
 #undef CTV_STAMP
@@ -873,9 +885,29 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   double *tv = Pn + NTR * TS;          // [16 NTR] y, then the running right-hand side of the back-substitution
   double *xs = tv + 16 * NTR;          // [16 NTR] solution
   int &s_fail = *reinterpret_cast<int *>(xs + 16 * NTR);
+  double *park = xs + 16 * NTR + 2;    // [8][64] two tiles of the wave that factors a diagonal tile wait here meanwhile (see step A)
   const double *S = d.S + m.H0, *y = d.rhs + m.p0;
+  const double *Hc = d.HppS[lm.cur] + m.H0;
+  const bool from_h = d.schur_plain_in_H != 0;
+  const int K6 = 6 * m.K;
+  // (the same tile classification as k_schur_window_f64: W is non-zero in the knot columns, the line-delay column and the rhs row)
+  auto nz_row = [&](int b) { return (16 * b < K6) || (P >= 16 * b && P - 1 < 16 * b + 16); };
+  auto nz_col = [&](int b) { return (16 * b < K6) || (P - 1 >= 16 * b && P - 1 < 16 * b + 16); };
   if (tid == 0) s_fail = 0;
   for (int i = tid; i < 16 * NTR; i += NT) tv[i] = 0.0;
+  // activity of the unknowns as four 64-bit masks in SGPRs (each wave builds its own: four byte loads per lane, no LDS, no barrier)
+  unsigned long long amask[4] = {0ull, 0ull, 0ull, 0ull};
+  if (from_h) {
+    unsigned char ab[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ab[k] = d.active[m.u0 + min(lane + 64 * k, P - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) amask[k] = __ballot(lane + 64 * k < P && ab[k] != 0);
+  }
+  auto active_bit = [&](int i) {   // (i < 256; lane-variant)
+    const unsigned long long wlo = (i & 128) ? amask[2] : amask[0], whi = (i & 128) ? amask[3] : amask[1];
+    return (int)((((i & 64) ? whi : wlo) >> (i & 63)) & 1ull);
+  };
   for (int i = tid; i < TS; i += NT) Id[i] = (i / 17 == i % 17) ? 1.0 : 0.0;
   // ---- this wave's tiles (SGPRs) and their contents
   int ti[NS], tj[NS];
@@ -888,16 +920,28 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
     ti[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? a : -1);
     tj[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? b : 1 << 20);   // (never equal to a panel, never a trailing tile: ti < tj)
     // unconditional loads on clamped addresses straight into the tile registers; fixed up below
+    const bool plain = from_h && !(nz_row(a) && nz_col(b));   // (wave-uniform)
+    const double *src = plain ? Hc : S;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rc = min(16 * a + q4 + 4 * r, P - 1);
-      acc[q][r] = S[(long long)rc * ldh + min(16 * b + l15, rc)];
+      acc[q][r] = src[(long long)rc * ldh + min(16 * b + l15, rc)];
     }
   }
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     if (ti[q] < 0) continue;
     const int col = 16 * tj[q] + l15;
+    if (from_h && !(nz_row(ti[q]) && nz_col(tj[q]))) {   // a tile without Schur products, straight from Hpp: damping and fixed unknowns here
+      const int a_j = active_bit(col);
+      double ddiag = 0.0;   // (a diagonal tile among them: a few bias-bias blocks per window; one L2 round trip for its wave)
+      if (ti[q] == tj[q]) ddiag = d.dd[m.u0 + min(col, P - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti[q] + q4 + 4 * r;
+        acc[q][r] = (active_bit(row) & a_j) ? acc[q][r] + (row == col ? ddiag : 0.0) : (row == col ? 1.0 : 0.0);
+      }
+    }
     if (ti[q] == tj[q]) {             // diagonal tile: the upper half is not stored in S
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[q][r] = (col <= 16 * ti[q] + q4 + 4 * r) ? acc[q][r] : 0.0;
@@ -930,6 +974,12 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 #pragma unroll
           for (int r = 0; r < 4; ++r) Dg[(q4 + 4 * r) * 17 + l15] = acc[q][r];
         }
+      // The tile's 16 columns, the multipliers and the pivot chain do not fit beside seven resident tiles in 128 registers: two tiles wait in
+      // LDS meanwhile (left to the compiler they went to scratch: a dozen scratch round trips per panel on the critical path).
+      if constexpr (NS >= 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { park[(2 * r) * 64 + lane] = acc[0][r]; park[(2 * r + 1) * 64 + lane] = acc[1][r]; }
+      }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       double v[16];
@@ -955,6 +1005,10 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
         for (int c = 0; c < 16; ++c) if (c < rp) tv[16 * ip + c] = v[c];
       }
       if (lane == 0 && bad) s_fail = 1;
+      if constexpr (NS >= 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[0][r] = park[(2 * r) * 64 + lane]; acc[1][r] = park[(2 * r + 1) * 64 + lane]; }
+      }
     }
     if (k < 4) CTV_STAMP();
     __builtin_amdgcn_s_waitcnt(0xc07f);
