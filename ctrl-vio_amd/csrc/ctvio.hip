@@ -645,7 +645,7 @@ class SolverImpl : public SolverBase {
     // 223 unknowns: the panel kernel, with 8 waves when there are fewer windows than CUs
     if (chol_tiles()) {
       const int ntr = d.maxP / 16 + 1;
-      const size_t lds = (size_t)(272 + 2 * ntr * 272 + 32 * ntr + 4 + 512) * sizeof(double);   // identity + panel + inverses + vectors + parked tiles
+      const size_t lds = (size_t)(272 + 2 * ntr * 272 + 32 * ntr + 4 + 768) * sizeof(double);   // identity + panel + inverses + vectors + parked tiles
       if (chol_tiles() == 2) hipLaunchKernelGGL((k_cholesky_tiles<8, 14>), dim3(nw), dim3(512), lds, stream_, d);   // (A/B variant: 8 waves x 14 tiles)
       else hipLaunchKernelGGL((k_cholesky_tiles<16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
     }

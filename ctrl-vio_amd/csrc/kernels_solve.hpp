@@ -859,6 +859,24 @@ __device__ __forceinline__ void chol16_dpp(double (&v)[16], int nreal, int &bad)
   if (!(last - last == 0.0)) bad = 1;
 }
 
+// the sum of a value over the four 16-lane row groups of the wave, in every lane (the tree of two __shfl_xor steps, without the LDS crossbar)
+__device__ __forceinline__ double rowgroup_sum(double p) {
+  unsigned lo = (unsigned)__double2loint(p), hi = (unsigned)__double2hiint(p);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0] = {g0, g0, g2, g2}, [1] = {g1, g1, g3, g3}
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  lo = (unsigned)__double2loint(s); hi = (unsigned)__double2hiint(s);
+  const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [0] = {lower half, lower half}, [1] = {upper, upper}
+  const auto e = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)e[0], (int)c[0]) + __hiloint2double((int)e[1], (int)c[1]);
+}
+// acc += sum_k t[lane k of this lane's row] * lk[k], k = K .. 15
+template <int K> __device__ __forceinline__ void dpp_dot16(double &acc, double t, const double (&lk)[16]) {
+  if constexpr (K < 16) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(lk[K]), "n"(K));
+    dpp_dot16<K + 1>(acc, t, lk);
+  }
+}
 __device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
 
 // (A BLOCKED diagonal tile -- the 16 pivots in four blocks of four, at most three broadcast-and-FMA per pivot inside a block and the block's
@@ -885,7 +903,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   double *tv = Pn + NTR * TS;          // [16 NTR] y, then the running right-hand side of the back-substitution
   double *xs = tv + 16 * NTR;          // [16 NTR] solution
   int &s_fail = *reinterpret_cast<int *>(xs + 16 * NTR);
-  double *park = xs + 16 * NTR + 2;    // [8][64] two tiles of the wave that factors a diagonal tile wait here meanwhile (see step A)
+  double *park = xs + 16 * NTR + 2;    // [12][64] three tiles of the wave that factors a diagonal tile wait here meanwhile (see step A)
   const double *S = d.S + m.H0, *y = d.rhs + m.p0;
   const double *Hc = d.HppS[lm.cur] + m.H0;
   const bool from_h = d.schur_plain_in_H != 0;
@@ -974,11 +992,11 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 #pragma unroll
           for (int r = 0; r < 4; ++r) Dg[(q4 + 4 * r) * 17 + l15] = acc[q][r];
         }
-      // The tile's 16 columns, the multipliers and the pivot chain do not fit beside seven resident tiles in 128 registers: two tiles wait in
+      // The tile's 16 columns, the multipliers and the pivot chain do not fit beside seven resident tiles in 128 registers: three tiles wait in
       // LDS meanwhile (left to the compiler they went to scratch: a dozen scratch round trips per panel on the critical path).
-      if constexpr (NS >= 2) {
+      if constexpr (NS >= 3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { park[(2 * r) * 64 + lane] = acc[0][r]; park[(2 * r + 1) * 64 + lane] = acc[1][r]; }
+        for (int r = 0; r < 4; ++r) { park[(3 * r) * 64 + lane] = acc[0][r]; park[(3 * r + 1) * 64 + lane] = acc[1][r]; park[(3 * r + 2) * 64 + lane] = acc[2][r]; }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
@@ -1005,9 +1023,9 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
         for (int c = 0; c < 16; ++c) if (c < rp) tv[16 * ip + c] = v[c];
       }
       if (lane == 0 && bad) s_fail = 1;
-      if constexpr (NS >= 2) {
+      if constexpr (NS >= 3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[0][r] = park[(2 * r) * 64 + lane]; acc[1][r] = park[(2 * r + 1) * 64 + lane]; }
+        for (int r = 0; r < 4; ++r) { acc[0][r] = park[(3 * r) * 64 + lane]; acc[1][r] = park[(3 * r + 1) * 64 + lane]; acc[2][r] = park[(3 * r + 2) * 64 + lane]; }
       }
     }
     if (k < 4) CTV_STAMP();
@@ -1064,28 +1082,51 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   CTV_STAMP();
   __syncthreads();
   CTV_STAMP();
-  // ---- back-substitution L^T x = y over the tiles in registers
-  for (int b = NTR - 1; b >= 0; --b) {
-    if (wave == (b % NW)) {   // x_b[j] = sum_k Linv[k][j] t[k]: lane (q4, j = l15) sums k = 4 q4 .. 4 q4 + 3, two shuffles add the quarters
-      const double *Lb = Li + b * TS;
-      double xa = 0.0;
+  // ---- back-substitution L^T x = y over the tiles in registers: ONE barrier per block.  After x_b is known, the only contribution t_{b-1}
+  // still lacks is that of tile (b, b - 1): its owner finishes t_{b-1} in registers and forms x_{b-1} = L_{b-1,b-1}^-T t_{b-1} at once (the sixteen
+  // t[k] read across the 16-lane rows by v_fmac_f64_dpp row_newbcast, the sum over the four row groups by v_permlane16/32_swap -- no LDS round
+  // trip on the chain); the owners of the other tiles (b, j) subtract their parts from t_j in LDS meanwhile.  (x_b by one wave, barrier, the
+  // updates, barrier: 19.7 k of a factorisation's 143 k cycles.)
+  if (wave == ((NTR - 1) % NW)) {   // x_b[j] = sum_k Linv[k][j] t[k] of the last block: lane (q4, j = l15) sums k = 4 q4 .. 4 q4 + 3
+    const int bl = NTR - 1;
+    const double *Lb = Li + bl * TS;
+    double xa = 0.0;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) xa += Lb[(4 * q4 + kk) * 17 + l15] * tv[16 * b + 4 * q4 + kk];
-      xa += __shfl_xor(xa, 16);
-      xa += __shfl_xor(xa, 32);
-      if (q4 == 0) xs[16 * b + l15] = xa;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
+    for (int kk = 0; kk < 4; ++kk) xa += Lb[(4 * q4 + kk) * 17 + l15] * tv[16 * bl + 4 * q4 + kk];
+    xa += __shfl_xor(xa, 16);
+    xa += __shfl_xor(xa, 32);
+    if (q4 == 0) xs[16 * bl + l15] = xa;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+  for (int b = NTR - 1; b >= 1; --b) {
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       if (ti[q] != b || tj[q] >= b) continue;   // tiles (b, j), j < b: t_j -= L_bj^T x_b
-      double part = 0.0;
+      double xb[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part += acc[q][r] * xs[16 * b + q4 + 4 * r];
-      part += __shfl_xor(part, 16);
-      part += __shfl_xor(part, 32);
-      if (q4 == 0) tv[16 * tj[q] + l15] -= part;
+      for (int r = 0; r < 4; ++r) xb[r] = xs[16 * b + q4 + 4 * r];
+      if (tj[q] == b - 1) {                     // (uniform) the chain
+        const double *Lb = Li + (b - 1) * TS;
+        double lk[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) lk[kk] = Lb[kk * 17 + l15];
+        const double tb = tv[16 * (b - 1) + l15];
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += acc[q][r] * xb[r];
+        const double t = tb - rowgroup_sum(part);   // t_{b-1}[l15], in every row group
+        double xa = 0.0;
+        dpp_dot16<0>(xa, t, lk);
+        if (q4 == 0) xs[16 * (b - 1) + l15] = xa;
+      } else {
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += acc[q][r] * xb[r];
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (q4 == 0) tv[16 * tj[q] + l15] -= part;
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();

@@ -142,5 +142,20 @@ int main() {
              cyc[1], ok ? "ok" : "MISMATCH");
     }
   }
+  // a tile that is not positive definite (one diagonal entry negated): both variants must flag it
+  {
+    std::vector<double> bad_tile(tiles.begin(), tiles.begin() + 256);
+    bad_tile[16 * 9 + 9] = -bad_tile[16 * 9 + 9];
+    hipMemcpy(dt, bad_tile.data(), 256 * 8, hipMemcpyHostToDevice);
+    for (int variant = 0; variant < 2; ++variant) {
+      long long cyc[4];
+      if (variant == 0) hipLaunchKernelGGL(k_probe<0>, dim3(1), dim3(1024), 0, 0, dt, dout, dc, 1, 16);
+      else hipLaunchKernelGGL(k_probe<1>, dim3(1), dim3(1024), 0, 0, dt, dout, dc, 1, 16);
+      hipDeviceSynchronize();
+      hipMemcpy(cyc, dc, 32, hipMemcpyDeviceToHost);
+      printf("indefinite tile, %-9s: flagged %lld  %s\n", variant ? "dpp" : "readlane", cyc[1], cyc[1] ? "ok" : "NOT FLAGGED");
+      fail |= cyc[1] == 0;
+    }
+  }
   return fail;
 }

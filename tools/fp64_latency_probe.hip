@@ -45,9 +45,9 @@ __global__ void k_lat(double *out, double *sink, int which) {
 }
 
 int main() {
-  const char *names[] = {"fma dep", "fma 4 chains (per 4)", "mul dep", "rsq dep", "rsq indep (per 4)", "rsq->mul (per pair)", "fmac_dpp dep via acc", "fmac_dpp indep (per 4)",
-                         "fmac_dpp dep via dpp src", "readlane x2 -> fma -> mov", "readlane indep (per 4)", "permlane16_swap dep", "cmp+cndmask+cvt dep", "v_mov_b32 dep", "add dep", "rcp dep",
-                         "fma dep + 3 dpp (per 4)", "fma dep + 3 fma (per 4)"};
+  const char *names[] = {"fma dep", "fma 4 chains", "mul dep", "rsq dep", "rsq indep", "rsq, nop, mul (per triple)", "fmac_dpp dep via acc", "fmac_dpp indep",
+                         "nop 1 + fmac_dpp on its own result", "readlane x2, nop, fma, cvt, nop (per group)", "readlane indep", "nop 1 + permlane16_swap dep", "cmp, cndmask, cvt (per triple)", "v_mov_b32 dep", "add dep", "rcp dep",
+                         "fma dep + 3 dpp between", "fma dep + 3 fma between"};
   double *out, *sink, h[18];
   hipMalloc(&out, sizeof(h));
   hipMalloc(&sink, 64 * 8);
@@ -55,6 +55,6 @@ int main() {
   for (int pass = 0; pass < 2; ++pass)
     for (int w = 0; w < 18; ++w) { hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), 0, 0, out, sink, w); hipDeviceSynchronize(); }
   hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-  for (int w = 0; w < 18; ++w) printf("%-28s %7.1f clocks per repetition\n", names[w], h[w]);
+  for (int w = 0; w < 18; ++w) printf("%-44s %7.1f clocks per instruction (per listed group where the pattern is one)\n", names[w], h[w]);
   return 0;
 }
