@@ -774,13 +774,15 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
 // belongs to wave t % NW, slot t / NW: 105 tiles at P = 211 -> 7 slots x 4 registers per lane on 16 waves).  S is read from HBM
 // exactly once and never written back; the right-hand side rides along as row P (so y = L^-1 b falls out of the factorisation).
 // Per 16-column panel k:
-//   A. the owner of the diagonal tile moves it through LDS into row-per-lane form and factors it with 16 v_readlane pivots
-//      (lanes 0-15 the rows, lanes 16-31 the columns of the inverse: the fused scheme of k_cholesky_solve), leaves L_kk^-1 in LDS;
+//   A. the owner of the diagonal tile moves it through LDS into row-per-lane form and factors it with 16 pivots whose column updates are single
+//      v_fmac_f64_dpp row_newbcast instructions (chol16_dpp: even 16-lane rows of the wave the tile's rows, odd rows the columns of the inverse),
+//      leaves L_kk^-1 in LDS; three of its resident tiles wait in LDS meanwhile;
 //   C. the owners of the tiles below it form L_ik = A_ik L_kk^-T (4 MFMAs; the accumulator -> operand transposition goes through
 //      the tile's slice of the LDS panel) and publish L_ik there;
 //   E. every owner of a trailing tile (i, j), j > k, subtracts L_ik L_jk^T (4 MFMAs, operands from the LDS panel).
 // Back-substitution L^T x = y runs over the tiles still in registers: x_b = L_bb^-T t_b, then t_j -= L_bj^T x_b by the single
-// owner of tile (b, j) -- no atomics anywhere, the summation order is fixed (bitwise reproducible).
+// owner of tile (b, j) -- no atomics anywhere, the summation order is fixed (bitwise reproducible); one barrier per block.
+// With Dev::schur_plain_in_H the tiles without Schur products are read from Hpp (damping and fixed unknowns applied here), the others from S.
 // Pivots with index >= P (the rhs row, padding rows) are forced to 1 and never flagged.
 template <int J, int C> __device__ __forceinline__ void chol16_row_updates(double (&v)[16], int lo, int hi) {
   if constexpr (C + 3 <= 15) {
@@ -879,14 +881,12 @@ template <int K> __device__ __forceinline__ void dpp_dot16(double &acc, double t
 }
 __device__ __forceinline__ double f64x4_get(const f64x4 &a, int r) { return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3])); }
 
-// (A BLOCKED diagonal tile -- the 16 pivots in four blocks of four, at most three broadcast-and-FMA per pivot inside a block and the block's
-//  rank-4 update of the later columns, for the tile and for the inverse in the making, as two v_mfma_f64_16x16x4 -- was built and measured in
-//  round 4: 8.7 k cycles per tile against 8.3 k, the factorisation unchanged at 84 us.  The tile's time is not its row updates but the
-//  sixteen sequential pivots: readlane -> class test -> v_rsq_f64 -> two Newton steps -> scale -> readlane is ~300 dependent cycles each,
-//  211 of them per factorisation, whatever happens between them.  Not kept.  Nor was the second attempt: columns left unscaled while they are
-//  used, so that the next pivot waits for a reciprocal (v_rcp_f64 + one third-order correction) instead of v_rsq_f64 + two Newton steps,
-//  with the square root computed beside it -- 9.0 k cycles per tile against 8.3 k.  A lone wave issues in order: work "beside" the chain is
-//  work in front of it, and the extra v_readfirstlane / multiplies cost more than the shorter dependence saved.)
+// (History of the diagonal tile.  With v_readlane broadcasts -- chol16_from above, still the cross-check in tools/chol16_probe.hip -- a BLOCKED
+//  variant (four blocks of four pivots, rank-4 updates as two v_mfma_f64_16x16x4) and a reciprocal-based pivot chain were built early in round 4
+//  and found no faster: 8.7 k / 9.0 k vs 8.3 k cycles per tile.  The explanation given then -- "300 dependent cycles per pivot" -- was wrong: a
+//  lone wave issues one fp64 instruction per ~5.3 clocks whether it depends on the previous one or not (tools/fp64_latency_probe.hip), the tile
+//  was 760 instructions, and 2.2 k of its clocks were the tile's LOAD, compiled into 16 branches with a ds_read and an s_waitcnt each.
+//  chol16_dpp + the branch-free load: 3.2 k clocks per tile.)
 template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_tiles(Dev d) {
   constexpr int NT = 64 * NW, TS = 16 * 17;    // a 16 x 16 block in LDS: row stride 17
   const int w = blockIdx.x;
