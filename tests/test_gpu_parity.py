@@ -220,6 +220,43 @@ def test_large_batch_kernels_match_small_batch_kernels(cv, prec):
         assert cv.rel_state_error(big[i], small[i % 8])["state"] < tol, i
 
 
+def test_large_batch_fixed_unknowns_and_tiles_taken_from_hpp(cv, oracle, monkeypatch):
+    """Large batches: k_schur_window_f64 leaves the 16 x 16 tiles W never reaches unwritten and k_cholesky_tiles forms them from Hpp + D itself,
+    fixed unknowns included (activity as ballot masks).  208 windows (4 distinct: constant knots in and out of the prefix, a fixed line
+    delay, locked gyro biases) against the same 4 in a small batch (tile Schur kernel: S written whole) and the oracle -- and against the same batch with
+    the tiles copied by the Schur kernel as before (CTVIO_SCHUR_COPY_PLAIN: identical arithmetic, S in HBM instead of straight from Hpp)."""
+    base = [cv.synth.make_window("config1", seed=1300 + i) for i in range(4)]
+    base[0].knot_const = np.zeros(base[0].K, np.uint8); base[0].knot_const[[0, 1, 2]] = 1
+    base[1].knot_const = np.zeros(base[1].K, np.uint8); base[1].knot_const[[0, 4, 11, base[1].K - 1]] = 1
+    base[2].fix_ld = True
+    base[3].lock_bg = True      # fixed unknowns INSIDE the tiles that come from Hpp (bias rows and columns)
+    def run(n):
+        with cv.Solver() as s:
+            ws = [base[i % 4].copy() for i in range(n)]
+            s.set_windows(ws)
+            return ws, s.solve(15)
+    small, sm_small = run(4)
+    big, sm_big = run(208)
+    monkeypatch.setenv("CTVIO_SCHUR_COPY_PLAIN", "1")
+    big_copy, sm_copy = run(208)
+    monkeypatch.delenv("CTVIO_SCHUR_COPY_PLAIN")
+    for i in range(208):
+        assert sm_big[i]["iterations"] == sm_small[i % 4]["iterations"]
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 4]["final_cost"], rel=1e-10)
+        assert cv.rel_state_error(big[i], small[i % 4])["state"] < 1e-7, i
+        # (throughput mode accumulates with atomics: two runs of the SAME path differ in the last bits as well)
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_copy[i]["final_cost"], rel=1e-12) and sm_big[i]["iterations"] == sm_copy[i]["iterations"]
+        assert cv.rel_state_error(big[i], big_copy[i])["state"] < 1e-9, i
+    np.testing.assert_array_equal(big[0].quat[[0, 1, 2]], base[0].quat[[0, 1, 2]])
+    np.testing.assert_array_equal(big[1].pos[[0, 4, 11, base[1].K - 1]], base[1].pos[[0, 4, 11, base[1].K - 1]])
+    for i in range(4):
+        wo = base[i].copy()
+        so = oracle.OracleWindow(wo).solve(15)
+        assert sm_big[i]["iterations"] == so.iterations
+        assert sm_big[i]["final_cost"] == pytest.approx(so.final_cost, rel=1e-8)
+        assert cv.rel_state_error(big[i], wo)["state"] < 1e-6
+
+
 @pytest.mark.parametrize("dt_ms,K", [(42, 26), (40, 27)])
 def test_large_batch_schur_variants_k26_k27(cv, oracle, dt_ms, K):
     """The other instantiations of the per-window fp64 Schur kernel: K = 26 (66 tiles with products: 14 accumulators per wave,
