@@ -376,28 +376,47 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-  for (int l0 = 0; l0 < lend; l0 += 16) {
-    double wa[2][4], wb[2][4], dv[4], gv[4];
+  // Two chunks of 16 landmarks in flight: the 24 operand loads of the next chunk are requested before the 16 products of the current one
+  // (a trip used to be "load, wait, multiply": the matrix cores idle for a memory round trip per chunk, 0.34 of the fp64 peak at three
+  // waves per SIMD).  Fences keep the scheduler from moving the requests back behind the products.
+  struct Chunk { double wa[2][4], wb[2][4], dv[4], gv[4]; };
+  auto fetch = [&](int l0, Chunk &c) {   // unconditional loads on clamped rows, masked in `products`
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {   // unconditional loads on clamped rows, masked below
+    for (int s = 0; s < 4; ++s) {
       const int lc = min(l0 + 4 * s + q4, L - 1);
       const double *row = Wp + (long long)lc * ldw;
-      wa[0][s] = row[ci[0]]; wa[1][s] = row[ci[1]];
-      wb[0][s] = row[cj[0]]; wb[1][s] = row[cj[1]];
-      dv[s] = dinv[lc];
-      gv[s] = gl[lc];
+      c.wa[0][s] = row[ci[0]]; c.wa[1][s] = row[ci[1]];
+      c.wb[0][s] = row[cj[0]]; c.wb[1][s] = row[cj[1]];
+      c.dv[s] = dinv[lc];
+      c.gv[s] = gl[lc];
     }
+  };
+  auto products = [&](int l0, const Chunk &c) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bool lv = l0 + 4 * s + q4 < L;
-      const double dvs = lv ? dv[s] : 0.0;
-      const double a0 = rhs_lane[0] ? gv[s] : wa[0][s] * ai[0], a1 = rhs_lane[1] ? gv[s] : wa[1][s] * ai[1];
-      const double b0 = wb[0][s] * aj[0] * dvs, b1 = wb[1][s] * aj[1] * dvs;
+      const double dvs = lv ? c.dv[s] : 0.0;
+      const double a0 = rhs_lane[0] ? c.gv[s] : c.wa[0][s] * ai[0], a1 = rhs_lane[1] ? c.gv[s] : c.wa[1][s] * ai[1];
+      const double b0 = c.wb[0][s] * aj[0] * dvs, b1 = c.wb[1][s] * aj[1] * dvs;
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
       if (Bi != Bj) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);   // (uniform; on the diagonal block this tile is above the diagonal)
     }
+  };
+  // (The requests are unconditional -- past the end they re-read the last rows: a request behind a uniform branch makes the compiler wait,
+  // at the join, as if the OLDER chunk were the newest one: vmcnt(23) instead of vmcnt(47).)
+  Chunk ca, cb;
+  fetch(0, ca);
+  for (int l0 = 0; l0 < lend; l0 += 32) {
+    fetch(l0 + 16, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    products(l0, ca);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(l0 + 32, ca);
+    __builtin_amdgcn_sched_barrier(0);
+    if (l0 + 16 < lend) products(l0 + 16, cb);   // (uniform)
+    __builtin_amdgcn_sched_barrier(0);
   }
   double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
   const double *H = d.HppS[cur] + m.H0, *gp = d.gS[cur] + u0;
@@ -410,12 +429,21 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
       const int jj = 16 * bj + l15, jc = min(jj, P - 1);
       const bool act_j = d.active[u0 + jc] != 0;
       const double dd_j = d.dd[u0 + jc], g_j = gp[jc];
+      double hv[4];          // requested together, before any branch (inside the branch each was a round trip of its own)
+      unsigned char av[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ii = 16 * bi + q4 + 4 * r, ic = min(ii, P - 1);
+        const int ic = min(16 * bi + q4 + 4 * r, P - 1);
+        hv[r] = H[(long long)ic * ldh + min(jc, ic)];
+        av[r] = d.active[u0 + ic];
+      }
+      asm volatile("" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * bi + q4 + 4 * r;
         if (ii < P && jj <= ii) {
-          const bool on = d.active[u0 + ic] && act_j;
-          S[(long long)ii * ldh + jj] = on ? H[(long long)ic * ldh + min(jc, ic)] - acc[a][b][r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
+          const bool on = av[r] && act_j;
+          S[(long long)ii * ldh + jj] = on ? hv[r] - acc[a][b][r] + (ii == jj ? dd_j : 0.0) : (ii == jj ? 1.0 : 0.0);
         } else if (ii == P && jj < P) {
           rhs[jj] = act_j ? acc[a][b][r] - g_j : 0.0;   // reduced right-hand side: -g_p + W^T diag(dinv) g_rho
         }
