@@ -244,9 +244,11 @@ def test_large_batch_fixed_unknowns_and_tiles_taken_from_hpp(cv, oracle, monkeyp
         assert sm_big[i]["iterations"] == sm_small[i % 4]["iterations"]
         assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 4]["final_cost"], rel=1e-10)
         assert cv.rel_state_error(big[i], small[i % 4])["state"] < 1e-7, i
-        # (throughput mode accumulates with atomics: two runs of the SAME path differ in the last bits as well)
-        assert sm_big[i]["final_cost"] == pytest.approx(sm_copy[i]["final_cost"], rel=1e-12) and sm_big[i]["iterations"] == sm_copy[i]["iterations"]
-        assert cv.rel_state_error(big[i], big_copy[i])["state"] < 1e-8, i
+        # (throughput mode accumulates with atomics: two runs of the SAME path differ as well -- seed 1300 with its three constant knots by
+        # 5e-11 in the state as a rule and 4e-9 / 1.4e-12 in the cost once in a while, tools/studies/r4_margins.py -- so: the bounds of the
+        # comparison with the small batch)
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_copy[i]["final_cost"], rel=1e-10) and sm_big[i]["iterations"] == sm_copy[i]["iterations"]
+        assert cv.rel_state_error(big[i], big_copy[i])["state"] < 1e-7, i
     np.testing.assert_array_equal(big[0].quat[[0, 1, 2]], base[0].quat[[0, 1, 2]])
     np.testing.assert_array_equal(big[1].pos[[0, 4, 11, base[1].K - 1]], base[1].pos[[0, 4, 11, base[1].K - 1]])
     for i in range(4):
