@@ -149,7 +149,6 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<13, 14, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
@@ -210,8 +209,6 @@ class SolverImpl : public SolverBase {
     int64_t H0 = 0, W0 = 0, pH0 = 0;
     int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0, A0 = 0;
     int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0, maxK = 0, maxSchurTiles = 0;
-    bool big_schur_ok = true;
-    int bigPartMax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     for (int wi = 0; wi < nw; ++wi) {
       const ctvio_window &w = *wins[wi];
@@ -252,20 +249,6 @@ class SolverImpl : public SolverBase {
             cnt += (nzr && nzc) ? 1 : 0;
           }
         maxSchurTiles = std::max(maxSchurTiles, cnt);
-        // the staged window kernel for P > 223 (k_schur_window_f64<.., true>): tile t goes to workgroup t % parts; how full does the fullest get?
-        if (m.ldw > 224) {
-          if (K6 % 16 != 0) big_schur_ok = false;
-          for (int np = 1; np <= 8; ++np) {
-            int cnts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int ti = 0, t = 0; ti < ntl; ++ti)
-              for (int tj = 0; tj <= ti; ++tj, ++t) {
-                const bool nzr = (16 * ti < K6) || (m.P >= 16 * ti && m.P - 1 < 16 * ti + 16);
-                const bool nzc = (16 * tj < K6) || (m.P - 1 >= 16 * tj && m.P - 1 < 16 * tj + 16);
-                if (nzr && nzc) ++cnts[t % np];
-              }
-            for (int q = 0; q < np; ++q) bigPartMax[np - 1] = std::max(bigPartMax[np - 1], cnts[q]);
-          }
-        }
       }
     }
     const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
@@ -442,9 +425,6 @@ class SolverImpl : public SolverBase {
     std::memset(&d, 0, sizeof d);
     d.nwin = nw; d.Ktot = K0; d.Ftot = F0; d.Ltot = L0; d.Mtot = M0; d.Gtot = G0; d.Vtot = V0; d.Atot = A0;
     d.NBtot = B0; d.Utot = U0; d.maxN = maxN; d.maxP = maxP; d.maxPn = maxPn; d.maxL = maxL; d.maxLdw = maxLdw; maxK_ = maxK; max_schur_tiles_ = maxSchurTiles;
-    big_schur_parts_ = 0;      // workgroups per window of the staged Schur kernel for P > 223: the fewest that keep every workgroup's tile list
-    if (big_schur_ok && maxLdw > 224)   // within 14 accumulators per wave; 0 = not applicable (the tile kernels take such a batch)
-      for (int np = 1; np <= 8 && !big_schur_parts_; ++np) if (bigPartMax[np - 1] <= 8 * 14) big_schur_parts_ = np;
     d.wins = CTV_D(WinMeta, o_meta);
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
@@ -1248,7 +1228,7 @@ class SolverImpl : public SolverBase {
   bool deterministic_ = false;   // order-fixed accumulation for this batch (ctvio_options.deterministic)
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false, all_windows_have_imu_ = false;
-  int maxK_ = 0, max_schur_tiles_ = 0, big_schur_parts_ = 0;
+  int maxK_ = 0, max_schur_tiles_ = 0;
 };
 
 void SolverImpl::launch_imu_linearize(size_t lds, int mode) {
@@ -1293,12 +1273,6 @@ void SolverImpl::launch_schur() {
       if (16 * nc <= 5 * 512 && max_schur_tiles_ <= 56) hipLaunchKernelGGL((k_schur_window_f64<5, 7>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
-      schur_rhs_done_ = true;
-    } else if (const size_t ldsb = ((size_t)2 * 16 * (6 * maxK_ + 32) + 3 * d.maxLdw + 32 + 64) * sizeof(double);
-               !small && big_schur_parts_ > 0 && ldsb <= 160 * 1024 && 16 * nc <= 13 * 512 && ntile <= 8 * 8 * 14 * 8 && !std::getenv("CTVIO_SCHUR_TILE2")) {
-      // windows beyond 223 unknowns with 16-aligned knot columns (config 5): W staged through LDS as above, compact column blocks, a window's
-      // tiles over several workgroups; S written whole for the panel Cholesky
-      hipLaunchKernelGGL((k_schur_window_f64<13, 14, true>), dim3(d.nwin, big_schur_parts_), dim3(512), ldsb, stream_, d);
       schur_rhs_done_ = true;
     } else {
       const int nt2 = d.maxP / 16 + 1, ntile2 = nt2 * (nt2 + 1) / 2;   // tile rows up to index P (the rhs row)

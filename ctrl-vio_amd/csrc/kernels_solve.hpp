@@ -61,23 +61,15 @@ __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> 
 // 16 x 16 (v_mfma_f64_16x16x4_f64, K = 4 landmarks per instruction); tile t of the lower triangle belongs to wave t % 8, which
 // keeps its <= NTQ accumulators in registers over the whole landmark loop; tiles over bias-only columns have no products.
 // NPRE = compact chunk elements per thread (16 (6K + 2) / 512 rounded up); NTQ = ceil(tiles with products / 8).
-// BIG (windows beyond 223 unknowns, K6 a multiple of 16: config 5): the staging buffers hold only the column blocks W reaches -- the K6 / 16 knot
-// blocks and the one or two blocks of the line-delay column and the rhs row, K6 + 32 columns instead of ldw -- and a window's tiles are dealt to
-// gridDim.y workgroups (tile t to workgroup t % gridDim.y), each staging W for itself; S is written whole (the panel Cholesky reads it).
-template <int NPRE, int NTQ, bool BIG = false> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2) void k_schur_window_f64(Dev d) {
+template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2) void k_schur_window_f64(Dev d) {
   const int w = blockIdx.x;
   if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
   const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
   const int nt = ldw >> 4, ntile = nt * (nt + 1) / 2;
-  const int part = BIG ? (int)blockIdx.y : 0, nparts = BIG ? (int)gridDim.y : 1;
-  const int kb = K6 >> 4, sb = (P - 1) >> 4;                 // (BIG) knot blocks; the first of the special blocks
-  const int sw = BIG ? K6 + 32 : ldw;                        // row stride of the staging buffers
-  auto cblk = [&](int t) { return BIG ? (t < kb ? t : kb + (t - sb)) : t; };                                  // tile block -> staged block
-  auto cstage = [&](int c) { return BIG ? (c < K6 ? c : 16 * (kb + (c >> 4) - sb) + (c & 15)) : c; };        // window column -> staged column
   extern __shared__ __attribute__((aligned(16))) double smd64[];
-  double *Wb = smd64;                    // [2][16][sw]
-  double *acts = Wb + 2 * 16 * sw;       // [ldw] 1 / 0 (0 beyond P)      } per-column vectors of the epilogue, staged once: no global
+  double *Wb = smd64;                    // [2][16][ldw]
+  double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)      } per-column vectors of the epilogue, staged once: no global
   double *ddv = acts + ldw;              // [ldw] D of the column            } round trip per tile there (the activity of a STAGED column
   double *gv = ddv + ldw;                // [ldw] gradient                   } travels in pre_lc)
   double *dch = gv + ldw;                // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
@@ -100,11 +92,11 @@ template <int NPRE, int NTQ, bool BIG = false> __global__ __launch_bounds__(512,
   for (int t = tid; t < ntile; t += 512) {
     int ti, tj;
     tile_decode(t, ti, tj);
-    if (nz_row(ti) && nz_col(tj) && t % nparts == part) { const int pos = atomicAdd(&tcount, 1); if (pos < 8 * NTQ) tlist[pos] = (ti << 8) | tj; }
+    if (nz_row(ti) && nz_col(tj)) { const int pos = atomicAdd(&tcount, 1); if (pos < 8 * NTQ) tlist[pos] = (ti << 8) | tj; }
   }
   // Only the knot columns [0, 6K), the line-delay column P - 1 and the appended g_rho column P are fetched and staged (NC
   // compact columns per landmark); every other column of the two LDS buffers is zeroed once and stays zero.
-  const int nchunk = (L + 15) >> 4, nel = 16 * sw, NC = K6 + 2, nelc = 16 * NC;
+  const int nchunk = (L + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
   for (int e = tid; e < 2 * nel; e += 512) Wb[e] = 0.0;
   double pre[NPRE];
   double pre_d = 0.0;
@@ -129,7 +121,7 @@ template <int NPRE, int NTQ, bool BIG = false> __global__ __launch_bounds__(512,
     for (int k = 0; k < NPRE; ++k) {
       const int lr = (pre_lc[k] >> 16) & 0xff, c = pre_lc[k] & 0xffff;
       const bool lv = 16 * ch + lr < L && (pre_lc[k] >> 30) != 0;
-      if (tid + 512 * k < nelc) Wb[buf * nel + lr * sw + cstage(c)] = lv ? pre[k] : 0.0;
+      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? pre[k] : 0.0;
     }
     if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
   };
@@ -170,7 +162,7 @@ template <int NPRE, int NTQ, bool BIG = false> __global__ __launch_bounds__(512,
   for (int ch = 0; ch < nchunk && nact > 0; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) fetch(ch + 1);
-    const double *B = Wb + buf * nel + q4 * sw + l15;
+    const double *B = Wb + buf * nel + q4 * ldw + l15;
     double dl[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
@@ -182,8 +174,8 @@ template <int NPRE, int NTQ, bool BIG = false> __global__ __launch_bounds__(512,
       double a[4], b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[s] = B[4 * s * sw + 16 * cblk(tij[q] >> 8)];
-        b[s] = B[4 * s * sw + 16 * cblk(tij[q] & 255)];
+        a[s] = B[4 * s * ldw + 16 * (tij[q] >> 8)];
+        b[s] = B[4 * s * ldw + 16 * (tij[q] & 255)];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -237,7 +229,7 @@ template <int NPRE, int NTQ, bool BIG = false> __global__ __launch_bounds__(512,
     for (; t < ntile; t += 8) {
       int ti, tj;
       tile_decode(t, ti, tj);
-      if (!(nz_row(ti) && nz_col(tj)) && t % nparts == part) break;
+      if (!(nz_row(ti) && nz_col(tj))) break;
     }
     return t;
   };
