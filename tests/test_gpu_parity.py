@@ -663,6 +663,39 @@ def test_imu_only_window_without_landmarks(cv, oracle, prec):
     assert cv.rel_state_error(wg, wo)["state"] < (1e-6 if prec == "fp64" else 5e-2)
 
 
+def test_large_batch_with_imu_only_windows(cv, oracle):
+    """A large batch (per-window Schur kernel, tiles without products read from Hpp by the tile Cholesky) in which every other window has no
+    landmarks at all: no chunk of W to stage, accumulators that only ever hold -Hpp, the rhs from the gradient alone.  Against the same
+    windows in a small batch and the oracle's cost."""
+    def imu_only(seed):
+        w = cv.synth.make_window("config1", seed=seed)
+        z = lambda a: a[:0]
+        w.v_lm, w.v_ti, w.v_tj, w.v_rowi, w.v_rowj, w.v_pi, w.v_pj = z(w.v_lm), z(w.v_ti), z(w.v_tj), z(w.v_rowi), z(w.v_rowj), z(w.v_pi), z(w.v_pj)
+        w.rho = w.rho[:0]
+        w.fix_ld = True
+        w.normalize()
+        return w
+    base = [cv.synth.make_window("config1", seed=1310), imu_only(1311), cv.synth.make_window("config1", seed=1312), imu_only(1313)]
+    assert base[1].L == 0 and base[1].V == 0
+    def run(n):
+        with cv.Solver() as s:
+            ws = [base[i % 4].copy() for i in range(n)]
+            s.set_windows(ws)
+            return ws, s.solve(15)
+    small, sm_small = run(4)
+    big, sm_big = run(208)
+    for i in range(208):
+        assert np.isfinite(sm_big[i]["final_cost"]) and sm_big[i]["termination"] != "failure"
+        assert sm_big[i]["iterations"] == sm_small[i % 4]["iterations"]
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 4]["final_cost"], rel=1e-9)
+        # (an IMU-only window has unobservable directions in which its 15th iterate drifts: cost parity only)
+        if base[i % 4].L > 0:
+            assert cv.rel_state_error(big[i], small[i % 4])["state"] < 1e-7, i
+    for i in range(4):
+        so = oracle.OracleWindow(base[i].copy()).solve(15)
+        assert sm_big[i]["final_cost"] == pytest.approx(so.final_cost, rel=1e-8)
+
+
 def test_mixed_batch_tiny_window_and_imu_only_long_spline_deterministic(cv, oracle):
     """A window whose packed Hessian does not fit in LDS (K >= 25) and that has NO visual blocks -- the IMU-only predict of a long
     spline -- batched with an LDS-resident window, deterministic mode on: the store-semantics tail only finishes LDS-resident windows,
