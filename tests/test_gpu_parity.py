@@ -525,6 +525,26 @@ def test_ragged_batch_equals_single(cv):
         assert cv.rel_state_error(batch[i], w1)["state"] < 1e-7
 
 
+def test_large_ragged_batch_equals_small_batch(cv):
+    """The same in a LARGE batch (per-window kernels: each workgroup takes its tile grid, its staged columns and the tiles it reads from Hpp
+    from its own window's sizes): 210 windows of five shapes -- config 1 / 2, the tiny window, 8 and 9 frames (K = 21 / 24) -- against the
+    five solved in a small batch."""
+    base = [cv.synth.make_window("config1", seed=1320), cv.synth.make_window("tiny", seed=6), cv.synth.make_window("config2", seed=1321),
+            cv.synth.make_window("config1", seed=1322, F=8), cv.synth.make_window("config1", seed=1323, F=9)]
+    assert len({w.P for w in base}) >= 4
+    def run(n):
+        with cv.Solver() as s:
+            ws = [base[i % 5].copy() for i in range(n)]
+            s.set_windows(ws)
+            return ws, s.solve(15)
+    small, sm_small = run(5)
+    big, sm_big = run(210)
+    for i in range(210):
+        assert sm_big[i]["iterations"] == sm_small[i % 5]["iterations"]
+        assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 5]["final_cost"], rel=1e-9)
+        assert cv.rel_state_error(big[i], small[i % 5])["state"] < 1e-7, i
+
+
 def test_random_factor_structures_match_oracle(cv, oracle):
     """Randomised structure, one ragged batch: random subsets of the visual blocks (landmarks left with one block or none, frame pairs
     thinned out), blocks with their own i end (several anchors per landmark), blocks reordered, free / fixed line delay at random
