@@ -57,6 +57,12 @@ PMC_KERNELS = {"k_imu_linearize": ["k_imu_linearize_f64"], "k_vis_eval": ["k_vis
 VIS_BLOCK_FLOP, VIS_ANCHOR_FLOP = 972 + 2 * (24 + 6) + 2 * 72 // 4, 1190
 
 
+def synth_window(cv, config, seed):
+    w = cv.synth.make_window(config, seed=seed)
+    w._bench_key = (config, seed)
+    return w
+
+
 def imu_groups(w):
     return len({(int((t - w.t0_ns) // w.dt_ns), int(b)) for t, b in zip(w.imu_t, w.imu_bias)})
 
@@ -71,12 +77,40 @@ def workload_label(w, config, iters):
             f"<= {iters} LM iterations (Ceres 1.14 trust region + projected line search)")
 
 
+_CV = None
+_MEMO = {}
+
+
+def _cv():
+    global _CV
+    if _CV is None:
+        _CV = importlib.import_module("ctrl-vio_amd")
+    return _CV
+
+
+def sparsity(w):
+    """Per distinct window (memoised): non-zeros of W by landmark (its planned knot span's columns + the line delay), entries of the reduced
+    system's lower triangle inside the envelope, and the 16 x 16 tiles of it that receive Schur products (packer.py mirrors host_pack.hpp)."""
+    key = getattr(w, "_bench_key", None) or id(w)     # (copies of a synthetic window carry the (config, seed) tag of their original)
+    if key not in _MEMO:
+        pk = _cv().packer
+        klo, khi = pk.landmark_spans(w)
+        nnz = [6 * int(b - a + 1) + 1 if b >= 0 else 0 for a, b in zip(klo, khi)]
+        P, K6 = w.P, 6 * w.K
+        nzr = lambda b: 16 * b < K6 or (P >= 16 * b and P - 1 < 16 * b + 16)
+        nzc = lambda b: 16 * b < K6 or (P - 1 >= 16 * b and P - 1 < 16 * b + 16)
+        nt = P // 16 + 1
+        _MEMO[key] = {"w_nnz": sum(nnz), "nz_flops": pk.schur_nonzero_flops(w), "env": pk.envelope_entries(w, dense=P <= 223),
+                      "product_tiles": sum(1 for i in range(nt) for j in range(i + 1) if nzr(i) and nzc(j)), "groups": imu_groups(w), "anchors": vis_anchors(w)}
+    return _MEMO[key]
+
+
 def algorithmic_bytes(w, phase, fp_bytes):
-    """Algorithmic HBM bytes of ONE window for one launch of a kernel group; fp_bytes = size of the
-    linearisation scalar (8 in the product path)."""
+    """Algorithmic HBM bytes of ONE window for one launch of a kernel group: what the launch must move if every operand
+    is touched once; fp_bytes = size of the linearisation scalar (8 in the product path)."""
     K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
-    G = imu_groups(w)
-    A = vis_anchors(w)
+    sp = sparsity(w)
+    G, A = sp["groups"], sp["anchors"]
     if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
         return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
     # A block's record is 40 doubles (rotation columns of its own end 24, inverse depth 2, line delay 2, residual 2, A~ 6, cp1 4); an
@@ -84,15 +118,21 @@ def algorithmic_bytes(w, phase, fp_bytes):
     if phase == "k_vis_eval":        # anchors: inputs (t, row, obs, indices: 36 B) in, record out and in again once (the blocks read it);
         # blocks: own inputs (t, row, 2 obs, 3 indices, loss width: 48 B), record out; the knots are shared by the window's blocks and come
         # out of cache: counted once per window; the rows of W (knot + line-delay columns), Hll, g_rho
-        return A * (36 + 2 * 50 * 8) + V * (48 + 40 * fp_bytes) + K * 7 * 8 + L * (8 + (6 * K + 1) * fp_bytes + 16)
+        # -- the rows of W over their landmarks' knot spans only (+ line delay), Hll, g_rho
+        return A * (36 + 2 * 50 * 8) + V * (48 + 40 * fp_bytes) + K * 7 * 8 + sp["w_nnz"] * fp_bytes + L * (8 + 16)
     if phase == "k_assemble_vis":    # block records read once (38 of the 40 entries: the depth column is not needed) + keys + slot lists, GR
         # and cp0 of every anchor once (40 doubles), the packed fp64 Hessian flushed once
         K6 = 6 * K   # + the knot x knot part (24 x 24) of every IMU group tile, added into the same LDS Hessian
         return V * (38 * fp_bytes + 16) + A * 40 * 8 + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
-    if phase == "k_cholesky_solve":  # lower triangle read + written once, rhs in, solution out
-        return (P * (P + 1) // 2) * 8 * 2 + 2 * P * 8
-    if phase == "k_schur_mfma":      # W read, Hpp lower read, S lower written
-        return L * P * fp_bytes + (P * (P + 1) // 2) * 16
+    if phase == "k_cholesky_solve":
+        # P <= 223 (k_cholesky_tiles): the triangle is READ once into registers and never written back; beyond (k_cholesky_solve): the entries
+        # inside the envelope read and written once (the factor is needed by the back-substitution); rhs in, solution out
+        return sp["env"] * 8 * (1 if P <= 223 else 2) + 2 * P * 8
+    if phase == "k_schur_mfma":
+        # the non-zeros of W + g_rho + 1 / (Hll + D) per row; P <= 223 (k_schur_window_f64): Hpp read and S written for the tiles that receive
+        # products only (the factorisation takes the others straight from Hpp); beyond: every entry inside the envelope read (Hpp) and written (S)
+        tri = sp["product_tiles"] * 256 if P <= 223 else sp["env"]
+        return (sp["w_nnz"] + 2 * L) * fp_bytes + tri * 16
     return 0
 
 
@@ -105,29 +145,43 @@ def algorithmic_flops(w, phase):
         # form (csrc/factors.hpp: 632 FMAs + 623 multiplies / adds per sample, counted in the ISA)
         return M * (2 * (3 * (28 * 29 // 2 - 12 * 13 // 2) + 10) + 2 * 3 * (16 * 17 // 2) + 1900)
     if phase == "k_vis_eval":        # counted in the ISA (tools/vis_isa_count.sh): one spline end per block, one per anchor
-        return V * VIS_BLOCK_FLOP + vis_anchors(w) * VIS_ANCHOR_FLOP
+        return V * VIS_BLOCK_FLOP + sparsity(w)["anchors"] * VIS_ANCHOR_FLOP
     if phase == "k_assemble_vis":    # 48 x 48 lower triangle + line-delay and residual columns, 2 rows per block
         return V * 2 * 2 * (48 * 49 // 2 + 2 * 49)
     if phase == "k_cholesky_solve":
         return P ** 3 // 3 + 2 * P * P
-    if phase == "k_schur_mfma":      # SYRK count
-        return P * (P + 1) * L
+    if phase == "k_schur_mfma":      # the NON-ZERO products of the SYRK (SURVEY 8d's nominal count P (P + 1) L is reported beside it)
+        return sparsity(w)["nz_flops"]
     return 0
 
 
-def structural_schur_flops(w):
-    """Products the Schur SYRK actually has: W carries no bias columns, so only the (6K + 1) knot / line-delay columns (plus the rhs
-    column that rides along) meet: (6K + 1)(6K + 2) L against SURVEY's nominal P (P + 1) L."""
-    return (6 * w.K + 1) * (6 * w.K + 2) * w.L
+def nonzero_schur_flops(w):
+    """Flops of the Schur complement's non-zero products: landmark l's row of W has nnz_l = 6 (knots of its span) + 1 entries, and
+    contributes the lower triangle of their outer product: sum_l nnz_l (nnz_l + 1) -- config 2: 1.2 MF against the (6K + 1)(6K + 2) L = 4.2 MF
+    of a W without bias columns and SURVEY's nominal P (P + 1) L = 8.9 MF; config 5: 6.7 MF against 148.6 / 326.6."""
+    return sparsity(w)["nz_flops"]
 
 
-def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device, with_oracle, profile=False):
-    """Device-resident rate of another BASELINE config on one handle, plus the state error of nseed distinct windows against the oracle.
-    profile: one more solve with HIP events around every launch group -> phase times and the Schur SYRK's MFMA roofline for this shape."""
-    import ctypes as C
+def mfma_line(kernel, wl, avg_s, nwin):
+    """The Schur SYRK against the fp64 matrix peak, by the products W's non-zeros have; the two larger counts are what a kernel blind to
+    the sparsity would multiply."""
+    pk = MFMA_PEAK_TFLOPS["fp64"]
+    nz = sum(nonzero_schur_flops(w) for w in wl)
+    return {"kernel": kernel, "bound": "mfma", "achieved": nz / avg_s / 1e12, "peak": pk, "unit": "TFLOP/s", "frac": nz / avg_s / 1e12 / pk,
+            "avg_launch_us": 1e6 * avg_s, "flops_per_launch": nz, "flop_count": "non-zero products: sum over landmarks of nnz_l (nnz_l + 1), nnz_l = 6 x (knots of its span) + 1",
+            "no_bias_columns_flops_per_launch": sum((6 * w.K + 1) * (6 * w.K + 2) * w.L for w in wl),
+            "nominal_flops_per_launch": sum(w.P * (w.P + 1) * w.L for w in wl), "windows_per_launch": nwin}
+
+
+def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device, with_oracle, profile=False, label=None):
+    """Device-resident rate of another BASELINE config on one handle, plus the state error of the first nseed windows OF THE TIMED BATCH (same
+    handle, same launch shape, hence the same kernels) against the oracle.  profile: one more solve with HIP events around every launch
+    group -> phase times, the dominant kernel's roofline line and the Schur SYRK's for this shape."""
     import numpy as np
-    uniq = [cv.synth.make_window(config, seed=1000 + i) for i in range(max(nuniq, nseed))]
+    uniq = [synth_window(cv, config, 1000 + i) for i in range(max(nuniq, nseed))]
     out = {"windows_per_launch": nwin, "distinct_windows": nuniq}
+    if label:
+        out["workload"] = label
     with cv.Solver(device=device) as sv:
         wl = [uniq[i % nuniq].copy() for i in range(nwin)]
         sv.set_windows(wl)
@@ -151,29 +205,40 @@ def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device
             ms, n = sv.last_timing()
             names = cv.Solver.PHASES
             out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}
-            pk = MFMA_PEAK_TFLOPS["fp64"]
-            fls = sum(structural_schur_flops(w) for w in wl)
-            fl = sum(w.P * (w.P + 1) * w.L for w in wl)
-            avg = 1e-3 * ms[4] / max(int(n[4]), 1)
-            out["roofline_mfma"] = {"kernel": "k_schur_window_f64 (K = %d, P = %d)" % (wl[0].K, wl[0].P), "bound": "mfma", "achieved": fls / avg / 1e12,
-                                    "peak": pk, "unit": "TFLOP/s", "frac": fls / avg / 1e12 / pk, "avg_launch_us": 1e6 * avg,
-                                    "flops_per_launch": fls, "flop_count": "structural: (6K + 1)(6K + 2) L", "nominal_flops_per_launch": fl,
-                                    "nominal_frac": fl / avg / 1e12 / pk, "windows_per_launch": nwin}
-            chol = 1e-3 * ms[5] / max(int(n[5]), 1)
-            out["cholesky_us_per_launch"] = 1e6 * chol
+            big = wl[0].P > 223
+            kn = {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_anchor + k_vis_eval", "k_assemble_vis": "k_assemble_vis_mfma",
+                  "k_schur_mfma": "k_schur_tile2_f64" if big else "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve<8> (envelope panels)" if big else "k_cholesky_tiles"}
+            lines = []
+            for i in range(6):
+                if n[i] <= 0 or names[i] not in kn:
+                    continue
+                avg_s = 1e-3 * ms[i] / int(n[i])
+                nb = sum(algorithmic_bytes(w, names[i], 8) for w in wl); nf = sum(algorithmic_flops(w, names[i]) for w in wl)
+                hb, ff = nb / avg_s / 1e9 / HBM_PEAK_GBS, nf / avg_s / 1e12 / MFMA_PEAK_TFLOPS["fp64"]
+                lines.append({"kernel": kn[names[i]], "bound": "mfma" if ff > hb else "hbm", "achieved": nf / avg_s / 1e12 if ff > hb else nb / avg_s / 1e9,
+                              "peak": MFMA_PEAK_TFLOPS["fp64"] if ff > hb else HBM_PEAK_GBS, "unit": "TFLOP/s" if ff > hb else "GB/s", "frac": max(hb, ff),
+                              "hbm_frac": hb, "fp64_frac": ff, "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": int(n[i]),
+                              "share_of_profiled_solve": float(ms[i] / max(sum(ms[:7]), 1e-12)), "windows_per_launch": nwin})
+            lines.sort(key=lambda l: -l["share_of_profiled_solve"])
+            out["roofline"] = lines[0] if lines else None
+            out["roofline_kernels"] = lines
+            out["roofline_mfma"] = mfma_line(kn["k_schur_mfma"] + " (K = %d, P = %d)" % (wl[0].K, wl[0].P), wl, 1e-3 * ms[4] / max(int(n[4]), 1), nwin)
+            out["cholesky_us_per_launch"] = 1e3 * ms[5] / max(int(n[5]), 1)
+            out["schur_plus_cholesky_ms_per_solve"] = float(ms[4] + ms[5])
         if with_oracle:
             import pyctvo
-            batch = [uniq[i].copy() for i in range(nseed)]
-            sv.set_windows(batch)
+            # the first nseed windows of the TIMED batch are uniq[0 .. nseed): one more solve of that very batch, states read back from it
+            sv.restore_state()
             sms = sv.solve(iters)
             errs = []
             for i in range(nseed):
                 ref = uniq[i].copy()
                 so = pyctvo.OracleWindow(ref).solve(iters)
                 assert sms[i]["iterations"] == so.iterations, (config, i, sms[i], so.iterations)
-                errs.append(cv.rel_state_error(batch[i], ref)["state"])
+                errs.append(cv.rel_state_error(wl[i], ref)["state"])
             out["max_rel_state_err"] = float(max(errs))
             out["parity_windows"] = nseed
+            out["parity_from"] = "timed batch (the first %d windows of the %d-window launch that was timed: same handle, same kernels)" % (nseed, nwin)
     return out
 
 
@@ -283,6 +348,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="packing threads per handle (0: cores / streams, at most 16)")
     ap.add_argument("--device-resident-only", action="store_true", help="time the device-resident solve instead (diagnostics)")
     ap.add_argument("--quick", action="store_true", help="skip the side measurements (single window, configs 3 / 5, tumrs, 8-rank host share)")
+    ap.add_argument("--shared-caller-buffers", action="store_true",
+                    help="replicas of a distinct window share its caller buffers (rounds 1-4: the packer then reads 11 MB out of the host's L3 instead of streaming 1.5 GB)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -317,22 +384,28 @@ def main():
     # ---- synthetic windows: global window id g = rank + world * j (sharding.shard), content = one of this rank's
     #      `unique` windows (seeds 1000 + unique * rank + i; configs[3] names seeds 1000..1063)
     nuniq = max(1, min(args.unique, args.windows))
-    uniq = [cv.synth.make_window(args.config, seed=1000 + rank * nuniq + i) for i in range(nuniq)]
+    uniq = [synth_window(cv, args.config, 1000 + rank * nuniq + i) for i in range(nuniq)]
     nstream = max(1, min(args.streams, args.windows))
     per = [args.windows // nstream + (1 if i < args.windows % nstream else 0) for i in range(nstream)]
     first = np.concatenate([[0], np.cumsum(per)])          # local window index range of every handle
     my_ids = cv.sharding.shard(args.windows * world, rank, world)
     hthreads = args.host_threads or max(1, min(16, (os.cpu_count() or 8) // (nstream * max(world, 1))))
     solvers, cbatches, keeps, outs = [], [], [], []
+    cbatches_shared = []
     for si in range(nstream):
         sv = cv.Solver(device=local, precision=args.precision, host_threads=hthreads)
         keep = []
         arr = (cv.capi.CWindow * per[si])()
+        arr_sh = (cv.capi.CWindow * per[si])()
         wl = []
         for j in range(per[si]):
             w = uniq[(int(first[si]) + j) % nuniq]
-            arr[j] = cv.capi.to_cwindow(w, keep)
+            # EVERY window of a step owns its caller buffers (a copy of the distinct window it replicates): validate + pack stream the
+            # whole batch from DRAM (8192 x 178 KB = 1.46 GB per step), as a caller with 8192 different windows would make them
+            arr[j] = cv.capi.to_cwindow(w if args.shared_caller_buffers else w.copy(), keep)
+            arr_sh[j] = cv.capi.to_cwindow(w, keep)
             wl.append(w)
+        cbatches_shared.append(arr_sh)
         K = sum(w.K for w in wl); F = sum(w.F for w in wl); L = sum(w.L for w in wl)
         outs.append((np.zeros((K, 4)), np.zeros((K, 3)), np.zeros((F, 6)), np.zeros(max(L, 1)), np.zeros(per[si])))
         solvers.append(sv); cbatches.append(arr); keeps.append((keep, wl))
@@ -343,6 +416,9 @@ def main():
     nslots = args.gpu_slots if args.gpu_slots > 0 else max(1, nstream // 2)
     slots = threading.Semaphore(nslots)
 
+    batches = {"own": cbatches, "shared": cbatches_shared}
+    which = ["own"]
+
     def run_handle_steps(si, nsteps, resident):
         sv = solvers[si]
         for _ in range(nsteps):
@@ -351,7 +427,7 @@ def main():
                 with slots:
                     sv.solve_raw(args.iters)
                 continue
-            cv.capi.check(lib.ctvio_set_batch(sv._h, per[si], C.cast(cbatches[si], C.c_void_p)))      # validate + pack + H2D
+            cv.capi.check(lib.ctvio_set_batch(sv._h, per[si], C.cast(batches[which[0]][si], C.c_void_p)))      # validate + pack + H2D
             with slots:
                 cv.capi.check(lib.ctvio_solve(sv._h, args.iters, None))                                 # device-resident LM
             o = outs[si]
@@ -375,6 +451,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rank_times = []
+
     def timed(nsteps, resident):
         barrier()
         t0 = time.perf_counter()
@@ -382,10 +460,12 @@ def main():
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         barrier()
+        rank_times[:] = [t]
         if dist is not None:
-            tt = torch.tensor([t], device=coll_device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t = float(tt.item())
+            every = [torch.zeros(1, device=coll_device, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(every, torch.tensor([t], device=coll_device, dtype=torch.float64))
+            rank_times[:] = [float(x.item()) for x in every]     # each rank's own clock: the first real SCALE run shows imbalance directly
+            t = max(rank_times)
         return t
 
     def prepare_resident():
@@ -399,6 +479,7 @@ def main():
         prepare_resident()
     steps(args.warmup, resident_headline)
     t_total = timed(args.steps, resident_headline)
+    per_rank_rate = [args.windows * args.steps / t for t in rank_times]
     n_solved = args.windows * world * args.steps
     fp_bytes = 8 if args.precision == "fp64" else 4
     w_lab = uniq[0]
@@ -412,8 +493,14 @@ def main():
                                    "end to end per batch: validate + pack (host threads) + H2D + LM solve + D2H of every state",
                    "windows_per_gpu_per_step": args.windows, "distinct_windows_per_gpu": nuniq, "streams_per_gpu": nstream, "concurrent_solves_per_gpu": nslots,
                    "pack_threads_per_stream": hthreads,
+                   "caller_buffers": ("shared by the replicas of a distinct window (L3-resident input)" if args.shared_caller_buffers else
+                                      "one set per window: pack + H2D stream the whole batch from DRAM"),
                    "sharding": f"independent windows, window id mod {world} rank(s), no data-path collective"},
+        "per_rank_solves_per_s": per_rank_rate,
     }
+    if args.windows <= 64:   # BASELINE configs[3] as written (64 windows over 8 GPUs = 8 per rank) is launch-latency territory: say what a step took
+        out["small_batch_latency"] = {"windows_per_rank": args.windows, "end_to_end_ms_per_step_by_rank": [1e3 * t / args.steps for t in rank_times],
+                                      "note": "one step = set_batch + solve + get_batch_state of this many windows on every rank, concurrently"}
     # ---- device-resident rate next to it (no packing, no PCIe: ctvio_restore_state on the device between solves)
     if not resident_headline:
         prepare_resident()
@@ -471,7 +558,7 @@ def main():
             avg_s = 1e-3 * ms[i] / max(int(n[i]), 1)
             kname = kmap.get(names[i], names[i])
             tparts = [pmc.get(k, {}).get(str(per[0]), {}).get("traffic_bytes") for k in PMC_KERNELS.get(names[i], [])]
-            traffic = sum(tparts) if tparts and all(t is not None for t in tparts) else None
+            traffic = sum(tparts) if tparts and all(t is not None for t in tparts) else None   # (committed rocprofv3 --pmc passes: see traffic_source)
             # Which roof?  Both fractions are computed; the label follows the LARGER one (the resource the kernel is closer to), and the
             # issue counters of the committed rocprofv3 pass (profiles/pmc_issue.json: tools/profile_round4.sh) ride along -- a kernel at a
             # quarter of either roof is bound by neither, and `limiter` says by what instead.
@@ -499,14 +586,9 @@ def main():
         dom = max(range(6), key=lambda i: ms[i])            # named kernels only (0..5)
         out["roofline"] = kernel_line(dom)
         out["roofline"]["measured"] = "HIP events on the solver's stream around every launch, other handles idle"
+        out["roofline"]["traffic_source"] = pmc.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile run, not of this run)")
         out["roofline_kernels"] = [kernel_line(i) for i in sorted(range(6), key=lambda i: -ms[i]) if n[i] > 0 and names[i] in kmap]
-        fl = w_ref.P * (w_ref.P + 1) * w_ref.L * per[0]      # nominal SYRK count
-        fls = sum(structural_schur_flops(w) for w in wl0)    # the products W actually has (no bias columns)
-        avg_schur = 1e-3 * ms[4] / max(int(n[4]), 1)
-        out["roofline_mfma"] = {"kernel": kmap["k_schur_mfma"], "bound": "mfma", "achieved": fls / avg_schur / 1e12, "peak": pk,
-                                "unit": "TFLOP/s", "frac": fls / avg_schur / 1e12 / pk, "avg_launch_us": 1e6 * avg_schur,
-                                "flops_per_launch": fls, "flop_count": "structural: (6K + 1)(6K + 2) L (W has no bias columns)",
-                                "nominal_flops_per_launch": fl, "nominal_frac": fl / avg_schur / 1e12 / pk}
+        out["roofline_mfma"] = mfma_line(kmap["k_schur_mfma"], wl0, 1e-3 * ms[4] / max(int(n[4]), 1), per[0])
         out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}   # handle 0 only
         # ---- parity of what was timed + CPU baseline: the oracle solves a sample of the same windows on one host core
         # ---- the reference's operating mode: ONE window per solve (one UpdateTrajectory per image, odometry_manager.cpp:268-277)
@@ -562,10 +644,22 @@ def main():
             # (512 windows per launch: the one-workgroup-per-window kernels of this shape -- panel Cholesky at P = 571 -- need at least one
             #  window per CU, and the tile Schur kernel's 2 x 2 blocked form is chosen by tile count; 128 / 256 / 512 windows per launch
             #  measured 2.9 k / 3.5 k / 3.7 k solves/s)
-            out["config5"] = side_config(cv, lib, torch, "config5", 512, 8, args.iters, 2, 8, local, ora, profile=True)
-            out["tumrs"] = side_config(cv, lib, torch, "tumrs", 2048, 16, args.iters, 2, 8, local, ora)
+            out["config5"] = side_config(cv, lib, torch, "config5", 512, 8, args.iters, 2, 8, local, ora, profile=True,
+                                         label="30 KF / 1000 landmarks / 6000 IMU, SURVEY's recipe: landmark l anchored in frame l mod 8, tracked <= 8 frames -- "
+                                               "frames 16..30 (knots >= 32 of 64) carry no visual factor")
+            out["config5_spread"] = side_config(cv, lib, torch, "config5_spread", 512, 8, args.iters, 2, 4, local, ora, profile=True,
+                                                label="the same sizes with landmark l anchored in frame l mod 28: visual factors all along the window")
+            out["tumrs"] = side_config(cv, lib, torch, "tumrs", 2048, 16, args.iters, 2, 8, local, ora, profile=True,
+                                       label="the reference's native operating point: 200 Hz IMU (10 samples per group), <= 150 features per frame")
             wt = cv.synth.make_window("tumrs", seed=1000)
             out["tumrs"]["imu_lane_utilisation"] = wt.M / (64.0 * imu_groups(wt))   # one 64-lane pass per (segment, bias) group
+            # ---- rounds 1-4 let the replicas of a distinct window share its caller buffers (the packer read 11 MB out of L3): once, beside the headline
+            if not args.shared_caller_buffers:
+                which[0] = "shared"
+                steps(1)
+                tsh = timed(3, False)
+                which[0] = "own"
+                out["end_to_end_shared_caller_buffers_solves_per_s"] = args.windows * 3 / tsh
             # ---- what an 8-rank run leaves one rank on the host: pack threads = cores / (streams x 8)
             ht8 = max(1, (os.cpu_count() or 8) // (nstream * 8))
             for sv in solvers:

@@ -114,6 +114,7 @@ struct SolverBase {
   virtual int last_timing(double *ms8, int32_t *n8) = 0;
   virtual int set_profiling(int on) = 0;
   virtual void *stream() = 0;
+  virtual int graph_captures() const = 0;
 };
 
 class SolverImpl : public SolverBase {
@@ -155,6 +156,7 @@ class SolverImpl : public SolverBase {
   int clear() override { own_.clear(); uploaded_ = false; return CTVIO_OK; }
   int num_windows() const override { return uploaded_ ? (int)meta_.size() : (int)own_.size(); }
   void *stream() override { return (void *)stream_; }
+  int graph_captures() const override { return graph_captures_; }
 
   int add_window(const ctvio_window *w, int32_t *id) override {
     std::string err;
@@ -190,6 +192,11 @@ class SolverImpl : public SolverBase {
     const int nth = host_threads(opt_.host_threads);
     std::vector<PackTmp> tmp((size_t)nw);
     std::atomic<int> first_bad{nw};
+    // The batch's factorisation: P <= 223 for every window -> the register-resident tile Cholesky, which keeps the whole triangle (dense
+    // envelope); otherwise the panel kernel, which works inside every window's envelope.  (Sizes alone decide: known before planning.)
+    int maxP_pre = 0;
+    for (int wi = 0; wi < nw; ++wi) if (wins[wi]) maxP_pre = std::max(maxP_pre, 6 * wins[wi]->K + 6 * wins[wi]->F + 1);
+    const bool dense_env = chol_tiles_for(maxP_pre) != 0 || sparsity_off();
     parallel_for(nw, nth, [&](int wi) {
       if (validate && !validate_window(wins[wi], tmp[wi].err)) {
         int cur = first_bad.load();
@@ -197,6 +204,7 @@ class SolverImpl : public SolverBase {
         return;
       }
       plan_window(wins[wi], VCH, tmp[wi]);
+      if (tmp[wi].err.empty()) plan_sparsity(wins[wi], dense_env, sparsity_off(), tmp[wi]);
       if (!tmp[wi].err.empty()) {
         int cur = first_bad.load();
         while (wi < cur && !first_bad.compare_exchange_weak(cur, wi)) {}
@@ -207,7 +215,7 @@ class SolverImpl : public SolverBase {
     meta_.assign(nw, WinMeta());
     t0_.resize(nw);
     int64_t H0 = 0, W0 = 0, pH0 = 0;
-    int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0, A0 = 0;
+    int K0 = 0, F0 = 0, L0 = 0, M0 = 0, V0 = 0, B0 = 0, U0 = 0, Pp0 = 0, pv0 = 0, pb = 0, G0 = 0, I0 = 0, A0 = 0, TR0 = 0, maxSpan = 1;
     int maxN = 0, maxP = 0, maxPn = 0, maxL = 0, maxLdw = 0, maxK = 0, maxSchurTiles = 0;
     size_t vis_lds_bytes = vis_stage_bytes(), vis_glb_bytes = vis_stage_bytes();
     for (int wi = 0; wi < nw; ++wi) {
@@ -219,6 +227,7 @@ class SolverImpl : public SolverBase {
       m.knot0 = K0; m.bias0 = F0; m.lm0 = L0; m.imu0 = M0; m.vis0 = V0; m.bc0 = B0; m.u0 = U0; m.p0 = Pp0;
       m.grp0 = G0; m.ngrp = tmp[wi].ngrp; m.vitem0 = I0; m.nvitem = tmp[wi].nvitem; m.Vp = tmp[wi].Vp;
       m.anc0 = A0; m.A = tmp[wi].A;
+      m.tr0 = TR0; m.ntr = tmp[wi].ntr; m.Lobs = tmp[wi].Lobs; TR0 += tmp[wi].ntr; maxSpan = std::max(maxSpan, tmp[wi].max_span);
       m.ldw = (m.P + 1 + 31) / 32 * 32; m.Lpad = std::max(2, (w.L + 1) / 2 * 2);
       m.pv0 = pv0; m.pblk0 = pb; m.fix_ld = w.fix_ld; m.lock_bg = w.lock_bg; m.lock_ba = w.lock_ba; m.fixed_upto = w.fixed_upto;
       m.H0 = H0; m.W0 = W0; m.pH0 = pH0; m.ldh = (m.P + 15) / 16 * 16; m.dt_ns = w.dt_ns; m.inv_dt = 1e9 / (double)w.dt_ns;
@@ -251,7 +260,7 @@ class SolverImpl : public SolverBase {
         maxSchurTiles = std::max(maxSchurTiles, cnt);
       }
     }
-    const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
+    const size_t chol_lds = (size_t)(2 * 32 * 34 + 32 + 34 + 32 + (size_t)((std::max(maxP - 32, 0) + 1 + 15) / 16 * 16) * 32) * sizeof(double);
     if (chol_lds > 160 * 1024) return fail(CTVIO_ERR_INVALID, "window too large for the single-workgroup Cholesky (P > ~600)");
     const size_t Mt = (size_t)std::max(M0, 1), Vt = (size_t)std::max(V0, 1), At = (size_t)std::max(A0, 1);
     Mtot_ = M0; Vtot_ = V0;
@@ -274,6 +283,8 @@ class SolverImpl : public SolverBase {
     const size_t o_pcol = seg(4 * (size_t)pv0), o_p_kind = seg(4 * (size_t)pb), o_p_index = seg(4 * (size_t)pb), o_p_off = seg(4 * (size_t)pb);
     const size_t o_pinv = seg(4 * (size_t)Pp0), o_bgl_off = seg(4 * ((size_t)F0 + nw)), o_bgl = seg(4 * (size_t)std::max(G0, 1));
     const size_t o_active = seg((size_t)U0);
+    const size_t o_lm_pos = seg(4 * (size_t)L0), o_lm_at = seg(4 * (size_t)L0), o_lm_klo = seg(4 * (size_t)L0), o_lm_khi = seg(4 * (size_t)L0);
+    const size_t o_tl_beg = seg(4 * (size_t)TR0), o_tl_end = seg(4 * (size_t)TR0), o_env_first = seg(4 * (size_t)TR0);
     const size_t in_bytes = off;
     bool grew = false;
     HIPCHK(hipStreamSynchronize(stream_));   // the previous batch may still be reading the staging arena (H2D in flight)
@@ -303,6 +314,9 @@ class SolverImpl : public SolverBase {
     int32_t *h_pcol = CTV_H(int32_t, o_pcol), *h_p_kind = CTV_H(int32_t, o_p_kind), *h_p_index = CTV_H(int32_t, o_p_index), *h_p_off = CTV_H(int32_t, o_p_off);
     uint8_t *h_active = CTV_H(uint8_t, o_active);
     int32_t *h_pinv = CTV_H(int32_t, o_pinv), *h_bgl_off = CTV_H(int32_t, o_bgl_off), *h_bgl = CTV_H(int32_t, o_bgl);
+    int32_t *h_lm_pos = CTV_H(int32_t, o_lm_pos), *h_lm_at = CTV_H(int32_t, o_lm_at), *h_lm_klo = CTV_H(int32_t, o_lm_klo), *h_lm_khi = CTV_H(int32_t, o_lm_khi);
+    int32_t *h_tl_beg = CTV_H(int32_t, o_tl_beg), *h_tl_end = CTV_H(int32_t, o_tl_end), *h_env_first = CTV_H(int32_t, o_env_first);
+    h_lm_pos_ = h_lm_pos; h_ld_ = h_ld;
     // ---- second pass: every window fills its own slices
     parallel_for(nw, nth, [&](int wi) {
       const ctvio_window &w = *wins[wi];
@@ -316,6 +330,12 @@ class SolverImpl : public SolverBase {
       std::fill(h_knot_win + m.knot0, h_knot_win + m.knot0 + w.K, wi);
       std::fill(h_bias_win + m.bias0, h_bias_win + m.bias0 + w.F, wi);
       std::fill(h_lm_win + m.lm0, h_lm_win + m.lm0 + w.L, wi);
+      if (w.L) {   // sparsity plan: rows of W in sorted landmark order and their knot spans
+        std::memcpy(h_lm_pos + m.lm0, t.lm_pos.data(), 4 * (size_t)w.L); std::memcpy(h_lm_at + m.lm0, t.lm_at.data(), 4 * (size_t)w.L);
+        std::memcpy(h_lm_klo + m.lm0, t.row_klo.data(), 4 * (size_t)w.L); std::memcpy(h_lm_khi + m.lm0, t.row_khi.data(), 4 * (size_t)w.L);
+      }
+      std::memcpy(h_tl_beg + m.tr0, t.tl_beg.data(), 4 * (size_t)m.ntr); std::memcpy(h_tl_end + m.tr0, t.tl_end.data(), 4 * (size_t)m.ntr);
+      std::memcpy(h_env_first + m.tr0, t.env_first.data(), 4 * (size_t)m.ntr);
       // IMU samples in (segment, bias) order; groups = runs of equal (segment, bias)
       int g = m.grp0 - 1;
       for (int i = 0; i < w.M; ++i) {
@@ -441,6 +461,9 @@ class SolverImpl : public SolverBase {
     d.pcol = CTV_D(int32_t, o_pcol); d.p_kind = CTV_D(int32_t, o_p_kind); d.p_index = CTV_D(int32_t, o_p_index); d.p_off = CTV_D(int32_t, o_p_off);
     d.active = CTV_D(uint8_t, o_active);
     d.pinv = CTV_D(int32_t, o_pinv); d.bgl_off = CTV_D(int32_t, o_bgl_off); d.bgl = CTV_D(int32_t, o_bgl);
+    d.lm_pos = CTV_D(int32_t, o_lm_pos); d.lm_at = CTV_D(int32_t, o_lm_at); d.lm_klo = CTV_D(int32_t, o_lm_klo); d.lm_khi = CTV_D(int32_t, o_lm_khi);
+    d.tl_beg = CTV_D(int32_t, o_tl_beg); d.tl_end = CTV_D(int32_t, o_tl_end); d.env_first = CTV_D(int32_t, o_env_first);
+    d.max_span6 = 6 * maxSpan;
 #undef CTV_H
 #undef CTV_D
     HIPCHK(hipMemcpyAsync(in_.dev, in_.host, in_bytes, hipMemcpyHostToDevice, stream_));
@@ -452,6 +475,9 @@ class SolverImpl : public SolverBase {
     all_windows_have_imu_ = !meta_.empty();
     for (const auto &mm : meta_) if (mm.ngrp == 0) all_windows_have_imu_ = false;
     deterministic_ = opt_.deterministic > 0 || (opt_.deterministic < 0 && nw <= 64);
+    // (the member goes into the launch signature and selects kernels: it must say what RUNS -- the default falls back to the accumulate path
+    //  for batches the order-fixed assembly cannot cover, and then it is off)
+    if (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_) { if (opt_.deterministic <= 0) deterministic_ = false; }
     // The order-fixed accumulation exists for batches whose every window keeps its packed Hessian in LDS, on the matrix-core kernels.
     // An explicit request that cannot be honoured is an error; the default (-1) falls back to the accumulate path for such batches.
     if (opt_.deterministic > 0 && (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_))
@@ -478,7 +504,7 @@ class SolverImpl : public SolverBase {
                  o_g = seg(8 * (size_t)U0), o_g1 = seg(8 * (size_t)U0), o_delta = seg(8 * (size_t)U0),
                  o_cscale = seg(8 * (size_t)U0), o_lm = seg(sizeof(Lm) * (size_t)nw), o_nact = seg(16), o_dbg = seg(8 * 128);
     const size_t o_zero1 = off;   // ---- ... to here
-    const size_t o_rhs = seg(8 * (size_t)Pp0), o_dd = seg(8 * (size_t)U0), o_dinv = seg(8 * (size_t)L0);
+    const size_t o_rhs = seg(8 * (size_t)Pp0), o_dd = seg(8 * (size_t)U0), o_dinv = seg(8 * (size_t)L0), o_grs = seg(8 * (size_t)L0);
     d.chol_nblk = (maxP + 31) / 32;
     d.line_search = opt_.line_search ? 1 : 0;
     const size_t o_chol_inv = seg(8 * (size_t)nw * d.chol_nblk * 1024);
@@ -495,9 +521,9 @@ class SolverImpl : public SolverBase {
     d.HppS[0] = CTV_W(double, o_Hpp); d.HppS[1] = CTV_W(double, o_Hpp1); d.S = CTV_W(double, o_S);
     d.WS[0] = CTV_W(double, o_W); d.WS[1] = CTV_W(double, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
     d.gS[0] = CTV_W(double, o_g); d.gS[1] = CTV_W(double, o_g1);
-    d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact);
+    d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact); d.span_viol = d.n_active + 1;
     d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;
-    d.rhs = CTV_W(double, o_rhs); d.dd = CTV_W(double, o_dd); d.dinv = CTV_W(double, o_dinv); d.chol_inv = CTV_W(double, o_chol_inv);
+    d.rhs = CTV_W(double, o_rhs); d.dd = CTV_W(double, o_dd); d.dinv = CTV_W(double, o_dinv); d.grs = CTV_W(double, o_grs); d.chol_inv = CTV_W(double, o_chol_inv);
 #undef CTV_W
     HIPCHK(hipMemsetAsync(wb + o_zero0, 0, o_zero1 - o_zero0, stream_));
     // pinned landing areas of the results
@@ -510,6 +536,7 @@ class SolverImpl : public SolverBase {
     snap_valid_ = false;
     vis_lds_ = vis_lds_bytes;
     vis_glb_ = vis_glb_bytes;
+    d.schur_plain_in_H = schur_plain_in_H_for_batch();
     uploaded_ = true;
     return CTVIO_OK;
   }
@@ -649,7 +676,9 @@ class SolverImpl : public SolverBase {
       if (chol_tiles() == 2) hipLaunchKernelGGL((k_cholesky_tiles<8, 14>), dim3(nw), dim3(512), lds, stream_, d);   // (A/B variant: 8 waves x 14 tiles)
       else hipLaunchKernelGGL((k_cholesky_tiles<16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
     }
-    else if (nw <= 192) hipLaunchKernelGGL((k_cholesky_solve<8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
+    // (8 waves also when the panel's LDS footprint allows one workgroup per CU anyway -- P = 571: 157 KB -- where 4 waves left three quarters
+    //  of the CU's wave slots empty)
+    else if (nw <= 192 || chol_lds_ > 80 * 1024) hipLaunchKernelGGL((k_cholesky_solve<8>), dim3(nw), dim3(512), chol_lds_, stream_, d);
     else hipLaunchKernelGGL((k_cholesky_solve<4>), dim3(nw), dim3(256), chol_lds_, stream_, d);
     ph_end();
     ph_begin(PH_REST);
@@ -681,12 +710,30 @@ class SolverImpl : public SolverBase {
     else hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true, 8, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
   }
   bool schur_makes_rhs() const { return schur_rhs_done_; }
+  // Large batches of small windows take the per-window Schur kernel (W staged through LDS once); everything else the tile kernels.
+  bool schur_window_path() const {
+    const Dev &d = dev_;
+    if (!opt_.use_mfma) return false;
+    const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
+    const size_t lds = schur_window_lds();
+    const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
+    const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
+    return !small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224;
+  }
+  size_t schur_window_lds() const { return ((size_t)2 * 16 * dev_.maxLdw + 3 * dev_.maxLdw + 32 + 64) * sizeof(double); }   // + column vectors + the list of tiles with products
+  // Dev::schur_plain_in_H is part of the Dev struct the captured graph is keyed on: decided once per upload, never inside a launch
+  // (launch_schur used to set it, so every upload -- which clears Dev -- invalidated the cached hipGraph of the headline configuration).
+  int schur_plain_in_H_for_batch() const { return (schur_window_path() && chol_tiles() != 0 && !std::getenv("CTVIO_SCHUR_COPY_PLAIN")) ? 1 : 0; }
   // CTVIO_CHOL_TILES = 0 / 1 / 2 forces the choice (A/B measurements: panel kernel / 16 waves x 7 tiles / 8 waves x 14 tiles)
-  int chol_tiles() const {
-    if (dev_.maxP > 223) return 0;
+  static int chol_tiles_for(int maxP) {
+    if (maxP > 223) return 0;
     if (const char *e = std::getenv("CTVIO_CHOL_TILES")) return e[0] - '0';
     return 1;   // (16 waves x 7 tiles: 10.7 ms per 2048-window solve against 11.2 ms for the panel kernel, and a fifth of its HBM traffic)
   }
+  int chol_tiles() const { return chol_tiles_for(dev_.maxP); }
+  // CTVIO_DENSE=1: the sparsity plan degenerates to the dense one (every row range = all landmarks, envelope = the whole triangle) -- the
+  // A/B switch of the sparsity-aware kernels and the cross-check of tests/test_gpu_sparsity.py
+  static bool sparsity_off() { const char *e = std::getenv("CTVIO_DENSE"); return e && e[0] == '1'; }
   bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
   int n_state() const { return dev_.Ktot + dev_.Ftot + dev_.Ltot + dev_.nwin; }
 
@@ -739,6 +786,7 @@ class SolverImpl : public SolverBase {
     if (e != hipSuccess) { graph_exec_ = nullptr; return fail(CTVIO_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     graph_dev_ = dev_;
     graph_sig_ = sig;
+    ++graph_captures_;
     return CTVIO_OK;
   }
 
@@ -775,8 +823,11 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipEventRecord(ev_[9], stream_));
     Lm *lm = lm_host_;   // pinned: the copy does not stage through a runtime bounce buffer
     HIPCHK(hipMemcpyAsync(lm, d.lm, sizeof(Lm) * nw, hipMemcpyDeviceToHost, stream_));
+    int32_t *viol = reinterpret_cast<int32_t *>(lm_host_ + lm_host_cap_ - 1) + 2;   // (same pinned scratch record as the "still running" word)
+    HIPCHK(hipMemcpyAsync(viol, d.span_viol, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    if (*viol != 0) return fail(CTVIO_ERR_HIP, "internal: " + std::to_string(*viol) + " evaluation(s) fell outside the planned knot span of their landmark (host_pack.hpp: plan_sparsity)");
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev_[8], ev_[9]));
     if (profiling_) ph_collect(); else { std::fill(ph_ms_, ph_ms_ + 8, 0.0); std::fill(ph_n_, ph_n_ + 8, 0); }
@@ -795,7 +846,7 @@ class SolverImpl : public SolverBase {
       std::fprintf(stderr, "\n[ctvio] vis_eval<LIN> wave 1000, clock64 deltas (evaluation | contributions + segmented sums | record copy-out | per sweep: scatter, rows out):");
       for (int i = 32; i < 40; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, " | landmarks %lld, rows per sweep %lld", st[42] / 1000000, st[43] / 1000);
-      std::fprintf(stderr, "\n[ctvio] schur_window clock64 deltas (prologue + first chunk staged | chunks 0-2: products, stash, barrier | rest of the loop | product tiles out | other tiles out):");
+      std::fprintf(stderr, "\n[ctvio] schur_window clock64 deltas (prologue + first chunk staged | the chunk loop | product tiles out | other tiles out):");
       for (int i = 97; i < 128 && st[i] != 0; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
       std::fprintf(stderr, "\n[ctvio] assemble_vis clock64 deltas (zero | per item of rounds 0, 1: staged, run products.., scatter | rounds | imu tiles | H flush | g flush):");
       for (int i = 49; i < 63; ++i) std::fprintf(stderr, " %lld", st[i] - st[i - 1]);
@@ -828,6 +879,7 @@ class SolverImpl : public SolverBase {
     if (id < 0 || id >= dev_.nwin) return fail(CTVIO_ERR_INVALID, "window id out of range");
     const WinMeta &m = meta_[id];
     if (!m.fix_ld) ld = std::min(std::max(ld, m.ld_lo), m.ld_hi);
+    else if (ld != h_ld_[id]) return fail(CTVIO_ERR_INVALID, "the line delay of a fix_ld window cannot change after the upload: the knot spans of its landmarks were planned for it");
     if (quat) HIPCHK(hipMemcpyAsync(dev_.quat + 4 * (size_t)m.knot0, quat, sizeof(double) * 4 * m.K, hipMemcpyHostToDevice, stream_));
     if (pos) HIPCHK(hipMemcpyAsync(dev_.pos + 3 * (size_t)m.knot0, pos, sizeof(double) * 3 * m.K, hipMemcpyHostToDevice, stream_));
     if (bias) HIPCHK(hipMemcpyAsync(dev_.bias + 6 * (size_t)m.bias0, bias, sizeof(double) * 6 * m.F, hipMemcpyHostToDevice, stream_));
@@ -898,7 +950,7 @@ class SolverImpl : public SolverBase {
         for (int j = i + 1; j < P; ++j) Hpp[(size_t)i * P + j] = Hpp[(size_t)j * P + i];
     if (W && m.L)
       for (int i = 0; i < P; ++i)
-        for (int l = 0; l < m.L; ++l) W[(size_t)i * m.L + l] = (double)Wh[(size_t)l * m.ldw + i];
+        for (int l = 0; l < m.L; ++l) W[(size_t)i * m.L + l] = (double)Wh[(size_t)h_lm_pos_[m.lm0 + l] * m.ldw + i];   // (rows of W: sorted landmark order)
     if (cost) *cost = lm.cost;
     return CTVIO_OK;
   }
@@ -1222,6 +1274,7 @@ class SolverImpl : public SolverBase {
   bool marg_attr_set_ = false;
   double *snap_ = nullptr;   // state snapshot (inside work_)
   Lm *lm_host_ = nullptr; size_t lm_host_cap_ = 0;
+  int graph_captures_ = 0;                // how many times the pass was captured (ctvio_graph_captures: a stream of equal batches captures once)
   hipGraphExec_t graph_exec_ = nullptr;   // one LM pass (launch_pass) as a graph, valid while dev_ == graph_dev_
   Dev graph_dev_;
   std::vector<long long> graph_sig_;
@@ -1229,6 +1282,8 @@ class SolverImpl : public SolverBase {
   double *state_host_ = nullptr; size_t state_host_cap_ = 0;
   bool snap_valid_ = false, any_vis_lds_ = false, any_vis_glb_ = false, all_windows_have_imu_ = false;
   int maxK_ = 0, max_schur_tiles_ = 0;
+  const double *h_ld_ = nullptr;        // the line delays as uploaded (same arena)
+  const int32_t *h_lm_pos_ = nullptr;   // host mirror of Dev::lm_pos (inside in_.host: valid while the batch is uploaded)
 };
 
 void SolverImpl::launch_imu_linearize(size_t lds, int mode) {
@@ -1260,16 +1315,12 @@ void SolverImpl::launch_assemble_vis_glb(int parts, int mode) {
 void SolverImpl::launch_schur() {
   const Dev &d = dev_;
   schur_rhs_done_ = false;
-  dev_.schur_plain_in_H = 0;
   if (opt_.use_mfma) {   // fp64 matrix cores
-    const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
-    const size_t lds = ((size_t)2 * 16 * d.maxLdw + 3 * d.maxLdw + 32 + 64) * sizeof(double);   // + column vectors + the list of tiles with products
     // large batches: one workgroup per window, W staged through LDS once, reduced rhs produced on the way; small batches: one
     // wave per 16 x 16 tile (shorter latency, W re-read per tile), k_rhs forms the reduced right-hand side
-    const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
     const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
-    if (!small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224) {
-      dev_.schur_plain_in_H = (chol_tiles() != 0 && !std::getenv("CTVIO_SCHUR_COPY_PLAIN")) ? 1 : 0;   // (d is dev_: the Cholesky launch sees it too)
+    if (schur_window_path()) {
+      const size_t lds = schur_window_lds();
       if (16 * nc <= 5 * 512 && max_schur_tiles_ <= 56) hipLaunchKernelGGL((k_schur_window_f64<5, 7>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
       else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
@@ -1394,6 +1445,15 @@ int32_t ctvio_shard_count(int32_t n, int32_t device, int32_t n_devices) {
   return n / n_devices + (device < n % n_devices ? 1 : 0);
 }
 namespace {
+// (memcmp over the struct would compare its tail padding: indeterminate bytes of a caller's stack object)
+bool same_options(const ctvio_options &a, const ctvio_options &b) {
+  return a.device == b.device && a.precision == b.precision && a.use_mfma == b.use_mfma && a.check_every == b.check_every &&
+         a.function_tolerance == b.function_tolerance && a.gradient_tolerance == b.gradient_tolerance && a.parameter_tolerance == b.parameter_tolerance &&
+         a.initial_radius == b.initial_radius && a.max_radius == b.max_radius && a.min_radius == b.min_radius &&
+         a.min_relative_decrease == b.min_relative_decrease && a.min_lm_diagonal == b.min_lm_diagonal && a.max_lm_diagonal == b.max_lm_diagonal &&
+         a.max_consecutive_invalid_steps == b.max_consecutive_invalid_steps && a.deterministic == b.deterministic && a.host_threads == b.host_threads &&
+         a.use_graph == b.use_graph && a.line_search == b.line_search;
+}
 std::mutex g_shard_mu;
 std::vector<ctvio_solver *> g_shard_solvers;   // one per shard, created on first use (and again when the options change)
 std::vector<ctvio_options> g_shard_opts;       // the options each handle was created with
@@ -1469,7 +1529,7 @@ int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t
     ctvio_options o;
     if (opt) o = *opt; else ctvio_default_options(&o);
     o.device = g % ndev;
-    if (g_shard_solvers[g] && std::memcmp(&o, &g_shard_opts[g], sizeof o) != 0) {   // the caller changed the options: a fresh handle
+    if (g_shard_solvers[g] && !same_options(o, g_shard_opts[g])) {   // the caller changed the options: a fresh handle
       ctvio_destroy(g_shard_solvers[g]);
       g_shard_solvers[g] = nullptr;
     }
@@ -1512,8 +1572,15 @@ int32_t ctvio_solve_sharded(const ctvio_options *opt, int32_t n_devices, int32_t
     ShardWorker *wk = g_shard_workers.back().get();
     wk->th = std::thread([wk] { wk->loop(); });
   }
-  for (int g = 1; g < G; ++g) g_shard_workers[g - 1]->post([&work, g] { work(g); });
-  work(0);
+  // (jobs hold references to this frame: whatever was posted is waited for before the function unwinds, also when a later post throws)
+  int posted = 0;
+  try {
+    for (int g = 1; g < G; ++g) { g_shard_workers[g - 1]->post([&work, g] { work(g); }); posted = g; }
+    work(0);
+  } catch (...) {
+    for (int g = 1; g <= posted; ++g) g_shard_workers[g - 1]->wait();
+    return ctv::fail(CTVIO_ERR_HIP, "ctvio_solve_sharded: could not hand a shard to its worker thread");
+  }
   for (int g = 1; g < G; ++g) g_shard_workers[g - 1]->wait();
   for (int g = 0; g < G; ++g) if (rcs[g] != CTVIO_OK) return ctv::fail(rcs[g], errs[g]);
   return CTVIO_OK;
@@ -1524,5 +1591,6 @@ int32_t ctvio_snapshot_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(
 int32_t ctvio_restore_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(1); }
 int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on) { CHK_S; return s->impl->set_profiling(on); }
 void *ctvio_stream(ctvio_solver *s) { return s ? s->impl->stream() : nullptr; }
+int32_t ctvio_graph_captures(const ctvio_solver *s) { return s ? s->impl->graph_captures() : 0; }
 
 }  // extern "C"

@@ -26,6 +26,9 @@ struct WinMeta {
   int32_t ldh;                 // row stride of Hpp / S: P rounded up to 16 doubles, so every row starts on a 128-byte line
   int64_t W0;                  // offset of W (elements)
   int64_t pH0;                 // offset of the prior's J0^T J0 (pn*pn doubles)
+  int32_t tr0, ntr;            // sparsity plan (host_pack.hpp: plan_sparsity): offset of the window's per-tile-row entries in Dev::env_first / tl_beg / tl_end;
+                               // ntr = P / 16 + 1 tile rows (the rhs row P rides along as a row of the reduced system)
+  int32_t Lobs, pad_sp;        // rows of W that can be non-zero (landmarks with observations sort first)
   int64_t dt_ns;
   double inv_dt;               // 1e9 / dt_ns  (reference spline_segment.h:58)
   double q_CI[4], p_CI[3], gravity[3], imu_w[6], img_w, cauchy_a, ld_lo, ld_hi;
@@ -120,6 +123,20 @@ struct Dev {
   const int32_t *vblk;   // [Vtot] block slots in frame-pair order, window by window (VisItem::start indexes it)
   const int32_t *vblk_anc; // [Vtot] the anchors (absolute) of those blocks
   int32_t maxL, maxLdw;
+  // ---- sparsity plan of the reduced system (the reference solves with SPARSE_NORMAL_CHOLESKY, trajectory_estimator.cpp:371-384: a visual block
+  // touches <= 2 x (4-5) knots, :293-309).  The rows of W are stored in SORTED landmark order (by first, then last touched knot): row r of
+  // window w belongs to landmark lm_at[lm0 + r]; lm_pos is the inverse.  A row is non-zero only in the knot columns [6 lm_klo, 6 lm_khi + 6),
+  // the line-delay column P - 1 (and g_rho, which rides as column P): conservative over the line delay's box (the segment of an observation moves
+  // with row * line delay).  Everything else of the row is never written and stays zero from the upload's memset.
+  const int32_t *lm_pos, *lm_at;   // [Ltot]
+  const int32_t *lm_klo, *lm_khi;  // [Ltot] by ROW (sorted): first / last knot (khi < klo: the landmark has no observation, its row is zero)
+  // per 16-column tile c of the window (tr0 + c, c < ntr): the rows [tl_beg, tl_end) of W that can be non-zero in the tile's columns (bias-only
+  // tiles: empty), and env_first: the first tile column of tile row c inside the ENVELOPE of the reduced system S (and of its Cholesky factor:
+  // fill stays inside the row envelope) -- tiles (r, c < env_first[r]) are structurally zero: not formed, not stored, not multiplied.
+  const int32_t *tl_beg, *tl_end, *env_first;
+  double *grs;                     // [Ltot] g_rho by ROW (written with dinv by begin_iteration): the Schur kernels stream rows, not landmarks
+  int32_t *span_viol;              // device counter: an evaluation fell outside its landmark's planned span (never, unless the plan is wrong)
+  int32_t max_span6, pad_ms;       // 6 x the widest landmark span of the batch (knot columns): LDS row width of k_vis_eval
   // bias chain
   const int32_t *bc_win, *bc_i, *bc_j;
   const double *bc_w;    // [NBtot][6]
@@ -142,7 +159,7 @@ struct Dev {
   double *S, *rhs;       // Schur complement (lower) and its right-hand side [sum P]
   double *chol_inv;      // [nwin][chol_nblk][32][32] inverses of the diagonal blocks of the Cholesky factor (row-major)
   int32_t chol_nblk;
-  double *dd, *dinv;     // LM damping per unknown [Utot]; 1/(Hll + dd) [Ltot]
+  double *dd, *dinv;     // LM damping per unknown [Utot]; 1/(Hll + dd) [Ltot] by ROW of W (sorted landmark order)
   double *cscale;        // Jacobi scaling [Utot]
   double *delta;         // step [Utot]
   const uint8_t *active; // [Utot] unknown is in the reduced program

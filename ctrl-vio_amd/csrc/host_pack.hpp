@@ -79,6 +79,9 @@ struct PackTmp {
   std::vector<int32_t> anc_of, anc_rep; // anchors (distinct i ends), numbered landmark-major: anchor of every block / a block that carries it
   int32_t ngrp = 0, nvitem = 0, Vp = 0; // Vp: slots incl. padding, a multiple of 64
   int32_t A = 0;                        // number of anchors
+  // sparsity plan (plan_sparsity): rows of W in sorted landmark order, their knot spans, per-tile row ranges, envelope of the reduced system
+  std::vector<int32_t> lm_pos, lm_at, row_klo, row_khi, tl_beg, tl_end, env_first;
+  int32_t Lobs = 0, max_span = 0, ntr = 0;
   std::string err;
 };
 
@@ -89,6 +92,7 @@ inline bool validate_window(const ctvio_window *w, std::string &err) {
   if (w->K < 4 || w->F < 1 || w->L < 0 || w->M < 0 || w->NB < 0 || w->V < 0 || w->dt_ns <= 0 || w->pn < 0 || w->pnb < 0)
     return bad("bad sizes (need K >= 4, F >= 1, dt_ns > 0)");
   if (!w->quat || !w->pos || !w->bias || (w->L && !w->rho)) return bad("null state pointer");
+  if (!w->fix_ld && !(w->ld_lo <= w->ld_hi)) return bad("line-delay bounds: need ld_lo <= ld_hi");
   if (w->M && (!w->imu_t || !w->imu_gyro || !w->imu_acc || !w->imu_bias)) return bad("null IMU pointer");
   if (w->NB && (!w->bc_i || !w->bc_j || !w->bc_w)) return bad("null bias-chain pointer");
   if (w->V && (!w->v_lm || !w->v_ti || !w->v_tj || !w->v_rowi || !w->v_rowj || !w->v_pi || !w->v_pj)) return bad("null visual pointer");
@@ -104,6 +108,8 @@ inline bool validate_window(const ctvio_window *w, std::string &err) {
     const int64_t a = w->v_ti[v], b = w->v_tj[v];
     if (a < w->t0_ns || b < w->t0_ns || a + w->v_rowi[v] * ldmax_ns >= tmax || b + w->v_rowj[v] * ldmax_ns >= tmax)
       return bad("visual time (+ row * line delay) outside the spline");
+    if (!std::isfinite(w->v_pi[2 * v]) || !std::isfinite(w->v_pi[2 * v + 1]) || !std::isfinite(w->v_pj[2 * v]) || !std::isfinite(w->v_pj[2 * v + 1]))
+      return bad("non-finite visual observation");
   }
   for (int b = 0; b < w->NB; ++b)
     if (w->bc_i[b] < 0 || w->bc_i[b] >= w->F || w->bc_j[b] < 0 || w->bc_j[b] >= w->F) return bad("bias chain index out of range");
@@ -174,9 +180,10 @@ inline void plan_window(const ctvio_window *w, int vch, PackTmp &t) {
     return w->v_ti[a] == w->v_ti[b] && w->v_rowi[a] == w->v_rowi[b] && w->v_pi[2 * a] == w->v_pi[2 * b] && w->v_pi[2 * a + 1] == w->v_pi[2 * b + 1];
   };
   std::vector<int32_t> lcount((size_t)L + 1, 0);
+  for (int v = 0; v < V; ++v)   // (before the anchor search below: its per-landmark lists are linear, a malformed window must not make it quadratic)
+    if (++lcount[w->v_lm[v]] > 64) { t.err = "more than 64 observations of one landmark"; return; }
   for (int i = 0; i < V; ++i) {
     const int v = t.vord[i], l = w->v_lm[v];
-    lcount[l]++;
     int a = first[l], prev = -1;
     while (a >= 0 && !same_anchor(rep[a], v)) { prev = a; a = next[a]; }
     if (a < 0) {
@@ -196,7 +203,6 @@ inline void plan_window(const ctvio_window *w, int vch, PackTmp &t) {
   int pos = 0, na = 0;
   for (int l = 0; l < L; ++l) {
     const int c = lcount[l];
-    if (c > 64) { t.err = "more than 64 observations of one landmark"; return; }
     if ((pos & 63) + c > 64) pos = (pos + 63) & ~63;
     for (int a = first[l]; a >= 0; a = next[a]) {
       newid[a] = na; t.anc_rep[na] = rep[a]; astart[na] = pos;
@@ -214,6 +220,107 @@ inline void plan_window(const ctvio_window *w, int vch, PackTmp &t) {
     t.lord[slot] = v;
     t.vpos[v] = slot;
     t.anc_of[v] = a;
+  }
+}
+
+// The segment (first active knot) of an observation at line delay `ld`, exactly as the device computes it (kernels_visual.hpp: vis_times + clamp).
+inline int vis_segment(const ctvio_window *w, int64_t t, int row, double ld) {
+  const long long ld_ns = (long long)(ld * 1e9);
+  const long long tau = (t - w->t0_ns) + (long long)row * ld_ns;
+  const int s = (int)(tau / w->dt_ns);
+  return std::max(0, std::min(s, w->K - 4));
+}
+
+// Sparsity plan of one window: what the reference leaves to SPARSE_NORMAL_CHOLESKY (trajectory_estimator.cpp:371-384) is decided here, once per
+// upload, from the factor structure alone.
+//   * Every landmark's KNOT SPAN [klo, khi]: the knots its residual blocks can touch (4 per spline end, image_feature_factor.h:79-101), over the
+//     whole box of the line delay -- the row time t + row * ld moves with ld (image_feature_factor.h:72), and both extremes of a monotone
+//     function bound it.  The rows of W are ordered by (klo, khi), landmarks without observations last.
+//   * For every 16-column tile of the pose unknowns: the range of sorted rows that can be non-zero there (the Schur kernels multiply only those).
+//   * The ENVELOPE of the reduced system S = Hpp - W^T Hll^-1 W: first[u] = the smallest unknown coupled to u by an IMU group (4 knots + its bias
+//     state), a bias-chain link, the prior (all its columns mutually), or a landmark (its span's knots mutually, and each with the line delay);
+//     Cholesky fill stays inside the row envelope, so tiles (r, c < env_first[r]) are never formed, stored or multiplied.  dense = true (batches
+//     whose factorisation keeps the whole triangle in registers: P <= 223) sets env_first = 0; full_ranges widens every non-empty row range to
+//     all observed rows (the dense cross-check).
+inline void plan_sparsity(const ctvio_window *w, bool dense, bool full_ranges, PackTmp &t) {
+  const int K = w->K, F = w->F, L = w->L, V = w->V, K6 = 6 * K, P = K6 + 6 * F + 1;
+  std::vector<int32_t> klo((size_t)L, K), khi((size_t)L, -1);
+  const double ld_a = w->fix_ld ? w->ld : w->ld_lo, ld_b = w->fix_ld ? w->ld : w->ld_hi;
+  for (int v = 0; v < V; ++v) {
+    const int l = w->v_lm[v];
+    const int s[4] = {vis_segment(w, w->v_ti[v], w->v_rowi[v], ld_a), vis_segment(w, w->v_ti[v], w->v_rowi[v], ld_b),
+                      vis_segment(w, w->v_tj[v], w->v_rowj[v], ld_a), vis_segment(w, w->v_tj[v], w->v_rowj[v], ld_b)};
+    const int lo = std::min(std::min(s[0], s[1]), std::min(s[2], s[3])), hi = std::max(std::max(s[0], s[1]), std::max(s[2], s[3])) + 3;
+    klo[l] = std::min(klo[l], lo); khi[l] = std::max(khi[l], hi);
+  }
+  t.lm_at.resize((size_t)L); t.lm_pos.resize((size_t)L); t.row_klo.resize((size_t)L); t.row_khi.resize((size_t)L);
+  std::iota(t.lm_at.begin(), t.lm_at.end(), 0);
+  std::stable_sort(t.lm_at.begin(), t.lm_at.end(), [&](int a, int b) { return klo[a] != klo[b] ? klo[a] < klo[b] : khi[a] < khi[b]; });
+  t.Lobs = 0; t.max_span = 0;
+  for (int r = 0; r < L; ++r) {
+    const int l = t.lm_at[r];
+    t.lm_pos[l] = r; t.row_klo[r] = klo[l]; t.row_khi[r] = khi[l];
+    if (khi[l] >= 0) { t.Lobs = r + 1; t.max_span = std::max(t.max_span, khi[l] - klo[l] + 1); }
+  }
+  const int ntr = P / 16 + 1;
+  t.ntr = ntr;
+  t.tl_beg.assign((size_t)ntr, 0); t.tl_end.assign((size_t)ntr, 0); t.env_first.assign((size_t)ntr, 0);
+  for (int c = 0; c < ntr; ++c) {
+    int beg = L, end = 0;
+    if (16 * c < K6) {
+      const int kf = 16 * c / 6, kl = std::min(16 * c + 15, K6 - 1) / 6;
+      for (int r = 0; r < t.Lobs; ++r)
+        if (t.row_klo[r] <= kl && t.row_khi[r] >= kf) { beg = std::min(beg, r); end = r + 1; }
+    }
+    if (16 * c <= P - 1 && P - 1 < 16 * c + 16 && t.Lobs > 0) { beg = 0; end = t.Lobs; }   // the line-delay column: every observed landmark
+    if (end <= beg) beg = end = 0;
+    if (full_ranges && end > 0) { beg = 0; end = t.Lobs; }     // (CTVIO_DENSE: the A/B switch -- every tile with products multiplies every row)
+    t.tl_beg[c] = beg; t.tl_end[c] = end;
+  }
+  if (dense) return;
+  // envelope, in columns: per knot block, per bias block, line delay
+  std::vector<int32_t> fk((size_t)K), fb((size_t)F);
+  for (int k = 0; k < K; ++k) fk[k] = 6 * k;
+  for (int f = 0; f < F; ++f) fb[f] = K6 + 6 * f;
+  int fld = P - 1;
+  for (int i = 0; i < w->M; ++i) {
+    const int s = t.iseg[i], b = w->imu_bias[i];
+    for (int j = 1; j < 4; ++j) fk[s + j] = std::min(fk[s + j], 6 * s);
+    fb[b] = std::min(fb[b], 6 * s);
+  }
+  for (int b = 0; b < w->NB; ++b) {
+    const int i = std::min(w->bc_i[b], w->bc_j[b]), j = std::max(w->bc_i[b], w->bc_j[b]);
+    fb[j] = std::min(fb[j], K6 + 6 * i);
+  }
+  for (int l = 0; l < L; ++l) {
+    if (khi[l] < 0) continue;
+    for (int k = klo[l] + 1; k <= khi[l]; ++k) fk[k] = std::min(fk[k], 6 * klo[l]);
+    fld = std::min(fld, 6 * klo[l]);
+  }
+  if (w->pn > 0) {
+    int m = P;
+    auto col0 = [&](int b) {
+      const int kind = w->p_kind[b], idx = w->p_index[b];
+      return kind == CTVIO_PK_ROT ? 6 * idx : kind == CTVIO_PK_POS ? 6 * idx + 3 : kind == CTVIO_PK_BG ? K6 + 6 * idx : kind == CTVIO_PK_BA ? K6 + 6 * idx + 3 : P - 1;
+    };
+    for (int b = 0; b < w->pnb; ++b) m = std::min(m, col0(b));
+    for (int b = 0; b < w->pnb; ++b) {
+      const int kind = w->p_kind[b], idx = w->p_index[b];
+      if (kind <= CTVIO_PK_POS) fk[idx] = std::min(fk[idx], m);
+      else if (kind <= CTVIO_PK_BA) fb[idx] = std::min(fb[idx], m);
+      else fld = std::min(fld, m);
+    }
+  }
+  for (int r = 0; r < ntr; ++r) {
+    int f = 16 * r;                                            // (a row's own diagonal entry)
+    for (int u = 16 * r; u < std::min(16 * r + 16, P); ++u) f = std::min(f, u < K6 ? fk[u / 6] : (u < P - 1 ? fb[(u - K6) / 6] : fld));
+    if (16 * r <= P && P < 16 * r + 16) f = 0;                 // the rhs row rides along as row P: dense
+    // The panel Cholesky (k_cholesky_solve) works in 32-column panels: the envelope starts on a panel boundary (even tile column), and every
+    // tile row reaches at least the panel before its own 32-row block (so that the next diagonal block always takes part in a panel's
+    // trailing update: its look-ahead relies on that).  The tiles this adds hold zeros.
+    int ft = f / 16;
+    if (r >= 2) ft = std::min(ft, 2 * (r / 2) - 2);
+    t.env_first[r] = r < 2 ? 0 : (ft & ~1);
   }
 }
 

@@ -40,7 +40,11 @@ __device__ __forceinline__ void begin_iteration(const Dev &d, int w, int *s_go) 
     const double sc = fmin(fmax(c * c * h, d.prm.min_diag), d.prm.max_diag);
     const double dd = act ? sc / (mu * c * c) : 0.0;
     d.dd[m.u0 + j] = dd;
-    if (j >= m.P) d.dinv[m.lm0 + j - m.P] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
+    if (j >= m.P) {   // by ROW of W (sorted landmark order, Dev::lm_pos): the Schur kernels and the back-substitution stream rows
+      const int row = m.lm0 + d.lm_pos[m.lm0 + j - m.P];
+      d.dinv[row] = (act && (h + dd) > 0.0) ? 1.0 / (h + dd) : 0.0;
+      d.grs[row] = d.gS[lm.cur][m.u0 + j];
+    }
   }
 }
 // The first iteration of a solve (every later one starts at the end of the previous pass: k_pass_end).
@@ -53,6 +57,16 @@ __device__ __forceinline__ void tile_decode(int t, int &bi, int &bj) {  // t -> 
   bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
   bj = t - bi * (bi + 1) / 2;
+}
+
+// Rows of W (sorted landmark order) that can be non-zero in BOTH the columns of tile row bi and those of tile column bj: the intersection of the
+// host's per-tile ranges (host_pack.hpp: plan_sparsity); the tile row that holds index P carries g_rho on its A side for EVERY observed row.
+// Tiles over bias-only columns come out empty.
+__device__ __forceinline__ void schur_row_range(const Dev &d, const WinMeta &m, int bi, int bj, int &lbeg, int &lend) {
+  int rb = d.tl_beg[m.tr0 + bi], re = d.tl_end[m.tr0 + bi];
+  if (16 * bi <= m.P && m.P < 16 * bi + 16) { rb = 0; re = m.Lobs; }
+  lbeg = max(rb, d.tl_beg[m.tr0 + bj]);
+  lend = min(re, d.tl_end[m.tr0 + bj]);
 }
 
 // fp64 product path, large batches: the window kernel on the fp64 matrix cores.  One workgroup (8 waves) per window; W is read
@@ -77,7 +91,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   int &tcount = tlist[8 * NTQ];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, q4 = lane >> 4, l15 = lane & 15;
   const double *Wp = d.WS[d.lm[w].cur] + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
+  const double *dinv = d.dinv + m.lm0, *gl = d.grs + m.lm0;   // (by row of W: sorted landmark order)
   for (int c = tid; c < ldw; c += 512) {
     const int cc = min(c, P - 1);
     acts[c] = (c < P && d.active[u0 + cc]) ? 1.0 : 0.0; ddv[c] = d.dd[u0 + cc]; gv[c] = d.gS[d.lm[w].cur][u0 + cc];
@@ -96,7 +110,9 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   }
   // Only the knot columns [0, 6K), the line-delay column P - 1 and the appended g_rho column P are fetched and staged (NC
   // compact columns per landmark); every other column of the two LDS buffers is zeroed once and stays zero.
-  const int nchunk = (L + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
+  // SPARSITY: the rows of W are sorted by knot span (host_pack.hpp: plan_sparsity); rows past Lobs are zero, and a tile multiplies only the
+  // chunks that overlap the row range of its two column tiles (cbeg / cend below).
+  const int nchunk = (m.Lobs + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
   for (int e = tid; e < 2 * nel; e += 512) Wb[e] = 0.0;
   double pre[NPRE];
   double pre_d = 0.0;
@@ -140,6 +156,16 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   int tij[NTQ];
 #pragma unroll
   for (int q = 0; q < NTQ; ++q) tij[q] = __builtin_amdgcn_readfirstlane(tlist[(wave + 8 * q < nact) ? wave + 8 * q : min(wave, max(nact - 1, 0))]);   // SGPRs
+  // the chunks a tile has products with ride in bits 16-23 (first) and 24-31 (end; 255 = no upper limit) of its SGPR -- separate registers
+  // sent the kernel's scalar file over the edge
+#pragma unroll
+  for (int q = 0; q < NTQ; ++q) {
+    int lb, le;
+    schur_row_range(d, m, tij[q] >> 8, tij[q] & 255, lb, le);
+    const bool real = wave + 8 * q < nact && le > lb;   // (a slot past the end of the list repeats the wave's first tile: no products for it)
+    const int cb = real ? min(lb >> 4, 254) : 0, ce = real ? min((le + 15) >> 4, 255) : 0;
+    tij[q] = __builtin_amdgcn_readfirstlane(tij[q] | (cb << 16) | (ce << 24));
+  }
   // The accumulators start at -Hpp (rows beyond the unknowns -- the rhs row -- at 0): the tile's Hpp entries arrive with the first chunk of W
   // instead of costing the epilogue a global round trip per tile, and S = -(acc) + D needs no second operand there.
   const double *H = d.HppS[d.lm[w].cur] + m.H0;
@@ -148,7 +174,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
 #pragma unroll
   for (int q = 0; q < NTQ; ++q) {
-    const int tq = tij[q] + opq, jc = min(16 * (tq & 255) + l15, P - 1);
+    const int tq = (tij[q] & 0xffff) + opq, jc = min(16 * (tq & 255) + l15, P - 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ii = 16 * (tq >> 8) + q4 + 4 * r, ic = min(ii, P - 1);
@@ -171,10 +197,11 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     // against 0.9 k of matrix-core time).  One round trip per tile is hidden by the other three waves of the SIMD.
 #pragma unroll
     for (int q = 0; q < NTQ; ++q) {
+      { const int cb = (tij[q] >> 16) & 255, ce = (tij[q] >> 24) & 255; if (ch < cb || (ch >= ce && ce != 255)) continue; }   // (uniform) no row of this chunk reaches both column tiles
       double a[4], b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[s] = B[4 * s * ldw + 16 * (tij[q] >> 8)];
+        a[s] = B[4 * s * ldw + 16 * ((tij[q] >> 8) & 255)];
         b[s] = B[4 * s * ldw + 16 * (tij[q] & 255)];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -182,11 +209,8 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
       for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s] * dl[s], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ch < 3) CTV_STAMP();
     if (ch + 1 < nchunk) stash(ch + 1, buf ^ 1);
-    if (ch < 3) CTV_STAMP();
     __syncthreads();
-    if (ch < 3) CTV_STAMP();
   }
   CTV_STAMP();
   // epilogue: S = Hpp - W^T Hll^-1 W + D on the active lower triangle, identity rows for fixed unknowns; rhs row.  The per-column vectors
@@ -220,7 +244,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     double hs[4], bs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hs[r] = -acc[q][r]; bs[r] = acc[q][r]; }
-    store_tile(tij[q] >> 8, tij[q] & 255, hs, bs);
+    store_tile((tij[q] >> 8) & 255, tij[q] & 255, hs, bs);
   }
   CTV_STAMP();
   // tiles without products (S = Hpp + D): this wave's list first (scalar), then the Hpp entries of four tiles requested together -- every tile used
@@ -266,7 +290,8 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
 // fp64 path: the same SYRK on the fp64 matrix cores, one wave per 16 x 16 tile of the lower triangle
 // (v_mfma_f64_16x16x4_f64: A operand lane l = X[k = l/16][i = l%16], B operand lane l = Y[k = l/16][j = l%16],
 // D register r of lane l = D[(l/16) + 4r][l%16]; measured with tools/mfma_f64_layout.hip).  Operands straight from W,
-// 16 landmarks (4 products) per trip with all loads of a trip in flight; the reduced rhs is left to k_rhs.
+// 16 rows (4 products) per trip with all loads of a trip in flight; the reduced rhs rides along as row P.  SPARSITY: a tile outside the window's
+// envelope (Dev::env_first) is not formed at all; inside it the tile multiplies only the rows of W whose knot span meets both its column ranges.
 __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev d, int ntile_max) {
   // XCD-aware tile -> workgroup map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles of one
   // window get ids that are congruent mod 8: they all run on one XCD and the window's W (re-read by every tile) comes out of
@@ -276,24 +301,23 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev d, int ntile_max) {
   if (w >= d.nwin) return;
   if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
-  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, ldh = m.ldh;
   const int nt = P / 16 + 1;   // tile rows up to index P: the rhs rides along as row P (g_rho on the A side), so the tile row that
   if (tile >= nt * (nt + 1) / 2) return;   // holds it also produces W^T diag(dinv) g_rho -- no separate k_rhs pass
   int bi, bj;
   tile_decode(tile, bi, bj);
+  if (bj < d.env_first[m.tr0 + bi]) return;   // structurally zero: never read by the factorisation
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const int i = min(16 * bi + l15, ldw - 1), j = min(16 * bj + l15, ldw - 1);
   const bool rhs_lane = 16 * bi + l15 == P;
   const double ai = (16 * bi + l15 < P && d.active[u0 + min(i, P - 1)]) ? 1.0 : 0.0;
   const double aj = (16 * bj + l15 < P && d.active[u0 + min(j, P - 1)]) ? 1.0 : 0.0;
   const double *Wp = d.WS[d.lm[w].cur] + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + u0 + P;
-  // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1: tiles over bias columns skip the loop
-  const bool nz_i = (16 * bi < K6) || (P >= 16 * bi && P - 1 < 16 * bi + 16);
-  const bool nz_j = (16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16);
-  const int lend = (nz_i && nz_j) ? L : 0;   // L == 0: the loop (and its clamped row L - 1) is skipped
+  const double *dinv = d.dinv + m.lm0, *gl = d.grs + m.lm0;
+  int lbeg, lend;
+  schur_row_range(d, m, bi, bj, lbeg, lend);   // (empty: the loop -- and its clamped row -- is skipped)
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int l0 = 0; l0 < lend; l0 += 16) {
+  for (int l0 = lbeg; l0 < lend; l0 += 16) {
     double wa[4], wb[4], dv[4], gv[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {   // unconditional loads on clamped rows, masked below
@@ -307,7 +331,7 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev d, int ntile_max) {
     for (int s = 0; s < 4; ++s) wa[s] = rhs_lane ? gv[s] : wa[s] * ai;   // (unconditional loads, selected afterwards)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bool lv = l0 + 4 * s + q4 < L;
+      const bool lv = l0 + 4 * s + q4 < lend;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], lv ? wb[s] * aj * dv[s] : 0.0, acc, 0, 0, 0);
     }
   }
@@ -341,13 +365,15 @@ __global__ __launch_bounds__(64) void k_schur_tile_f64(Dev d, int ntile_max) {
 // one-tile kernel is bound by L2 bandwidth once there are enough waves to fill the chip (config 5, P = 571: 666 tiles x 128 windows, every
 // tile wave re-reading 2 x 16 columns of its window's 4.9 MB W: 0.19 of the fp64 matrix peak); half the loads per product.  For batches
 // whose tile count fills the chip; a single small window keeps the one-tile form (more waves in flight, shorter latency).
+// SPARSITY: a block whose four tiles all lie outside the envelope exits at once; the others multiply the union of their tiles' row ranges (the
+// rows of W are sorted by knot span, so the union is a short interval: config 5, K = 64 -- ~60 of 1000 rows per block instead of all).
 __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;     // (XCD-aware map as above: a window's blocks share one L2)
   const int w = (slot / nblk_max) * 8 + xcd, blk = slot % nblk_max;
   if (w >= d.nwin) return;
   if (d.lm[w].status || d.lm[w].ls_active) return;
   const WinMeta &m = d.wins[w];
-  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
+  const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, ldh = m.ldh;
   const int nt = P / 16 + 1, nb = (nt + 1) / 2;   // tile rows up to index P (the rhs row rides along as row P); 32-row blocks
   if (blk >= nb * (nb + 1) / 2) return;
   int Bi, Bj;
@@ -355,9 +381,9 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
   const int lane = threadIdx.x, q4 = lane >> 4, l15 = lane & 15;
   const int cur = d.lm[w].cur;
   const double *Wp = d.WS[cur] + m.W0;
-  const double *dinv = d.dinv + m.lm0, *gl = d.gS[cur] + u0 + P;
+  const double *dinv = d.dinv + m.lm0, *gl = d.grs + m.lm0;
   int ci[2], cj[2];
-  bool rhs_lane[2], nz_i[2], nz_j[2];
+  bool rhs_lane[2];
   double ai[2], aj[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -366,24 +392,39 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
     rhs_lane[a] = 16 * bi + l15 == P;
     ai[a] = (16 * bi + l15 < P && d.active[u0 + min(ci[a], P - 1)]) ? 1.0 : 0.0;
     aj[a] = (16 * bj + l15 < P && d.active[u0 + min(cj[a], P - 1)]) ? 1.0 : 0.0;
-    // W is non-zero only in the knot columns [0, 6K) and the line-delay column P-1
-    nz_i[a] = bi < nt && ((16 * bi < K6) || (P >= 16 * bi && P - 1 < 16 * bi + 16));
-    nz_j[a] = bj < nt && ((16 * bj < K6) || (P - 1 >= 16 * bj && P - 1 < 16 * bj + 16));
   }
-  const int lend = ((nz_i[0] || nz_i[1]) && (nz_j[0] || nz_j[1])) ? L : 0;   // (uniform)
+  // which of the four tiles exist (inside the triangle, inside the envelope), and the union of their row ranges (all uniform)
+  bool live[2][2];
+  int lbeg = L, lend = 0;
+  bool any = false;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int bi = 2 * Bi + a, bj = 2 * Bj + b;
+      live[a][b] = bi < nt && bj <= bi && bj >= d.env_first[m.tr0 + min(bi, nt - 1)];
+      if (live[a][b]) {
+        any = true;
+        int rb, re;
+        schur_row_range(d, m, bi, bj, rb, re);
+        if (re > rb) { lbeg = min(lbeg, rb); lend = max(lend, re); }
+      }
+    }
+  if (!any) return;
+  if (lend <= lbeg) { lbeg = 0; lend = 0; }
   f64x4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-  // Two chunks of 16 landmarks in flight: the 24 operand loads of the next chunk are requested before the 16 products of the current one
+  // Two chunks of 16 rows in flight: the 24 operand loads of the next chunk are requested before the 16 products of the current one
   // (a trip used to be "load, wait, multiply": the matrix cores idle for a memory round trip per chunk, 0.34 of the fp64 peak at three
   // waves per SIMD).  Fences keep the scheduler from moving the requests back behind the products.
   struct Chunk { double wa[2][4], wb[2][4], dv[4], gv[4]; };
   auto fetch = [&](int l0, Chunk &c) {   // unconditional loads on clamped rows, masked in `products`
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int lc = min(l0 + 4 * s + q4, L - 1);
+      const int lc = max(0, min(l0 + 4 * s + q4, L - 1));
       const double *row = Wp + (long long)lc * ldw;
       c.wa[0][s] = row[ci[0]]; c.wa[1][s] = row[ci[1]];
       c.wb[0][s] = row[cj[0]]; c.wb[1][s] = row[cj[1]];
@@ -391,32 +432,35 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
       c.gv[s] = gl[lc];
     }
   };
+  const bool upper = Bi != Bj;   // (uniform; on a diagonal block tile (0, 1) is above the diagonal)
   auto products = [&](int l0, const Chunk &c) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bool lv = l0 + 4 * s + q4 < L;
+      const bool lv = l0 + 4 * s + q4 < lend;
       const double dvs = lv ? c.dv[s] : 0.0;
       const double a0 = rhs_lane[0] ? c.gv[s] : c.wa[0][s] * ai[0], a1 = rhs_lane[1] ? c.gv[s] : c.wa[1][s] * ai[1];
       const double b0 = c.wb[0][s] * aj[0] * dvs, b1 = c.wb[1][s] * aj[1] * dvs;
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-      if (Bi != Bj) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);   // (uniform; on the diagonal block this tile is above the diagonal)
+      if (upper) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
     }
   };
   // (The requests are unconditional -- past the end they re-read the last rows: a request behind a uniform branch makes the compiler wait,
   // at the join, as if the OLDER chunk were the newest one: vmcnt(23) instead of vmcnt(47).)
-  Chunk ca, cb;
-  fetch(0, ca);
-  for (int l0 = 0; l0 < lend; l0 += 32) {
-    fetch(l0 + 16, cb);
-    __builtin_amdgcn_sched_barrier(0);
-    products(l0, ca);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(l0 + 32, ca);
-    __builtin_amdgcn_sched_barrier(0);
-    if (l0 + 16 < lend) products(l0 + 16, cb);   // (uniform)
-    __builtin_amdgcn_sched_barrier(0);
+  if (L > 0 && lend > lbeg) {
+    Chunk ca, cb;
+    fetch(lbeg, ca);
+    for (int l0 = lbeg; l0 < lend; l0 += 32) {
+      fetch(l0 + 16, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      products(l0, ca);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(l0 + 32, ca);
+      __builtin_amdgcn_sched_barrier(0);
+      if (l0 + 16 < lend) products(l0 + 16, cb);   // (uniform)
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   double *S = d.S + m.H0, *rhs = d.rhs + m.p0;
   const double *H = d.HppS[cur] + m.H0, *gp = d.gS[cur] + u0;
@@ -425,7 +469,7 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int bi = 2 * Bi + a, bj = 2 * Bj + b;
-      if (bi >= nt || bj > bi) continue;   // (uniform)
+      if (!live[a][b]) continue;   // (uniform)
       const int jj = 16 * bj + l15, jc = min(jj, P - 1);
       const bool act_j = d.active[u0 + jc] != 0;
       const double dd_j = d.dd[u0 + jc], g_j = gp[jc];
@@ -483,7 +527,7 @@ __global__ __launch_bounds__(256) void k_rhs(Dev d) {
   double v = 0.0;
   if (i < m.P && d.active[m.u0 + i]) {
     const double *Wp = d.WS[d.lm[w].cur] + m.W0 + i;
-    const double *dinv = d.dinv + m.lm0, *gl = d.gS[d.lm[w].cur] + m.u0 + m.P;
+    const double *dinv = d.dinv + m.lm0, *gl = d.grs + m.lm0;   // (both by row of W)
     for (int l = sl; l < m.L; l += 4) v += (double)Wp[(long long)l * m.ldw] * (dinv[l] * gl[l]);
   }
   part[sl][li] = v;
@@ -586,6 +630,11 @@ __device__ __forceinline__ void chol_diag_all(double (&v)[32], int &bad) {
 }
 // NW waves per window: 4 for large batches (two windows share a CU), 8 when there are fewer windows than CUs (the parallel
 // phases -- L21, trailing update, staging -- go twice as fast; the diagonal blocks hide behind the trailing updates).
+// SPARSITY (the reference factors with SPARSE_NORMAL_CHOLESKY, trajectory_estimator.cpp:371-384): the kernel works inside the window's ENVELOPE
+// (Dev::env_first, host_pack.hpp: plan_sparsity -- per 16-row tile the first tile column that can be non-zero; fill stays inside the row envelope).
+// A 16-row tile R below panel jb TAKES PART in it iff env_first[R] <= jb / 16 + 1; only those tiles are staged, solved against L11 and updated,
+// and a trailing tile (Ri, Rj) is touched only when both rows take part.  Config 5 (K = 64, P = 571): 1.9 k of 7.8 k tile products.  The host
+// aligns the envelope to the 32-column panels and makes the next diagonal block take part in every panel (its look-ahead below).
 template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cholesky_solve(Dev d) {
   constexpr int NT = 64 * NW;
   const int w = blockIdx.x;
@@ -600,10 +649,12 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
   double *yb = dinvs + 32;          // [32]
   int &s_fail = *reinterpret_cast<int *>(yb + 32);
   int &s_trip = reinterpret_cast<int *>(yb + 32)[1];   // next unclaimed tile of the trailing update
-  double *LpT = yb + 34;            // [32][RS] panel (+ rhs row) k-major: LpT[k][r]
+  int *plist = reinterpret_cast<int *>(yb + 34);       // [64] the local 16-row tiles that take part in the current panel, ascending
+  double *LpT = yb + 34 + 32;       // [32][RS] panel (+ rhs row) k-major: LpT[k][r]
   double *S = d.S + m.H0;
   double *y = d.rhs + m.p0;         // augmented row; becomes L^-1 rhs
   double *x = d.delta + m.u0;
+  const int32_t *ef = d.env_first + m.tr0;   // [P / 16 + 1]
   if (tid == 0) s_fail = 0;
   for (int e = tid; e < 32 * 32; e += NT) {   // first diagonal block -> LDS (rows / columns clamped; masked when read)
     const int r = e >> 5, c = e & 31;
@@ -648,12 +699,19 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
   for (int jb = 0; jb < P; jb += 32) {
     const int nb = min(32, P - jb), r0 = jb + nb, nt = P - r0, ntr = nt + 1;  // ntr: trailing rows incl. the rhs row
     const int RS = (ntr + 15) & ~15, ntile = RS >> 4;
+    // ---- the tiles that take part (every wave forms the same mask: one ballot; <= 36 local tiles).  The last wave lists them in LDS.
+    const int R0 = r0 >> 4;
+    const bool mine = lane < ntile && ef[min(R0 + lane, P / 16)] <= (jb >> 4) + 1;
+    const unsigned long long pmask = __ballot(mine);
+    const int np = __popcll(pmask);
+    if (wave == NW - 1 && mine) plist[__popcll(pmask & ((1ull << lane) - 1ull))] = lane;
     // ---- panel rows (and the rhs row) into the LDS panel, LpT[k][r].  First panel: wave 0 factors the diagonal block
     //      meanwhile; the later diagonal blocks were factored during the previous trailing update (look-ahead, below).
     {
       const int first = jb == 0 ? 64 : 0, nthr = NT - first;
       if (jb == 0 && wave == 0) diag_block(0);
       for (int r = tid - first; r >= 0 && r < RS; r += nthr) {
+        if (!((pmask >> (r >> 4)) & 1ull)) continue;   // a tile outside the panel's envelope: nothing of it is read below
         const double *src = (r < nt) ? S + (long long)(r0 + r) * ldh + jb : y + jb;
         double tmp[32];
 #pragma unroll
@@ -664,13 +722,14 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
       }
     }
     if (tid == 0) s_trip = 4;   // wave 0 starts with tiles 0-3 (they hold the next diagonal block)
-    // LDS-only barrier: what the next phase reads (LiT, LpT) is in LDS; wave 0's global stores of the block inverse may
+    // LDS-only barrier: what the next phase reads (LiT, LpT, plist) is in LDS; wave 0's global stores of the block inverse may
     // stay in flight (a full __syncthreads would wait for them; they are read after later full barriers only)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     CTV_STAMP();
     // ---- L21 = A21 L11^-T, in place: Linv is lower triangular, so output columns 0..15 need k < 16 only
-    for (int tr = wave; tr < ntile; tr += NW) {
+    for (int it = wave; it < np; it += NW) {
+      const int tr = plist[it];
       f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
       const double *pa = LpT + 16 * tr + l15;
 #pragma unroll
@@ -694,11 +753,11 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
     }
     __syncthreads();
     CTV_STAMP();
-    // ---- trailing update A22 -= L21 L21^T on the lower triangle (16 x 16 tiles) and the rhs row.  Trips of 4 consecutive
-    //      tiles are claimed from an LDS counter.  Wave 0 takes tiles 0-3 first -- (0,0), (1,0), (1,1) are the next diagonal
-    //      block, left in Lb -- then factors that block (LOOK-AHEAD: 21 k cycles on one wave that used to sit between the
-    //      panels with three waves idle) while the other waves work through the rest, then joins them.
-    const int ntt = nt > 0 ? ntile * (ntile + 1) / 2 : 0;   // last panel: nothing left to update
+    // ---- trailing update A22 -= L21 L21^T on the lower triangle (16 x 16 tiles) and the rhs row, over the PAIRS of tiles that take part.
+    //      Trips of 4 consecutive pairs are claimed from an LDS counter.  Wave 0 takes pairs 0-3 first -- (0,0), (1,0), (1,1) are the next
+    //      diagonal block (local tiles 0 and 1 always take part), left in Lb -- then factors that block (LOOK-AHEAD: 21 k cycles on one wave
+    //      that used to sit between the panels with three waves idle) while the other waves work through the rest, then joins them.
+    const int ntt = nt > 0 ? np * (np + 1) / 2 : 0;   // last panel: nothing left to update
     // (requesting the next trip's S values before the current products was tried: no gain, it is bandwidth not latency)
     bool first_trip = wave == 0;
     while (true) {   // 4 tiles per trip: 16 loads in flight, 32 MFMAs, 16 stores
@@ -710,7 +769,9 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
       int ti4[4], tj4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        tile_decode(min(tb + u, ntt - 1), ti4[u], tj4[u]);
+        int pa_, pb_;
+        tile_decode(min(tb + u, ntt - 1), pa_, pb_);
+        ti4[u] = plist[pa_]; tj4[u] = plist[pb_];
         const int col = 16 * tj4[u] + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -751,19 +812,22 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
   }
   // ---- block back-substitution L^T x = y with the stored block inverses: x_b = Linv_b^T t_b, then t_j -= L[b][j]^T x_b
   //      for the rows above.  x lives in LDS; per block the loads of Linv_b (wave 0) and of the panel rows (everyone) do
-  //      not depend on x and are issued together, before the block solve.
+  //      not depend on x and are issued together, before the block solve.  Block row b reaches back to column 16 env_first only: the two
+  //      16-row tiles of the block have their own starts (ca <= cb or cb <= ca), columns before a tile's start are not stored at all.
   double *xs = LpT;   // the panel is no longer needed
   for (int i = tid; i < P; i += NT) xs[i] = y[i];
   __syncthreads();
   const int nblk = (P + 31) / 32;
   for (int b = nblk - 1; b >= 0; --b) {
     const int jb = 32 * b, nb = min(32, P - jb);
+    const int ca = 16 * ef[2 * b], cb = 16 * ef[min(2 * b + 1, P / 16)], c0 = min(ca, cb);
     double lv[32];   // column j of the panel rows of this block: L[jb + ii][j]
-    const bool upd = tid < jb;
+    const int j0 = c0 + tid;
+    const bool upd = j0 < jb;
     {
-      const int j = min(tid, max(jb - 1, 0));
+      const int j = min(j0, max(jb - 1, 0)), ja = max(j, ca), jc = max(j, cb);   // (clamped into each tile's stored range; masked below)
 #pragma unroll
-      for (int ii = 0; ii < 32; ++ii) lv[ii] = S[(long long)(jb + min(ii, nb - 1)) * ldh + j];
+      for (int ii = 0; ii < 32; ++ii) lv[ii] = S[(long long)(jb + min(ii, nb - 1)) * ldh + (ii < 16 ? ja : jc)];
     }
     if (wave == 0) {
       const double *gi = d.chol_inv + ((size_t)w * d.chol_nblk + b) * 1024;
@@ -780,13 +844,14 @@ template <int NW> __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_wa
     __syncthreads();
     if (upd) {
       double sacc = 0.0;
+      const bool ma = j0 >= ca, mb = j0 >= cb;
 #pragma unroll
-      for (int ii = 0; ii < 32; ++ii) sacc += lv[ii] * ((ii < nb) ? yb[ii] : 0.0);
-      xs[tid] -= sacc;
+      for (int ii = 0; ii < 32; ++ii) sacc += ((ii < 16 ? ma : mb) && ii < nb) ? lv[ii] * yb[ii] : 0.0;
+      xs[j0] -= sacc;
     }
-    for (int j = tid + NT; j < jb; j += NT) {   // P > NT + 32: remaining rows
+    for (int j = j0 + NT; j < jb; j += NT) {   // remaining columns of a wide block row
       double sacc = 0.0;
-      for (int ii = 0; ii < nb; ++ii) sacc += S[(long long)(jb + ii) * ldh + j] * yb[ii];
+      for (int ii = 0; ii < nb; ++ii) sacc += (j >= (ii < 16 ? ca : cb)) ? S[(long long)(jb + ii) * ldh + j] * yb[ii] : 0.0;
       xs[j] -= sacc;
     }
     __syncthreads();
@@ -1199,33 +1264,40 @@ template <int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev
   for (int i = tid; i < P; i += NT) xs[i] = x[i];
   if (tid == 0) bad = 0;
   __syncthreads();
-  // delta_rho_l = -(g_l + W_l . delta_p) / (Hll_l + D_l): a wave takes 8 rows of W per pass, 32 loads per lane in flight
+  // delta_rho = -(g_rho + W_r . delta_p) / (Hll + D) of the landmark of row r: a wave takes 8 ROWS of W per pass.  The rows are sorted by knot
+  // span (host_pack.hpp: plan_sparsity), so the 8 rows of a pass share most of their columns: only the union of their spans' knot columns and the
+  // line-delay column are read (config 2: ~100 of 145 columns; K = 64: ~110 of 385) -- the rest of a row is zero and never touched.
+  const int32_t *klo = d.lm_klo + lm0, *khi = d.lm_khi + lm0, *lat = d.lm_at + lm0;
   for (int l0 = 8 * wave; l0 < L; l0 += 8 * NWV) {
     double acc8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc8[u] = 0.0;
-    // the row this lane will finish (see the reduction below): its g, 1/(Hll + D) and active flag travel with the W loads
+    // the row this lane will finish (see the reduction below): its landmark's g, 1/(Hll + D) and active flag travel with the W loads
     const int lrow = min(l0 + (lane >> 3), L - 1);
-    const double g_l = g[P + lrow], dinv_l = d.dinv[lm0 + lrow];
-    const bool act_l = d.active[u0 + P + lrow] != 0;
-    // W is non-zero in the knot columns [0, 6K) and the line-delay column P - 1 only: NCB compact columns
-    const int K6 = 6 * m.K, NCB = K6 + 1;
-    for (int i0 = 0; i0 < NCB; i0 += 256) {
-      double wv[8][4];
-      int col[4];
+    const int lmk = lat[lrow];
+    const double g_l = g[P + lmk], dinv_l = d.dinv[lm0 + lrow];
+    const bool act_l = d.active[u0 + P + lmk] != 0;
+    int kmin = klo[lrow], kmax = khi[lrow];      // (a row without observations: klo = K, khi = -1 -- it widens nothing)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const int cc = min(i0 + lane + 64 * k, NCB - 1); col[k] = cc < K6 ? cc : P - 1; }
+    for (int off = 8; off < 64; off <<= 1) { kmin = min(kmin, __shfl_xor(kmin, off)); kmax = max(kmax, __shfl_xor(kmax, off)); }
+    const int c_lo = __builtin_amdgcn_readfirstlane(6 * kmin), nkc = __builtin_amdgcn_readfirstlane(max(6 * (kmax + 1) - 6 * kmin, 0));
+    const int NCB = nkc + 1;                     // compact columns: the knot columns of the union, then the line delay
+    for (int i0 = 0; i0 < NCB; i0 += 128) {
+      double wv[8][2];
+      int col[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { const int cc = min(i0 + lane + 64 * k, NCB - 1); col[k] = cc < nkc ? c_lo + cc : P - 1; }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
           // clamped, unconditional loads (a predicated load compiles to branch + load + s_waitcnt: one round trip EACH);
           // out-of-range columns are masked through xi below, out-of-range rows are never written
           const int l = min(l0 + u, L - 1);
           wv[u][k] = Wp[(long long)l * ldw + col[k]];
         }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 2; ++k) {
         const double xi = (i0 + lane + 64 * k < NCB) ? xs[col[k]] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc8[u] += (double)wv[u][k] * xi;
@@ -1243,7 +1315,7 @@ template <int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev
     v1 += __shfl_xor(v1, 4);
     v1 += __shfl_xor(v1, 2);
     v1 += __shfl_xor(v1, 1);
-    if ((lane & 7) == 0 && l0 + (lane >> 3) < L) x[P + l0 + (lane >> 3)] = act_l ? (-g_l - v1) * dinv_l : 0.0;
+    if ((lane & 7) == 0 && l0 + (lane >> 3) < L) x[P + lmk] = act_l ? (-g_l - v1) * dinv_l : 0.0;
   }
   __syncthreads();
   double mc = 0.0, gd = 0.0, dm = 0.0;   // model change; g . delta and |delta|_inf for the projected line search

@@ -109,7 +109,7 @@ struct VisNullSink {
 // set the mode selects.  The wave's share of the cost goes to Dev::vis_cost (a window's block slots start on a wave boundary: one window
 // per wave).  A window on its last allowed iteration is only costed (residuals, no Jacobians, nothing else written).
 constexpr int VIS_LDS_BYTES = 64 * VT_LD * 8;   // the records of a wave's 64 blocks, afterwards the fp64 rows of W of the wave's landmarks
-__device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned char *smt, long long *rowoff, int *rlm, int vblock) {
+__device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned char *smt, long long *rowoff, int *rlm, int *rspan, int vblock) {
   const int v = vblock * 64 + threadIdx.x;
   const long long t_entry = d.dbg ? clock64() : 0ll;
   constexpr int LDS_BYTES = VIS_LDS_BYTES;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
     const int first_on = __ffsll((long long)on_mask) - 1;
     const int tgw = __builtin_amdgcn_readfirstlane(__shfl(tg, first_on)), wu = __builtin_amdgcn_readfirstlane(__shfl(w, first_on));
     const WinMeta &mu = d.wins[wu];
-    const int P = mu.P, K6 = 6 * mu.K, ldw = mu.ldw, lm0 = mu.lm0, u0 = mu.u0;
+    const int P = mu.P, ldw = mu.ldw, lm0 = mu.lm0, u0 = mu.u0;
     const long long W0 = mu.W0;
     double *Wset = d.WS[tgw];
     double *Hllset = d.HllS[tgw], *gset = d.gS[tgw];
@@ -225,12 +225,16 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
     // the anchor record's GR and cp0 again (every lane asks for its own anchor's: same lines as during the evaluation; only the head
     // lane of an anchor uses them) -- requested here, consumed after the copy-out below, which hides the round trip
     double hg[40];
-    int ksi;
+    int ksi, my_row, my_klo, my_khi;
     {
       const double *rec = reinterpret_cast<const double *>(__builtin_assume_aligned(d.arec + (size_t)max(my_anc, 0) * AREC, 16));
 #pragma unroll
       for (int e = 0; e < 40; ++e) hg[e] = rec[AR_GR + e];     // GR[12][3], cp0[4]: entries 3 .. 42
       ksi = d.a_s[max(my_anc, 0)];
+      // the landmark's row of W (sorted landmark order) and its planned knot span (host_pack.hpp: plan_sparsity): the row is formed, and
+      // written, over the span's columns only
+      my_row = d.lm_pos[lm0 + max(my_lm, 0)];
+      my_klo = d.lm_klo[lm0 + my_row]; my_khi = d.lm_khi[lm0 + my_row];
     }
     // ---- rows of W.  A landmark's blocks are consecutive lanes (the host keeps a landmark inside one wave), anchor by anchor.
     const int prev_lm = __shfl_up(my_lm, 1), prev_anc = __shfl_up(my_anc, 1);
@@ -275,14 +279,20 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
         wi[cc] = s6[0] * hg[3 * cc] + s6[1] * hg[3 * cc + 1] + s6[2] * hg[3 * cc + 2];
         wi[12 + cc] = hg[36 + k] * s6[b];
       }
-    // The buffer becomes NR fp64 rows ([0, K6) knot columns, K6 line delay, K6 + 1 Hll, K6 + 2 g_rho); every lane adds the 24 values of
-    // its own end into the row of its landmark (LDS atomics: the ends of different blocks may share knots), the head lane of every
-    // anchor the anchor end's 24 + 3; NR landmarks per sweep; then the knot and line-delay columns of every row, Hll and g_rho are
-    // written: W is complete when this kernel ends.
+    // The buffer becomes NR fp64 rows ([0, SPW) the knot columns FROM THE LANDMARK'S FIRST KNOT on -- SPW = 6 x the widest span of the batch --,
+    // SPW line delay, SPW + 1 Hll, SPW + 2 g_rho); every lane adds the 24 values of its own end into the row of its landmark (LDS atomics: the
+    // ends of different blocks may share knots), the head lane of every anchor the anchor end's 24 + 3; NR landmarks per sweep; then the span's
+    // knot columns and the line-delay column of every row, Hll and g_rho are written: W is complete when this kernel ends (the columns
+    // outside a landmark's span are never written by anybody: zero since the upload).
     double *rows = reinterpret_cast<double *>(smt);
-    const int RS = K6 + 3;                                             // odd row stride (K6 is even)
-    const int NR = max(1, min(nlm, (int)(LDS_BYTES / 8) / RS));
-    if (head) { rowoff[ord] = W0 + (long long)my_lm * ldw; rlm[ord] = my_lm; }
+    const int SPW = d.max_span6;
+    const int RS = SPW + 3;                                            // odd row stride (SPW is even)
+    const int NR = max(1, min(nlm, ((int)(LDS_BYTES / 8) - 1) / RS));
+    if (head) { rowoff[ord] = W0 + (long long)my_row * ldw; rlm[ord] = my_lm; rspan[ord] = (my_klo << 16) | max(my_khi - my_klo + 1, 0); }
+    // an end outside the planned span would corrupt a neighbour's row: counted (ctvio_solve fails loudly) and clamped
+    int ri = ksi - my_klo, rj = ksj - my_klo;
+    if (on && (rj < 0 || ksj + 3 > my_khi || (head_a && (ri < 0 || ksi + 3 > my_khi)))) atomicAdd(d.span_viol, 1);
+    ri = max(0, min(ri, SPW / 6 - 4)); rj = max(0, min(rj, SPW / 6 - 4));
     LDS_SYNC();   // every lane has read its record, the copy-out has read them all
     for (int c0 = 0; c0 < nlm; c0 += NR) {
       const int nr = min(NR, nlm - c0);
@@ -295,45 +305,45 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
           for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-              atomicAdd(&row[6 * (ksi + k) + b], wi[3 * k + b]);
-              atomicAdd(&row[6 * (ksi + k) + 3 + b], wi[12 + 3 * k + b]);
+              atomicAdd(&row[6 * (ri + k) + b], wi[3 * k + b]);
+              atomicAdd(&row[6 * (ri + k) + 3 + b], wi[12 + 3 * k + b]);
             }
-          atomicAdd(&row[K6], s6[3]);
-          atomicAdd(&row[K6 + 1], s6[4]);
-          atomicAdd(&row[K6 + 2], s6[5]);
+          atomicAdd(&row[SPW], s6[3]);
+          atomicAdd(&row[SPW + 1], s6[4]);
+          atomicAdd(&row[SPW + 2], s6[5]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
-            atomicAdd(&row[6 * (ksj + k) + b], wj[3 * k + b]);
-            atomicAdd(&row[6 * (ksj + k) + 3 + b], wj[12 + 3 * k + b]);
+            atomicAdd(&row[6 * (rj + k) + b], wj[3 * k + b]);
+            atomicAdd(&row[6 * (rj + k) + 3 + b], wj[12 + 3 * k + b]);
           }
       }
       LDS_SYNC();
       if (dbg && lane == 0) dbg[3 + 2 * (c0 / NR)] = clock64();
-      // write-out: the nr rows' knot columns as ONE flat list of 16-byte column pairs (K6 is even, a row starts on a 256-byte boundary),
-      // 64 pairs per store instruction -- row by row it took three mostly empty stores per row, and under load a store costs ~100
-      // cycles whatever its width.  The rows of a wave belong to one window: same K6.
+      // write-out: a row's span columns as 16-byte column pairs (a span starts on a 48-byte boundary of a 256-byte aligned row), four rows
+      // per store instruction -- one row per 16-lane group
       {
-        const int npair = K6 >> 1;                             // column pairs per row
-        const int total = nr * npair;
-        int q = lane / npair, cp = lane - q * npair;           // (one division per lane; afterwards incremental)
-        for (int it = lane; it < total; it += 64) {
-          double *Wr = Wset + rowoff[c0 + q];
-          const double *row = rows + (size_t)q * RS;
-          VecN<double, 2> rv;
-          rv.v[0] = row[2 * cp]; rv.v[1] = row[2 * cp + 1];
-          *reinterpret_cast<VecN<double, 2> *>(Wr + 2 * cp) = rv;
-          cp += 64;
-          while (cp >= npair) { cp -= npair; ++q; }
+        for (int rb = 0; rb < nr; rb += 4) {
+          const int q = rb + (lane >> 4);
+          if (q < nr) {
+            const int sp = rspan[c0 + q], k0 = sp >> 16, npair = 3 * (sp & 0xffff);
+            double *Wr = Wset + rowoff[c0 + q] + 6 * k0;
+            const double *row = rows + (size_t)q * RS;
+            for (int cp = lane & 15; cp < npair; cp += 16) {
+              VecN<double, 2> rv;
+              rv.v[0] = row[2 * cp]; rv.v[1] = row[2 * cp + 1];
+              *reinterpret_cast<VecN<double, 2> *>(Wr + 2 * cp) = rv;
+            }
+          }
         }
         if (lane < nr) {                                       // the line-delay column of row `lane`, its Hll and g_rho
           const double *row = rows + (size_t)lane * RS;
           const int l = rlm[c0 + lane];
-          Wset[rowoff[c0 + lane] + P - 1] = row[K6];
-          Hllset[lm0 + l] = row[K6 + 1];
-          gset[u0 + P + l] = row[K6 + 2];
+          Wset[rowoff[c0 + lane] + P - 1] = row[SPW];
+          Hllset[lm0 + l] = row[SPW + 1];
+          gset[u0 + P + l] = row[SPW + 2];
         }
       }
       LDS_SYNC();
@@ -346,8 +356,8 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_vis_eval(Dev d, int mode) {
   __shared__ __attribute__((aligned(16))) unsigned char smt[VIS_LDS_BYTES];
   __shared__ long long rowoff[64];
-  __shared__ int rlm[64];
-  vis_eval_body(d, mode, smt, rowoff, rlm, blockIdx.x);
+  __shared__ int rlm[64], rspan[64];
+  vis_eval_body(d, mode, smt, rowoff, rlm, rspan, blockIdx.x);
 }
 
 // Both evaluations in ONE launch: workgroups [0, Gtot) take an IMU group each, the others a wave of 64 visual block slots.  The two are
@@ -357,10 +367,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   static_assert(VIS_LDS_BYTES >= (72 * 33 + 64) * 8, "the IMU rows use the head of the visual body's LDS buffer");
   __shared__ __attribute__((aligned(32))) unsigned char smt[VIS_LDS_BYTES];
   __shared__ long long rowoff[64];
-  __shared__ int rlm[64];
+  __shared__ int rlm[64], rspan[64];
   if ((int)blockIdx.x < d.Gtot) {
     if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smt), blockIdx.x, d.Gtot, zero_mode);   // (one group per wave here)
-  } else vis_eval_body(d, mode, smt, rowoff, rlm, blockIdx.x - d.Gtot);
+  } else vis_eval_body(d, mode, smt, rowoff, rlm, rspan, blockIdx.x - d.Gtot);
 }
 
 }  // namespace ctv

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_marginalize(Dev d, MargMeta *metas, con
       double v;
       if (i < P && j < P) v = H[(long long)max(i, j) * wm.ldh + min(i, j)];
       else if (i >= P && j >= P) v = (i == j) ? d.HllS[cset][wm.lm0 + i - P] : 0.0;
-      else v = (double)Wp[(long long)(max(i, j) - P) * wm.ldw + min(i, j)];
+      else v = (double)Wp[(long long)d.lm_pos[wm.lm0 + max(i, j) - P] * wm.ldw + min(i, j)];   // (rows of W: sorted landmark order)
       A[e] = v;
     }
   }

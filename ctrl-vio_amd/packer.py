@@ -99,3 +99,86 @@ def depths_from_solution(rho: np.ndarray):
     with np.errstate(divide="ignore"):
         depth = 1.0 / rho
     return depth, ~(depth < 0)
+
+
+# ------------------------------------------------------------------------------------------------ sparsity of the reduced system
+# Python mirror of csrc/host_pack.hpp: plan_sparsity (the device library plans for itself; this copy serves bench.py's flop / byte counts and
+# the tests, which check it against the C++ planner entry for entry).
+
+def landmark_spans(w):
+    """(klo, khi) per landmark: first / last knot its residual blocks can touch over the whole box of the line delay (4 knots per spline
+    end at t + row * ld, image_feature_factor.h:72-101; both ends of the box bound the monotone row time).  khi = -1, klo = K: no observation."""
+    K, L = w.K, w.L
+    ld_a, ld_b = (w.ld, w.ld) if w.fix_ld else (w.ld_lo, w.ld_hi)
+    klo = np.full(L, K, np.int64); khi = np.full(L, -1, np.int64)
+
+    def seg(t, row, ld):
+        ld_ns = int(ld * 1e9)                        # C++ (long long)(ld * 1e9): truncation toward zero
+        tau = (np.asarray(t, np.int64) - w.t0_ns) + np.asarray(row, np.int64) * ld_ns
+        s = np.where(tau >= 0, tau // w.dt_ns, -((-tau) // w.dt_ns))       # C++ integer division truncates toward zero
+        return np.clip(s, 0, K - 4)
+    if w.V:
+        ss = np.stack([seg(w.v_ti, w.v_rowi, ld_a), seg(w.v_ti, w.v_rowi, ld_b), seg(w.v_tj, w.v_rowj, ld_a), seg(w.v_tj, w.v_rowj, ld_b)])
+        np.minimum.at(klo, w.v_lm, ss.min(axis=0))
+        np.maximum.at(khi, w.v_lm, ss.max(axis=0) + 3)
+    return klo, khi
+
+
+def schur_nonzero_flops(w):
+    """Flops of the Schur complement's NON-ZERO products: landmark l's row of W has nnz_l = 6 (khi - klo + 1) + 1 entries (its span's knot
+    columns and the line delay), and contributes the lower triangle of their outer product: sum_l nnz_l (nnz_l + 1)."""
+    klo, khi = landmark_spans(w)
+    nnz = np.where(khi >= 0, 6 * (khi - klo + 1) + 1, 0)
+    return int(np.sum(nnz * (nnz + 1)))
+
+
+def reduced_system_envelope(w, align_panels=True):
+    """env_first per 16-row tile of the reduced system S (P // 16 + 1 entries: the rhs rides along as row P): the first tile column that can
+    be non-zero in S -- and in its Cholesky factor, whose fill stays inside the row envelope.  Couplings: an IMU group's 4 knots + bias state,
+    bias-chain links, the prior's columns mutually, a landmark's span knots mutually and each with the line delay.  align_panels: the
+    device's rounding to 32-column panels (host_pack.hpp)."""
+    K, F, P = w.K, w.F, w.P
+    K6 = 6 * K
+    fk = 6 * np.arange(K); fb = K6 + 6 * np.arange(F); fld = P - 1
+    seg = (w.imu_t - w.t0_ns) // w.dt_ns
+    for s, b in {(int(a), int(c)) for a, c in zip(seg, w.imu_bias)}:
+        fk[s + 1:s + 4] = np.minimum(fk[s + 1:s + 4], 6 * s)
+        fb[b] = min(fb[b], 6 * s)
+    for i, j in zip(w.bc_i, w.bc_j):
+        fb[max(i, j)] = min(fb[max(i, j)], K6 + 6 * min(i, j))
+    klo, khi = landmark_spans(w)
+    for a, b in zip(klo, khi):
+        if b >= 0:
+            fk[a + 1:b + 1] = np.minimum(fk[a + 1:b + 1], 6 * a)
+            fld = min(fld, 6 * a)
+    if w.pn > 0:
+        col0 = [{0: 6 * i, 1: 6 * i + 3, 2: K6 + 6 * i, 3: K6 + 6 * i + 3, 4: P - 1}[int(k)] for k, i in zip(w.p_kind, w.p_index)]
+        m = min(col0)
+        for k, i in zip(w.p_kind, w.p_index):
+            if k <= 1:
+                fk[i] = min(fk[i], m)
+            elif k <= 3:
+                fb[i] = min(fb[i], m)
+            else:
+                fld = min(fld, m)
+    first = np.concatenate([np.repeat(fk, 6), np.repeat(fb, 6), [fld]])
+    ntr = P // 16 + 1
+    env = np.zeros(ntr, np.int64)
+    for r in range(ntr):
+        f = min(16 * r, int(first[16 * r:min(16 * r + 16, P)].min()) if 16 * r < P else 16 * r)
+        if 16 * r <= P < 16 * r + 16:
+            f = 0
+        ft = f // 16
+        if align_panels:
+            ft = 0 if r < 2 else (min(ft, 2 * (r // 2) - 2) & ~1)
+        env[r] = ft
+    return env
+
+
+def envelope_entries(w, dense=False):
+    """Entries of the lower triangle of S inside the envelope (what a factorisation must read at least once); dense: P (P + 1) / 2."""
+    P = w.P
+    if dense:
+        return P * (P + 1) // 2
+    env = reduced_system_envelope(w)
+    return int(sum(i - 16 * int(env[i // 16]) + 1 for i in range(P)))

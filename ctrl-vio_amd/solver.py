@@ -280,5 +280,10 @@ class Solver:
         return ms, n
 
     @property
+    def graph_captures(self) -> int:
+        """hipGraph captures of the LM pass so far (a stream of equally shaped batches captures once)."""
+        return int(self._lib.ctvio_graph_captures(self._h))
+
+    @property
     def stream(self) -> int:
         return int(self._lib.ctvio_stream(self._h) or 0)

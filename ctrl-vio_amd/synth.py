@@ -25,6 +25,9 @@ CONFIGS = {
     "config2": dict(F=11, L=200, M=2000),
     "config3": dict(F=11, L=300, M=2000, img_h=640, ld_true=3.0e-5),
     "config5": dict(F=31, L=1000, M=6000),
+    # SURVEY's recipe anchors every landmark in frames 0..7 (feature_manager.h:58-65 is written for WINDOW_SIZE = 10), which leaves frames
+    # 16..30 of a 30-KF window without a single visual factor; this variant anchors landmark l in frame l mod (F - 3): tracks all along the window
+    "config5_spread": dict(F=31, L=1000, M=6000, anchor_frames="spread"),
     # the reference's native TUM-RSVI operating point: 11 frames at 10 Hz (config/tumrs/cam_tumrs.yaml:25), IMU at 200 Hz
     # (~10 samples per (segment, bias) group at the 0.05 s knot spacing of config/ct_odometry_tumrs.yaml:13), at most 150 tracked
     # features per frame (cam_tumrs.yaml:23 max_cnt) with track lengths of 2..11 frames (cut at the window end), WINDOW_SIZE = 10 (parameters.h:8)
@@ -46,7 +49,7 @@ def make_window(config: str = "config2", seed: int = 1000, *, with_prior: bool =
                 **overrides):
     """Build one synthetic window.  Returns Window (initial guess) [, truth Window]."""
     cfg = dict(F=11, L=200, M=2000, img_w=1280, img_h=1024, focal=740.0, ld_true=2.94737e-5,
-               dt_ns=50_000_000, frame_dt_ns=100_000_000, pix_sigma=0.5, track=(3, 1, 6))
+               dt_ns=50_000_000, frame_dt_ns=100_000_000, pix_sigma=0.5, track=(3, 1, 6), anchor_frames="first8")
     cfg.update(CONFIGS[config])
     cfg.update(overrides)
     F, L, M = cfg["F"], cfg["L"], cfg["M"]
@@ -111,7 +114,8 @@ def make_window(config: str = "config2", seed: int = 1000, *, with_prior: bool =
         return u, v, ok
 
     # landmarks are placed by rejection, all still-unplaced ones per round (vectorised; deterministic for a given seed)
-    anchors = np.arange(L) % min(8, max(F - 2, 1))               # anchor frame < WINDOW_SIZE-2 (feature_manager.h:58-65)
+    n_anchor = max(F - 3, 1) if cfg["anchor_frames"] == "spread" else min(8, max(F - 2, 1))
+    anchors = np.arange(L) % n_anchor                            # anchor frame < WINDOW_SIZE-2 (feature_manager.h:58-65)
     t_base, t_mul, t_mod = cfg["track"]                          # track length of landmark l: base + (mul l) mod `mod`, cut at the window
     n_obs = np.minimum(F - anchors, t_base + (t_mul * np.arange(L)) % t_mod)
     max_obs = int(n_obs.max()) if L else 0

@@ -256,6 +256,9 @@ int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on);
 int32_t ctvio_last_timing(ctvio_solver *s, double *ms8, int32_t *launches8);
 /* The HIP stream every kernel of this solver is launched on (hipStream_t), for external event timing. */
 void *ctvio_stream(ctvio_solver *s);
+/* How many times this handle captured its LM pass into a hipGraph so far (diagnostic: a stream of equally shaped batches captures
+ * once; the launch sequence the reference replaces is ceres::Solve's per-iteration Evaluate loop, trajectory_estimator.cpp:399). */
+int32_t ctvio_graph_captures(const ctvio_solver *s);
 
 #ifdef __cplusplus
 }

@@ -33,3 +33,18 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle_solved(cv, oracle):
+    """(config, seed) -> (the oracle's solved copy of the synthetic window, its summary), computed once per test session: several GPU tests
+    compare different batch shapes of the same seeds with the same 15-iteration oracle solve (a config-5 solve takes the oracle 5 s)."""
+    cache = {}
+
+    def get(cfg, seed, iters=15):
+        key = (cfg, seed, iters)
+        if key not in cache:
+            ref = cv.synth.make_window(cfg, seed=seed)
+            cache[key] = (ref, oracle.OracleWindow(ref).solve(iters))
+        return cache[key]
+    return get

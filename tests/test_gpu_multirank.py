@@ -39,6 +39,22 @@ def test_bench_two_ranks_on_one_device():
     assert d["config"]["windows_per_gpu_per_step"] == 128 and "mod 2" in d["config"]["sharding"]
 
 
+def test_bench_eight_ranks_on_one_device_config4_shape():
+    """BASELINE configs[3] as literally written: 64 windows over 8 ranks = 8 per rank, launched as the driver launches an 8-GPU run (all eight
+    ranks share device 0 here; collectives over gloo).  The contract line must say n_gpus 8, carry every window id exactly once, one rate per
+    rank (the first real SCALE run shows imbalance directly) and the per-step latency of the 8-per-rank shape."""
+    d = _bench_line(["--gpus", "8", "--quick", "--windows", "8", "--streams", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=1500)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 2
+    assert abs(d["value"] - 8 * 8 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]          # whole-job aggregate over the 8 ranks
+    ss = d["solve_summary"]
+    assert ss["windows"] == 64 and ss["window_ids_gathered_once"] is True
+    assert len(d["per_rank_solves_per_s"]) == 8 and all(r > 0 for r in d["per_rank_solves_per_s"])
+    assert max(8 * 2 / r for r in d["per_rank_solves_per_s"]) == pytest.approx(2 * d["ms_per_step"] / 1e3, rel=1e-9)   # the slowest rank sets the step time
+    lat = d["small_batch_latency"]
+    assert lat["windows_per_rank"] == 8 and len(lat["end_to_end_ms_per_step_by_rank"]) == 8 and max(lat["end_to_end_ms_per_step_by_rank"]) == pytest.approx(d["ms_per_step"], rel=1e-9)
+    assert "mod 8" in d["config"]["sharding"]
+
+
 def test_sharded_entry_two_shards_on_one_device(cv):
     lib = cv.capi.load_library()
     n = 7

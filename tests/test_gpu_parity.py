@@ -155,7 +155,7 @@ N_SEEDS = 32
 
 
 @pytest.mark.parametrize("cfg", ["config1", "config2", "config3", "tumrs"])
-def test_product_parity_every_window(cv, oracle, cfg):
+def test_product_parity_every_window(cv, oracle_solved, cfg):
     """BASELINE target: final state within 1e-4 (relative) of the fp64 reference solve with identical Ceres settings (15
     iterations, function tolerance 1e-6, projected line search) on EVERY window -- 32 seeds per config, solved as one batch
     by the product path (all-fp64 HIP); "tumrs" is the reference's native operating point (200 Hz IMU: 10 samples per group; <= 150
@@ -163,8 +163,7 @@ def test_product_parity_every_window(cv, oracle, cfg):
     reference's decisions: iteration count, successful / unsuccessful steps and line-search steps are compared exactly; the
     contract bound is 1e-4, the engineering bound asserted on top of it is 1e-6 (measured ~1e-9)."""
     ws = [cv.synth.make_window(cfg, seed=1000 + i) for i in range(N_SEEDS)]
-    refs = [w.copy() for w in ws]
-    sms_o = [oracle.OracleWindow(r).solve(15) for r in refs]
+    refs, sms_o = zip(*[oracle_solved(cfg, 1000 + i) for i in range(N_SEEDS)])
     with cv.Solver() as s:
         batch = [w.copy() for w in ws]
         s.set_windows(batch)
@@ -822,12 +821,11 @@ def test_bench_size_fd_fixtures_through_the_hip_path(cv, golden_dir, name):
     assert np.abs(gg - d["g"])[gm].max() / gs < 1e-5 and abs(gg[ld] - d["g"][ld]) / abs(d["g"][ld]) < 1e-4
 
 
-def test_config5_large_window_vs_oracle(cv, oracle):
+def test_config5_large_window_vs_oracle(cv, oracle_solved):
     """BASELINE configs[4]: 30 KF / 1000 landmarks / 6000 IMU (K = 64, P = 571, dense N = 1571): the product path against the
     oracle's solve, iterate for iterate, on 8 seeds solved as one batch."""
     ws = [cv.synth.make_window("config5", seed=1011 + i) for i in range(8)]
-    refs = [w.copy() for w in ws]
-    sms_o = [oracle.OracleWindow(r).solve(15) for r in refs]
+    refs, sms_o = zip(*[oracle_solved("config5", 1011 + i) for i in range(8)])
     with cv.Solver() as s:
         batch = [w.copy() for w in ws]
         s.set_windows(batch)

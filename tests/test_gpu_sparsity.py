@@ -1,0 +1,157 @@
+"""GPU (-m gpu): the sparsity-aware step -- rows of W in sorted landmark order over their planned knot spans, Schur tiles that multiply
+only the rows reaching both of their column tiles, the panel Cholesky inside the envelope of the reduced system (the reference factors
+with SPARSE_NORMAL_CHOLESKY, trajectory_estimator.cpp:371-384) -- against the oracle's DENSE solve of the un-eliminated system, against
+the same kernels with the plan degenerated to the dense one (CTVIO_DENSE=1), and on the batch sizes that select the large-batch kernels
+(the shapes bench.py times: >= 128 config-5 windows, >= 192 config-3 / tumrs windows)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_track_window(cv, cfg="config1", seed=1600, **kw):
+    """A window in which landmark 0 is seen in TWO ADJACENT frames only (the narrowest span the factor set allows) and landmark 1 in EVERY
+    frame (the widest): the extremes of the sparsity plan side by side."""
+    w = cv.synth.make_window(cfg, seed=seed, **kw)
+    frames = np.unique(np.concatenate([w.v_ti, w.v_tj]))
+    l0 = w.v_lm == 0
+    first_tj = w.v_tj[l0].min()
+    keep = ~l0 | (w.v_tj == first_tj)                 # landmark 0: anchor frame + the next frame
+    # landmark 1: an observation in every later frame -- re-use its existing blocks' geometry, re-timed (the residuals grow, the
+    # structure is what matters; rows stay inside the image)
+    l1 = np.flatnonzero(w.v_lm == 1)
+    t_anchor = w.v_ti[l1[0]]
+    later = frames[frames > t_anchor]
+    add = {a: [] for a in ("v_lm", "v_ti", "v_tj", "v_rowi", "v_rowj", "v_pi", "v_pj")}
+    have = set(w.v_tj[l1].tolist())
+    for t in later:
+        if int(t) in have:
+            continue
+        src = l1[-1]
+        add["v_lm"].append(1); add["v_ti"].append(t_anchor); add["v_tj"].append(t)
+        add["v_rowi"].append(w.v_rowi[src]); add["v_rowj"].append(w.v_rowj[src]); add["v_pi"].append(w.v_pi[src]); add["v_pj"].append(w.v_pj[src] + 1e-3)
+    for a in add:
+        base = getattr(w, a)[keep]
+        extra = np.asarray(add[a], dtype=base.dtype).reshape((-1,) + base.shape[1:])
+        setattr(w, a, np.concatenate([base, extra]) if len(add[a]) else base)
+    return w.normalize()
+
+
+@pytest.mark.parametrize("shape", ["small_p_single", "large_p_single", "small_p_large_batch", "large_p_blocked_tiles"])
+def test_schur_step_equals_the_dense_solve(cv, oracle, shape, monkeypatch):
+    """One LM step: the device's Schur complement + factorisation + back-substitution against the oracle's dense Cholesky of the full
+    (un-eliminated) system, on a window holding a two-frame landmark and an every-frame landmark -- through every Schur / Cholesky pairing:
+    tile kernel + register-resident tiles, tile kernel + envelope panel kernel, per-window kernel + tiles (>= 192 windows), 2 x 2 blocked
+    tile kernel + envelope panel kernel."""
+    if shape.startswith("small_p"):
+        w = _two_track_window(cv, "config1", 1600)
+        assert w.P <= 223
+    else:
+        w = _two_track_window(cv, "config1", 1601, F=16, L=60, M=750)       # K = 34, P = 301: the panel kernel
+        assert w.P > 223
+    n = {"small_p_single": 1, "large_p_single": 1, "small_p_large_batch": 200, "large_p_blocked_tiles": 3}[shape]
+    if shape == "large_p_blocked_tiles":
+        monkeypatch.setenv("CTVIO_SCHUR_TILE2", "1")
+    d_o, mc_o = oracle.OracleWindow(w.copy()).lm_step(1e4, use_schur=False)
+    with cv.Solver() as s:
+        s.set_windows([w.copy() for _ in range(n)])
+        for wid in sorted({0, n - 1}):
+            d_g, mc_g = s.lm_step(wid, 1e4)
+            assert np.abs(d_g - d_o).max() <= 1e-8 * np.abs(d_o).max(), (shape, wid)
+            assert mc_g == pytest.approx(mc_o, rel=1e-9)
+        H, W, Hll, g, cost = s.linearize(0)
+    Ho, go, co = oracle.OracleWindow(w.copy()).build_normal()
+    P = w.P
+    sc = np.sqrt(np.maximum(np.diag(Ho), 1e-30))
+    assert np.abs((W - Ho[:P, P:]) / np.outer(sc[:P], sc[P:])).max() < 1e-10      # rows of W come back in the caller's landmark order
+    assert np.count_nonzero(W[:, 0]) < np.count_nonzero(W[:, 1])                  # the two-frame landmark's row is the short one
+
+
+@pytest.mark.parametrize("cfg,kw,n", [("config1", dict(F=16, L=60, M=750), 4), ("config2", {}, 4), ("config1", dict(F=16, L=60, M=750), 200), ("config2", {}, 200)])
+def test_sparse_plan_equals_the_dense_plan(cv, cfg, kw, n, monkeypatch):
+    """The same batch solved with the sparsity plan and with CTVIO_DENSE=1 (every tile multiplies every row, envelope = whole triangle):
+    same decisions, same state -- small and large batches of a register-resident (P = 211) and of a panel-kernel (P = 301) shape."""
+    base = [cv.synth.make_window(cfg, seed=1700 + i, **kw) for i in range(4)]
+    res = {}
+    for dense in ("0", "1"):
+        monkeypatch.setenv("CTVIO_DENSE", dense)
+        with cv.Solver() as s:
+            batch = [base[i % 4].copy() for i in range(n)]
+            s.set_windows(batch)
+            res[dense] = (batch, s.solve(15))
+    monkeypatch.delenv("CTVIO_DENSE")
+    for i in range(n):
+        a, b = res["0"][1][i], res["1"][1][i]
+        assert (a["iterations"], a["num_successful"], a["num_unsuccessful"]) == (b["iterations"], b["num_successful"], b["num_unsuccessful"]), i
+        assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-10)
+        assert cv.rel_state_error(res["0"][0][i], res["1"][0][i])["state"] < 1e-7, i
+
+
+def test_long_windows_vs_oracle(cv, oracle):
+    """Windows whose envelope is far from dense (K = 34, K = 42 and K = 30 knots, short-lived landmarks), one ragged batch, solved by the
+    panel kernel inside their envelopes -- against the oracle iterate for iterate."""
+    ws = [cv.synth.make_window("config1", seed=1400, F=16, L=60, M=750), cv.synth.make_window("config1", seed=1401, F=20, L=40, M=900),
+          cv.synth.make_window("tiny", seed=1402, F=14, L=30, M=400)]
+    refs = [w.copy() for w in ws]
+    sms_o = [oracle.OracleWindow(r).solve(15) for r in refs]
+    with cv.Solver() as s:
+        batch = [w.copy() for w in ws]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    for i, (sm, so) in enumerate(zip(sms, sms_o)):
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), i
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        assert cv.rel_state_error(batch[i], refs[i])["state"] < 1e-6, i
+
+
+def test_config5_timed_shape_vs_oracle(cv, oracle_solved):
+    """The shape bench.py times for BASELINE configs[4]: 128 config-5 windows in one launch (8 distinct seeds, 16 copies each) -- enough
+    tiles for the 2 x 2 blocked Schur kernel to be selected WITHOUT the A/B switch, the 8-wave envelope panel Cholesky, atomic assembly --
+    every copy against the oracle's solve of its seed."""
+    uniq = [cv.synth.make_window("config5", seed=1011 + i) for i in range(8)]
+    refs, sms_o = zip(*[oracle_solved("config5", 1011 + i) for i in range(8)])
+    assert "CTVIO_SCHUR_TILE2" not in os.environ
+    with cv.Solver() as s:
+        batch = [uniq[i % 8].copy() for i in range(128)]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    for i, sm in enumerate(sms):
+        so = sms_o[i % 8]
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), i
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        assert cv.rel_state_error(batch[i], refs[i % 8])["state"] < 1e-6, i
+
+
+@pytest.mark.parametrize("cfg", ["config3", "tumrs"])
+def test_large_batch_timed_shapes_vs_oracle(cv, oracle_solved, cfg):
+    """The shapes bench.py times for BASELINE configs[2] and the reference's native operating point: 192 windows in one launch (16 distinct
+    seeds): per-window Schur kernel, register-resident tile Cholesky reading the plain tiles from Hpp, atomic single-part assembly -- the
+    large-batch kernels, not the small-batch ones the 32-seed parity test selects -- every copy against the oracle's solve of its seed."""
+    uniq = [cv.synth.make_window(cfg, seed=1000 + i) for i in range(16)]
+    refs, sms_o = zip(*[oracle_solved(cfg, 1000 + i) for i in range(16)])
+    with cv.Solver() as s:
+        batch = [uniq[i % 16].copy() for i in range(192)]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    for i, sm in enumerate(sms):
+        so = sms_o[i % 16]
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), i
+        assert (sm["num_line_search_steps"], sm["num_line_search_reduced"]) == (so.num_line_search_steps, so.num_line_search_reduced), i
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        assert cv.rel_state_error(batch[i], refs[i % 16])["state"] < 1e-6, i
+
+
+def test_equal_batches_capture_the_pass_once(cv):
+    """A stream of equally shaped large batches (the headline configuration: >= 192 windows, P <= 223) captures its LM pass into a hipGraph
+    ONCE: ctvio_set_batch clears the device descriptor, and a field that a launch used to set afterwards made every solve re-capture."""
+    base = [cv.synth.make_window("config1", seed=1800 + i) for i in range(4)]
+    with cv.Solver() as s:
+        for rep in range(3):
+            s.set_windows([base[i % 4].copy() for i in range(200)])
+            s.solve(4)
+        assert s.graph_captures == 1
+        s.set_windows([base[i % 4].copy() for i in range(8)])      # another shape: one more capture
+        s.solve(4)
+        assert s.graph_captures == 2
