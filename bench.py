@@ -402,7 +402,9 @@ def main():
             w = uniq[(int(first[si]) + j) % nuniq]
             # EVERY window of a step owns its caller buffers (a copy of the distinct window it replicates): validate + pack stream the
             # whole batch from DRAM (8192 x 178 KB = 1.46 GB per step), as a caller with 8192 different windows would make them
-            arr[j] = cv.capi.to_cwindow(w if args.shared_caller_buffers else w.copy(), keep)
+            wc = w if args.shared_caller_buffers else w.copy()
+            keep.append(wc)                                   # (the C window points into the copy's arrays)
+            arr[j] = cv.capi.to_cwindow(wc, keep)
             arr_sh[j] = cv.capi.to_cwindow(w, keep)
             wl.append(w)
         cbatches_shared.append(arr_sh)
