@@ -284,7 +284,7 @@ class SolverImpl : public SolverBase {
     const size_t o_pinv = seg(4 * (size_t)Pp0), o_bgl_off = seg(4 * ((size_t)F0 + nw)), o_bgl = seg(4 * (size_t)std::max(G0, 1));
     const size_t o_active = seg((size_t)U0);
     const size_t o_lm_pos = seg(4 * (size_t)L0), o_lm_at = seg(4 * (size_t)L0), o_lm_klo = seg(4 * (size_t)L0), o_lm_khi = seg(4 * (size_t)L0);
-    const size_t o_tl_beg = seg(4 * (size_t)TR0), o_tl_end = seg(4 * (size_t)TR0), o_env_first = seg(4 * (size_t)TR0);
+    const size_t o_tl_beg = seg(4 * (size_t)TR0), o_tl_end = seg(4 * (size_t)TR0), o_env_first = seg(4 * (size_t)TR0), o_env_tile = seg(4 * (size_t)TR0);
     const size_t in_bytes = off;
     bool grew = false;
     HIPCHK(hipStreamSynchronize(stream_));   // the previous batch may still be reading the staging arena (H2D in flight)
@@ -315,7 +315,7 @@ class SolverImpl : public SolverBase {
     uint8_t *h_active = CTV_H(uint8_t, o_active);
     int32_t *h_pinv = CTV_H(int32_t, o_pinv), *h_bgl_off = CTV_H(int32_t, o_bgl_off), *h_bgl = CTV_H(int32_t, o_bgl);
     int32_t *h_lm_pos = CTV_H(int32_t, o_lm_pos), *h_lm_at = CTV_H(int32_t, o_lm_at), *h_lm_klo = CTV_H(int32_t, o_lm_klo), *h_lm_khi = CTV_H(int32_t, o_lm_khi);
-    int32_t *h_tl_beg = CTV_H(int32_t, o_tl_beg), *h_tl_end = CTV_H(int32_t, o_tl_end), *h_env_first = CTV_H(int32_t, o_env_first);
+    int32_t *h_tl_beg = CTV_H(int32_t, o_tl_beg), *h_tl_end = CTV_H(int32_t, o_tl_end), *h_env_first = CTV_H(int32_t, o_env_first), *h_env_tile = CTV_H(int32_t, o_env_tile);
     h_lm_pos_ = h_lm_pos; h_ld_ = h_ld;
     // ---- second pass: every window fills its own slices
     parallel_for(nw, nth, [&](int wi) {
@@ -335,7 +335,7 @@ class SolverImpl : public SolverBase {
         std::memcpy(h_lm_klo + m.lm0, t.row_klo.data(), 4 * (size_t)w.L); std::memcpy(h_lm_khi + m.lm0, t.row_khi.data(), 4 * (size_t)w.L);
       }
       std::memcpy(h_tl_beg + m.tr0, t.tl_beg.data(), 4 * (size_t)m.ntr); std::memcpy(h_tl_end + m.tr0, t.tl_end.data(), 4 * (size_t)m.ntr);
-      std::memcpy(h_env_first + m.tr0, t.env_first.data(), 4 * (size_t)m.ntr);
+      std::memcpy(h_env_first + m.tr0, t.env_first.data(), 4 * (size_t)m.ntr); std::memcpy(h_env_tile + m.tr0, t.env_tile.data(), 4 * (size_t)m.ntr);
       // IMU samples in (segment, bias) order; groups = runs of equal (segment, bias)
       int g = m.grp0 - 1;
       for (int i = 0; i < w.M; ++i) {
@@ -462,7 +462,7 @@ class SolverImpl : public SolverBase {
     d.active = CTV_D(uint8_t, o_active);
     d.pinv = CTV_D(int32_t, o_pinv); d.bgl_off = CTV_D(int32_t, o_bgl_off); d.bgl = CTV_D(int32_t, o_bgl);
     d.lm_pos = CTV_D(int32_t, o_lm_pos); d.lm_at = CTV_D(int32_t, o_lm_at); d.lm_klo = CTV_D(int32_t, o_lm_klo); d.lm_khi = CTV_D(int32_t, o_lm_khi);
-    d.tl_beg = CTV_D(int32_t, o_tl_beg); d.tl_end = CTV_D(int32_t, o_tl_end); d.env_first = CTV_D(int32_t, o_env_first);
+    d.tl_beg = CTV_D(int32_t, o_tl_beg); d.tl_end = CTV_D(int32_t, o_tl_end); d.env_first = CTV_D(int32_t, o_env_first); d.env_tile = CTV_D(int32_t, o_env_tile);
     d.max_span6 = 6 * maxSpan;
 #undef CTV_H
 #undef CTV_D
@@ -720,7 +720,7 @@ class SolverImpl : public SolverBase {
     const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
     return !small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224;
   }
-  size_t schur_window_lds() const { return ((size_t)2 * 16 * dev_.maxLdw + 3 * dev_.maxLdw + 32 + 64) * sizeof(double); }   // + column vectors + the list of tiles with products
+  size_t schur_window_lds() const { return ((size_t)2 * 16 * (dev_.maxLdw + 16) + 3 * dev_.maxLdw + 32 + 64) * sizeof(double); }   // + column vectors + the list of tiles with products
   // Dev::schur_plain_in_H is part of the Dev struct the captured graph is keyed on: decided once per upload, never inside a launch
   // (launch_schur used to set it, so every upload -- which clears Dev -- invalidated the cached hipGraph of the headline configuration).
   int schur_plain_in_H_for_batch() const { return (schur_window_path() && chol_tiles() != 0 && !std::getenv("CTVIO_SCHUR_COPY_PLAIN")) ? 1 : 0; }

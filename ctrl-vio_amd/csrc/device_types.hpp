@@ -134,6 +134,7 @@ struct Dev {
   // tiles: empty), and env_first: the first tile column of tile row c inside the ENVELOPE of the reduced system S (and of its Cholesky factor:
   // fill stays inside the row envelope) -- tiles (r, c < env_first[r]) are structurally zero: not formed, not stored, not multiplied.
   const int32_t *tl_beg, *tl_end, *env_first;
+  const int32_t *env_tile;         // the raw (unaligned) tile envelope, also for batches whose env_first is the whole triangle: k_cholesky_tiles skips empty tiles' products
   double *grs;                     // [Ltot] g_rho by ROW (written with dinv by begin_iteration): the Schur kernels stream rows, not landmarks
   int32_t *span_viol;              // device counter: an evaluation fell outside its landmark's planned span (never, unless the plan is wrong)
   int32_t max_span6, pad_ms;       // 6 x the widest landmark span of the batch (knot columns): LDS row width of k_vis_eval

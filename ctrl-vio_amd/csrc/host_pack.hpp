@@ -80,7 +80,7 @@ struct PackTmp {
   int32_t ngrp = 0, nvitem = 0, Vp = 0; // Vp: slots incl. padding, a multiple of 64
   int32_t A = 0;                        // number of anchors
   // sparsity plan (plan_sparsity): rows of W in sorted landmark order, their knot spans, per-tile row ranges, envelope of the reduced system
-  std::vector<int32_t> lm_pos, lm_at, row_klo, row_khi, tl_beg, tl_end, env_first;
+  std::vector<int32_t> lm_pos, lm_at, row_klo, row_khi, tl_beg, tl_end, env_first, env_tile;
   int32_t Lobs = 0, max_span = 0, ntr = 0;
   std::string err;
 };
@@ -240,8 +240,9 @@ inline int vis_segment(const ctvio_window *w, int64_t t, int row, double ld) {
 //   * The ENVELOPE of the reduced system S = Hpp - W^T Hll^-1 W: first[u] = the smallest unknown coupled to u by an IMU group (4 knots + its bias
 //     state), a bias-chain link, the prior (all its columns mutually), or a landmark (its span's knots mutually, and each with the line delay);
 //     Cholesky fill stays inside the row envelope, so tiles (r, c < env_first[r]) are never formed, stored or multiplied.  dense = true (batches
-//     whose factorisation keeps the whole triangle in registers: P <= 223) sets env_first = 0; full_ranges widens every non-empty row range to
-//     all observed rows (the dense cross-check).
+//     whose factorisation keeps the whole triangle in registers: P <= 223) sets env_first = 0 -- every tile is formed and loaded -- and leaves
+//     the raw tile envelope in env_tile, by which k_cholesky_tiles skips the PRODUCTS of empty tiles; full_ranges widens every non-empty row
+//     range to all observed rows and drops the envelope (the dense cross-check).
 inline void plan_sparsity(const ctvio_window *w, bool dense, bool full_ranges, PackTmp &t) {
   const int K = w->K, F = w->F, L = w->L, V = w->V, K6 = 6 * K, P = K6 + 6 * F + 1;
   std::vector<int32_t> klo((size_t)L, K), khi((size_t)L, -1);
@@ -264,7 +265,7 @@ inline void plan_sparsity(const ctvio_window *w, bool dense, bool full_ranges, P
   }
   const int ntr = P / 16 + 1;
   t.ntr = ntr;
-  t.tl_beg.assign((size_t)ntr, 0); t.tl_end.assign((size_t)ntr, 0); t.env_first.assign((size_t)ntr, 0);
+  t.tl_beg.assign((size_t)ntr, 0); t.tl_end.assign((size_t)ntr, 0); t.env_first.assign((size_t)ntr, 0); t.env_tile.assign((size_t)ntr, 0);
   for (int c = 0; c < ntr; ++c) {
     int beg = L, end = 0;
     if (16 * c < K6) {
@@ -277,7 +278,7 @@ inline void plan_sparsity(const ctvio_window *w, bool dense, bool full_ranges, P
     if (full_ranges && end > 0) { beg = 0; end = t.Lobs; }     // (CTVIO_DENSE: the A/B switch -- every tile with products multiplies every row)
     t.tl_beg[c] = beg; t.tl_end[c] = end;
   }
-  if (dense) return;
+  if (full_ranges) return;   // (CTVIO_DENSE: no envelope at all)
   // envelope, in columns: per knot block, per bias block, line delay
   std::vector<int32_t> fk((size_t)K), fb((size_t)F);
   for (int k = 0; k < K; ++k) fk[k] = 6 * k;
@@ -319,8 +320,9 @@ inline void plan_sparsity(const ctvio_window *w, bool dense, bool full_ranges, P
     // tile row reaches at least the panel before its own 32-row block (so that the next diagonal block always takes part in a panel's
     // trailing update: its look-ahead relies on that).  The tiles this adds hold zeros.
     int ft = f / 16;
+    t.env_tile[r] = ft;                                        // the envelope as it is (k_cholesky_tiles skips the products of empty tiles)
     if (r >= 2) ft = std::min(ft, 2 * (r / 2) - 2);
-    t.env_first[r] = r < 2 ? 0 : (ft & ~1);
+    t.env_first[r] = (dense || r < 2) ? 0 : (ft & ~1);
   }
 }
 

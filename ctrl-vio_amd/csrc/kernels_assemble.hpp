@@ -296,7 +296,10 @@ __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __
 // Dev::Hpart and k_reduce_finalize sums them in part order.
 template <int CH, bool LDSH, int NW = 8, bool STORE = false> __global__ __launch_bounds__(64 * NW) void k_assemble_vis_mfma(Dev d, int mode) {
   typedef f64x4 acc_t;
-  constexpr int CHP = CH + 2, RPP = 64 / CH, NT = 64 * NW;
+  // Row stride of a staged item: CH + 1 = 9 doubles.  The MFMA operand reads are ds_read_b64 of lanes (l15, k-row): row 2 (16 I + l15) + rr, so
+  // consecutive l15 are 2 x 9 x 2 = 36 four-byte banks apart -- 16 distinct bank pairs, the rr = 1 half on the odd pairs: conflict-free.  With the
+  // stride 10 of rounds 1-4 (40 banks apart: period 8) lanes l15 and l15 + 8 met on one bank and every operand read took twice its cycles.
+  constexpr int CHP = CH + 1, RPP = 64 / CH, NT = 64 * NW;
   static_assert(!STORE || LDSH, "the store-semantics tail needs the LDS-resident Hessian");
   // staged rows per item: 0..95 pose columns (row = 2 * column + residual row), 98/99 line delay, 100/101 residual, 102..107 A~,
   // 108..111 cp0, 112..115 cp1.  38 of them come from the block records in HBM (rows 48..71 = the j end's rotation columns, 98..107,
@@ -556,7 +559,7 @@ template <int CH, bool LDSH, int NW = 8, bool STORE = false> __global__ __launch
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int blk = v8 + 2 * s + bsel;
-          const int bc = min(blk, CH + 1);   // a valid LDS address even when past the run (value discarded)
+          const int bc = min(blk, CH);       // a valid LDS address even when past the run (value discarded)
 #pragma unroll
           for (int I = 0; I < 3; ++I) a[s][I] = Js[orow[I] + bc];
           ldv[s] = Js[ldrow + bc];

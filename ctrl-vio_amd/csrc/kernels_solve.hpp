@@ -82,8 +82,12 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   const int P = m.P, L = m.L, ldw = m.ldw, u0 = m.u0, K6 = 6 * m.K, ldh = m.ldh;
   const int nt = ldw >> 4, ntile = nt * (nt + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double smd64[];
-  double *Wb = smd64;                    // [2][16][ldw]
-  double *acts = Wb + 2 * 16 * ldw;      // [ldw] 1 / 0 (0 beyond P)      } per-column vectors of the epilogue, staged once: no global
+  // LDS row stride of a staged chunk: ldw + 16 doubles.  ds_read_b64 serves lanes 0-31 in one cycle if they hit 64 distinct 4-byte banks: the 16
+  // lanes of a k-row read 128 contiguous bytes, and the next k-row (lanes 16-31) must start 128 bytes (mod 256) away -- with the row stride ldw
+  // (a multiple of 32 doubles = 256 bytes) both halves fell on the same 32 banks and every operand read took twice its cycles.
+  const int ldl = ldw + 16;
+  double *Wb = smd64;                    // [2][16][ldl]
+  double *acts = Wb + 2 * 16 * ldl;      // [ldw] 1 / 0 (0 beyond P)      } per-column vectors of the epilogue, staged once: no global
   double *ddv = acts + ldw;              // [ldw] D of the column            } round trip per tile there (the activity of a STAGED column
   double *gv = ddv + ldw;                // [ldw] gradient                   } travels in pre_lc)
   double *dch = gv + ldw;                // [2][16] 1 / (Hll + D) of the chunk's landmarks (0 beyond L)
@@ -112,7 +116,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   // compact columns per landmark); every other column of the two LDS buffers is zeroed once and stays zero.
   // SPARSITY: the rows of W are sorted by knot span (host_pack.hpp: plan_sparsity); rows past Lobs are zero, and a tile multiplies only the
   // chunks that overlap the row range of its two column tiles (cbeg / cend below).
-  const int nchunk = (m.Lobs + 15) >> 4, nel = 16 * ldw, NC = K6 + 2, nelc = 16 * NC;
+  const int nchunk = (m.Lobs + 15) >> 4, nel = 16 * ldl, NC = K6 + 2, nelc = 16 * NC;
   for (int e = tid; e < 2 * nel; e += 512) Wb[e] = 0.0;
   double pre[NPRE];
   double pre_d = 0.0;
@@ -137,7 +141,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
     for (int k = 0; k < NPRE; ++k) {
       const int lr = (pre_lc[k] >> 16) & 0xff, c = pre_lc[k] & 0xffff;
       const bool lv = 16 * ch + lr < L && (pre_lc[k] >> 30) != 0;
-      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldw + c] = lv ? pre[k] : 0.0;
+      if (tid + 512 * k < nelc) Wb[buf * nel + lr * ldl + c] = lv ? pre[k] : 0.0;
     }
     if (tid < 16) dch[16 * buf + tid] = (16 * ch + tid < L) ? pre_d : 0.0;
   };
@@ -188,7 +192,7 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
   for (int ch = 0; ch < nchunk && nact > 0; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) fetch(ch + 1);
-    const double *B = Wb + buf * nel + q4 * ldw + l15;
+    const double *B = Wb + buf * nel + q4 * ldl + l15;
     double dl[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) dl[s] = dch[16 * buf + 4 * s + q4];
@@ -201,8 +205,8 @@ template <int NPRE, int NTQ> __global__ __launch_bounds__(512, NTQ <= 7 ? 4 : 2)
       double a[4], b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        a[s] = B[4 * s * ldw + 16 * ((tij[q] >> 8) & 255)];
-        b[s] = B[4 * s * ldw + 16 * (tij[q] & 255)];
+        a[s] = B[4 * s * ldl + 16 * ((tij[q] >> 8) & 255)];
+        b[s] = B[4 * s * ldl + 16 * (tij[q] & 255)];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1021,7 +1025,10 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   };
   for (int i = tid; i < TS; i += NT) Id[i] = (i / 17 == i % 17) ? 1.0 : 0.0;
   // ---- this wave's tiles (SGPRs) and their contents
-  int ti[NS], tj[NS];
+  // SPARSITY: tile (i, c) of the factor is empty for c < env_tile[i] (host_pack.hpp: plan_sparsity; fill stays inside the row envelope), so
+  // panel k neither solves nor updates with a tile whose row starts after it: ek = the first panel either row of the tile takes part in.
+  // (The tiles themselves are all resident -- the empty ones hold exact zeros -- so loads, layout and the back-substitution do not change.)
+  int ti[NS], tj[NS], ek[NS];
   f64x4 acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
@@ -1030,6 +1037,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
     tile_decode(min(t, ntiles - 1), a, b);
     ti[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? a : -1);
     tj[q] = __builtin_amdgcn_readfirstlane(t < ntiles ? b : 1 << 20);   // (never equal to a panel, never a trailing tile: ti < tj)
+    ek[q] = __builtin_amdgcn_readfirstlane(max(d.env_tile[m.tr0 + a], d.env_tile[m.tr0 + b]));
     // unconditional loads on clamped addresses straight into the tile registers; fixed up below
     const bool plain = from_h && !(nz_row(a) && nz_col(b));   // (wave-uniform)
     const double *src = plain ? Hc : S;
@@ -1129,7 +1137,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
     const double *Lk = Li + k * TS;
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      if (tj[q] != k || ti[q] <= k) continue;   // (uniform)
+      if (tj[q] != k || ti[q] <= k || k < ek[q]) continue;   // (uniform; an empty tile stays zero and publishes nothing)
       double *blk = Pnk + ti[q] * TS;
 #pragma unroll
       for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = acc[q][r];
@@ -1155,7 +1163,7 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
     // ---- E. trailing tiles (i, j), j > k: A_ij -= L_ik L_jk^T
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      if (ti[q] < 0 || tj[q] <= k || tj[q] >= (1 << 20)) continue;   // (uniform)
+      if (ti[q] < 0 || tj[q] <= k || tj[q] >= (1 << 20) || k < ek[q]) continue;   // (uniform; L_ik or L_jk is empty)
       const double *pa = Pnk + ti[q] * TS + l15 * 17 + q4, *pb = Pnk + tj[q] * TS + l15 * 17 + q4;
       double a[4], b[4];
 #pragma unroll

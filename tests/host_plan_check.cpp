@@ -31,7 +31,7 @@ int hp_plan(int V, int L, const int32_t *v_lm, const int64_t *v_ti, const int64_
 // The sparsity plan of a whole window (host_pack.hpp: plan_sparsity, after plan_window): rows of W in sorted landmark order with their knot
 // spans, per-tile row ranges, envelope of the reduced system.  `w` is the C-ABI window as the caller hands it over.
 extern "C" int hp_sparsity(const ctvio_window *w, int dense, int full_ranges, int32_t *lm_pos, int32_t *lm_at, int32_t *row_klo, int32_t *row_khi,
-                           int32_t *tl_beg, int32_t *tl_end, int32_t *env_first, int32_t *Lobs, int32_t *max_span, int32_t *ntr, char *err_out, int err_cap) {
+                           int32_t *tl_beg, int32_t *tl_end, int32_t *env_first, int32_t *env_tile, int32_t *Lobs, int32_t *max_span, int32_t *ntr, char *err_out, int err_cap) {
   std::string err;
   if (!ctv::validate_window(w, err)) { std::snprintf(err_out, (size_t)err_cap, "%s", err.c_str()); return 1; }
   ctv::PackTmp t;
@@ -39,7 +39,7 @@ extern "C" int hp_sparsity(const ctvio_window *w, int dense, int full_ranges, in
   if (!t.err.empty()) { std::snprintf(err_out, (size_t)err_cap, "%s", t.err.c_str()); return 1; }
   ctv::plan_sparsity(w, dense != 0, full_ranges != 0, t);
   for (int l = 0; l < w->L; ++l) { lm_pos[l] = t.lm_pos[l]; lm_at[l] = t.lm_at[l]; row_klo[l] = t.row_klo[l]; row_khi[l] = t.row_khi[l]; }
-  for (int r = 0; r < t.ntr; ++r) { tl_beg[r] = t.tl_beg[r]; tl_end[r] = t.tl_end[r]; env_first[r] = t.env_first[r]; }
+  for (int r = 0; r < t.ntr; ++r) { tl_beg[r] = t.tl_beg[r]; tl_end[r] = t.tl_end[r]; env_first[r] = t.env_first[r]; env_tile[r] = t.env_tile[r]; }
   *Lobs = t.Lobs; *max_span = t.max_span; *ntr = t.ntr;
   return 0;
 }

@@ -33,11 +33,11 @@ def plan(hp, cv, w, dense=False, full=False):
     keep = []
     cw = cv.capi.to_cwindow(w, keep)
     L, ntr = w.L, w.P // 16 + 1
-    a = {k: np.zeros(max(n, 1), np.int32) for k, n in (("lm_pos", L), ("lm_at", L), ("klo", L), ("khi", L), ("tl_beg", ntr), ("tl_end", ntr), ("env", ntr))}
+    a = {k: np.zeros(max(n, 1), np.int32) for k, n in (("lm_pos", L), ("lm_at", L), ("klo", L), ("khi", L), ("tl_beg", ntr), ("tl_end", ntr), ("env", ntr), ("env_tile", ntr))}
     Lobs = C.c_int32(); ms = C.c_int32(); nt = C.c_int32()
     err = C.create_string_buffer(256)
     p = lambda x: x.ctypes.data_as(C.c_void_p)
-    rc = hp.hp_sparsity(C.byref(cw), int(dense), int(full), p(a["lm_pos"]), p(a["lm_at"]), p(a["klo"]), p(a["khi"]), p(a["tl_beg"]), p(a["tl_end"]), p(a["env"]),
+    rc = hp.hp_sparsity(C.byref(cw), int(dense), int(full), p(a["lm_pos"]), p(a["lm_at"]), p(a["klo"]), p(a["khi"]), p(a["tl_beg"]), p(a["tl_end"]), p(a["env"]), p(a["env_tile"]),
                         C.byref(Lobs), C.byref(ms), C.byref(nt), err, 256)
     assert rc == 0, err.value.decode()
     assert nt.value == ntr
@@ -85,6 +85,10 @@ def check_against_dense(cv, oracle, w, pl, lds):
         if cols.size:
             assert cols.min() // 16 >= env[r], (r, cols.min(), env[r])
     assert env[P // 16] == 0                                    # the rhs row rides along as row P: dense
+    et = pl["env_tile"]                                         # the raw tile envelope: tight where the aligned one is padded
+    for r in range(ntr):
+        cols = np.flatnonzero(nzS[16 * r:min(16 * r + 16, P), :16 * r + 16].any(axis=0))
+        assert et[r] <= r and (cols.size == 0 or cols.min() // 16 >= et[r]) and env[r] <= et[r]
     return nzS, env
 
 
@@ -110,8 +114,9 @@ def test_plan_of_a_long_window_is_sparse(hp, cv, oracle):
     tiles = sum(r - env[r] + 1 for r in range(len(env)))
     assert tiles < len(env) * (len(env) + 1) // 2
     pd = plan(hp, cv, w, dense=True)
-    assert not pd["env"].any() and np.array_equal(pd["lm_pos"], pl["lm_pos"])
+    assert not pd["env"].any() and np.array_equal(pd["lm_pos"], pl["lm_pos"]) and np.array_equal(pd["env_tile"], pl["env_tile"])
     pf = plan(hp, cv, w, dense=True, full=True)                 # CTVIO_DENSE: every tile with products multiplies every observed row
+    assert not pf["env"].any() and not pf["env_tile"].any()
     assert all((b, e) in ((0, 0), (0, pf["Lobs"])) for b, e in zip(pf["tl_beg"], pf["tl_end"]))
 
 
