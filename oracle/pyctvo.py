@@ -55,7 +55,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # CTVO_ORACLE_LIB: another build of the same source (tests/test_oracle_asan.py: the -fsanitize=address,undefined target of the Makefile)
+        _lib = C.CDLL(os.environ.get("CTVO_ORACLE_LIB") or build())
         _lib.ctvo_cost.restype = C.c_double
         _lib.ctvo_build_normal.restype = C.c_double
         _lib.ctvo_lm_step.restype = C.c_double

@@ -282,30 +282,34 @@ def test_large_batch_schur_variants_k26_k27(cv, oracle, dt_ms, K):
     for i in range(208):
         assert sm_big[i]["iterations"] == sm_small[i % 4]["iterations"]
         assert sm_big[i]["final_cost"] == pytest.approx(sm_small[i % 4]["final_cost"], rel=1e-6 if ill(i) else 1e-8)
-        if not ill(i):
-            assert cv.rel_state_error(big[i], small[i % 4])["state"] < 1e-6, i
+        # (the ill-determined seed keeps a loose but non-trivial bound -- its 15th iterate moves by ~1e-4 under a change of the
+        #  summation order, 1e-3 would be a different solution)
+        assert cv.rel_state_error(big[i], small[i % 4])["state"] < (1e-3 if ill(i) else 1e-6), i
     for i in range(4):
         wo = base[i].copy()
         so = oracle.OracleWindow(wo).solve(15)
         assert sm_big[i]["final_cost"] == pytest.approx(so.final_cost, rel=1e-6 if ill(i) else 1e-8)
+        assert cv.rel_state_error(big[i], wo)["state"] < (1e-3 if ill(i) else 1e-6)
         if not ill(i):
             assert sm_big[i]["iterations"] == so.iterations
-            assert cv.rel_state_error(big[i], wo)["state"] < 1e-6
 
 
-def test_golden_converged_state(cv, golden_dir):
+def test_golden_converged_state(cv, oracle, golden_dir):
     """Committed scipy fixture (tests/golden/config1_seed1000_converged.npz): independent minimiser."""
     d = np.load(os.path.join(golden_dir, "config1_seed1000_converged.npz"))
     w = cv.Window.from_dict(d, "w_")
     wf = cv.Window.from_dict(d, "f_")
+    wo = w.copy()
+    so = oracle.OracleWindow(wo).solve(50)
     with cv.Solver() as s:
         s.set_windows([w])
         sm = s.solve(50)[0]
     assert sm["final_cost"] == pytest.approx(float(d["final_cost"]), rel=2e-6)
-    # the fixture is scipy's tightly converged minimiser; Ceres' function tolerance stops ~2.5e-4 short of it on this
-    # window (the oracle does too: tests/test_oracle_golden.py), so this bound is the stopping slop, not a precision
-    assert cv.rel_state_error(w, wf)["state"] < 1e-3
-    # with the tolerances tightened (as tests/test_oracle_golden.py does for the oracle) the device lands on scipy's minimiser: cost to
+    # With Ceres' default tolerances the solve stops ~2.5e-4 short of scipy's tightly converged minimiser on this window (the function
+    # tolerance fires) -- so at these settings the device is held to the ORACLE's stopping point, iterate for iterate ...
+    assert sm["iterations"] == so.iterations and sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9)
+    assert cv.rel_state_error(w, wo)["state"] < 1e-6
+    # ... and with the tolerances tightened (as tests/test_oracle_golden.py does for the oracle) it lands on scipy's minimiser: cost to
     # 5e-9, state to the 2e-5 the two independent optimisers agree on (Jacobi-scaled condition number ~1e10 in the near-gauge directions)
     w2 = cv.Window.from_dict(d, "w_")
     with cv.Solver(function_tolerance=1e-15, gradient_tolerance=1e-15, parameter_tolerance=1e-14) as s:
