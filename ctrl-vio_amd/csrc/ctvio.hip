@@ -150,6 +150,7 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<7, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_schur_window_f64<5, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_misc, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));   // (+ 2 KB of static LDS)
     return CTVIO_OK;
   }
   int bind() override { HIPCHK(hipSetDevice(opt_.device)); return CTVIO_OK; }
@@ -649,7 +650,12 @@ class SolverImpl : public SolverBase {
     ph_end();
     ph_begin(PH_ASM_REST);
     // (the IMU tiles' bias rows, the bias chain and the prior in ONE launch: k_misc with assemble_imu_window in front)
-    hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 0, d.Gtot ? 1 : 0);
+    {
+      // (windows without the LDS-resident Hessian: the IMU knot blocks are summed in an LDS band before they go to Hpp -- when it fits)
+      const size_t dxb = (size_t)((std::max(d.maxPn, 1) + 1) & ~1) * sizeof(double), bandb = (size_t)144 * maxK_ * sizeof(double);
+      const bool band = any_vis_glb_ && d.Gtot && dxb + bandb <= 150 * 1024 && !std::getenv("CTVIO_NO_IMU_BAND");
+      hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), band ? dxb + bandb : dxb, stream_, d, mode, 0, d.Gtot ? (band ? 2 : 1) : 0);
+    }
     if (mode != LIN_SPEC) hipLaunchKernelGGL(k_post_linearize, dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
     ph_end();
   }

@@ -726,7 +726,9 @@ __device__ __forceinline__ const double *prior_block_ptr(const WinMeta &m, int k
 // with_imu != 0: the window's IMU group tiles are scattered first (assemble_imu_window: the accumulate path's k_assemble_imu, fused).
 __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int with_imu) {
   const int w = blockIdx.x;
-  if (with_imu) assemble_imu_window(d, mode, w);
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  // with_imu == 2: the launch carries 144 maxK doubles of LDS behind the prior's dx for the band of the IMU knot blocks (windows with K > 24)
+  if (with_imu) { assemble_imu_window(d, mode, w, with_imu == 2 ? smd + ((max(d.maxPn, 1) + 1) & ~1) : nullptr); __syncthreads(); }
   const Lm &lm = d.lm[w];
   if (!lin_run(lm, mode)) return;
   const bool LIN = !lin_cost_only(lm, mode, d.prm) && !store;
@@ -735,7 +737,6 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
   const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *bias = at_cand ? d.cbias : d.bias, *ldp = at_cand ? d.cld : d.ld;
   const int tg = lin_target(lm, mode);
   double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
-  extern __shared__ __attribute__((aligned(16))) double smd[];
   double *dx = smd;                 // [pn]
   __shared__ double red[256];
   const int tid = threadIdx.x;

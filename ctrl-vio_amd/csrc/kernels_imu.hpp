@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // One workgroup per WINDOW walking its groups (one per group was 43 k workgroups of 195 useful threads: dispatch-bound).
 // (a device function: k_misc runs it in front of the bias chain and the prior -- the two were separate launches of the same shape, one
 //  256-thread workgroup per window, each a chain of dependent loads followed by atomics)
-__device__ __forceinline__ void assemble_imu_window(const Dev &d, int mode, int w) {
+__device__ __forceinline__ void assemble_imu_window(const Dev &d, int mode, int w, double *band /* LDS [144 K] or null */) {
   if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
   const WinMeta &m = d.wins[w];
   const int K = m.K, ldh = m.ldh, tg = lin_target(d.lm[w], mode);
@@ -644,6 +644,54 @@ __device__ __forceinline__ void assemble_imu_window(const Dev &d, int mode, int 
       } else { a = t - 165; b = 30; }
       // (the tile is symmetric: the gradient column is read as row 30, next to the bias rows -- 7 consecutive rows of the tile instead of a
       //  cache line of every row)
+      const double v = (double)(b == 30 ? tile[30 * 32 + a] : tile[a * 32 + b]);
+      const int ga = imu_col(a, grp.s, K, grp.bias);
+      if (b == 30) { atomicAdd(&g[ga], v); continue; }
+      const int gb = imu_col(b, grp.s, K, grp.bias);
+      atomicAdd(&Hpp[(long long)max(ga, gb) * ldh + min(ga, gb)], v);
+    }
+    return;
+  }
+  // Windows whose packed Hessian does not fit in LDS (K > 24).  The 24 x 24 knot blocks of consecutive segments overlap in three of their four
+  // knots (and two groups of one segment coincide): added one by one with global atomics they cost 300 atomics per group -- config 5 (K = 64):
+  // 27 k per window, 0.45 ms per 512 windows.  They are summed first in an LDS BAND [K][4 knots][6][6] (a knot couples with itself and the three
+  // before it: 74 KB at K = 64) and every band entry goes out once; the bias rows and the gradient (195 per group) stay as they were.
+  if (band) {
+    const int nb = 144 * K;
+    for (int i = threadIdx.x; i < nb; i += 256) band[i] = 0.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 300 * m.ngrp; i += 256) {
+      const int gi = i / 300, t = i - 300 * gi;
+      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);     // t -> (a >= b), row-major over the lower triangle of 24 x 24
+      a += ((a + 1) * (a + 2) / 2 <= t) ? 1 : 0;
+      a -= (a * (a + 1) / 2 > t) ? 1 : 0;
+      const int b = t - a * (a + 1) / 2;
+      const ImuGroup grp = d.groups[m.grp0 + gi];
+      const double v = d.imu_tiles[(size_t)(m.grp0 + gi) * 1024 + a * 32 + b];
+      int ga = imu_col(a, grp.s, K, grp.bias), gb = imu_col(b, grp.s, K, grp.bias);
+      if (ga < gb) { const int tmp = ga; ga = gb; gb = tmp; }            // (local order [rot | pos]: a >= b does not order the unknowns)
+      const int k1 = ga / 6, k2 = gb / 6;
+      atomicAdd(&band[((k2 * 4 + (k1 - k2)) * 6 + (ga - 6 * k1)) * 6 + (gb - 6 * k2)], v);   // (every unordered local pair once)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 256) {
+      const double v = band[i];
+      if (v == 0.0) continue;
+      const int r2 = i % 6, r1 = (i / 6) % 6, dk = (i / 36) % 4, k2 = i / 144;
+      const int ga = 6 * (k2 + dk) + r1, gb = 6 * k2 + r2;
+      atomicAdd(&Hpp[(long long)ga * ldh + gb], v);
+    }
+    for (int i = threadIdx.x; i < 195 * m.ngrp; i += 256) {              // bias rows, bias block, gradient: as in the LDS-resident case above
+      const int gi = i / 195, t = i - 195 * gi;
+      const ImuGroup grp = d.groups[m.grp0 + gi];
+      const double *tile = d.imu_tiles + (size_t)(m.grp0 + gi) * 1024;
+      int a, b;
+      if (t < 144) { a = 24 + t / 24; b = t % 24; }
+      else if (t < 165) {
+        const int q = t - 144;
+        const int r = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : q < 10 ? 3 : q < 15 ? 4 : 5;
+        a = 24 + r; b = 24 + q - r * (r + 1) / 2;
+      } else { a = t - 165; b = 30; }
       const double v = (double)(b == 30 ? tile[30 * 32 + a] : tile[a * 32 + b]);
       const int ga = imu_col(a, grp.s, K, grp.bias);
       if (b == 30) { atomicAdd(&g[ga], v); continue; }
