@@ -643,6 +643,25 @@ def test_invalid_inputs(cv):
     with cv.Solver() as s:
         with pytest.raises(cv.capi.CtvioError, match="64 observations"):
             s.set_windows([big])
+        # what the sparsity plan needs from its inputs: finite observations, an ordered line-delay box ...
+        bad = w.copy(); bad.v_pj = bad.v_pj.copy(); bad.v_pj[3, 1] = np.nan
+        with pytest.raises(cv.capi.CtvioError, match="non-finite"):
+            s.set_windows([bad])
+        bad = w.copy(); bad.ld_lo, bad.ld_hi = 3.0e-5, 1.0e-5
+        with pytest.raises(cv.capi.CtvioError, match="ld_lo <= ld_hi"):
+            s.set_windows([bad])
+        # ... and a FIXED line delay stays what it was at upload (the landmarks' knot spans were planned for it); a free one is projected
+        fx = w.copy(); fx.fix_ld = True; fx.ld = 2.0e-5
+        s.set_windows([fx])
+        moved = fx.copy(); moved.ld = 2.5e-5
+        with pytest.raises(cv.capi.CtvioError, match="fix_ld"):
+            s.set_state(0, moved)
+        s.set_state(0, fx)                       # the same value: fine
+        fr = w.copy(); fr.ld = 1.0e-5
+        s.set_windows([fr])
+        out = fr.copy(); out.ld = 9.0e-5         # outside the box [0, 3.5e-5]: projected, as Ceres projects a bounded parameter
+        s.set_state(0, out)
+        assert s.get_state(0).ld == pytest.approx(fr.ld_hi)
 
 
 def test_full_size_properties(cv):
