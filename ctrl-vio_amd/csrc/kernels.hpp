@@ -67,47 +67,47 @@ __device__ __forceinline__ int vis_col(int c, int si, int sj, int P) {
 }
 
 __device__ __forceinline__ void load_knots(const double *quat, const double *pos, int k0, const double *origin,
-                                                            Knots4<double> &k) {
+                                                            Knots4 &k) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const double *q = quat + 4 * (k0 + i), *p = pos + 3 * (k0 + i);
-    k.q[i] = qmk<double>((double)q[0], (double)q[1], (double)q[2], (double)q[3]);
-    k.p[i] = mk<double>((double)(p[0] - origin[0]), (double)(p[1] - origin[1]), (double)(p[2] - origin[2]));
+    k.q[i] = qmk((double)q[0], (double)q[1], (double)q[2], (double)q[3]);
+    k.p[i] = mk((double)(p[0] - origin[0]), (double)(p[1] - origin[1]), (double)(p[2] - origin[2]));
   }
 }
 
 // Knots k0..k0+3 in the local frame of the reference knot `kref` (fp64 arithmetic, then cast):
 //   q'_k = q_ref^-1 q_k (near identity), p'_k = R_ref^T (p_k - p_ref).
 struct LocalFrame {
-  Q4<double> qref_inv;
-  M3<double> RT;      // R_ref^T
+  Q4 qref_inv;
+  M3 RT;      // R_ref^T
   double o[3];
   __device__ __forceinline__ void init(const double *quat, const double *pos, int kref) {
     const double *q = quat + 4 * kref, *p = pos + 3 * kref;
-    qref_inv = qmk<double>(-q[0], -q[1], -q[2], q[3]);
-    const M3<double> R = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
+    qref_inv = qmk(-q[0], -q[1], -q[2], q[3]);
+    const M3 R = q2R(qmk(q[0], q[1], q[2], q[3]));
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) RT.m[3 * i + j] = R.m[3 * j + i];
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
   }
-  __device__ __forceinline__ void load(const double *quat, const double *pos, int k0, Knots4<double> &k) const {
+  __device__ __forceinline__ void load(const double *quat, const double *pos, int k0, Knots4 &k) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const double *q = quat + 4 * (k0 + i), *p = pos + 3 * (k0 + i);
-      const Q4<double> ql = qmul_raw(qref_inv, qmk<double>(q[0], q[1], q[2], q[3]));   // unit x unit: no renormalisation in fp64
-      const V3<double> pl = mul(RT, mk<double>(p[0] - o[0], p[1] - o[1], p[2] - o[2]));
-      k.q[i] = qmk<double>((double)ql.x, (double)ql.y, (double)ql.z, (double)ql.w);
-      k.p[i] = mk<double>((double)pl.x, (double)pl.y, (double)pl.z);
+      const Q4 ql = qmul_raw(qref_inv, qmk(q[0], q[1], q[2], q[3]));   // unit x unit: no renormalisation in fp64
+      const V3 pl = mul(RT, mk(p[0] - o[0], p[1] - o[1], p[2] - o[2]));
+      k.q[i] = qmk((double)ql.x, (double)ql.y, (double)ql.z, (double)ql.w);
+      k.p[i] = mk((double)pl.x, (double)pl.y, (double)pl.z);
     }
   }
-  __device__ __forceinline__ V3<double> rotate(const double *v) const {  // R_ref^T v
-    const V3<double> r = mul(RT, mk<double>(v[0], v[1], v[2]));
-    return mk<double>((double)r.x, (double)r.y, (double)r.z);
+  __device__ __forceinline__ V3 rotate(const double *v) const {  // R_ref^T v
+    const V3 r = mul(RT, mk(v[0], v[1], v[2]));
+    return mk((double)r.x, (double)r.y, (double)r.z);
   }
-  __device__ __forceinline__ M3<double> RrefT() const {
-    M3<double> r;
+  __device__ __forceinline__ M3 RrefT() const {
+    M3 r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.m[i] = (double)RT.m[i];
     return r;

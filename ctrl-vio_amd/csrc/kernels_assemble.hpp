@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
       const double *x = prior_block_ptr(m, kind, idx, quat, pos, bias, ldp, w);
       const double *x0 = d.p_x0 + 4 * (size_t)(m.pblk0 + b);
       if (kind == 0) {  // dx = 2 vec(q0^-1 q), sign-fixed (marginalization_factor.cpp:344-350)
-        const Q4<double> dq = qmul_raw(qmk<double>(-x0[0], -x0[1], -x0[2], x0[3]), qmk<double>(x[0], x[1], x[2], x[3]));
+        const Q4 dq = qmul_raw(qmk(-x0[0], -x0[1], -x0[2], x0[3]), qmk(x[0], x[1], x[2], x[3]));
         const double sg = (dq.w >= 0) ? 2.0 : -2.0;
         dx[off] = sg * dq.x; dx[off + 1] = sg * dq.y; dx[off + 2] = sg * dq.z;
       } else {
@@ -814,8 +814,8 @@ __device__ __forceinline__ double grad_norm_entry(const Dev &d, const WinMeta &m
     const int k = j / 6, c = j % 6;
     if (c == 0) {  // rotation block: ambient difference q - q*exp(-g)
       const double *q = squat + 4 * (m.knot0 + k);
-      const Q4<double> q0 = qmk<double>(q[0], q[1], q[2], q[3]);
-      const Q4<double> q1 = qmul(q0, so3_exp(mk<double>(-g[j], -g[j + 1], -g[j + 2])));
+      const Q4 q0 = qmk(q[0], q[1], q[2], q[3]);
+      const Q4 q1 = qmul(q0, so3_exp(mk(-g[j], -g[j + 1], -g[j + 2])));
       return fmax(fmax(fabs(q0.x - q1.x), fabs(q0.y - q1.y)), fmax(fabs(q0.z - q1.z), fabs(q0.w - q1.w)));
     }
     return c >= 3 ? fabs(g[j]) : 0.0;

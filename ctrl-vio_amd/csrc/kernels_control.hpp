@@ -290,7 +290,7 @@ __global__ void k_knot_prep(Dev d) {
   const int w = d.knot_win[g];
   const WinMeta &m = d.wins[w];
   if (g - m.knot0 >= m.K - 1) return;   // the last knot of a window starts no pair
-  knot_pair_const<double>(d.quat + 4 * g, d.quat + 4 * g + 4, d.lkd + 3 * g, d.kjri + 9 * g);
+  knot_pair_const(d.quat + 4 * g, d.quat + 4 * g + 4, d.lkd + 3 * g, d.kjri + 9 * g);
 }
 
 }  // namespace ctv

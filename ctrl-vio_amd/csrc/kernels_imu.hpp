@@ -36,21 +36,21 @@ template <int CHUNK> __global__ __launch_bounds__(64) __attribute__((amdgpu_wave
   const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);
   const WinMeta &m = d.wins[w];
   const int lane = threadIdx.x;
-  Knots4<double> k;
+  Knots4 k;
   LocalFrame lf;
   const bool at_cand = mode == LIN_SPEC;
   double csum = 0.0;
   const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
   lf.init(s_quat, s_pos, m.knot0 + grp.s);
   lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
-  const M3<double> RrefT = lf.RrefT();
-  SegConst<double> sc;
+  const M3 RrefT = lf.RrefT();
+  SegConst sc;
   seg_const_load(d.lkd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc, true);
   double bias[6], wgt[6];
   const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { bias[i] = (double)bp[i]; wgt[i] = (double)m.imu_w[i]; }
-  const V3<double> grav = lf.rotate(m.gravity);
+  const V3 grav = lf.rotate(m.gravity);
   const double idt = (double)m.inv_dt;
   const int ti = lane >> 3, tj = lane & 7;
   double acc[4][4];
@@ -70,7 +70,7 @@ template <int CHUNK> __global__ __launch_bounds__(64) __attribute__((amdgpu_wave
     const int kmax = (6 * nval + 3) & ~3;
     ImuLdsSink sink{A, lane, KS};
     if (lane < nval) {
-      imu_eval<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, jac, sink);
+      imu_eval(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, jac, sink);
 #pragma unroll
       for (int i = 0; i < 6; ++i) csum += 0.5 * (double)(r[i] * r[i]);
       sink.put_col(30, r);
@@ -146,18 +146,18 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev &d, int mode, d
   const bool at_cand = mode == LIN_SPEC;
   double csum = 0.0;
   const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
-  Knots4<double> k;
+  Knots4 k;
   LocalFrame lf;
   lf.init(s_quat, s_pos, m.knot0 + grp.s);
   lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
-  const M3<double> RrefT = lf.RrefT();
-  SegConstLazy<double> sc;   // Jr^-1 of the three knot pairs: fetched from the table where it is used
+  const M3 RrefT = lf.RrefT();
+  SegConstLazy sc;   // Jr^-1 of the three knot pairs: fetched from the table where it is used
   seg_const_lazy(d.lkd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc);
   double bias[6], wgt[6];
   const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { bias[i] = bp[i]; wgt[i] = m.imu_w[i]; }
-  const V3<double> grav = lf.rotate(m.gravity);
+  const V3 grav = lf.rotate(m.gravity);
   const double idt = m.inv_dt;
   f64x4 acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = {0.0, 0.0, 0.0, 0.0}, acc11 = {0.0, 0.0, 0.0, 0.0}, gacc = {0.0, 0.0, 0.0, 0.0};
   const size_t Mt = (size_t)d.Mtot;
@@ -170,8 +170,8 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev &d, int mode, d
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
 #pragma unroll
       for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
-      ImuJac<double> J;
-      imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, false, J);
+      ImuJac J;
+      imu_eval_core(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, false, J);
 #pragma unroll
       for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
     }
@@ -193,15 +193,15 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev &d, int mode, d
 #pragma unroll
     for (int i = 0; i < 6; ++i) wl[i] = live ? wgt[i] : 0.0;
     const int kmax = (nval + 3) & ~3;
-    ImuJac<double> J;
-    imu_eval_core<double>(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, true, J);
+    ImuJac J;
+    imu_eval_core(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wl, RrefT, r, true, J);
 #pragma unroll
     for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
     // ---- accelerometer rows: 32 columns, tiles (0,0), (1,0), (1,1)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
       double row[32];
-      imu_row_accel<double>(J, wl, r, a, row);
+      imu_row_accel(J, wl, r, a, row);
       __builtin_amdgcn_wave_barrier();   // the previous phase's operand reads are complete (consumed by its MFMAs)
 #pragma unroll
       for (int c = 0; c < 32; ++c) A[lane * 33 + c] = row[c];
@@ -218,7 +218,7 @@ __device__ __forceinline__ void imu_linearize_f64_body(const Dev &d, int mode, d
 #pragma unroll
     for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static (a dynamic index would push ImuJac to scratch)
       double row[16];
-      imu_row_gyro<double>(J, wl, r, a, row);
+      imu_row_gyro(J, wl, r, a, row);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
@@ -377,10 +377,10 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev &d, int mode, d
   // the group's constants: knot-pair logs and Jr^-1 (used a dozen times per pass) in scalar registers, the rest (used once or twice per
   // pass) in LDS behind the row buffer -- [0..11] knot positions relative to knot 0, [12..20] R_0^T, [21..23] gravity, [24..29] bias,
   // [30..35] weights.  (All of them in scalar registers overflow the SGPR file: 250 v_readlane per pass to fetch them back.)
-  SegConstS<double> sc;
+  SegConstS sc;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    sc.d[i] = mk<double>(readlane_d(cur.pc, 3 * i), readlane_d(cur.pc, 3 * i + 1), readlane_d(cur.pc, 3 * i + 2));
+    sc.d[i] = mk(readlane_d(cur.pc, 3 * i), readlane_d(cur.pc, 3 * i + 1), readlane_d(cur.pc, 3 * i + 2));
 #pragma unroll
     for (int e = 0; e < 9; ++e) sc.JrI[i].m[e] = readlane_d(cur.pc, 9 + 9 * i + e);
   }
@@ -402,7 +402,7 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev &d, int mode, d
   double *gc = A + 72 * 33;   // (8 spare rows behind the 64: the chains' last prefetch)
   {
     double gcv = cur.kq;      // lanes 21..35: gravity, bias, weights as requested
-    const M3<double> R0 = q2R(qmk<double>(readlane_d(cur.kq, 0), readlane_d(cur.kq, 1), readlane_d(cur.kq, 2), readlane_d(cur.kq, 3)));
+    const M3 R0 = q2R(qmk(readlane_d(cur.kq, 0), readlane_d(cur.kq, 1), readlane_d(cur.kq, 2), readlane_d(cur.kq, 3)));
     const double pk = __shfl(cur.kq, 4 + min(lane, 11)), p0 = __shfl(cur.kq, 4 + min(lane, 11) % 3);
     if (lane < 12) gcv = pk - p0;
     else if (lane < 21) {   // R_0^T, row major (a select chain: no dynamically indexed register array)
@@ -426,8 +426,8 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev &d, int mode, d
       for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * Mt + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * Mt + idx]; }
 #pragma unroll
       for (int i = 0; i < 6; ++i) wl[i] = live ? gc[30 + i] : 0.0;
-      ImuMid3<double> md;
-      imu_eval_values3<double>(gc, sc, d.imu_u[idx], idt, gy, ac, wl, r, md);
+      ImuMid3 md;
+      imu_eval_values3(gc, sc, d.imu_u[idx], idt, gy, ac, wl, r, md);
 #pragma unroll
       for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];
     }
@@ -460,19 +460,19 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev &d, int mode, d
 #pragma unroll
     for (int i = 0; i < 6; ++i) wl[i] = live ? gc[30 + i] : 0.0;
     const int kmax = (nval + 3) & ~3;
-    ImuMid3<double> md;
-    imu_eval_values3<double>(gc, sc, u, idt, gy, ac, wl, r, md);
+    ImuMid3 md;
+    imu_eval_values3(gc, sc, u, idt, gy, ac, wl, r, md);
 #pragma unroll
     for (int i = 0; i < 6; ++i) csum += 0.5 * r[i] * r[i];   // (dead lanes: zero weights, zero residual)
     CTV_ISTAMP(csum);
     {
-      M3<double> Jw[4];
-      imu_jac_gyro3<double>(md, sc, Jw);
+      M3 Jw[4];
+      imu_jac_gyro3(md, sc, Jw);
       CTV_ISTAMP(Jw[3].m[8]);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {   // unrolled: the row index must be static
         double row[16];
-        imu_row_gyro2<double>(Jw, wl, r, a, row);
+        imu_row_gyro2(Jw, wl, r, a, row);
         __builtin_amdgcn_wave_barrier();   // the previous phase's operand reads are complete (consumed by its MFMAs)
 #pragma unroll
         for (int c = 0; c < 16; ++c) A[lane * 17 + c] = row[c];
@@ -483,8 +483,8 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev &d, int mode, d
     }
     CTV_ISTAMP(gacc[0]);
     {
-      M3<double> Ja[4], Rinv_g;
-      imu_jac_accel3<double>(md, sc, gc, Ja, Rinv_g);
+      M3 Ja[4], Rinv_g;
+      imu_jac_accel3(md, sc, gc, Ja, Rinv_g);
       CTV_ISTAMP(Ja[3].m[8] + Rinv_g.m[8]);
       {
         double la[4];
@@ -499,7 +499,7 @@ __device__ __forceinline__ void imu_linearize_f64_fast(const Dev &d, int mode, d
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         double row[28];
-        imu_row_accel3<double>(Ja, md.lamA, Rinv_g, wl, r, a, row);
+        imu_row_accel3(Ja, md.lamA, Rinv_g, wl, r, a, row);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = 0; c < 28; ++c) A[lane * 33 + c] = row[c];   // (columns 28..31 feed accumulator rows nobody reads)

@@ -16,9 +16,9 @@ __global__ void k_gauge_restore(Dev d, int n, const int32_t *ids, const int32_t 
   __shared__ double sh[16];   // Rd (9), td (3), qd (4)
   if (threadIdx.x == 0) {
     const double *qr = d.quat + 4 * (base + k0), *pr = d.pos + 3 * (base + k0);
-    const M3<double> R0 = q2R(qmk<double>(q0[4 * e], q0[4 * e + 1], q0[4 * e + 2], q0[4 * e + 3]));
-    const M3<double> R00 = q2R(qmk<double>(qr[0], qr[1], qr[2], qr[3]));
-    auto ypr = [](const M3<double> &R, double &y, double &p) {   // degrees
+    const M3 R0 = q2R(qmk(q0[4 * e], q0[4 * e + 1], q0[4 * e + 2], q0[4 * e + 3]));
+    const M3 R00 = q2R(qmk(qr[0], qr[1], qr[2], qr[3]));
+    auto ypr = [](const M3 &R, double &y, double &p) {   // degrees
       y = atan2(R.m[3], R.m[0]);
       p = atan2(-R.m[6], R.m[0] * cos(y) + R.m[3] * sin(y)) / 3.14159265358979323846 * 180.0;
       y = y / 3.14159265358979323846 * 180.0;
@@ -26,13 +26,13 @@ __global__ void k_gauge_restore(Dev d, int n, const int32_t *ids, const int32_t 
     double y0, p0, y00, p00;
     ypr(R0, y0, p0);
     ypr(R00, y00, p00);
-    M3<double> Rd;
+    M3 Rd;
     if (fabs(fabs(p0) - 90.0) < 1.0 || fabs(fabs(p00) - 90.0) < 1.0) {   // Euler singularity: R0 R00^T
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) Rd.m[3 * i + j] = R0.m[3 * i] * R00.m[3 * j] + R0.m[3 * i + 1] * R00.m[3 * j + 1] + R0.m[3 * i + 2] * R00.m[3 * j + 2];
     } else {
       const double y = (y0 - y00) / 180.0 * 3.14159265358979323846;
-      Rd = m3_id<double>();
+      Rd = m3_id();
       Rd.m[0] = cos(y); Rd.m[1] = -sin(y); Rd.m[3] = sin(y); Rd.m[4] = cos(y);
     }
     for (int i = 0; i < 9; ++i) sh[i] = Rd.m[i];
@@ -77,18 +77,18 @@ __global__ __launch_bounds__(256) void k_residual_summary(Dev d, int w, double *
   for (int i = tid; i < m.M; i += 256) {
     const int idx = m.imu0 + i;
     const ImuGroup grp = d.groups[d.imu_grp[idx]];
-    Knots4<double> k;
+    Knots4 k;
     LocalFrame lf;
     lf.init(d.quat, d.pos, m.knot0 + grp.s);
     lf.load(d.quat, d.pos, m.knot0 + grp.s, k);
-    SegConst<double> sc;
+    SegConst sc;
     seg_const(k, sc, false);
     double b[6], wgt[6], gy[3], ac[3], r[6];
     const double *bp = d.bias + 6 * (m.bias0 + grp.bias);
     for (int c = 0; c < 6; ++c) { b[c] = bp[c]; wgt[c] = m.imu_w[c]; }
     for (int c = 0; c < 3; ++c) { gy[c] = (double)d.imu_meas[(size_t)c * d.Mtot + idx]; ac[c] = (double)d.imu_meas[(size_t)(3 + c) * d.Mtot + idx]; }
-    ImuJac<double> J;
-    imu_eval_core<double>(k, sc, (double)d.imu_u[idx], m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, J);
+    ImuJac J;
+    imu_eval_core(k, sc, (double)d.imu_u[idx], m.inv_dt, lf.rotate(m.gravity), b, gy, ac, wgt, lf.RrefT(), r, false, J);
     for (int c = 0; c < 6; ++c) atomicAdd(&sums[c], fabs(r[c]));
   }
   for (int e = tid; e < m.NB * 6; e += 256) {
@@ -110,17 +110,17 @@ __global__ __launch_bounds__(256) void k_residual_summary(Dev d, int w, double *
     vis_times(m, d.a_t[a], rowi, ld, si, ui);
     vis_times(m, d.v_tj[v], rowj, ld, sj, uj);
     si = max(0, min(si, m.K - 4)); sj = max(0, min(sj, m.K - 4));
-    Knots4<double> gi, gj;
+    Knots4 gi, gj;
     const double z3[3] = {0, 0, 0};
     load_knots(d.quat, d.pos, m.knot0 + si, z3, gi);
     load_knots(d.quat, d.pos, m.knot0 + sj, z3, gj);
-    SegConst<double> sci, scj;
+    SegConst sci, scj;
     seg_const(gi, sci, false);
     seg_const(gj, scj, false);
-    const Q4<double> q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
-    const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
-    const M3<double> R = q2R(q_CI);
-    M3<double> RCIT;
+    const Q4 q_CI = qmk(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
+    const V3 p_CI = mk(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+    const M3 R = q2R(q_CI);
+    M3 RCIT;
     for (int aa = 0; aa < 3; ++aa) for (int bb = 0; bb < 3; ++bb) RCIT.m[3 * aa + bb] = R.m[3 * bb + aa];
     double rec[AREC], r[2];
     vis_anchor_eval<false>(gi.q[0], gi.p, sci, ui, m.inv_dt, q_CI, p_CI, d.a_obs[a], d.a_obs[(size_t)d.Atot + a], (double)rowi,
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_residual_summary(Dev d, int w, double *
       const double *x = prior_block_ptr(m, kind, idx, d.quat, d.pos, d.bias, d.ld, w);
       const double *x0 = d.p_x0 + 4 * (size_t)(m.pblk0 + b);
       if (kind == 0) {
-        const Q4<double> dq = qmul_raw(qmk<double>(-x0[0], -x0[1], -x0[2], x0[3]), qmk<double>(x[0], x[1], x[2], x[3]));
+        const Q4 dq = qmul_raw(qmk(-x0[0], -x0[1], -x0[2], x0[3]), qmk(x[0], x[1], x[2], x[3]));
         const double sg = (dq.w >= 0) ? 2.0 : -2.0;
         dx[off] = sg * dq.x; dx[off + 1] = sg * dq.y; dx[off + 2] = sg * dq.z;
       } else {
@@ -171,40 +171,40 @@ __global__ void k_spline_eval(Dev d, int w, const int32_t *win_ids, int n, const
   if (st < 0 || s < 0 || s + 3 >= m.K) { atomicExch(err, 1); return; }
   const double u = (double)(st % m.dt_ns) / (double)m.dt_ns;
   const double zero3[3] = {0, 0, 0};
-  Knots4<double> k;
+  Knots4 k;
   load_knots(d.quat, d.pos, m.knot0 + s, zero3, k);
-  SegConst<double> sc;
+  SegConst sc;
   seg_const(k, sc, false);
   const double idt = m.inv_dt;
   if (pose7) {
     double c[4];
-    basis<double, false, 0>(u, 1.0, c);
-    V3<double> p = mk<double>(0, 0, 0);
+    basis<false, 0>(u, 1.0, c);
+    V3 p = mk(0, 0, 0);
     for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
-    Q4<double> q = eval_R(k.q, sc, u);
+    Q4 q = eval_R(k.q, sc, u);
     if (ext.on) {   // Trajectory::GetSensorPose (trajectory.cpp:39-56): pose_S_to_G = pose_I_to_G * T_StoI
-      p = p + qrot(q, mk<double>(ext.p[0], ext.p[1], ext.p[2]));
-      q = qmul(q, qmk<double>(ext.q[0], ext.q[1], ext.q[2], ext.q[3]));
+      p = p + qrot(q, mk(ext.p[0], ext.p[1], ext.p[2]));
+      q = qmul(q, qmk(ext.q[0], ext.q[1], ext.q[2], ext.q[3]));
     }
     double *o = pose7 + 7 * (size_t)i;
     o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
   }
   if (vel3) {
     double c[4];
-    basis<double, false, 1>(u, idt, c);
-    V3<double> p = mk<double>(0, 0, 0);
+    basis<false, 1>(u, idt, c);
+    V3 p = mk(0, 0, 0);
     for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
     vel3[3 * (size_t)i] = p.x; vel3[3 * (size_t)i + 1] = p.y; vel3[3 * (size_t)i + 2] = p.z;
   }
   if (acc3) {
     double c[4];
-    basis<double, false, 2>(u, idt * idt, c);
-    V3<double> p = mk<double>(0, 0, 0);
+    basis<false, 2>(u, idt * idt, c);
+    V3 p = mk(0, 0, 0);
     for (int j = 0; j < 4; ++j) p = p + c[j] * k.p[j];
     acc3[3 * (size_t)i] = p.x; acc3[3 * (size_t)i + 1] = p.y; acc3[3 * (size_t)i + 2] = p.z;
   }
   if (omega3) {
-    const V3<double> o = eval_omega(sc, u, idt);
+    const V3 o = eval_omega(sc, u, idt);
     omega3[3 * (size_t)i] = o.x; omega3[3 * (size_t)i + 1] = o.y; omega3[3 * (size_t)i + 2] = o.z;
   }
 }

@@ -1364,9 +1364,9 @@ template <int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev
       if (t < m.K) {
         const int gk = m.knot0 + t;
         const bool ar = act[6 * t] != 0, ap = act[6 * t + 3] != 0;
-        const Q4<double> q0 = qmk<double>(d.quat[4 * gk], d.quat[4 * gk + 1], d.quat[4 * gk + 2], d.quat[4 * gk + 3]);
-        Q4<double> q1 = q0;
-        if (ar) q1 = qmul(q0, so3_exp(mk<double>(al * dl[6 * t], al * dl[6 * t + 1], al * dl[6 * t + 2])));
+        const Q4 q0 = qmk(d.quat[4 * gk], d.quat[4 * gk + 1], d.quat[4 * gk + 2], d.quat[4 * gk + 3]);
+        Q4 q1 = q0;
+        if (ar) q1 = qmul(q0, so3_exp(mk(al * dl[6 * t], al * dl[6 * t + 1], al * dl[6 * t + 2])));
         d.cquat[4 * gk] = q1.x; d.cquat[4 * gk + 1] = q1.y; d.cquat[4 * gk + 2] = q1.z; d.cquat[4 * gk + 3] = q1.w;
         if (ar) {
           step2 += (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) + (q1.z - q0.z) * (q1.z - q0.z) + (q1.w - q0.w) * (q1.w - q0.w);
@@ -1415,7 +1415,7 @@ template <int NWV> __global__ __launch_bounds__(64 * NWV) void k_step_finish(Dev
   // ---- knot-pair constants of the candidate (shared by all residual blocks of the linearisation that follows)
   for (int t = tid; t < m.K - 1; t += NT) {
     const int gk = m.knot0 + t;
-    knot_pair_const<double>(d.cquat + 4 * gk, d.cquat + 4 * gk + 4, d.lkd + 3 * gk, d.kjri + 9 * gk);
+    knot_pair_const(d.cquat + 4 * gk, d.cquat + 4 * gk + 4, d.lkd + 3 * gk, d.kjri + 9 * gk);
   }
 }
 

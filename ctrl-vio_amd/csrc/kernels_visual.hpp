@@ -55,19 +55,19 @@ __global__ __launch_bounds__(64) void k_vis_anchor(Dev d, int mode) {
   const int rowi = d.a_row[a];
   vis_times(m, d.a_t[a], rowi, ldp[w], si, ui);
   si = max(0, min(si, m.K - 4));   // host validated the worst case; clamp keeps loads in range regardless
-  SegConstLazy<double> sc;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+  SegConstLazy sc;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
   seg_const_lazy(d.lkd + 3 * (m.knot0 + si), d.kjri + 9 * (m.knot0 + si), sc);
   double dmax = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) dmax = fmax(dmax, dot(sc.d[i], sc.d[i]));
   const bool small = __ballot(dmax >= 0.25) == 0ull;
   const double *qi = quat + 4 * (m.knot0 + si), *pi = pos + 3 * (m.knot0 + si);
-  const Q4<double> q0 = qmk<double>(qi[0], qi[1], qi[2], qi[3]);
-  V3<double> p[4];
+  const Q4 q0 = qmk(qi[0], qi[1], qi[2], qi[3]);
+  V3 p[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = mk<double>(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]);
-  const Q4<double> q_CI = qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
-  const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+  for (int i = 0; i < 4; ++i) p[i] = mk(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]);
+  const Q4 q_CI = qmk(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]);
+  const V3 p_CI = mk(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
   double *rec = srec + AREC_LD * threadIdx.x;
   if (!jac)                                    // (a costed record carries p_G alone; the rest goes out as zeros, not as stale LDS)
     for (int e = 0; e < AREC; ++e) rec[e] = 0.0;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
       const int rowj = d.v_rowj[v];
       vis_times(m, d.v_tj[v], rowj, ldp[w], sj, uj);
       sj = max(0, min(sj, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
-      SegConstLazy<double> scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
+      SegConstLazy scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
       seg_const_lazy(d.lkd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
       // The usual wave: every knot-pair log of its blocks below 0.5 rad -> series-only evaluation (uniform choice: a ballot over the
       // running lanes); otherwise the general form.  Global frame, absolute positions (fp64).
@@ -141,21 +141,21 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
       for (int i = 0; i < 3; ++i) dmax = fmax(dmax, dot(scj.d[i], scj.d[i]));
       const bool small = __ballot(dmax >= 0.25) == 0ull;
       const double *qj = quat + 4 * (m.knot0 + sj), *pj = pos + 3 * (m.knot0 + sj);
-      const Q4<double> q0 = qmk<double>(qj[0], qj[1], qj[2], qj[3]);
-      V3<double> p[4];
+      const Q4 q0 = qmk(qj[0], qj[1], qj[2], qj[3]);
+      V3 p[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = mk<double>(pj[3 * i], pj[3 * i + 1], pj[3 * i + 2]);
+      for (int i = 0; i < 4; ++i) p[i] = mk(pj[3 * i], pj[3 * i + 1], pj[3 * i + 2]);
       const int anc = d.v_anc[v];
       const double *rec = reinterpret_cast<const double *>(__builtin_assume_aligned(d.arec + (size_t)anc * AREC, 16));
-      M3<double> RCIT;
+      M3 RCIT;
       {
-        const M3<double> R = q2R(qmk<double>(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]));
+        const M3 R = q2R(qmk(m.q_CI[0], m.q_CI[1], m.q_CI[2], m.q_CI[3]));
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int b = 0; b < 3; ++b) RCIT.m[3 * a + b] = R.m[3 * b + a];
       }
-      const V3<double> p_CI = mk<double>(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
+      const V3 p_CI = mk(m.p_CI[0], m.p_CI[1], m.p_CI[2]);
       const double pjx = d.v_obs[v], pjy = d.v_obs[(size_t)d.Vtot + v], ca = d.v_cauchy[v];
       double r[2];
       if (jac) {

@@ -8,9 +8,9 @@ using namespace ctv;
 constexpr int VT_ROWS_HOST = 40;   // = device_types.hpp: VT_ROWS (entries of a block record)
 
 namespace {
-template <class T> struct ImuSink {
-  T *J;
-  void put_col(int col, const T v[6]) { for (int r = 0; r < 6; ++r) J[r * 30 + col] = v[r]; }
+struct ImuSink {
+  double *J;
+  void put_col(int col, const double v[6]) { for (int r = 0; r < 6; ++r) J[r * 30 + col] = v[r]; }
 };
 struct RecSink {
   double *e;
@@ -18,44 +18,44 @@ struct RecSink {
 };
 
 // local frame of the reference knot (q_ref, p_ref): the same preparation the kernels do (LocalFrame in kernels.hpp)
-template <class T> struct HostLocalFrame {
-  Q4<double> qi; M3<double> RT; double o[3];
+struct HostLocalFrame {
+  Q4 qi; M3 RT; double o[3];
   HostLocalFrame(const double *q, const double *p) {
-    qi = qmk<double>(-q[0], -q[1], -q[2], q[3]);
-    const M3<double> R = q2R(qmk<double>(q[0], q[1], q[2], q[3]));
+    qi = qmk(-q[0], -q[1], -q[2], q[3]);
+    const M3 R = q2R(qmk(q[0], q[1], q[2], q[3]));
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RT.m[3 * i + j] = R.m[3 * j + i];
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
   }
-  void load(const double *q, const double *p, Knots4<T> &k) const {
+  void load(const double *q, const double *p, Knots4 &k) const {
     for (int i = 0; i < 4; ++i) {
-      const Q4<double> ql = qmul(qi, qmk<double>(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]));
-      const V3<double> pl = mul(RT, mk<double>(p[3 * i] - o[0], p[3 * i + 1] - o[1], p[3 * i + 2] - o[2]));
-      k.q[i] = qmk<T>((T)ql.x, (T)ql.y, (T)ql.z, (T)ql.w);
-      k.p[i] = mk<T>((T)pl.x, (T)pl.y, (T)pl.z);
+      const Q4 ql = qmul(qi, qmk(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]));
+      const V3 pl = mul(RT, mk(p[3 * i] - o[0], p[3 * i + 1] - o[1], p[3 * i + 2] - o[2]));
+      k.q[i] = qmk(ql.x, ql.y, ql.z, ql.w);
+      k.p[i] = mk(pl.x, pl.y, pl.z);
     }
   }
-  M3<T> RrefT() const { M3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = (T)RT.m[i]; return r; }
-  V3<T> rotate(const double *v) const { const V3<double> r = mul(RT, mk<double>(v[0], v[1], v[2])); return mk<T>((T)r.x, (T)r.y, (T)r.z); }
+  M3 RrefT() const { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = RT.m[i]; return r; }
+  V3 rotate(const double *v) const { const V3 r = mul(RT, mk(v[0], v[1], v[2])); return mk(r.x, r.y, r.z); }
 };
 
-template <class T>
+
 void imu_eval_t(const double *q, const double *p, double u, double idt, const double *g, const double *bias,
                 const double *gyro, const double *acc, const double *w, double *r, double *J) {
-  Knots4<T> k;
-  HostLocalFrame<T> lf(q, p);
+  Knots4 k;
+  HostLocalFrame lf(q, p);
   lf.load(q, p, k);
-  SegConst<T> sc;   // as on the device: pair constants from the fp64 table (k_knot_prep)
+  SegConst sc;   // as on the device: pair constants from the fp64 table (k_knot_prep)
   {
-    double dt[9]; T jt[27];
-    for (int i = 0; i < 3; ++i) knot_pair_const<T>(q + 4 * i, q + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    double dt[9]; double jt[27];
+    for (int i = 0; i < 3; ++i) knot_pair_const(q + 4 * i, q + 4 * i + 4, dt + 3 * i, jt + 9 * i);
     seg_const_load(dt, jt, sc, true);
   }
-  T b[6], gy[3], ac[3], ww[6], rr[6], JJ[180];
-  for (int i = 0; i < 6; ++i) { b[i] = (T)bias[i]; ww[i] = (T)w[i]; }
-  for (int i = 0; i < 3; ++i) { gy[i] = (T)gyro[i]; ac[i] = (T)acc[i]; }
+  double b[6], gy[3], ac[3], ww[6], rr[6], JJ[180];
+  for (int i = 0; i < 6; ++i) { b[i] = bias[i]; ww[i] = w[i]; }
+  for (int i = 0; i < 3; ++i) { gy[i] = gyro[i]; ac[i] = acc[i]; }
   for (int i = 0; i < 180; ++i) JJ[i] = 0;
-  ImuSink<T> sink{JJ};
-  imu_eval<T>(k, sc, (T)u, (T)idt, lf.rotate(g), b, gy, ac, ww, lf.RrefT(), rr, true, sink);
+  ImuSink sink{JJ};
+  imu_eval(k, sc, u, idt, lf.rotate(g), b, gy, ac, ww, lf.RrefT(), rr, true, sink);
   for (int i = 0; i < 6; ++i) r[i] = rr[i];
   for (int i = 0; i < 180; ++i) J[i] = JJ[i];
 }
@@ -67,27 +67,27 @@ template <bool SMALL>
 double visual_eval_t(const double *qi, const double *pi, const double *qj, const double *pj, double ui, double uj,
                      double idt, const double *q_CI, const double *p_CI, double img_w, double cauchy_a, const double *obs,
                      double rowi, double rowj, double d_inv, double *r, double *J) {
-  SegConst<double> sci, scj;   // as on the device: pair constants from the fp64 table (k_knot_prep)
+  SegConst sci, scj;   // as on the device: pair constants from the fp64 table (k_knot_prep)
   {
     double dt[9], jt[27];
-    for (int i = 0; i < 3; ++i) knot_pair_const<double>(qi + 4 * i, qi + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    for (int i = 0; i < 3; ++i) knot_pair_const(qi + 4 * i, qi + 4 * i + 4, dt + 3 * i, jt + 9 * i);
     seg_const_load(dt, jt, sci, true);
-    for (int i = 0; i < 3; ++i) knot_pair_const<double>(qj + 4 * i, qj + 4 * i + 4, dt + 3 * i, jt + 9 * i);
+    for (int i = 0; i < 3; ++i) knot_pair_const(qj + 4 * i, qj + 4 * i + 4, dt + 3 * i, jt + 9 * i);
     seg_const_load(dt, jt, scj, true);
   }
-  V3<double> Pi[4], Pj[4];
-  for (int i = 0; i < 4; ++i) { Pi[i] = mk<double>(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]); Pj[i] = mk<double>(pj[3 * i], pj[3 * i + 1], pj[3 * i + 2]); }
-  const Q4<double> qci = qmk<double>(q_CI[0], q_CI[1], q_CI[2], q_CI[3]);
-  const V3<double> pci = mk<double>(p_CI[0], p_CI[1], p_CI[2]);
+  V3 Pi[4], Pj[4];
+  for (int i = 0; i < 4; ++i) { Pi[i] = mk(pi[3 * i], pi[3 * i + 1], pi[3 * i + 2]); Pj[i] = mk(pj[3 * i], pj[3 * i + 1], pj[3 * i + 2]); }
+  const Q4 qci = qmk(q_CI[0], q_CI[1], q_CI[2], q_CI[3]);
+  const V3 pci = mk(p_CI[0], p_CI[1], p_CI[2]);
   double rec[AREC];
-  vis_anchor_eval<SMALL>(qmk<double>(qi[0], qi[1], qi[2], qi[3]), Pi, sci, ui, idt, qci, pci, obs[0], obs[1], rowi, d_inv, true, rec);
-  const M3<double> R = q2R(qci);
-  M3<double> RCIT;
+  vis_anchor_eval<SMALL>(qmk(qi[0], qi[1], qi[2], qi[3]), Pi, sci, ui, idt, qci, pci, obs[0], obs[1], rowi, d_inv, true, rec);
+  const M3 R = q2R(qci);
+  M3 RCIT;
   for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) RCIT.m[3 * a + b] = R.m[3 * b + a];
   double blk[VT_ROWS_HOST];
   for (int i = 0; i < VT_ROWS_HOST; ++i) blk[i] = 0;
   RecSink sink{blk};
-  const double cost = vis_block_eval<SMALL>(rec, qmk<double>(qj[0], qj[1], qj[2], qj[3]), Pj, scj, uj, idt, RCIT, pci, img_w, cauchy_a, obs[2], obs[3],
+  const double cost = vis_block_eval<SMALL>(rec, qmk(qj[0], qj[1], qj[2], qj[3]), Pj, scj, uj, idt, RCIT, pci, img_w, cauchy_a, obs[2], obs[3],
                                             rowj, r, true, sink);
   for (int rr = 0; rr < 2; ++rr) {
     double *Jr = J + 50 * rr;
@@ -108,7 +108,7 @@ double visual_eval_t(const double *qi, const double *pi, const double *qj, const
 extern "C" {
 void hm_imu_eval(const double *q, const double *p, double u, double idt, const double *g, const double *bias,
                  const double *gyro, const double *acc, const double *w, double *r, double *J) {
-  imu_eval_t<double>(q, p, u, idt, g, bias, gyro, acc, w, r, J);
+  imu_eval_t(q, p, u, idt, g, bias, gyro, acc, w, r, J);
 }
 double hm_visual_eval(int small_angle, const double *qi, const double *pi, const double *qj, const double *pj, double ui, double uj,
                       double idt, const double *q_CI, const double *p_CI, double img_w, double cauchy_a, const double *obs,
@@ -117,12 +117,12 @@ double hm_visual_eval(int small_angle, const double *qi, const double *pi, const
   return visual_eval_t<false>(qi, pi, qj, pj, ui, uj, idt, q_CI, p_CI, img_w, cauchy_a, obs, rowi, rowj, d_inv, r, J);
 }
 void hm_so3(const double *phi, double *exp_q, double *Jr, double *JrInv, double *log_of_exp) {
-  V3<double> v = mk<double>(phi[0], phi[1], phi[2]);
-  Q4<double> q = so3_exp(v);
+  V3 v = mk(phi[0], phi[1], phi[2]);
+  Q4 q = so3_exp(v);
   exp_q[0] = q.x; exp_q[1] = q.y; exp_q[2] = q.z; exp_q[3] = q.w;
-  M3<double> a = so3_Jr(v), b = so3_Jr_inv(v);
+  M3 a = so3_Jr(v), b = so3_Jr_inv(v);
   for (int i = 0; i < 9; ++i) { Jr[i] = a.m[i]; JrInv[i] = b.m[i]; }
-  V3<double> l = so3_log(q);
+  V3 l = so3_log(q);
   log_of_exp[0] = l.x; log_of_exp[1] = l.y; log_of_exp[2] = l.z;
 }
 }
