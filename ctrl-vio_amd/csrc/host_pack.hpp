@@ -92,7 +92,8 @@ inline bool validate_window(const ctvio_window *w, std::string &err) {
   if (w->K < 4 || w->F < 1 || w->L < 0 || w->M < 0 || w->NB < 0 || w->V < 0 || w->dt_ns <= 0 || w->pn < 0 || w->pnb < 0)
     return bad("bad sizes (need K >= 4, F >= 1, dt_ns > 0)");
   if (!w->quat || !w->pos || !w->bias || (w->L && !w->rho)) return bad("null state pointer");
-  if (!w->fix_ld && !(w->ld_lo <= w->ld_hi)) return bad("line-delay bounds: need ld_lo <= ld_hi");
+  if (!std::isfinite(w->ld)) return bad("non-finite line delay");
+  if (!w->fix_ld && !(w->ld_lo <= w->ld_hi && std::isfinite(w->ld_lo) && std::isfinite(w->ld_hi))) return bad("line-delay bounds: need finite ld_lo <= ld_hi");
   if (w->M && (!w->imu_t || !w->imu_gyro || !w->imu_acc || !w->imu_bias)) return bad("null IMU pointer");
   if (w->NB && (!w->bc_i || !w->bc_j || !w->bc_w)) return bad("null bias-chain pointer");
   if (w->V && (!w->v_lm || !w->v_ti || !w->v_tj || !w->v_rowi || !w->v_rowj || !w->v_pi || !w->v_pj)) return bad("null visual pointer");
