@@ -103,11 +103,13 @@ inline bool validate_window(const ctvio_window *w, std::string &err) {
     if (w->imu_bias[m] < 0 || w->imu_bias[m] >= w->F) return bad("IMU bias index out of range");
   }
   const int64_t ldmax_ns = (int64_t)((w->fix_ld ? w->ld : std::max(w->ld, w->ld_hi)) * 1e9);
+  const int64_t ldmin_ns = (int64_t)((w->fix_ld ? w->ld : std::min(w->ld, w->ld_lo)) * 1e9);
   for (int v = 0; v < w->V; ++v) {
     if (w->v_lm[v] < 0 || w->v_lm[v] >= w->L) return bad("visual landmark index out of range");
     if (w->v_rowi[v] < 0 || w->v_rowj[v] < 0) return bad("negative image row");
     const int64_t a = w->v_ti[v], b = w->v_tj[v];
-    if (a < w->t0_ns || b < w->t0_ns || a + w->v_rowi[v] * ldmax_ns >= tmax || b + w->v_rowj[v] * ldmax_ns >= tmax)
+    if (a < w->t0_ns || b < w->t0_ns || a + w->v_rowi[v] * ldmax_ns >= tmax || b + w->v_rowj[v] * ldmax_ns >= tmax ||
+        a + w->v_rowi[v] * ldmin_ns < w->t0_ns || b + w->v_rowj[v] * ldmin_ns < w->t0_ns)     // (a negative lower bound of the line delay)
       return bad("visual time (+ row * line delay) outside the spline");
     if (!std::isfinite(w->v_pi[2 * v]) || !std::isfinite(w->v_pi[2 * v + 1]) || !std::isfinite(w->v_pj[2 * v]) || !std::isfinite(w->v_pj[2 * v + 1]))
       return bad("non-finite visual observation");
