@@ -157,3 +157,22 @@ def test_equal_batches_capture_the_pass_once(cv):
         s.set_windows([base[i % 4].copy() for i in range(8)])      # another shape: one more capture
         s.solve(4)
         assert s.graph_captures == 2
+
+
+@pytest.mark.parametrize("n", [4, 200])
+def test_small_windows_through_the_envelope_panel_kernel(cv, oracle_solved, monkeypatch, n):
+    """CTVIO_CHOL_TILES=0 sends P = 211 windows -- whose register-resident factorisation keeps the whole triangle -- through the panel kernel
+    INSIDE their (non-trivial: 93 of 105 tiles) envelopes, with the tile Schur kernels leaving everything outside it unformed: config 2 and
+    config 3 seeds against the oracle, as a small batch and as a large one."""
+    monkeypatch.setenv("CTVIO_CHOL_TILES", "0")
+    cases = [("config2", 1000), ("config2", 1001), ("config3", 1000), ("config3", 1001)]
+    refs, sms_o = zip(*[oracle_solved(c, s) for c, s in cases])
+    with cv.Solver() as s:
+        batch = [cv.synth.make_window(*cases[i % 4][:1], seed=cases[i % 4][1]) for i in range(n)]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    for i, sm in enumerate(sms):
+        so = sms_o[i % 4]
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), i
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        assert cv.rel_state_error(batch[i], refs[i % 4])["state"] < 1e-6, i
