@@ -75,8 +75,11 @@ def lm_fixtures():
 
 # ---- fixtures at the sizes that are BENCHMARKED (round-3 verdict: the independent fixtures stopped at tiny / config-1 size)
 BENCH_FD = (("fd_config2_seed1000", "config2", 1000), ("fd_config3_seed1001", "config3", 1001))
-BENCH_LM = (("lm_config2_seed1002", "config2", 1002), ("lm_config3_seed1003", "config3", 1003),
-            ("lm_config3_seed1006", "config3", 1006))     # seed 1006: six steps shortened by the line search and one unsuccessful step
+BENCH_LM = (("lm_config2_seed1002", "config2", 1002, {}), ("lm_config3_seed1003", "config3", 1003, {}),
+            ("lm_config3_seed1006", "config3", 1006, {}),     # seed 1006: six steps shortened by the line search and one unsuccessful step
+            # round 5: a LONG window (16 frames, K = 34, P = 301) -- the shape the envelope panel Cholesky factors (its reduced system is far
+            # from dense); the independent loop solves the full un-eliminated system with numpy.linalg.solve: no sparsity anywhere
+            ("lm_long_k34_seed1400", "config1", 1400, dict(F=16, L=60, M=750)))
 
 
 def bench_size_fd():
@@ -100,10 +103,10 @@ def bench_size_lm():
     """(f) LM histories of the independent loop restatement (np_ceres) at config-2 and config-3 size."""
     import np_ceres
     import pyctvo
-    for name, cfg, seed in BENCH_LM:
+    for name, cfg, seed, kw in BENCH_LM:
         if len(sys.argv) > 2 and name not in sys.argv[2:]:
             continue
-        w0 = cv.synth.make_window(cfg, seed=seed)
+        w0 = cv.synth.make_window(cfg, seed=seed, **kw)
         active = pyctvo.OracleWindow(w0.copy()).active_mask()
         wf, h = np_ceres.solve(w0, active, 15)
         d = w0.to_dict("w_")

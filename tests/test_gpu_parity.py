@@ -955,7 +955,8 @@ def test_per_block_cauchy_and_non_prefix_constant_knots(cv, oracle):
 
 
 @pytest.mark.parametrize("name", ["lm_tiny_seed7", "lm_tiny_rs_seed3020", "lm_tiny_rs_seed3028", "lm_config1_seed1001",
-                                  "lm_config2_seed1002", "lm_config3_seed1003", "lm_config3_seed1006"])
+                                  "lm_config2_seed1002", "lm_config3_seed1003", "lm_config3_seed1006",
+                                  "lm_long_k34_seed1400"])       # (P = 301: tile Schur kernels inside the envelope + envelope panel Cholesky)
 def test_hip_path_reproduces_the_independent_lm_history(cv, golden_dir, name):
     """The device-resident LM (trust region + projected Armijo line search, speculative linearisation) against the committed
     per-iteration fixtures of the independent NumPy restatement of Ceres 1.14's loop (oracle/np_ceres.py, FD Jacobians): the same
