@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctvio.so")
+LIB_PATH = os.environ.get("CTVIO_LIB_PATH") or os.path.join(_HERE, "libctvio.so")   # (CTVIO_LIB_PATH: another build of the same source -- compiler-flag A/B runs)
 import glob
 SRC = [os.path.join(_HERE, "csrc", "ctvio.hip")] + sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")))   # every header is a dependency
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctvio.h")
