@@ -275,7 +275,7 @@ class SolverImpl : public SolverBase {
     const size_t o_imu_u = seg(sizeof(double) * Mt), o_imu_meas = seg(sizeof(double) * 6 * Mt);
     const size_t o_v_win = seg(4 * Vt), o_v_lm = seg(4 * Vt), o_v_anc = seg(4 * Vt), o_v_rowj = seg(4 * Vt);
     const size_t o_v_tj = seg(8 * Vt), o_v_obs = seg(sizeof(double) * 2 * Vt);
-    const size_t o_v_cauchy = seg(8 * Vt);
+    const size_t o_v_cauchy = seg(8 * Vt), o_vb_win = seg(4 * (Vt / 64 + 1));
     const size_t o_a_win = seg(4 * At), o_a_lm = seg(4 * At), o_a_row = seg(4 * At), o_a_t = seg(8 * At), o_a_obs = seg(8 * 2 * At);
     const size_t o_vitems = seg(sizeof(VisItem) * (size_t)std::max(I0, 1)), o_vblk = seg(4 * Vt), o_vblk_anc = seg(4 * Vt);
     const size_t o_bc_win = seg(4 * (size_t)B0), o_bc_i = seg(4 * (size_t)B0), o_bc_j = seg(4 * (size_t)B0), o_bc_w = seg(8 * 6 * (size_t)B0);
@@ -301,6 +301,7 @@ class SolverImpl : public SolverBase {
     int32_t *h_imu_grp = CTV_H(int32_t, o_imu_grp);
     double *h_imu_u = CTV_H(double, o_imu_u), *h_imu_meas = CTV_H(double, o_imu_meas), *h_v_obs = CTV_H(double, o_v_obs);
     double *h_v_cauchy = CTV_H(double, o_v_cauchy);
+    int32_t *h_vb_win = CTV_H(int32_t, o_vb_win);
     int32_t *h_v_win = CTV_H(int32_t, o_v_win), *h_v_lm = CTV_H(int32_t, o_v_lm), *h_v_anc = CTV_H(int32_t, o_v_anc), *h_v_rowj = CTV_H(int32_t, o_v_rowj);
     int64_t *h_v_tj = CTV_H(int64_t, o_v_tj);
     int32_t *h_a_win = CTV_H(int32_t, o_a_win), *h_a_lm = CTV_H(int32_t, o_a_lm), *h_a_row = CTV_H(int32_t, o_a_row);
@@ -362,6 +363,7 @@ class SolverImpl : public SolverBase {
         h_a_win[e] = wi; h_a_lm[e] = w.v_lm[v]; h_a_row[e] = w.v_rowi[v]; h_a_t[e] = w.v_ti[v] - w.t0_ns;
         h_a_obs[e] = w.v_pi[2 * v]; h_a_obs[At + e] = w.v_pi[2 * v + 1];
       }
+      std::fill(h_vb_win + m.vis0 / 64, h_vb_win + (m.vis0 + m.Vp) / 64, wi);
       for (int i = 0; i < m.Vp; ++i) {
         const int v = t.lord[i];
         const size_t e = (size_t)m.vis0 + i;
@@ -450,7 +452,7 @@ class SolverImpl : public SolverBase {
     d.quat = CTV_D(double, o_state); d.pos = d.quat + (size_t)4 * K0; d.bias = d.pos + (size_t)3 * K0; d.rho = d.bias + (size_t)6 * F0; d.ld = d.rho + L0;
     d.knot_win = CTV_D(int32_t, o_knot_win); d.bias_win = CTV_D(int32_t, o_bias_win); d.lm_win = CTV_D(int32_t, o_lm_win);
     d.groups = CTV_D(ImuGroup, o_groups); d.imu_grp = CTV_D(int32_t, o_imu_grp); d.imu_u = CTV_D(double, o_imu_u); d.imu_meas = CTV_D(double, o_imu_meas);
-    d.v_cauchy = CTV_D(double, o_v_cauchy);
+    d.v_cauchy = CTV_D(double, o_v_cauchy); d.vb_win = CTV_D(int32_t, o_vb_win);
     d.v_win = CTV_D(int32_t, o_v_win); d.v_lm = CTV_D(int32_t, o_v_lm); d.v_anc = CTV_D(int32_t, o_v_anc); d.v_rowj = CTV_D(int32_t, o_v_rowj);
     d.v_tj = CTV_D(int64_t, o_v_tj); d.v_obs = CTV_D(double, o_v_obs);
     d.a_win = CTV_D(int32_t, o_a_win); d.a_lm = CTV_D(int32_t, o_a_lm); d.a_row = CTV_D(int32_t, o_a_row); d.a_t = CTV_D(int64_t, o_a_t);

@@ -108,6 +108,7 @@ struct Dev {
   int32_t *a_s;                 // [Atot] first active knot of the anchor end
   int32_t Atot, pad_at;
   const int32_t *v_win, *v_lm, *v_anc;   // [Vtot] window (-1: padding slot), landmark, anchor (absolute) of the block slot
+  const int32_t *vb_win;                 // [Vtot / 64] the window of every group of 64 block slots (a window's slots start on a group boundary)
   const int64_t *v_tj;          // relative to the window's t0
   const int32_t *v_rowj;
   const double *v_obs;        // [2][Vtot] pjx, pjy

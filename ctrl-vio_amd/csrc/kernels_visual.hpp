@@ -117,20 +117,23 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
   const bool at_cand = mode == LIN_SPEC;
   const double *quat = at_cand ? d.cquat : d.quat, *pos = at_cand ? d.cpos : d.pos, *ldp = at_cand ? d.cld : d.ld;
   double c = 0.0;
-  int w = -1, ksj = 0, my_lm = -1, my_anc = -1, tg = 0;
+  int ksj = 0, my_lm = -1, my_anc = -1;
   bool on = false, costed = false;
-  if (v < d.Vtot) {
-    w = d.v_win[v];
-    const Lm &lm = d.lm[max(w, 0)];
-    const bool run = w >= 0 && lin_run(lm, mode);
-    if (run) {
-      const WinMeta &m = d.wins[w];
-      const bool jac = !lin_cost_only(lm, mode, d.prm);
-      tg = lin_target(lm, mode);
+  // The wave's window is known from the block index alone (a window's slots start on a wave boundary: Dev::vb_win): its descriptor, LM state and
+  // line delay arrive through the scalar unit while the per-block inputs are on their way -- "slot arrays, then the window, then the knots"
+  // used to be three dependent round trips, the window one a vector load of a uniform address per field.
+  const int wu = d.vb_win[vblock];
+  const Lm &lmw = d.lm[wu];
+  const WinMeta &m = d.wins[wu];
+  if (!lin_run(lmw, mode)) return;               // (wave-uniform: nothing of this window is evaluated on this pass)
+  const bool jac = !lin_cost_only(lmw, mode, d.prm);
+  const int tgw = lin_target(lmw, mode);
+  if (v < d.Vtot && d.v_win[v] >= 0) {           // (padding slots carry window -1)
+    {
       int sj;
       double uj;
       const int rowj = d.v_rowj[v];
-      vis_times(m, d.v_tj[v], rowj, ldp[w], sj, uj);
+      vis_times(m, d.v_tj[v], rowj, ldp[wu], sj, uj);
       sj = max(0, min(sj, m.K - 4));  // host validated the worst case; clamp keeps loads in range regardless
       SegConstLazy scj;   // Jr^-1 of the knot pairs stays in the table until the streamed Jacobians need it
       seg_const_lazy(d.lkd + 3 * (m.knot0 + sj), d.kjri + 9 * (m.knot0 + sj), scj);
@@ -173,8 +176,6 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
         costed = true;
         c = vis_block_eval<false>(rec, q0, p, scj, uj, m.inv_dt, RCIT, p_CI, m.img_w, ca, pjx, pjy, (double)rowj, r, false, nsink);
       }
-    } else {
-      w = -1;
     }
   }
   {
@@ -187,12 +188,9 @@ __device__ __forceinline__ void vis_eval_body(const Dev &d, int mode, unsigned c
       if (lane == 0) d.vis_cost[vblock] = cs;
     }
     if (on_mask == 0) return;                  // (wave-uniform)
-    // the wave's window (a window's slots start on a wave boundary) and its normal-equation set
-    const int first_on = __ffsll((long long)on_mask) - 1;
-    const int tgw = __builtin_amdgcn_readfirstlane(__shfl(tg, first_on)), wu = __builtin_amdgcn_readfirstlane(__shfl(w, first_on));
-    const WinMeta &mu = d.wins[wu];
-    const int P = mu.P, ldw = mu.ldw, lm0 = mu.lm0, u0 = mu.u0;
-    const long long W0 = mu.W0;
+    // the wave's window and its normal-equation set
+    const int P = m.P, ldw = m.ldw, lm0 = m.lm0, u0 = m.u0;
+    const long long W0 = m.W0;
     double *Wset = d.WS[tgw];
     double *Hllset = d.HllS[tgw], *gset = d.gS[tgw];
     // One wave per workgroup: LDS hand-overs only need the wave's own LDS operations to have completed.  (__syncthreads() also
