@@ -137,8 +137,11 @@ void ctvio_destroy(ctvio_solver *s);
 int32_t ctvio_clear(ctvio_solver *s);
 /* The Add*Factor calls of one UpdateTrajectory, recorded as one window; returns the window id in *id. */
 int32_t ctvio_add_window(ctvio_solver *s, const ctvio_window *w, int32_t *id);
-/* Pack (sort IMU samples into (segment,bias) groups, visual blocks landmark by landmark, prior J0^T J0, ...) and copy to HBM.
- * Limits checked here: P = 6K + 6F + 1 <= ~600, at most 64 visual blocks per landmark (CTVIO_ERR_INVALID otherwise). */
+/* Pack (sort IMU samples into (segment,bias) groups, visual blocks landmark by landmark, prior J0^T J0, ...), PLAN THE SPARSITY of the
+ * reduced system -- what the reference leaves to Ceres' SPARSE_NORMAL_CHOLESKY (trajectory_estimator.cpp:371-384): every landmark's knot span
+ * over the box [ld_lo, ld_hi] of the line delay, the row order of Hpl, the envelope of the Schur complement -- and copy to HBM.
+ * Checked here (CTVIO_ERR_INVALID otherwise): P = 6K + 6F + 1 <= ~600; at most 64 visual blocks per landmark; finite observations and line
+ * delay; ld_lo <= ld_hi for a free line delay; every row time t + row * ld inside the spline for ld at both ends of the box. */
 int32_t ctvio_upload(ctvio_solver *s);
 /* ctvio_clear + n x ctvio_add_window + ctvio_upload in one call, without the intermediate host copy: the n windows are
  * validated and packed straight from the caller's buffers (read during this call only) by opt.host_threads threads into a
@@ -155,7 +158,8 @@ int32_t ctvio_get_state(ctvio_solver *s, int32_t id, double *quat, double *pos, 
 /* The state of EVERY window of the batch with one device-to-host copy: quat (sum K x 4), pos (sum K x 3), bias (sum F x 6),
  * rho (sum L), ld (n), each concatenated in window order.  Any pointer may be NULL. */
 int32_t ctvio_get_batch_state(ctvio_solver *s, double *quat, double *pos, double *bias, double *rho, double *ld);
-/* Overwrite the state of an uploaded window (re-solve the same factors from another initial guess). */
+/* Overwrite the state of an uploaded window (re-solve the same factors from another initial guess).  A free line delay is projected on
+ * [ld_lo, ld_hi]; the line delay of a fix_ld window must equal the uploaded one (the landmarks' knot spans were planned for it). */
 int32_t ctvio_set_state(ctvio_solver *s, int32_t id, const double *quat, const double *pos, const double *bias,
                         const double *rho, double ld);
 
