@@ -14,7 +14,11 @@ N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run
 windows are sharded by id (w mod N), no data-path collective (independent windows); RCCL carries the
 barrier, the max-over-ranks time and the all-gather of the per-window result records (every id must come back exactly once).
 
-Extra objects on the JSON line:
+Output contract: the LAST stdout line is ONE compact JSON object (< 4 KB: the driver keeps an 8 KB tail) -- the contract keys, `config`,
+`roofline` (dominant kernel), `cpu_baseline`, `parity`, `device_resident_solves_per_s`, a few headline scalars and `details_file`.  Everything
+else (per-kernel rooflines, configs 3 / 5 / tumrs, small batches, host-side figures) goes to that file: gpurun_out/bench_details_n<N>.json.
+
+Objects (compact line: roofline, parity, cpu_baseline; the rest in the details file):
   roofline       dominant kernel of a profiled solve of one handle (HIP events on the solver's stream, other handles idle):
                  achieved = algorithmic bytes or flops per launch / average launch duration, against 8 TB/s HBM
                  or 78.6 TFLOP/s fp64 -- whichever roof the kernel is closer to; both fractions, the PMC traffic and the issue counters
@@ -323,6 +327,83 @@ def cpu_all_cores(config, iters, seed0, n):
                       f"of a host with {r['host_cores']} logical CPUs, {r['seconds']:.1f} s"}
 
 
+COMPACT_LIMIT = 4096     # bytes of the final stdout line (tests/test_bench_line.py)
+
+
+def csrc_sha256():
+    """Hash of the kernel sources: profiles/pmc_traffic.json records the one its counters were collected with (tools/prof_summary.py), and a
+    traffic figure from other sources is not printed -- a kernel change must not silently stale it.  (No git on the GPU box: a content hash.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ctrl-vio_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".hpp")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def compact_line(out, details_file):
+    """The driver-facing line: contract keys + config + the dominant kernel's roofline + cpu_baseline + parity + headline scalars."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in keep}
+    c = out.get("config", {})
+    line["config"] = {k: c.get(k) for k in ("workload", "timed_region", "windows_per_gpu_per_step", "distinct_windows_per_gpu", "streams_per_gpu",
+                                            "concurrent_solves_per_gpu", "pack_threads_per_stream", "sharding") if k in c}
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "avg_launch_us",
+                                                  "windows_per_launch", "hbm_frac", "fp64_frac", "share_of_profiled_solve", "limiter") if k in r}
+    m = out.get("roofline_mfma")
+    if m:
+        line["roofline_mfma"] = {k: m.get(k) for k in ("kernel", "frac", "avg_launch_us") if k in m}
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    p = out.get("parity")
+    line["parity"] = None if not p else {k: p.get(k) for k in ("max_rel_state_err", "windows", "tolerance", "pass")}
+    for k in ("device_resident_solves_per_s", "single_window_ms", "single_window_device_resident_ms"):
+        if k in out:
+            line[k] = out[k]
+    for cfg in ("config3", "config5", "config5_spread", "tumrs"):
+        if isinstance(out.get(cfg), dict) and "solves_per_s" in out[cfg]:
+            line.setdefault("other_configs_solves_per_s", {})[cfg] = round(out[cfg]["solves_per_s"], 1)
+    if "per_rank_solves_per_s" in out and out.get("n_gpus", 1) > 1:
+        line["per_rank_solves_per_s"] = [round(x, 1) for x in out["per_rank_solves_per_s"]]
+    if "small_batch_latency" in out:
+        line["small_batch_latency_ms"] = [round(x, 3) for x in out["small_batch_latency"]["end_to_end_ms_per_step_by_rank"]]
+
+    def rnd(v):   # 6 significant digits are plenty for a log line (and keep it short)
+        if isinstance(v, float):
+            return float(f"{v:.6g}")
+        if isinstance(v, dict):
+            return {k: rnd(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [rnd(x) for x in v]
+        return v
+    line = rnd(line)
+    line["details_file"] = details_file
+    s = json.dumps(line)
+    if len(s) >= COMPACT_LIMIT:          # never lose the record to its size: drop the optional extras first
+        for k in ("other_configs_solves_per_s", "roofline_mfma", "per_rank_solves_per_s", "small_batch_latency_ms"):
+            line.pop(k, None)
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:200]
+        s = json.dumps(line)
+    assert len(s) < COMPACT_LIMIT, len(s)
+    return s
+
+
+def write_details(out, world):
+    """Everything measured, in a side file (gpurun_out/ travels back from the GPU box); returns the path relative to the repo root."""
+    rel = os.path.join("gpurun_out", f"bench_details_n{world}.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(out, f, indent=1)
+        return rel
+    except OSError:
+        return None
+
+
 def respawn_under_torchrun(args):
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -551,7 +632,13 @@ def main():
             except Exception:
                 return {}
         pmc = load_json("pmc_traffic.json")      # per-kernel FETCH_SIZE / WRITE_SIZE of the committed rocprofv3 passes
+        # (counters of OTHER kernel sources say nothing about these kernels: no traffic figure then)
+        pmc_fresh = bool(pmc) and pmc.get("_csrc_sha256") == csrc_sha256()
+        if not pmc_fresh:
+            pmc = {"_source": "profiles/pmc_traffic.json was collected with other kernel sources (its _csrc_sha256 differs): traffic not reported"}
         issue = load_json("pmc_issue.json")      # per-kernel SQ issue counters of the committed pass
+        if issue.get("_csrc_sha256") != csrc_sha256():
+            issue = {}
 
         def kernel_line(i):
             """roofline entry of launch group i: HBM-bound unless its algorithmic intensity is beyond the ridge (peak flops / peak bytes)"""
@@ -570,7 +657,8 @@ def main():
             ach = nf / avg_s / 1e12 if compute else nb / avg_s / 1e9
             peak = pk if compute else HBM_PEAK_GBS
             line = {"kernel": kname, "bound": "mfma" if compute else "hbm", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s" if compute else "GB/s", "frac": ach / peak, "traffic": traffic, "avg_launch_us": 1e6 * avg_s,
+                    "unit": "TFLOP/s" if compute else "GB/s", "frac": ach / peak, "traffic": traffic,
+                    "traffic_over_algorithmic": (traffic / nb if traffic and nb else None), "avg_launch_us": 1e6 * avg_s,
                     "launches": int(n[i]), "windows_per_launch": per[0], "algorithmic_bytes_per_launch": nb,
                     "algorithmic_flops_per_launch": nf, "hbm_frac": hbm_frac, "fp64_frac": fl_frac,
                     "share_of_profiled_solve": float(ms[i] / max(sum(ms[:7]), 1e-12))}
@@ -719,7 +807,7 @@ def main():
                              "tolerance": 1e-4, "reference": "fp64 C oracle, same Ceres settings", "pass": bool(max(errs) <= 1e-4)}
             if not args.quick:   # configs[3]: 64 windows, one per thread, all host cores
                 out["cpu_baseline_all_cores"] = cpu_all_cores(args.config, args.iters, 1000, 256)
-        print(json.dumps(out))
+        print(compact_line(out, write_details(out, world)), flush=True)
     if dist is not None:
         dist.barrier()   # rank 0 prints after its extra measurements; nobody tears the communicator down under it
         dist.destroy_process_group()

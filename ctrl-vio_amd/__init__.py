@@ -10,8 +10,7 @@ The directory name contains a hyphen: import it with
   packer   factor packing rules of TrajectoryManager::UpdateTrajectory (bias index, bias chain weights)
   splines  host-side NumPy spline evaluation (generator / small queries)
   synth    deterministic synthetic windows for the BASELINE.json configs
-  window_io  flat binary file of a batch of windows (C++ twin: include/ctvio_window_io.hpp): the bench inputs for C / C++ callers
 """
 from .window import Window, rel_state_error  # noqa: F401
-from . import splines, packer, synth, capi, sharding, window_io  # noqa: F401
+from . import splines, packer, synth, capi, sharding  # noqa: F401
 from .solver import Solver  # noqa: F401

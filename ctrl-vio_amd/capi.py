@@ -79,7 +79,7 @@ SYMBOLS = ["ctvio_default_options", "ctvio_status_string", "ctvio_last_error", "
            "ctvio_destroy", "ctvio_clear", "ctvio_add_window", "ctvio_upload", "ctvio_set_batch", "ctvio_num_windows", "ctvio_solve",
            "ctvio_get_state", "ctvio_get_batch_state", "ctvio_set_state", "ctvio_snapshot_state", "ctvio_restore_state", "ctvio_linearize", "ctvio_cost", "ctvio_lm_step", "ctvio_spline_eval", "ctvio_sensor_pose", "ctvio_gauge_restore", "ctvio_marginalize", "ctvio_marginalize_batch", "ctvio_residual_summary",
            "ctvio_last_timing", "ctvio_set_profiling", "ctvio_stream", "ctvio_solve_sharded", "ctvio_sharded_release", "ctvio_shard_of",
-           "ctvio_shard_count", "ctvio_shards_used", "ctvio_spline_eval_batch", "ctvio_graph_captures"]
+           "ctvio_shard_count", "ctvio_shards_used", "ctvio_spline_eval_batch", "ctvio_graph_captures", "ctvio_marginalize_ran_on_host"]
 
 _lib = None
 
@@ -117,6 +117,7 @@ def load_library():
         lib.ctvio_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         lib.ctvio_stream.argtypes = [C.c_void_p]
         lib.ctvio_graph_captures.argtypes = [C.c_void_p]
+        lib.ctvio_marginalize_ran_on_host.argtypes = [C.c_void_p]
         lib.ctvio_solve_sharded.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 6
         lib.ctvio_shard_of.argtypes = [C.c_int32, C.c_int32]
         lib.ctvio_shard_count.argtypes = [C.c_int32, C.c_int32, C.c_int32]

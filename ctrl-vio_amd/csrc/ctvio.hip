@@ -39,6 +39,41 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return fail(CTVIO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Diagnostic / A-B switches (include/ctvio.h, "Diagnostic switches"): read from the environment ONCE per handle, in ctvio_create -- a later
+// change of the environment cannot make upload and solve disagree about a kernel choice.  None of them is needed in production.
+struct DebugSwitches {
+  int stamps = 0;            // CTVIO_DEBUG_STAMPS=1     clock64 stamps of a few kernels, printed by ctvio_solve (disables the hipGraph)
+  int store_path = -1;       // CTVIO_STORE_PATH=0/1     force the store-semantics assembly tail off / on
+  int split_linearize = 0;   // CTVIO_SPLIT_LINEARIZE=1  IMU and visual evaluation as separate launches also for small batches (rocprofv3 runs)
+  int merge_linearize = -1;  // CTVIO_MERGE_LINEARIZE=0/1 force the merged launch off / on
+  int no_imu_band = 0;       // CTVIO_NO_IMU_BAND=1      k_misc adds the IMU knot blocks to Hpp without the LDS band
+  int zero_kernel = 0;       // CTVIO_ZERO_KERNEL=1      k_zero_normal instead of the IMU kernel's zeroing share
+  int imu_waves = 2048;      // CTVIO_IMU_WAVES=n        walking waves of k_imu_linearize_f64
+  int imu_general = 0;       // CTVIO_IMU_GENERAL=1      every IMU group through the general body (same as use_mfma = 2)
+  int schur_tiles = 0;       // CTVIO_SCHUR_TILES=1      tile Schur kernels also for large batches of small windows
+  int schur_copy_plain = 0;  // CTVIO_SCHUR_COPY_PLAIN=1 the per-window Schur kernel copies product-free tiles to S
+  int chol_tiles = -1;       // CTVIO_CHOL_TILES=0/1/2   P <= 223: panel kernel / 16 waves x 7 tiles / 8 waves x 14 tiles
+  int dense = 0;             // CTVIO_DENSE=1            the sparsity plan degenerates to the dense one
+  int schur_tile2 = -1;      // CTVIO_SCHUR_TILE2=0/1    one wave per tile / per 2 x 2 tiles
+  int marg_debug = 0;        // CTVIO_MARG_DEBUG=1       sweep trace of the device eigen-solver on stderr
+  int marg_host = 0;         // CTVIO_MARG_HOST=1        ctvio_marginalize on the host factorisation
+  int shard_oversubscribe = 0;   // CTVIO_SHARD_OVERSUBSCRIBE=1  TEST ONLY: more shards than devices (ctvio_shards_used)
+};
+static DebugSwitches read_debug_switches() {
+  DebugSwitches g;
+  struct { const char *name; int *dst; } const tab[] = {
+      {"CTVIO_DEBUG_STAMPS", &g.stamps}, {"CTVIO_STORE_PATH", &g.store_path}, {"CTVIO_SPLIT_LINEARIZE", &g.split_linearize},
+      {"CTVIO_MERGE_LINEARIZE", &g.merge_linearize}, {"CTVIO_NO_IMU_BAND", &g.no_imu_band}, {"CTVIO_ZERO_KERNEL", &g.zero_kernel},
+      {"CTVIO_IMU_WAVES", &g.imu_waves}, {"CTVIO_IMU_GENERAL", &g.imu_general}, {"CTVIO_SCHUR_TILES", &g.schur_tiles},
+      {"CTVIO_SCHUR_COPY_PLAIN", &g.schur_copy_plain}, {"CTVIO_CHOL_TILES", &g.chol_tiles}, {"CTVIO_DENSE", &g.dense},
+      {"CTVIO_SCHUR_TILE2", &g.schur_tile2}, {"CTVIO_MARG_DEBUG", &g.marg_debug}, {"CTVIO_MARG_HOST", &g.marg_host},
+      {"CTVIO_SHARD_OVERSUBSCRIBE", &g.shard_oversubscribe}};
+  for (const auto &t : tab)
+    if (const char *e = std::getenv(t.name)) *t.dst = (e[0] == '\0') ? 1 : std::atoi(e);   // (set but empty counts as 1)
+  g.imu_waves = std::max(1, g.imu_waves);
+  return g;
+}
+
 template <class U> struct DBuf {
   U *p = nullptr;
   size_t n = 0;
@@ -115,14 +150,16 @@ struct SolverBase {
   virtual int set_profiling(int on) = 0;
   virtual void *stream() = 0;
   virtual int graph_captures() const = 0;
+  virtual int marg_ran_on_host() const = 0;
 };
 
 class SolverImpl : public SolverBase {
  public:
-  // visual blocks per work item (k_assemble_vis*): eight per-wave staging areas [116][VCH + 2] must fit beside the fp64 LDS Hessian
+  // visual blocks per work item (k_assemble_vis_mfma): eight per-wave staging areas must fit beside the fp64 LDS Hessian -- sized by the
+  // constexpr the kernel itself lays its LDS out with (kernels_assemble.hpp: vis_stage_bytes)
   static constexpr int VCH = 8;
-  static constexpr size_t vis_stage_bytes() { return (size_t)8 * 116 * (VCH + 2) * sizeof(double) + (size_t)8 * 2 * VCH * sizeof(int); }
-  explicit SolverImpl(const ctvio_options &o) : opt_(o) {}
+  static constexpr size_t vis_stage_bytes() { return ctv::vis_stage_bytes(8, VCH); }
+  explicit SolverImpl(const ctvio_options &o) : opt_(o), dbg_(read_debug_switches()) {}
   ~SolverImpl() override {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
@@ -141,8 +178,6 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<16, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<8, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis<VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -158,6 +193,7 @@ class SolverImpl : public SolverBase {
   int num_windows() const override { return uploaded_ ? (int)meta_.size() : (int)own_.size(); }
   void *stream() override { return (void *)stream_; }
   int graph_captures() const override { return graph_captures_; }
+  int marg_ran_on_host() const override { return marg_ran_on_host_; }
 
   int add_window(const ctvio_window *w, int32_t *id) override {
     std::string err;
@@ -197,7 +233,8 @@ class SolverImpl : public SolverBase {
     // envelope); otherwise the panel kernel, which works inside every window's envelope.  (Sizes alone decide: known before planning.)
     int maxP_pre = 0;
     for (int wi = 0; wi < nw; ++wi) if (wins[wi]) maxP_pre = std::max(maxP_pre, 6 * wins[wi]->K + 6 * wins[wi]->F + 1);
-    const bool dense_env = chol_tiles_for(maxP_pre) != 0 || sparsity_off();
+    chol_tiles_ = chol_tiles_for(maxP_pre);   // (decided here, once per batch: launch_step and the Schur launch use the member)
+    const bool dense_env = chol_tiles_ != 0 || sparsity_off();
     parallel_for(nw, nth, [&](int wi) {
       if (validate && !validate_window(wins[wi], tmp[wi].err)) {
         int cur = first_bad.load();
@@ -480,11 +517,11 @@ class SolverImpl : public SolverBase {
     deterministic_ = opt_.deterministic > 0 || (opt_.deterministic < 0 && nw <= 64);
     // (the member goes into the launch signature and selects kernels: it must say what RUNS -- the default falls back to the accumulate path
     //  for batches the order-fixed assembly cannot cover, and then it is off)
-    if (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_) { if (opt_.deterministic <= 0) deterministic_ = false; }
+    if (!any_vis_lds_ || any_vis_glb_) { if (opt_.deterministic <= 0) deterministic_ = false; }
     // The order-fixed accumulation exists for batches whose every window keeps its packed Hessian in LDS, on the matrix-core kernels.
     // An explicit request that cannot be honoured is an error; the default (-1) falls back to the accumulate path for such batches.
-    if (opt_.deterministic > 0 && (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_))
-      return fail(CTVIO_ERR_INVALID, "deterministic = 1 needs use_mfma != 0 and every window's packed Hessian in LDS (K <= 24): this batch would "
+    if (opt_.deterministic > 0 && (!any_vis_lds_ || any_vis_glb_))
+      return fail(CTVIO_ERR_INVALID, "deterministic = 1 needs every window's packed Hessian in LDS (K <= 25): this batch would "
                                      "fall back to floating-point atomics");
     maxK_ = maxK;
     // ---- work arena (device only)
@@ -525,7 +562,7 @@ class SolverImpl : public SolverBase {
     d.WS[0] = CTV_W(double, o_W); d.WS[1] = CTV_W(double, o_W1); d.HllS[0] = CTV_W(double, o_Hll); d.HllS[1] = CTV_W(double, o_Hll1);
     d.gS[0] = CTV_W(double, o_g); d.gS[1] = CTV_W(double, o_g1);
     d.delta = CTV_W(double, o_delta); d.cscale = CTV_W(double, o_cscale); d.lm = CTV_W(Lm, o_lm); d.n_active = CTV_W(int32_t, o_nact); d.span_viol = d.n_active + 1;
-    d.dbg = std::getenv("CTVIO_DEBUG_STAMPS") ? CTV_W(long long, o_dbg) : nullptr;
+    d.dbg = dbg_.stamps ? CTV_W(long long, o_dbg) : nullptr;
     d.rhs = CTV_W(double, o_rhs); d.dd = CTV_W(double, o_dd); d.dinv = CTV_W(double, o_dinv); d.grs = CTV_W(double, o_grs); d.chol_inv = CTV_W(double, o_chol_inv);
 #undef CTV_W
     HIPCHK(hipMemsetAsync(wb + o_zero0, 0, o_zero1 - o_zero0, stream_));
@@ -557,8 +594,8 @@ class SolverImpl : public SolverBase {
   // every window's packed Hessian is LDS resident.  (CTVIO_STORE_PATH=1 forces it for the throughput mode too: measured slower there,
   // the bias-row gather costs more than the zeroing + atomic passes it replaces -- 14.5 vs 13.4 ms per 2048-window solve.)
   bool store_path() const {
-    if (!opt_.use_mfma || !any_vis_lds_ || any_vis_glb_) return false;
-    if (const char *e = std::getenv("CTVIO_STORE_PATH")) return e[0] == '1';
+    if (!any_vis_lds_ || any_vis_glb_) return false;
+    if (dbg_.store_path >= 0) return dbg_.store_path == 1;
     return deterministic_;
   }
   void set_params(int max_iters) {
@@ -598,12 +635,10 @@ class SolverImpl : public SolverBase {
   void launch_linearize(int mode) {
     const Dev &d = dev_;
     const int nw = d.nwin;
-    constexpr int CH = 32;
     ph_begin(PH_ASM_REST);
     if (!store_path()) { if (!imu_zero_mode()) hipLaunchKernelGGL(k_zero_normal, dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode); }
     else hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1, 0);   // prior gradient + cost share
     ph_end();
-    const size_t imu_lds = (size_t)32 * (6 * CH + 4) * sizeof(double);
     if (merge_linearize()) {
       // one launch for both evaluations (independent work: their latencies overlap on batches smaller than the chip); a profiled
       // solve (and CTVIO_SPLIT_LINEARIZE=1, for rocprofv3 runs) keeps them apart so that each gets its own timing
@@ -612,7 +647,7 @@ class SolverImpl : public SolverBase {
       return;
     }
     ph_begin(PH_IMU_LIN);
-    if (d.Gtot) launch_imu_linearize(imu_lds, mode);
+    if (d.Gtot) launch_imu_linearize(mode);
     ph_end();
     ph_begin(PH_VIS_LIN);   // (one timed group: the anchors' records, then the blocks)
     if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, mode);   // the i ends, once per anchor
@@ -624,8 +659,8 @@ class SolverImpl : public SolverBase {
   // the choice (A/B measurements).
   bool merge_linearize() const {
     const Dev &d = dev_;
-    if (!(opt_.use_mfma && d.Gtot && d.Vtot && !profiling_ && !std::getenv("CTVIO_SPLIT_LINEARIZE"))) return false;
-    if (const char *e = std::getenv("CTVIO_MERGE_LINEARIZE")) return e[0] == '1';
+    if (!(d.Gtot && d.Vtot && !profiling_ && !dbg_.split_linearize)) return false;
+    if (dbg_.merge_linearize >= 0) return dbg_.merge_linearize == 1;
     return d.nwin <= 128;
   }
   void launch_assemble(int mode) {
@@ -655,7 +690,7 @@ class SolverImpl : public SolverBase {
     {
       // (windows without the LDS-resident Hessian: the IMU knot blocks are summed in an LDS band before they go to Hpp -- when it fits)
       const size_t dxb = (size_t)((std::max(d.maxPn, 1) + 1) & ~1) * sizeof(double), bandb = (size_t)144 * maxK_ * sizeof(double);
-      const bool band = any_vis_glb_ && d.Gtot && dxb + bandb <= 150 * 1024 && !std::getenv("CTVIO_NO_IMU_BAND");
+      const bool band = any_vis_glb_ && d.Gtot && dxb + bandb <= 150 * 1024 && !dbg_.no_imu_band;
       hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), band ? dxb + bandb : dxb, stream_, d, mode, 0, d.Gtot ? (band ? 2 : 1) : 0);
     }
     if (mode != LIN_SPEC) hipLaunchKernelGGL(k_post_linearize, dim3(nblk(d.maxN, 256), nw), dim3(256), 0, stream_, d, mode);
@@ -669,11 +704,6 @@ class SolverImpl : public SolverBase {
     ph_begin(PH_SCHUR);
     launch_schur();
     ph_end();
-    if (!schur_makes_rhs()) {
-      ph_begin(PH_REST);
-      hipLaunchKernelGGL(k_rhs, dim3(nblk(d.maxP, 64), nw), dim3(256), 0, stream_, d);
-      ph_end();
-    }
     ph_begin(PH_CHOL);
     // P <= 223: the register-resident tile kernel (S read once, nothing written back; 16 waves per window) for batches smaller than
     // the chip, where latency counts; large batches: the panel kernel with 4 waves, two windows per CU (throughput); windows beyond
@@ -698,17 +728,17 @@ class SolverImpl : public SolverBase {
     ph_end();
   }
   void launch_schur();
-  void launch_imu_linearize(size_t vals_lds, int mode);
+  void launch_imu_linearize(int mode);
   // use_mfma = 2 (or CTVIO_IMU_GENERAL=1): every IMU group through the general body (k_imu_linearize_rest) -- the cross-check of the
   // specialised one and the tests' way into the path that large knot-to-knot rotations / anisotropic accelerometer weights take
   // The IMU linearisation kernels clear the accumulated parts of the normal equations on the side (kernels.hpp: imu_zero_share) when every
   // window has IMU groups: 1 = bias rows only (one visual-assembly part stores the knot x knot block), 2 = everything; 0 = k_zero_normal.
   int imu_zero_mode() const {
-    if (!opt_.use_mfma || store_path() || !all_windows_have_imu_ || std::getenv("CTVIO_ZERO_KERNEL")) return 0;
+    if (store_path() || !all_windows_have_imu_ || dbg_.zero_kernel) return 0;
     return vis_parts() == 1 ? 1 : 2;
   }
-  static int imu_walk_waves() { static const int n = std::getenv("CTVIO_IMU_WAVES") ? std::max(1, std::atoi(std::getenv("CTVIO_IMU_WAVES"))) : 2048; return n; }
-  int imu_general_only() const { static const int env = std::getenv("CTVIO_IMU_GENERAL") ? 1 : 0; return (env || opt_.use_mfma == 2) ? 1 : 0; }
+  int imu_walk_waves() const { return dbg_.imu_waves; }
+  int imu_general_only() const { return (dbg_.imu_general || opt_.use_mfma == 2) ? 1 : 0; }
   void launch_linearize_merged(int mode);
   void launch_assemble_vis_lds(int parts, int mode);
   void launch_assemble_vis_glb(int parts, int mode);
@@ -717,32 +747,29 @@ class SolverImpl : public SolverBase {
     if (deterministic_) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true, 1, true>), dim3(d.nwin, parts), dim3(64), vis_lds_, stream_, d, mode);
     else hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true, 8, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
   }
-  bool schur_makes_rhs() const { return schur_rhs_done_; }
   // Large batches of small windows take the per-window Schur kernel (W staged through LDS once); everything else the tile kernels.
   bool schur_window_path() const {
     const Dev &d = dev_;
-    if (!opt_.use_mfma) return false;
     const int nt = (d.maxLdw + 15) / 16, ntile = nt * (nt + 1) / 2;
     const size_t lds = schur_window_lds();
-    const bool small = d.nwin < 192 || std::getenv("CTVIO_SCHUR_TILES");
+    const bool small = d.nwin < 192 || dbg_.schur_tiles;
     const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
     return !small && d.maxLdw <= 224 && ntile <= 112 && lds <= 160 * 1024 && nc <= 224;
   }
   size_t schur_window_lds() const { return ((size_t)2 * 16 * (dev_.maxLdw + 16) + 3 * dev_.maxLdw + 32 + 64) * sizeof(double); }   // + column vectors + the list of tiles with products
   // Dev::schur_plain_in_H is part of the Dev struct the captured graph is keyed on: decided once per upload, never inside a launch
   // (launch_schur used to set it, so every upload -- which clears Dev -- invalidated the cached hipGraph of the headline configuration).
-  int schur_plain_in_H_for_batch() const { return (schur_window_path() && chol_tiles() != 0 && !std::getenv("CTVIO_SCHUR_COPY_PLAIN")) ? 1 : 0; }
+  int schur_plain_in_H_for_batch() const { return (schur_window_path() && chol_tiles() != 0 && !dbg_.schur_copy_plain) ? 1 : 0; }
   // CTVIO_CHOL_TILES = 0 / 1 / 2 forces the choice (A/B measurements: panel kernel / 16 waves x 7 tiles / 8 waves x 14 tiles)
-  static int chol_tiles_for(int maxP) {
+  int chol_tiles_for(int maxP) const {
     if (maxP > 223) return 0;
-    if (const char *e = std::getenv("CTVIO_CHOL_TILES")) return e[0] - '0';
+    if (dbg_.chol_tiles >= 0) return dbg_.chol_tiles;
     return 1;   // (16 waves x 7 tiles: 10.7 ms per 2048-window solve against 11.2 ms for the panel kernel, and a fifth of its HBM traffic)
   }
-  int chol_tiles() const { return chol_tiles_for(dev_.maxP); }
+  int chol_tiles() const { return chol_tiles_; }   // the batch's choice, taken in pack_and_upload
   // CTVIO_DENSE=1: the sparsity plan degenerates to the dense one (every row range = all landmarks, envelope = the whole triangle) -- the
   // A/B switch of the sparsity-aware kernels and the cross-check of tests/test_gpu_sparsity.py
-  static bool sparsity_off() { const char *e = std::getenv("CTVIO_DENSE"); return e && e[0] == '1'; }
-  bool schur_rhs_done_ = false;   // set by launch_schur when the kernel it chose also wrote the reduced right-hand side
+  bool sparsity_off() const { return dbg_.dense == 1; }
   int n_state() const { return dev_.Ktot + dev_.Ftot + dev_.Ltot + dev_.nwin; }
 
   // One PASS of the device-resident LM: every running window advances by one phase -- a new trust-region iteration (damp, Schur,
@@ -779,7 +806,7 @@ class SolverImpl : public SolverBase {
   std::vector<long long> launch_signature() const {
     return {(long long)vis_lds_, (long long)vis_glb_, (long long)any_vis_lds_, (long long)any_vis_glb_, (long long)maxK_, (long long)max_schur_tiles_,
             (long long)chol_lds_, (long long)opt_.use_mfma, (long long)vis_parts(), (long long)deterministic_, (long long)chol_tiles(), (long long)imu_zero_mode(), (long long)merge_linearize(), (long long)dev_.nwin,
-            (long long)(std::getenv("CTVIO_SCHUR_TILE2") ? std::atoi(std::getenv("CTVIO_SCHUR_TILE2")) : -1)};
+            (long long)dbg_.schur_tile2};
   }
   int ensure_graph() {
     const std::vector<long long> sig = launch_signature();
@@ -796,6 +823,21 @@ class SolverImpl : public SolverBase {
     graph_sig_ = sig;
     ++graph_captures_;
     return CTVIO_OK;
+  }
+
+  // k_vis_eval counts evaluations that fall outside the knot span the packer planned for their landmark (host_pack.hpp: plan_sparsity): such a
+  // row of W was written into a neighbour's columns.  Every entry point that launches the kernel ends with this check; the counter is cleared
+  // again so that a later call on the same batch (after ctvio_set_state / ctvio_restore_state) starts clean.  The stream must be idle.
+  int check_span_violation() {
+    int32_t *viol = reinterpret_cast<int32_t *>(lm_host_ + lm_host_cap_ - 1) + 2;   // (pinned scratch record, beside the "still running" word)
+    HIPCHK(hipMemcpyAsync(viol, dev_.span_viol, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (*viol == 0) return CTVIO_OK;
+    const int n = *viol;
+    HIPCHK(hipMemsetAsync(dev_.span_viol, 0, sizeof(int32_t), stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return fail(CTVIO_ERR_INTERNAL, std::to_string(n) + " evaluation(s) fell outside the planned knot span of their landmark (host_pack.hpp: plan_sparsity): "
+                                    "the normal equations of this call are not to be trusted");
   }
 
   int solve(int max_iters, ctvio_summary *out) override {
@@ -831,11 +873,9 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipEventRecord(ev_[9], stream_));
     Lm *lm = lm_host_;   // pinned: the copy does not stage through a runtime bounce buffer
     HIPCHK(hipMemcpyAsync(lm, d.lm, sizeof(Lm) * nw, hipMemcpyDeviceToHost, stream_));
-    int32_t *viol = reinterpret_cast<int32_t *>(lm_host_ + lm_host_cap_ - 1) + 2;   // (same pinned scratch record as the "still running" word)
-    HIPCHK(hipMemcpyAsync(viol, d.span_viol, sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
-    if (*viol != 0) return fail(CTVIO_ERR_HIP, "internal: " + std::to_string(*viol) + " evaluation(s) fell outside the planned knot span of their landmark (host_pack.hpp: plan_sparsity)");
+    if (const int rc = check_span_violation()) return rc;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev_[8], ev_[9]));
     if (profiling_) ph_collect(); else { std::fill(ph_ms_, ph_ms_ + 8, 0.0); std::fill(ph_n_, ph_n_ + 8, 0); }
@@ -953,6 +993,7 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    if (const int rc = check_span_violation()) return rc;
     if (Hpp)
       for (int i = 0; i < P; ++i)
         for (int j = i + 1; j < P; ++j) Hpp[(size_t)i * P + j] = Hpp[(size_t)j * P + i];
@@ -970,7 +1011,7 @@ class SolverImpl : public SolverBase {
     set_params(1);
     hipLaunchKernelGGL(k_lm_init, dim3(wb), dim3(64), 0, stream_, d, opt_.initial_radius, 1);
     hipLaunchKernelGGL(k_knot_prep, dim3(nblk(d.Ktot, 256)), dim3(256), 0, stream_, d);
-    if (d.Gtot) launch_imu_linearize((size_t)32 * (6 * 32 + 4) * sizeof(double), COST_AT_X);
+    if (d.Gtot) launch_imu_linearize(COST_AT_X);
     if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
     if (d.Vtot) hipLaunchKernelGGL(k_vis_eval, dim3(nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, (int)COST_AT_X);
     hipLaunchKernelGGL(k_misc, dim3(d.nwin), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, (int)COST_AT_X, 0, 0);
@@ -979,6 +1020,7 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    if (const int rc = check_span_violation()) return rc;
     if (cost) *cost = lm.cand_cost;
     return CTVIO_OK;
   }
@@ -998,6 +1040,7 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(&lm, d.lm + id, sizeof(Lm), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    if (const int rc = check_span_violation()) return rc;
     if (mc) *mc = lm.step_valid ? lm.model_change : -1.0;
     return CTVIO_OK;
   }
@@ -1052,11 +1095,12 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipMemcpyAsync(metas.data(), mg_meta_.p, sizeof(MargMeta) * nw, hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipGetLastError());
+    if (const int rc = check_span_violation()) return rc;
     size_t oj = 0, orr = 0;
     for (int w = 0; w < nw; ++w) {
       const MargMeta &mm = metas[w];
       if (mm.n <= 0) continue;
-      if (std::getenv("CTVIO_MARG_DEBUG") && w == (only >= 0 ? only : 0)) {
+      if (dbg_.marg_debug && w == (only >= 0 ? only : 0)) {
         std::fprintf(stderr, "[ctvio] marg window %d: m %d n %d sweeps %d / %d; off/dia per sweep (A'):", w, mm.m, mm.n, mm.sweeps_m, mm.sweeps_n);
         for (int i = 0; i < 26 && i <= std::max(mm.sweeps_n, 0) + 1; ++i) std::fprintf(stderr, " %.2e", mm.trace[26 + i]);
         std::fprintf(stderr, "\n");
@@ -1074,6 +1118,7 @@ class SolverImpl : public SolverBase {
     for (int i = 0; i < dev_.Utot; ++i) if (role[i] < -1 || role[i] > 1) return fail(CTVIO_ERR_INVALID, "role must be -1, 0 or 1");
     bool too_large = false;
     int stalled = -1;
+    marg_ran_on_host_ = 0;
     const int rc = marg_device(role, -1, eps, n_keep, kept, J0, r0, &too_large, &stalled);
     if (rc != CTVIO_OK && stalled >= 0)
       return fail(CTVIO_ERR_HIP, "device eigen-solver did not converge for window " + std::to_string(stalled) + ": call ctvio_marginalize for it (host factorisation)");
@@ -1089,7 +1134,8 @@ class SolverImpl : public SolverBase {
     const WinMeta &m = meta_[id];
     const int N = m.N, P = m.P, L = m.L;
     for (int i = 0; i < N; ++i) if (role[i] < -1 || role[i] > 1) return fail(CTVIO_ERR_INVALID, "role must be -1, 0 or 1");
-    if (!std::getenv("CTVIO_MARG_HOST")) {
+    marg_ran_on_host_ = 0;
+    if (!dbg_.marg_host) {
       std::vector<int8_t> role_all((size_t)dev_.Utot, (int8_t)-1);
       std::copy(role, role + N, role_all.begin() + m.u0);
       std::vector<int32_t> nk((size_t)dev_.nwin), kv((size_t)dev_.Utot);
@@ -1104,6 +1150,10 @@ class SolverImpl : public SolverBase {
         return CTVIO_OK;
       }
     }
+    // Host leg (csrc/marginalize.hpp: Householder tridiagonalisation + QL on the host cores; the normal equations still come from the device
+    // kernels): taken when the window is beyond the device eigen-solver's size, when its Jacobi sweeps stalled, or when forced.  The caller
+    // can tell: ctvio_marginalize_ran_on_host.
+    marg_ran_on_host_ = 1;
     std::vector<double> Hpp((size_t)P * P), W((size_t)P * std::max(L, 1)), Hll(std::max(L, 1)), g(N);
     const int rc = linearize(id, Hpp.data(), L ? W.data() : nullptr, L ? Hll.data() : nullptr, g.data(), nullptr);
     if (rc != CTVIO_OK) return rc;
@@ -1249,6 +1299,9 @@ class SolverImpl : public SolverBase {
 
  private:
   ctvio_options opt_;
+  const DebugSwitches dbg_;   // environment switches as they were when the handle was created
+  int chol_tiles_ = 1;        // the uploaded batch's factorisation kernel (0 panel kernel, 1 / 2 register tiles): pack_and_upload
+  int marg_ran_on_host_ = 0;  // the last ctvio_marginalize(_batch) call: 1 if the factorisation ran on the host
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool uploaded_ = false, profiling_ = false, profiling_requested_ = false;
@@ -1294,15 +1347,11 @@ class SolverImpl : public SolverBase {
   const int32_t *h_lm_pos_ = nullptr;   // host mirror of Dev::lm_pos (inside in_.host: valid while the batch is uploaded)
 };
 
-void SolverImpl::launch_imu_linearize(size_t lds, int mode) {
+void SolverImpl::launch_imu_linearize(int mode) {
   const Dev &d = dev_;
-  // fp64 matrix cores (default); use_mfma = 0 keeps the VALU register-tile kernel as the cross-check
-  if (opt_.use_mfma) {
-    // (at most 2048 waves -- two rounds of one wave per SIMD -- each walking its share of the groups with the next group's data in flight)
-    hipLaunchKernelGGL(k_imu_linearize_f64, dim3(std::min(d.Gtot, imu_walk_waves())), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
-    hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
-  }
-  else hipLaunchKernelGGL((k_imu_linearize<32>), dim3(d.Gtot), dim3(64), lds, stream_, d, mode);
+  // (at most 2048 waves -- two rounds of one wave per SIMD -- each walking its share of the groups with the next group's data in flight)
+  hipLaunchKernelGGL(k_imu_linearize_f64, dim3(std::min(d.Gtot, imu_walk_waves())), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
+  hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
 }
 void SolverImpl::launch_linearize_merged(int mode) {
   const Dev &d = dev_;
@@ -1311,43 +1360,33 @@ void SolverImpl::launch_linearize_merged(int mode) {
 }
 void SolverImpl::launch_assemble_vis_lds(int parts, int mode) {
   const Dev &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
-  else hipLaunchKernelGGL((k_assemble_vis<VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
+  hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, true>), dim3(d.nwin, parts), dim3(512), vis_lds_, stream_, d, mode);
 }
 // windows whose packed Hessian does not fit in LDS (K > 25): run products on the MFMA units, added to Hpp with global atomics
 void SolverImpl::launch_assemble_vis_glb(int parts, int mode) {
   const Dev &d = dev_;
-  if (opt_.use_mfma) hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
-  else hipLaunchKernelGGL((k_assemble_vis<VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
+  hipLaunchKernelGGL((k_assemble_vis_mfma<VCH, false>), dim3(d.nwin, parts), dim3(512), vis_glb_, stream_, d, mode);
 }
 void SolverImpl::launch_schur() {
   const Dev &d = dev_;
-  schur_rhs_done_ = false;
-  if (opt_.use_mfma) {   // fp64 matrix cores
-    // large batches: one workgroup per window, W staged through LDS once, reduced rhs produced on the way; small batches: one
-    // wave per 16 x 16 tile (shorter latency, W re-read per tile), k_rhs forms the reduced right-hand side
-    const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
-    if (schur_window_path()) {
-      const size_t lds = schur_window_lds();
-      if (16 * nc <= 5 * 512 && max_schur_tiles_ <= 56) hipLaunchKernelGGL((k_schur_window_f64<5, 7>), dim3(d.nwin), dim3(512), lds, stream_, d);
-      else if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
-      else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
-      schur_rhs_done_ = true;
-    } else {
-      const int nt2 = d.maxP / 16 + 1, ntile2 = nt2 * (nt2 + 1) / 2;   // tile rows up to index P (the rhs row)
-      const int nb2 = (nt2 + 1) / 2, nblk2 = nb2 * (nb2 + 1) / 2;      // 32 x 32 blocks of the lower triangle
-      // enough tiles to fill the chip several times over (config 5: 666 per window): one wave per 2 x 2 tiles, half the operand loads
-      // per product; otherwise one wave per tile (more waves in flight).  CTVIO_SCHUR_TILE2 = 0 / 1 forces the choice (A/B).
-      const char *e2 = std::getenv("CTVIO_SCHUR_TILE2");
-      const int force2 = e2 ? std::atoi(e2) : -1;
-      const bool tile2 = force2 >= 0 ? force2 != 0 : (long long)d.nwin * ntile2 >= 16384;
-      if (tile2) hipLaunchKernelGGL(k_schur_tile2_f64, dim3(nblk2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nblk2);
-      else hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile2);
-      schur_rhs_done_ = true;
-    }
-  } else {
-    hipLaunchKernelGGL(k_schur_generic, dim3(nblk((long long)d.maxP * d.maxP, 256), d.nwin), dim3(256), 0, stream_, d);
+  // large batches: one workgroup per window, W staged through LDS once; small batches: one wave per 16 x 16 tile (shorter latency, W re-read
+  // per tile).  Every variant also produces the reduced right-hand side (g_rho rides as column P).
+  const int nc = 6 * maxK_ + 2;   // compact columns of W per landmark: knots, line delay, g_rho
+  if (schur_window_path()) {
+    const size_t lds = schur_window_lds();
+    if (16 * nc <= 5 * 512 && max_schur_tiles_ <= 56) hipLaunchKernelGGL((k_schur_window_f64<5, 7>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    else if (16 * nc <= 5 * 512) hipLaunchKernelGGL((k_schur_window_f64<5, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    else hipLaunchKernelGGL((k_schur_window_f64<7, 14>), dim3(d.nwin), dim3(512), lds, stream_, d);
+    return;
   }
+  const int nt2 = d.maxP / 16 + 1, ntile2 = nt2 * (nt2 + 1) / 2;   // tile rows up to index P (the rhs row)
+  const int nb2 = (nt2 + 1) / 2, nblk2 = nb2 * (nb2 + 1) / 2;      // 32 x 32 blocks of the lower triangle
+  // enough tiles to fill the chip several times over (config 5: 666 per window): one wave per 2 x 2 tiles, half the operand loads
+  // per product; otherwise one wave per tile (more waves in flight).  DebugSwitches::schur_tile2 = 0 / 1 forces the choice (A/B).
+  const int force2 = dbg_.schur_tile2;
+  const bool tile2 = force2 >= 0 ? force2 != 0 : (long long)d.nwin * ntile2 >= 16384;
+  if (tile2) hipLaunchKernelGGL(k_schur_tile2_f64, dim3(nblk2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, nblk2);
+  else hipLaunchKernelGGL(k_schur_tile_f64, dim3(ntile2 * 8 * ((d.nwin + 7) / 8)), dim3(64), 0, stream_, d, ntile2);
 }
 
 }  // namespace ctv
@@ -1373,6 +1412,7 @@ const char *ctvio_status_string(int32_t s) {
     case CTVIO_ERR_NO_DEVICE: return "no HIP device (the product path has no CPU fallback)";
     case CTVIO_ERR_HIP: return "HIP runtime error";
     case CTVIO_ERR_STATE: return "call order violated";
+    case CTVIO_ERR_INTERNAL: return "internal consistency check failed";
     default: return "unknown status";
   }
 }
@@ -1393,6 +1433,7 @@ int32_t ctvio_create(const ctvio_options *opt, ctvio_solver **out) {
   std::unique_ptr<ctvio_solver> s(new ctvio_solver);
   int rc;
   if (o.precision != CTVIO_FP64) return ctv::fail(CTVIO_ERR_INVALID, "precision: only CTVIO_FP64 exists (the mixed fp32 mode was removed: it missed the 1e-4 contract)");
+  if (o.use_mfma != 1 && o.use_mfma != 2) return ctv::fail(CTVIO_ERR_INVALID, "use_mfma: 1 or 2 (the vector-ALU cross-check kernels of use_mfma = 0 were removed: the oracle is the cross-check)");
   { auto *p = new ctv::SolverImpl(o); s->impl.reset(p); rc = p->init(); }
   if (rc != CTVIO_OK) return rc;
   *out = s.release();
@@ -1508,7 +1549,7 @@ std::vector<std::unique_ptr<ShardWorker>> g_shard_workers;   // [g - 1] for shar
 int32_t ctvio_shards_used(int32_t n_devices, int32_t n) {
   const int ndev = ctvio_device_count();
   if (ndev <= 0 || n <= 0) return 0;
-  if (std::getenv("CTVIO_SHARD_OVERSUBSCRIBE") && n_devices > 0) return std::min(n_devices, n);
+  if (ctv::read_debug_switches().shard_oversubscribe && n_devices > 0) return std::min(n_devices, n);
   return std::min(n_devices > 0 ? std::min(n_devices, ndev) : ndev, n);
 }
 void ctvio_sharded_release(void) {
@@ -1600,5 +1641,6 @@ int32_t ctvio_restore_state(ctvio_solver *s) { CHK_S; return s->impl->snapshot(1
 int32_t ctvio_set_profiling(ctvio_solver *s, int32_t on) { CHK_S; return s->impl->set_profiling(on); }
 void *ctvio_stream(ctvio_solver *s) { return s ? s->impl->stream() : nullptr; }
 int32_t ctvio_graph_captures(const ctvio_solver *s) { return s ? s->impl->graph_captures() : 0; }
+int32_t ctvio_marginalize_ran_on_host(const ctvio_solver *s) { return s ? s->impl->marg_ran_on_host() : 0; }
 
 }  // extern "C"

@@ -6,14 +6,14 @@
 //                         log(R_k^-1 R_k+1) and Jr^-1(d) of every knot pair, shared by all blocks; the candidate's table is made by k_step_finish)
 //   kernels_imu.hpp       k_imu_linearize_f64 (waves walking the IMU groups: rows through LDS, per-group A^T A on the fp64 matrix cores; it
 //                         also clears the accumulated parts of the normal equations), k_imu_linearize_rest (groups the specialised body
-//                         leaves out), k_imu_linearize<CHUNK> = vector-ALU cross-check (use_mfma = 0), assemble_imu_window (run by k_misc)
+//                         leaves out), assemble_imu_window (run by k_misc)
 //   kernels_visual.hpp    k_vis_anchor (one record per anchor end), k_vis_eval (landmark-major: block records via LDS, the rows of W, Hll,
 //                         g_rho formed in the same kernel), k_linearize_f64 (IMU + visual in one launch for small batches)
 //   kernels_assemble.hpp  k_assemble_vis_mfma (MFMA + fp64 LDS Hessian, or global atomics for K > 25; STORE = the order-fixed tail of the
-//                         deterministic mode with k_reduce_finalize / k_bias_rows; k_assemble_vis = register-tile cross-check), k_misc
+//                         deterministic mode with k_reduce_finalize / k_bias_rows), k_misc
 //                         (IMU tiles' bias rows + bias chain + prior), k_post_linearize (first linearisation only)
 //   kernels_solve.hpp     k_begin_iter, k_schur_window_f64 (large batches) / k_schur_tile_f64 (small; both also produce the reduced rhs),
-//                         k_schur_generic + k_rhs (vector fallback), k_cholesky_tiles (register-resident 16 x 16 tiles; k_cholesky_solve =
+//                         k_cholesky_tiles (register-resident 16 x 16 tiles; k_cholesky_solve =
 //                         panel kernel for P > 223), k_step_finish (back-substitution, candidate x (+) alpha delta, its knot-pair table)
 //   kernels_query.hpp     k_gauge_restore (double2vector), k_residual_summary, k_spline_eval (trajectory queries)
 #pragma once

@@ -1,195 +1,9 @@
 // kernels_assemble.hpp -- Assembly of the pose block: k_assemble_vis_mfma (fp64 matrix cores, LDS Hessian; STORE = order-fixed tail with k_reduce_finalize /
-// k_bias_rows), k_assemble_vis (register-tile cross-check), k_misc (bias chain + prior), k_post_linearize.
+// k_bias_rows), k_misc (bias chain + prior), k_post_linearize.
 // Part of kernels.hpp (included from there, in order; not a stand-alone header).
 #pragma once
 
 namespace ctv {
-
-// Visual assembly: gridDim.y workgroups (8 waves each) per window.  The host sorted the visual blocks by
-// frame pair and cut them into items of <= CH blocks; blocks of an item that evaluate on the same knot
-// quadruples (si, sj) form a run.  A wave stages its item's J~ (100 x n) and r~ in LDS (all loads of a pass
-// in flight together), then forms the run's 50 x 50 product [J~_pose | r~]^T [J~_pose | r~] with a 7 x 7
-// register tile per lane (rows {ti+8a}, cols {tj+8b}; K = 2 * run length) and adds it into an LDS-resident
-// copy of the window's visual Hessian (packed lower triangle over the 6K knot unknowns + the line-delay
-// row): ~1.2k ds_add per RUN instead of ~1.3k global atomics per BLOCK.  The two ends of a block may share
-// knots (reference image_feature_factor.h:165-180,215,233): every ordered column pair whose unknowns satisfy
-// g(a) >= g(b) is added, so shared knots sum correctly.  Landmark terms (W row, Hll, g_rho) stay per block.
-// Windows whose packed Hessian does not fit in LDS (vis_lds = 0) add straight into Hpp.
-template <int CH, bool LDSH> __global__ __launch_bounds__(512) void k_assemble_vis(Dev d, int mode) {
-  constexpr int CHP = CH + 2, NW = 8, RPP = 64 / CH, NPASS = (102 + RPP - 1) / RPP;   // even row stride: 8-byte aligned pairs
-  const long long t_begin = d.dbg ? clock64() : 0;
-  const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
-  if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;
-  const WinMeta &m = d.wins[w];
-  const int tgset = lin_target(d.lm[w], mode);
-  // fields used after LDS/global atomics are copied to registers: the compiler must otherwise re-read them from
-  // memory every time (a store could alias), one L2 round trip each
-  const int P = m.P, K = m.K, nvitem = m.nvitem, vitem0 = m.vitem0, ngrp = m.ngrp, grp0 = m.grp0, u0 = m.u0, ldh = m.ldh;
-  if ((m.vis_lds != 0) != LDSH) return;   // the host launches both variants; each window is handled by one of them
-  if (m.V == 0 && !LDSH) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smv[];
-  const int K6 = 6 * K, tri = K6 * (K6 + 1) / 2;
-  const int nHh = LDSH ? tri + K6 + 1 : 0;     // packed Hessian entries
-  double *gs = reinterpret_cast<double *>(smv);                       // [K6 + 1] pose gradient, fp64 (ds_add_f32 is ~20x slower)
-  double *Hs = reinterpret_cast<double *>(gs + ((K6 + 2) & ~1));                // [nHh]
-  double *stage = Hs + ((nHh + 3) & ~3);                                   // [NW][102][CHP]
-  int *keys = reinterpret_cast<int *>(stage + NW * 102 * CHP);        // [NW][2][CH]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < nHh; i += 512) Hs[i] = 0.0;
-  for (int i = tid; i < K6 + 1; i += 512) gs[i] = 0.0;
-  __syncthreads();
-  double *Js = stage + wave * 102 * CHP;
-  int *ks = keys + wave * 2 * CH;
-  const size_t V = (size_t)d.Vtot;
-  const int per_round = NW * nparts;
-  const int rounds = (nvitem + per_round - 1) / per_round;
-  double *Hg = d.HppS[tgset] + m.H0;
-  const int ti = lane >> 3, tj = lane & 7;
-  // local column c (0..47 knot columns, 48 line delay, 49 residual) -> first of its two staging rows
-  int rowa[7], rowb[7];
-#pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    const int ca = ti + 8 * a, cb = tj + 8 * a;
-    rowa[a] = ca < 48 ? 2 * ca : (ca == 48 ? 98 : (ca == 49 ? 100 : -1));
-    rowb[a] = cb < 48 ? 2 * cb : (cb == 48 ? 98 : (cb == 49 ? 100 : -1));
-  }
-  long long *dbg = (d.dbg && w == (d.nwin > 1000 ? 1000 : 0) && part == 0) ? d.dbg + 48 : nullptr;
-  int dbi = 0;
-#define CTV_STAMP() do { if (dbg && tid == 0 && dbi < 15) dbg[dbi++] = clock64(); } while (0)
-  if (dbg && tid == 0) dbg[dbi++] = t_begin;
-  CTV_STAMP();
-  for (int r = 0; r < rounds; ++r) {
-    const int it = (r * nparts + part) * NW + wave;
-    int n = 0, v0 = 0;
-    if (it < nvitem) { const VisItem I = d.vitems[vitem0 + it]; n = I.count; v0 = I.start; }
-    {
-      const int c = lane % CH, rr = lane / CH;
-      const unsigned blk = (unsigned)d.vblk[v0 + (c < n ? c : 0)];   // slot of the item's block c (landmark-major evaluation order)
-      const unsigned anc = (unsigned)d.vblk_anc[v0 + (c < n ? c : 0)];
-      double tmp[NPASS];
-#pragma unroll
-      for (int i = 0; i < NPASS; ++i) {
-        const int row = i * RPP + rr;
-        tmp[i] = 0.0;
-        if (row < 102 && c < n) tmp[i] = vis_J_entry(d, row, blk, anc);
-      }
-#pragma unroll
-      for (int i = 0; i < NPASS; ++i) {
-        const int row = i * RPP + rr;
-        if (row < 102) Js[row * CHP + c] = tmp[i];
-      }
-    }
-    if (lane < n) { ks[lane] = d.a_s[d.vblk_anc[v0 + lane]]; ks[CH + lane] = d.vsj[d.vblk[v0 + lane]]; }
-    __syncthreads();
-    
-    int start = 0;
-    while (start < n) {
-      const int si = ks[start], sj = ks[CH + start];
-      const bool diff = (lane > start && lane < n) && (ks[lane] != si || ks[CH + lane] != sj);
-      const unsigned long long mask = __ballot(diff);
-      const int end = mask ? (__ffsll((long long)mask) - 1) : n;
-      // two blocks per step (one 8-byte LDS read per operand); blocks outside [start, end) are masked to zero.
-      // (v_pk_fma_f32 on the block pair was measured slower than scalar FMAs here: 354k vs 308k cycles per window.)
-      double acc[7][7];
-#pragma unroll
-      for (int a = 0; a < 7; ++a)
-#pragma unroll
-        for (int b = 0; b < 7; ++b) acc[a][b] = 0.0;
-      for (int v2 = start & ~1; v2 < end; v2 += 2) {
-        const double m0 = (v2 >= start) ? 1.0 : 0.0, m1 = (v2 + 1 < end) ? 1.0 : 0.0;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          VecN<double, 2> av[7], bv[7];
-#pragma unroll
-          for (int a = 0; a < 7; ++a) {
-            av[a].v[0] = av[a].v[1] = bv[a].v[0] = bv[a].v[1] = 0.0;
-            if (rowa[a] >= 0) av[a] = *reinterpret_cast<const VecN<double, 2> *>(Js + (rowa[a] + rr) * CHP + v2);
-            if (rowb[a] >= 0) bv[a] = *reinterpret_cast<const VecN<double, 2> *>(Js + (rowb[a] + rr) * CHP + v2);
-            av[a].v[0] *= m0; av[a].v[1] *= m1;
-          }
-#pragma unroll
-          for (int a = 0; a < 7; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) acc[a][b] += av[a].v[0] * bv[b].v[0] + av[a].v[1] * bv[b].v[1];   // symmetric: blocks a >= b
-        }
-      }
-      int ga[7], gb[7];
-#pragma unroll
-      for (int a = 0; a < 7; ++a) {
-        const int ca = ti + 8 * a, cb = tj + 8 * a;
-        ga[a] = ca < 48 ? vis_col(ca, si, sj, P) : (ca == 48 ? P - 1 : (ca == 49 ? -2 : -1));
-        gb[a] = cb < 48 ? vis_col(cb, si, sj, P) : (cb == 48 ? P - 1 : (cb == 49 ? -2 : -1));
-      }
-      // Each unordered column pair {ca, cb} is held exactly once: blocks a > b by this lane, and for a == b by the lane
-      // with ti >= tj.  It goes to H[max(g)][min(g)]; two different local columns that map to the same unknown (ends
-      // sharing a knot) contribute twice to the diagonal entry.
-#pragma unroll
-      for (int a = 0; a < 7; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-          if (a == b && ti < tj) continue;
-          int gA = ga[a], gB = gb[b];
-          double hv = acc[a][b];
-          if (gA == -2 || gB == -2) {         // column 49 = residual: J~^T r~ (r~^T r~ itself is not needed)
-            const int gX = gA == -2 ? gB : gA;
-            if (gX >= 0) atomicAdd(&gs[gX == P - 1 ? K6 : gX], (double)hv);
-          } else if (gA >= 0 && gB >= 0) {
-            if (gA == gB && !(a == b && ti == tj)) hv *= 2.0;
-            if (gA < gB) { const int t = gA; gA = gB; gB = t; }
-            if (LDSH) atomicAdd(&Hs[(gA == P - 1) ? tri + (gB == P - 1 ? K6 : gB) : gA * (gA + 1) / 2 + gB], hv);
-            else atomicAdd(&Hg[(long long)gA * ldh + gB], (double)hv);
-          }
-        }
-      start = end;
-      
-    }
-    __syncthreads();
-    
-  }
-  CTV_STAMP();
-  if (LDSH) {
-    // IMU group tiles: the knot x knot part (24 x 24 per group, overlapping between consecutive segments)
-    for (int gi = part * NW + wave; gi < ngrp; gi += per_round) {
-      const ImuGroup grp = d.groups[grp0 + gi];
-      const double *tile = d.imu_tiles + (size_t)(grp0 + gi) * 1024;
-      double tv[9];   // 24 x 24 = 9 x 64 entries: all loads in flight together
-#pragma unroll
-      for (int u = 0; u < 9; ++u) { const int e = lane + 64 * u; tv[u] = tile[(e / 24) * 32 + e % 24]; }
-#pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int e = lane + 64 * u, a = e / 24, b = e % 24;
-        const int ga = imu_col(a, grp.s, K, grp.bias), gb = imu_col(b, grp.s, K, grp.bias);
-        if (ga >= gb) atomicAdd(&Hs[ga * (ga + 1) / 2 + gb], tv[u]);
-      }
-    }
-    __syncthreads();
-    CTV_STAMP();
-    for (int i = tid; i < nHh; i += 512) {
-      const double hv = Hs[i];
-      if (nparts > 1 && hv == 0.0) continue;
-      int ga, gb;
-      if (i < tri) {
-        ga = (int)((sqrtf(8.0f * (float)i + 1.0f) - 1.0f) * 0.5f);
-        while ((ga + 1) * (ga + 2) / 2 <= i) ++ga;
-        while (ga * (ga + 1) / 2 > i) --ga;
-        gb = i - ga * (ga + 1) / 2;
-      } else {
-        ga = P - 1;
-        gb = (i - tri) < K6 ? (i - tri) : P - 1;
-      }
-      if (nparts > 1) atomicAdd(&Hg[(long long)ga * ldh + gb], (double)hv);
-      else Hg[(long long)ga * ldh + gb] = (double)hv;  // first writer after k_zero_normal; later kernels add atomically
-    }
-  }
-  CTV_STAMP();
-  if (!LDSH) __syncthreads();
-  for (int i = tid; i < K6 + 1; i += 512) {
-    const double gv = gs[i];
-    if (gv != 0.0) atomicAdd(&d.gS[tgset][u0 + (i < K6 ? i : P - 1)], gv);
-  }
-  CTV_STAMP();
-#undef CTV_STAMP
-}
 
 // ---- store-semantics tail of the assembly (product path, windows whose packed Hessian is LDS resident).  Every entry of Hpp / g is
 // formed completely by ONE thread and written with a plain store -- the knot x knot block and the line-delay row from the packed
@@ -281,14 +95,23 @@ __device__ __forceinline__ void bias_rows_store(const Dev &d, const WinMeta &m, 
   }
 }
 
-// Visual assembly on the fp64 matrix cores.  Same decomposition as k_assemble_vis (items of <= CH = 8 blocks per frame pair, runs of
-// equal knot quadruples inside an item), but
+// Visual assembly on the fp64 matrix cores: gridDim.y workgroups (parts) per window.  The host sorted the visual blocks by frame pair and cut
+// them into items of <= CH = 8 blocks; blocks of an item that evaluate on the same knot quadruples (si, sj) form a run, whose product is added
+// into an LDS-resident copy of the window's visual Hessian (packed lower triangle over the 6K knot unknowns + the line-delay row).  The two ends
+// of a block may share knots (reference image_feature_factor.h:165-180,215,233): every ordered column pair whose unknowns satisfy g(a) >= g(b)
+// is added, so shared knots sum correctly.  Landmark terms (W row, Hll, g_rho) are formed by k_vis_eval.  Windows whose packed Hessian does
+// not fit in LDS (vis_lds = 0) add straight into Hpp.
 //   * the run's [J~_pose]^T [J~_pose] (48 x 48 = 3 x 3 tiles of 16; the lower 6 tiles) is formed with v_mfma_f64_16x16x4_f64: K = 4 is two
 //     blocks x two residual rows, the operands are plain LDS reads of the staged item ([116][CH + 2], row = 2 * column + residual row),
 //     the A and B operand of a tile pair are the same registers; the line-delay column and the residual ride along as plain FMAs;
 //   * the staging area of a wave is private, so there is no workgroup barrier inside the item loop, and the next item's records (15
 //     values per lane) are requested before the current item is processed: their latency hides under the products.
 // D register r of lane l = D[(l / 16) + 4 r][l % 16] (tools/mfma_f64_layout.hip); eight fp64 staging areas fit beside the packed Hessian.
+// LDS staging of one item: [VIS_SROWS][CH + 1] doubles per wave + 2 CH ints of keys.  The host sizes the dynamic LDS request -- and decides
+// whether a window keeps its packed Hessian in LDS -- from these same constants (ctvio.hip: SolverImpl::vis_stage_bytes).
+constexpr int VIS_SROWS = 116;
+constexpr int vis_stage_stride(int ch) { return ch + 1; }
+constexpr size_t vis_stage_bytes(int nw, int ch) { return (size_t)nw * VIS_SROWS * vis_stage_stride(ch) * sizeof(double) + (size_t)nw * 2 * ch * sizeof(int); }
 __device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 // NW = waves per workgroup: 8, or 1 in the deterministic mode (all LDS additions of a partial Hessian then come from one wave, in program
 // order).  STORE (LDS-resident windows of the product path): store-semantics tail -- with one part the workgroup finishes the window
@@ -299,7 +122,7 @@ template <int CH, bool LDSH, int NW = 8, bool STORE = false> __global__ __launch
   // Row stride of a staged item: CH + 1 = 9 doubles.  The MFMA operand reads are ds_read_b64 of lanes (l15, k-row): row 2 (16 I + l15) + rr, so
   // consecutive l15 are 2 x 9 x 2 = 36 four-byte banks apart -- 16 distinct bank pairs, the rr = 1 half on the odd pairs: conflict-free.  With the
   // stride 10 of rounds 1-4 (40 banks apart: period 8) lanes l15 and l15 + 8 met on one bank and every operand read took twice its cycles.
-  constexpr int CHP = CH + 1, RPP = 64 / CH, NT = 64 * NW;
+  constexpr int CHP = vis_stage_stride(CH), RPP = 64 / CH, NT = 64 * NW;
   static_assert(!STORE || LDSH, "the store-semantics tail needs the LDS-resident Hessian");
   // staged rows per item: 0..95 pose columns (row = 2 * column + residual row), 98/99 line delay, 100/101 residual, 102..107 A~,
   // 108..111 cp0, 112..115 cp1.  38 of them come from the block records in HBM (rows 48..71 = the j end's rotation columns, 98..107,
@@ -307,7 +130,7 @@ template <int CH, bool LDSH, int NW = 8, bool STORE = false> __global__ __launch
   // per lane, held in registers), the 48 position rows (24..47, 72..95) are rebuilt in LDS from rows 102..115; the inverse-depth
   // column is not needed here.
   static_assert(CH == 8, "the staging pattern is written for items of 8 blocks");
-  constexpr int SROWS = 116, NEXP = 48 / RPP;
+  constexpr int SROWS = VIS_SROWS, NEXP = 48 / RPP;
   const long long t_begin = d.dbg ? clock64() : 0;
   const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
   if (!lin_run(d.lm[w], mode) || lin_cost_only(d.lm[w], mode, d.prm)) return;

@@ -1,5 +1,5 @@
 // kernels_imu.hpp -- IMU linearisation: k_imu_linearize_f64 (the product path's walk over groups, fast body), the general body / k_imu_linearize_rest,
-// k_imu_linearize<CHUNK> (vector-ALU cross-check), assemble_imu_window (the bias rows of the group tiles: run by k_misc).
+// assemble_imu_window (the bias rows of the group tiles: run by k_misc).
 // Part of kernels.hpp (included from there, in order; not a stand-alone header).
 #pragma once
 
@@ -8,104 +8,7 @@ namespace ctv {
 // ------------------------------------------------------------------------------------------------ IMU
 template <class T, int N> struct alignas(N * sizeof(T)) VecN { T v[N]; };
 
-// VALU cross-check of k_imu_linearize_f64 (use_mfma = 0): the rows of A = [J | r] (row k = 6 * lane + r, 32 columns) staged
-// column-major in LDS, A^T[32][KS], 4 consecutive k per ds_read; 4 x 4 register tile per lane (rows {ti+8a}, cols {tj+8b}).
-struct ImuLdsSink {
-  double *A;
-  int lane, stride;
-  __device__ __forceinline__ void put_col(int col, const double v[6]) {
-#pragma unroll
-    for (int r = 0; r < 6; ++r) A[col * stride + 6 * lane + r] = v[r];
-  }
-};
-struct NullSink {
-  __device__ __forceinline__ void put_col(int, const double *) {}
-};
-
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-// One workgroup (one wave) per IMU group.  The 4 active knots of the group are loaded once; every lane evaluates one sample and
-// its 6 Jacobian rows + residual; then the wave forms the group's 31 x 31 block A^T A = [J^T J, J^T r; r^T J, r^T r].
-// The tile is stored, not accumulated -- no atomics, deterministic.
-template <int CHUNK> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_imu_linearize(Dev d, int mode) {
-  constexpr int KCH = 6 * CHUNK, KS = KCH + 4;
-  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  double *A = reinterpret_cast<double *>(smraw);
-  const ImuGroup grp = d.groups[blockIdx.x];
-  const int w = grp.win;
-  if (!lin_run(d.lm[w], mode)) return;
-  const bool jac = !lin_cost_only(d.lm[w], mode, d.prm);
-  const WinMeta &m = d.wins[w];
-  const int lane = threadIdx.x;
-  Knots4 k;
-  LocalFrame lf;
-  const bool at_cand = mode == LIN_SPEC;
-  double csum = 0.0;
-  const double *s_quat = at_cand ? d.cquat : d.quat, *s_pos = at_cand ? d.cpos : d.pos, *s_bias = at_cand ? d.cbias : d.bias;
-  lf.init(s_quat, s_pos, m.knot0 + grp.s);
-  lf.load(s_quat, s_pos, m.knot0 + grp.s, k);
-  const M3 RrefT = lf.RrefT();
-  SegConst sc;
-  seg_const_load(d.lkd + 3 * (m.knot0 + grp.s), d.kjri + 9 * (m.knot0 + grp.s), sc, true);
-  double bias[6], wgt[6];
-  const double *bp = s_bias + 6 * (m.bias0 + grp.bias);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { bias[i] = (double)bp[i]; wgt[i] = (double)m.imu_w[i]; }
-  const V3 grav = lf.rotate(m.gravity);
-  const double idt = (double)m.inv_dt;
-  const int ti = lane >> 3, tj = lane & 7;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  const double zero6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int c0 = 0; c0 < grp.count; c0 += CHUNK) {
-    const int nval = min(CHUNK, grp.count - c0);
-    const int idx = m.imu0 + grp.start + c0 + lane;
-    double gy[3], ac[3], r[6];
-    if (lane < nval) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { gy[i] = d.imu_meas[(size_t)i * d.Mtot + idx]; ac[i] = d.imu_meas[(size_t)(3 + i) * d.Mtot + idx]; }
-    }
-    const int kmax = (6 * nval + 3) & ~3;
-    ImuLdsSink sink{A, lane, KS};
-    if (lane < nval) {
-      imu_eval(k, sc, d.imu_u[idx], idt, grav, bias, gy, ac, wgt, RrefT, r, jac, sink);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) csum += 0.5 * (double)(r[i] * r[i]);
-      sink.put_col(30, r);
-      sink.put_col(31, zero6);
-    } else if (6 * lane < kmax) {  // at most one partial lane: rows up to the multiple of 4 must read as zero
-#pragma unroll
-      for (int c = 0; c < 32; ++c) sink.put_col(c, zero6);
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < kmax; k0 += 4) {
-      VecN<double, 4> av[4], bv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        av[a] = *reinterpret_cast<const VecN<double, 4> *>(A + (ti + 8 * a) * KS + k0);
-        bv[a] = *reinterpret_cast<const VecN<double, 4> *>(A + (tj + 8 * a) * KS + k0);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) acc[a][b] += av[a].v[kk] * bv[b].v[kk];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off);
-  if (lane == 0) d.imu_cost[blockIdx.x] = csum;
-  if (!jac) return;
-  double *tile = d.imu_tiles + (size_t)blockIdx.x * 1024;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) tile[(ti + 8 * a) * 32 + (tj + 8 * b)] = acc[a][b];
-}
 
 // The zeroing of the normal equations' accumulated parts, done by the IMU groups of the window instead of a pass of its own (k_zero_normal
 // is HBM-bound, ~100 us per 2048 windows; the stores cost this compute-bound kernel nothing): group gi of the window clears its

@@ -1,4 +1,4 @@
-// kernels_solve.hpp -- The step: begin_iteration / k_begin_iter, Schur complement (k_schur_window_f64, k_schur_tile_f64, k_schur_generic + k_rhs), Cholesky
+// kernels_solve.hpp -- The step: begin_iteration / k_begin_iter, Schur complement (k_schur_window_f64, k_schur_tile_f64, k_schur_tile2_f64), Cholesky
 // (k_cholesky_tiles register-resident, k_cholesky_solve panel kernel), k_step_finish (back-substitution, candidate, its pair table).
 // Part of kernels.hpp (included from there, in order; not a stand-alone header).
 #pragma once
@@ -497,49 +497,6 @@ __global__ __launch_bounds__(64) void k_schur_tile2_f64(Dev d, int nblk_max) {
         }
       }
     }
-}
-
-__global__ void k_schur_generic(Dev d) {
-  const int w = blockIdx.y;
-  if (d.lm[w].status || d.lm[w].ls_active) return;
-  const WinMeta &m = d.wins[w];
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long long)m.P * m.P) return;
-  const int ii = (int)(e / m.P), jj = (int)(e % m.P);
-  if (jj > ii) return;
-  const bool on = d.active[m.u0 + ii] && d.active[m.u0 + jj];
-  double val;
-  if (on) {
-    const double *Wp = d.WS[d.lm[w].cur] + m.W0;
-    double acc = 0.0;
-    for (int l = 0; l < m.L; ++l) acc += (double)Wp[(long long)l * m.ldw + ii] * (double)Wp[(long long)l * m.ldw + jj] * d.dinv[m.lm0 + l];
-    val = d.HppS[d.lm[w].cur][m.H0 + (long long)ii * m.ldh + jj] - acc + (ii == jj ? d.dd[m.u0 + ii] : 0.0);
-  } else {
-    val = (ii == jj) ? 1.0 : 0.0;
-  }
-  d.S[m.H0 + (long long)ii * m.ldh + jj] = val;
-}
-
-// rhs_p = -g_p + W^T diag(dinv) g_l.  256 threads = 64 unknowns x 4 landmark slices (coalesced over the unknowns).
-__global__ __launch_bounds__(256) void k_rhs(Dev d) {
-  const int w = blockIdx.y;
-  if (d.lm[w].status || d.lm[w].ls_active) return;
-  const WinMeta &m = d.wins[w];
-  __shared__ double part[4][64];
-  const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + li;
-  double v = 0.0;
-  if (i < m.P && d.active[m.u0 + i]) {
-    const double *Wp = d.WS[d.lm[w].cur] + m.W0 + i;
-    const double *dinv = d.dinv + m.lm0, *gl = d.grs + m.lm0;   // (both by row of W)
-    for (int l = sl; l < m.L; l += 4) v += (double)Wp[(long long)l * m.ldw] * (dinv[l] * gl[l]);
-  }
-  part[sl][li] = v;
-  __syncthreads();
-  if (sl == 0 && i < m.P) {
-    const double s = part[0][li] + part[1][li] + part[2][li] + part[3][li];
-    d.rhs[m.p0 + i] = d.active[m.u0 + i] ? s - d.gS[d.lm[w].cur][m.u0 + i] : 0.0;
-  }
 }
 
 // Dense fp64 Cholesky of the P x P reduced system + solve, one workgroup (4 waves) per window, right-looking with

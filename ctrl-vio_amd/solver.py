@@ -215,6 +215,10 @@ class Solver:
         n = n.value
         return kept[:n].copy(), J0[: n * n].reshape(n, n).copy(), r0[:n].copy()
 
+    def marginalize_ran_on_host(self) -> bool:
+        """Whether the last marginalize / marginalize_batch call factored on the host cores (ctvio_marginalize_ran_on_host)."""
+        return bool(self._lib.ctvio_marginalize_ran_on_host(self._h))
+
     def marginalize_batch(self, roles, eps: float = 1e-8):
         """ctvio_marginalize_batch: roles = list of per-window role arrays.  Returns a list of (kept, J0, r0) per window."""
         Ns = [w.N for w in self.windows]

@@ -33,7 +33,9 @@ enum ctvio_status {
   CTVIO_ERR_INVALID = 1,    /* bad argument / inconsistent sizes / time outside the spline */
   CTVIO_ERR_NO_DEVICE = 2,  /* no HIP device: the product path has NO CPU fallback */
   CTVIO_ERR_HIP = 3,        /* a HIP runtime call failed (ctvio_last_error has the text) */
-  CTVIO_ERR_STATE = 4       /* call order violated (e.g. solve before upload) */
+  CTVIO_ERR_STATE = 4,      /* call order violated (e.g. solve before upload) */
+  CTVIO_ERR_INTERNAL = 5    /* a device-side consistency check failed (an evaluation left the knot span planned for its landmark): the
+                               results of THIS call are not to be trusted; the counter is cleared, the batch stays usable */
 };
 
 /* CTVIO_FP64 (the only mode): every residual, Jacobian, product and factorisation in fp64, like the reference (Ceres / Eigen
@@ -51,9 +53,10 @@ enum { CTVIO_PK_ROT = 0, CTVIO_PK_POS = 1, CTVIO_PK_BG = 2, CTVIO_PK_BA = 3, CTV
 typedef struct ctvio_options {
   int32_t device;               /* HIP device ordinal */
   int32_t precision;            /* CTVIO_FP64 */
-  int32_t use_mfma;             /* 1 (default): products on v_mfma_f64_16x16x4_f64; 0: vector-ALU cross-check kernels;
-                                   2: as 1 with every IMU group evaluated by the general body (the one groups with knot-to-knot
-                                   rotations >= 0.5 rad or anisotropic accelerometer weights take): cross-check of the specialised body */
+  int32_t use_mfma;             /* 1 (default): products on v_mfma_f64_16x16x4_f64; 2: as 1 with every IMU group evaluated by the
+                                   general body (the one groups with knot-to-knot rotations >= 0.5 rad or anisotropic accelerometer
+                                   weights take): cross-check of the specialised body.  0 (the vector-ALU cross-check kernels of rounds
+                                   1-5) was removed: ctvio_create rejects it */
   int32_t check_every;          /* host polls "all windows terminated" every n LM iterations */
   double function_tolerance;    /* 1e-6  Ceres defaults, see SURVEY.md Appendix A */
   double gradient_tolerance;    /* 1e-10 */
@@ -64,8 +67,8 @@ typedef struct ctvio_options {
   double min_lm_diagonal, max_lm_diagonal; /* 1e-6, 1e32 */
   int32_t max_consecutive_invalid_steps;   /* 5 */
   int32_t deterministic;        /* 1: order-fixed accumulation everywhere (no floating-point atomics): two runs of the same batch
-                                   are bitwise equal.  It exists for batches whose every window has K <= 24 (packed Hessian in LDS)
-                                   with use_mfma != 0: ctvio_upload / ctvio_set_batch return CTVIO_ERR_INVALID for any other batch
+                                   are bitwise equal.  It exists for batches whose every window has K <= 25 (packed Hessian in LDS):
+                                   ctvio_upload / ctvio_set_batch return CTVIO_ERR_INVALID for any other batch
                                    instead of silently accumulating with atomics.  -1 (default): on for batches of <= 64 windows
                                    where it applies, the atomic path (run-to-run differences ~1e-13 in the state) otherwise; 0: off */
   int32_t host_threads;         /* host threads that validate / pack a batch (ctvio_set_batch, ctvio_upload); 0 = min(cores, 16) */
@@ -221,6 +224,11 @@ int32_t ctvio_marginalize(ctvio_solver *s, int32_t id, const int8_t *role, doubl
  * (offsets sum_{k<i} n_keep_k^2 / sum_{k<i} n_keep_k).  Every window needs <= 180 marginalised and <= 180 kept unknowns
  * (ctvio_marginalize falls back to a host factorisation beyond that). */
 int32_t ctvio_marginalize_batch(ctvio_solver *s, const int8_t *role, double eps, int32_t *n_keep, int32_t *kept, double *J0, double *r0);
+/* Where the LAST ctvio_marginalize / ctvio_marginalize_batch call of this handle factored: 0 = on the device (the product path), 1 = the
+ * eigen-decompositions ran on the HOST cores (csrc/marginalize.hpp: a window with more than 180 marginalised or kept unknowns, or one whose
+ * in-LDS Jacobi sweeps stalled; ctvio_marginalize only -- the batch entry fails instead).  The normal equations come from the device kernels
+ * either way.  Reference counterpart of the host leg: MarginalizationInfo::marginalize, marginalization_factor.cpp:178-265. */
+int32_t ctvio_marginalize_ran_on_host(const ctvio_solver *s);
 
 /* 4-DoF gauge restore after a solve, on the device, for n windows of the batch at once (reference
  * TrajectoryManager::double2vector, src/estimator/trajectory_manager.cpp:485-516, called at :467 right after Solve):
@@ -263,6 +271,14 @@ void *ctvio_stream(ctvio_solver *s);
 /* How many times this handle captured its LM pass into a hipGraph so far (diagnostic: a stream of equally shaped batches captures
  * once; the launch sequence the reference replaces is ceres::Solve's per-iteration Evaluate loop, trajectory_estimator.cpp:399). */
 int32_t ctvio_graph_captures(const ctvio_solver *s);
+
+/* ---- Diagnostic switches.  libctvio.so reads a fixed set of environment variables ONCE per handle, inside ctvio_create (csrc/ctvio.hip:
+ * DebugSwitches, the only getenv of the library), and never again: kernel selection cannot change between ctvio_upload and ctvio_solve.
+ * They exist for A/B measurements and for the tests' cross-checks; production callers set none of them.
+ *   CTVIO_DENSE=1 (dense sparsity plan)   CTVIO_CHOL_TILES=0|1|2   CTVIO_SCHUR_TILE2=0|1   CTVIO_SCHUR_TILES=1   CTVIO_SCHUR_COPY_PLAIN=1
+ *   CTVIO_STORE_PATH=0|1   CTVIO_SPLIT_LINEARIZE=1   CTVIO_MERGE_LINEARIZE=0|1   CTVIO_ZERO_KERNEL=1   CTVIO_NO_IMU_BAND=1   CTVIO_IMU_WAVES=n
+ *   CTVIO_IMU_GENERAL=1   CTVIO_MARG_HOST=1   CTVIO_MARG_DEBUG=1   CTVIO_DEBUG_STAMPS=1
+ *   CTVIO_SHARD_OVERSUBSCRIBE=1 (test only; read by ctvio_shards_used / ctvio_solve_sharded at call time) */
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,7 @@ struct MarginalizationInfo {
   std::vector<int> keep_block_size;            // 4 / 3 / 1 (global sizes)
   std::vector<int> keep_block_idx;             // column offset of each kept block (already minus m)
   std::vector<std::array<double, 4>> keep_block_data;  // linearisation point of each block
+  bool ran_on_host = false;                    // the eigen-decompositions of this prior ran on the host cores (ctvio_marginalize_ran_on_host)
 };
 
 // reference trajectory_estimator.h:37-59: per residual type, sum of |r_i| per component and the number of blocks
@@ -407,6 +408,7 @@ class TrajectoryEstimator {
     if (n <= 0) return false;
     MarginalizationInfo out;
     out.n = n;
+    out.ran_on_host = ctvio_marginalize_ran_on_host(s) != 0;
     out.linearized_jacobians.resize((size_t)n * n);
     out.linearized_residuals.assign(r0.begin(), r0.begin() + n);
     for (int i = 0; i < n; ++i)

@@ -25,7 +25,16 @@ def _bench_line(args, timeout=900):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]          # ONE JSON line, from rank 0 only
-    return json.loads(lines[0])
+    assert p.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096     # the LAST stdout line, inside the driver's 8 KB tail
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    with open(os.path.join(ROOT, line["details_file"])) as f:      # everything else (full precision) sits in the side file
+        d = json.load(f)
+    for k in ("value", "ms_per_step"):
+        assert line[k] == pytest.approx(d[k], rel=1e-5)
+    assert (line["n_gpus"], line["steps"], line["warmup"], line["scaling"], line["unit"]) == (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["unit"])
+    return d
 
 
 def test_bench_two_ranks_on_one_device():

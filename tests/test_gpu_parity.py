@@ -115,9 +115,10 @@ def test_imu_linearize_general_body(cv, oracle, win_cfg1, case):
 
 
 @pytest.mark.parametrize("prec,tol", [("fp64", 1e-8)])
-@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("mfma", [1, 2])
 def test_lm_step_matches_oracle(cv, oracle, win_cfg1, prec, tol, mfma):
-    """Schur complement (MFMA or vector ALU) + fp64 Cholesky + back-substitution == the oracle's dense solve."""
+    """Schur complement + fp64 Cholesky + back-substitution == the oracle's dense solve (use_mfma = 2: the IMU groups through the general
+    body)."""
     w = win_cfg1.copy()
     d_o, mc_o = oracle.OracleWindow(w.copy()).lm_step(1e4, use_schur=False)
     with cv.Solver(precision=prec, use_mfma=mfma) as s:
@@ -452,6 +453,7 @@ def test_marginalize_prior_construction(cv, oracle):
         with cv.Solver(precision=prec) as s:
             s.set_windows([w.copy()])
             kept, J0, r0 = s.marginalize(0, role, 1e-8)
+            assert not s.marginalize_ran_on_host()         # the product path: eliminated and factored on the device
         assert np.array_equal(kept, ko)
         assert np.abs(J0.T @ J0 - Ho).max() <= tol * np.abs(Ho).max(), prec
         assert np.abs(J0.T @ r0 - go).max() <= tol * np.abs(go).max(), prec
@@ -459,6 +461,31 @@ def test_marginalize_prior_construction(cv, oracle):
     with pytest.raises(cv.capi.CtvioError):
         bad = role.copy(); bad[3] = 2
         s2 = cv.Solver(); s2.set_windows([w.copy()]); s2.marginalize(0, bad)
+
+
+def test_marginalize_host_leg_is_reported(cv, oracle, monkeypatch):
+    """ctvio_marginalize has a host leg (csrc/marginalize.hpp: windows beyond the device eigen-solver's size or whose Jacobi sweeps stalled;
+    reference counterpart marginalization_factor.cpp:178-265).  It must not be silent: forced through the diagnostic switch, the handle says
+    so (ctvio_marginalize_ran_on_host), the next device call clears the flag, and both legs give the same quadratic form."""
+    w = cv.synth.make_window("config1", seed=1001)
+    w.cauchy_a = 1.0
+    role = np.zeros(w.N, np.int8)
+    role[:12] = 1; role[6 * w.K:6 * w.K + 6] = 1; role[w.P:w.P + w.L // 2] = 1
+    with cv.Solver() as s:
+        s.set_windows([w.copy()])
+        kd, Jd, rd = s.marginalize(0, role, 1e-8)
+        assert not s.marginalize_ran_on_host()
+    monkeypatch.setenv("CTVIO_MARG_HOST", "1")             # (read once, in ctvio_create)
+    with cv.Solver() as s:
+        s.set_windows([w.copy()])
+        kh, Jh, rh = s.marginalize(0, role, 1e-8)
+        assert s.marginalize_ran_on_host()
+        s.marginalize_batch([role], 1e-8)                  # the batch entry has no host leg
+        assert not s.marginalize_ran_on_host()
+    assert np.array_equal(kd, kh)
+    Hd, Hh = Jd.T @ Jd, Jh.T @ Jh
+    assert np.abs(Hd - Hh).max() <= 1e-9 * np.abs(Hh).max()
+    assert np.abs(Jd.T @ rd - Jh.T @ rh).max() <= 1e-9 * np.abs(Jh.T @ rh).max()
 
 
 def test_prior_chain_on_device(cv):

@@ -126,10 +126,10 @@ def test_config5_timed_shape_vs_oracle(cv, oracle_solved):
         assert cv.rel_state_error(batch[i], refs[i % 8])["state"] < 1e-6, i
 
 
-@pytest.mark.parametrize("cfg", ["config3", "tumrs"])
+@pytest.mark.parametrize("cfg", ["config2", "config3", "tumrs"])
 def test_large_batch_timed_shapes_vs_oracle(cv, oracle_solved, cfg):
-    """The shapes bench.py times for BASELINE configs[2] and the reference's native operating point: 192 windows in one launch (16 distinct
-    seeds): per-window Schur kernel, register-resident tile Cholesky reading the plain tiles from Hpp, atomic single-part assembly -- the
+    """The shapes bench.py times for BASELINE configs[1] (the headline), configs[2] and the reference's native operating point: 192 windows in
+    one launch (16 distinct seeds): per-window Schur kernel, register-resident tile Cholesky reading the plain tiles from Hpp, atomic single-part assembly -- the
     large-batch kernels, not the small-batch ones the 32-seed parity test selects -- every copy against the oracle's solve of its seed."""
     uniq = [cv.synth.make_window(cfg, seed=1000 + i) for i in range(16)]
     refs, sms_o = zip(*[oracle_solved(cfg, 1000 + i) for i in range(16)])
@@ -143,6 +143,28 @@ def test_large_batch_timed_shapes_vs_oracle(cv, oracle_solved, cfg):
         assert (sm["num_line_search_steps"], sm["num_line_search_reduced"]) == (so.num_line_search_steps, so.num_line_search_reduced), i
         assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
         assert cv.rel_state_error(batch[i], refs[i % 16])["state"] < 1e-6, i
+
+
+def test_headline_launch_vs_oracle(cv, oracle_solved):
+    """THE launch `value` is quoted on (bench.py's handle shape): 2048 config-2 windows in one ctvio_set_batch, 64 distinct seeds (1000..1063) x 32
+    copies, every copy with its OWN caller buffers -- per-window Schur kernel, tile Cholesky reading the plain tiles from Hpp, atomic
+    single-part assembly, the IMU kernel's 2048 walking waves each taking 21 groups -- every one of the 2048 against the oracle's solve of its
+    seed: iteration, accept / reject and line-search counts equal, cost to 1e-9, state to 1e-6 (the contract is 1e-4).
+    Reference: TrajectoryEstimator::Solve, trajectory_estimator.cpp:367-408."""
+    uniq = [cv.synth.make_window("config2", seed=1000 + i) for i in range(64)]
+    refs, sms_o = zip(*[oracle_solved("config2", 1000 + i) for i in range(64)])
+    with cv.Solver() as s:
+        batch = [uniq[i % 64].copy() for i in range(2048)]
+        s.set_windows(batch)
+        sms = s.solve(15)
+    worst = 0.0
+    for i, sm in enumerate(sms):
+        so = sms_o[i % 64]
+        assert (sm["iterations"], sm["num_successful"], sm["num_unsuccessful"]) == (so.iterations, so.num_successful, so.num_unsuccessful), i
+        assert (sm["num_line_search_steps"], sm["num_line_search_reduced"]) == (so.num_line_search_steps, so.num_line_search_reduced), i
+        assert sm["final_cost"] == pytest.approx(so.final_cost, rel=1e-9), i
+        worst = max(worst, cv.rel_state_error(batch[i], refs[i % 64])["state"])
+    assert worst < 1e-6, worst
 
 
 def test_equal_batches_capture_the_pass_once(cv):

@@ -14,6 +14,9 @@ import sqlite3
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha256   # the kernel sources these counters belong to: bench.py prints no traffic figure for other sources
+
 
 def short(name):
     m = re.search(r"(k_[a-z_A-Z0-9]+)(<[^>]*>)?", name)
@@ -51,6 +54,9 @@ def pmc(wpl, out, paths):
         if wb is not None: e["write_bytes"] = wb; e["launches"] = len(w)
         if "fetch_bytes" in e and "write_bytes" in e: e["traffic_bytes"] = e["fetch_bytes"] + e["write_bytes"]
         print(f"{k:58s} {max(len(f), len(w)):8d} {(fb or 0) / 1e6:10.3f} {(wb or 0) / 1e6:10.3f}")
+    res["_csrc_sha256"] = csrc_sha256()
+    res["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of tools/profile_round6.sh, {wpl} windows per launch, single stream; "
+                      "FETCH_SIZE doubled, KiB -> bytes (MI355X_MICROARCH.md); kernel sources: _csrc_sha256")
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
@@ -71,6 +77,7 @@ def counters(out, paths):
         if base not in res or res[base]["launches"] < e["launches"]:
             res[base] = e
         print(f"{k[:52]:52s} " + " ".join(f"{e.get(n, float('nan')):26.4g}" for n in names))
+    res["_csrc_sha256"] = csrc_sha256()
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
