@@ -122,3 +122,29 @@ def test_marginalize_batch_on_device(cv, slide_reference):
         assert np.abs(J0.T @ J0 - Ho).max() <= 1e-7 * np.abs(Ho).max()
         assert np.abs(J0.T @ r0 - go).max() <= 1e-7 * np.abs(go).max()
     print(f"marginalize_batch: {1e3 * dt / nb:.3f} ms per window ({nb} windows, {1e3 * dt:.1f} ms)")
+
+
+def test_marginalize_host_leg_is_reported(cv, slide_reference, monkeypatch):
+    """ctvio_marginalize has a host leg (csrc/marginalize.hpp: windows beyond the device eigen-solver's size or whose Jacobi sweeps stalled;
+    reference counterpart marginalization_factor.cpp:178-265).  It must not be silent: the reference's drop set (m = 26 / n = 91) factors on
+    the device and the handle says so; forced through the diagnostic switch (read once, in ctvio_create) the handle reports the host leg, the
+    batch entry (which has none) clears the flag, and both legs give the same quadratic form."""
+    sh, world, st_o, rec_o = slide_reference
+    st = sh.State(world)
+    w, info = sh.window_of(world, st, 0, sh.initial_prior(world))
+    m, role = sh.marg_window_of(world, st, 0, w, info)
+    with cv.Solver() as s:
+        s.set_windows([m.copy()])
+        kd, Jd, rd = s.marginalize(0, role)
+        assert not s.marginalize_ran_on_host()
+    monkeypatch.setenv("CTVIO_MARG_HOST", "1")
+    with cv.Solver() as s:
+        s.set_windows([m.copy()])
+        kh, Jh, rh = s.marginalize(0, role)
+        assert s.marginalize_ran_on_host()
+        s.marginalize_batch([role])
+        assert not s.marginalize_ran_on_host()
+    assert np.array_equal(kd, kh)
+    Hh = Jh.T @ Jh
+    assert np.abs(Jd.T @ Jd - Hh).max() <= 1e-8 * np.abs(Hh).max()
+    assert np.abs(Jd.T @ rd - Jh.T @ rh).max() <= 1e-8 * np.abs(Jh.T @ rh).max()
