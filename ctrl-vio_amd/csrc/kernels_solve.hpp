@@ -1134,6 +1134,11 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
     //  deferred to the next panel -- was built and measured slower too: 1.63 vs 1.30 ms per 16 single-window factorisations,
     //  13.5 vs 10.6 ms per 2048-window solve.  The pivot chain takes ~12 k cycles instead of ~7 k when the other 15 waves are
     //  busy on the same SIMDs / LDS, s_setprio 3 does not change that, and step C grows by the pending updates.)
+    //  ROUND 6: the same overlap with the pivot chain on a wave AND SIMD of its own (wave 0 factors, waves 4 / 8 / 12 -- its SIMD mates -- exit,
+    //  12 update waves x 9 tiles on the other three SIMDs, the owner of (k + 1, k) also updating (k + 1, k + 1)): parity-green, and no faster --
+    //  69 vs 71 us per factorisation, 45.8 vs 46.4 ms per 2048-window solve.  Early panels become bound by the updates on three SIMDs, late
+    //  panels by A -> L_(k+1,k) -> update of (k+1,k+1) -> A with the two middle steps serial in one wave (6.9 k cycles per panel against
+    //  ~5.7 k here): profiles/r06_chol_chain_experiment.txt.)
     // (the next panel's step C overwrites the LDS panel only after the barrier that follows its step A)
     if (k < 4) CTV_STAMP();
   }
@@ -1194,339 +1199,6 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
   for (int i = tid; i < P; i += NT) x[i] = xs[i];
   if (tid == 0) lm.chol_fail = s_fail;
 #undef CTV_STAMP
-}
-
-// ---- The same factorisation with the DIAGONAL TILES OFF THE OTHER WAVES' CRITICAL PATH (round 6).  k_cholesky_tiles runs, per panel,
-// "diagonal tile on one wave | barrier | L_ik | barrier | trailing updates": 14 x (3.2 k + 0.7 k + up to 5.8 k cycles) in a row, 63 % of the wave
-// cycles parked.  Round 3's look-ahead (the owner of the next diagonal tile factors it while the others update) lost because the pivot chain
-// shares its SIMD's fp64 datapath with three waves issuing 64-cycle MFMAs (section 3 of DESIGN.md: one datapath).  Here the roles are split by
-// SIMD instead:
-//   * wave 0 is the CHAIN wave: it owns no tile and does nothing but factor diagonal tiles (chol16_dpp), one per panel.  The three waves that
-//     share its SIMD (4, 8, 12: waves of a workgroup go to the SIMDs round robin -- checked by tools/simd_probe.hip; if a chip placed them
-//     otherwise the kernel would still be correct, only slower) exit at once, so the chain has the SIMD's issue slots and datapath to itself;
-//   * the other 12 waves (three SIMDs) are UPDATE waves with 9 tile slots each (105 tiles at P = 211).  Tile (j, j) and the tile (j, j - 1)
-//     left of it have the same owner, who -- in the short phase in which the L_ik of panel j - 1 are formed -- also applies that panel's update
-//     to (j, j) and hands the tile to the chain wave through LDS.
-// Per panel k:   phase 1: chain wave factors tile (k, k)   ||   update waves apply panel k - 1 to their trailing tiles (all but (k, k))
-//                barrier
-//                phase 2: update waves form L_ik = A_ik L_kk^-T (4 MFMAs each); the owner of (k + 1, k) also updates (k + 1, k + 1) and publishes it
-//                barrier
-// so the 3.2 k cycles of a diagonal tile overlap the previous panel's updates instead of preceding them.  Ownership comes from a compile-time
-// table (CHOL_MAP: tiles dealt in column-major order, so that the trailing tiles of every panel are spread evenly over the update waves).
-struct CholMap { signed char ti[15][12][9], tj[15][12][9]; };   // [tile rows NTR][update wave][slot]: tile (ti, tj), -1 = empty slot
-constexpr CholMap make_chol_map() {
-  CholMap mp{};
-  for (int n = 0; n < 15; ++n) {
-    int cnt[12] = {}, resv[12] = {};
-    for (int o = 0; o < 12; ++o)
-      for (int q = 0; q < 9; ++q) { mp.ti[n][o][q] = -1; mp.tj[n][o][q] = -1; }
-    for (int j = 1; j < n; ++j) resv[(j - 1) % 12] += 2;   // the pairs (j, j - 1), (j, j): owner (j - 1) mod 12
-    int rot = 0;
-    for (int j = 0; j < n; ++j)          // column-major
-      for (int i = j; i < n; ++i) {
-        int o = -1;
-        if (i == j && j >= 1) o = (j - 1) % 12;           // (j, j): with its left neighbour
-        else if (i == j + 1) o = j % 12;                  // (j + 1, j): pair of column j + 1
-        if (o >= 0) resv[o] -= 1;
-        else {                                            // anything else: the least loaded wave (reservations count), ties in rotation
-          int best = 1 << 20;
-          for (int c = 0; c < 12; ++c) {
-            const int cand = (rot + c) % 12, load = cnt[cand] + resv[cand];
-            if (load < best) { best = load; o = cand; }
-          }
-          rot = (o + 1) % 12;
-        }
-        if (cnt[o] < 9) { mp.ti[n][o][cnt[o]] = (signed char)i; mp.tj[n][o][cnt[o]] = (signed char)j; }
-        cnt[o] += 1;                                      // (n <= 14: 105 tiles, never more than 9 per wave -- static_assert below)
-      }
-  }
-  return mp;
-}
-constexpr bool chol_map_complete(const CholMap &mp) {   // every tile of every size exactly once, pairs with one owner
-  for (int n = 0; n < 15; ++n) {
-    int seen = 0;
-    for (int o = 0; o < 12; ++o)
-      for (int q = 0; q < 9; ++q) {
-        const int i = mp.ti[n][o][q], j = mp.tj[n][o][q];
-        if (i < 0) continue;
-        if (j < 0 || j > i || i >= n) return false;
-        seen += 1;
-        if (i == j && j >= 1) {   // its left neighbour sits in the same wave
-          bool ok = false;
-          for (int q2 = 0; q2 < 9; ++q2) ok = ok || (mp.ti[n][o][q2] == i && mp.tj[n][o][q2] == i - 1);
-          if (!ok) return false;
-        }
-      }
-    if (seen != n * (n + 1) / 2) return false;
-  }
-  return true;
-}
-static_assert(chol_map_complete(make_chol_map()), "CHOL_MAP must hold every tile once, within 9 slots per update wave");
-__constant__ const CholMap CHOL_MAP = make_chol_map();
-
-__global__ __launch_bounds__(1024) void k_cholesky_chain(Dev d) {
-  constexpr int NU = 12, NS = 9, NTU = 64 * NU, TS = 16 * 17;    // update waves, tile slots per wave; a 16 x 16 block in LDS: row stride 17
-  const int w = blockIdx.x;
-  Lm &lm = d.lm[w];
-  if (lm.status || lm.ls_active) return;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  if (wave != 0 && (wave & 3) == 0) return;     // the chain wave's SIMD mates: gone (a barrier waits for the surviving waves only)
-  const bool chain = wave == 0;
-  const int uw = wave - 1 - (wave >> 2);        // update wave index 0 .. 11 (waves 1-3, 5-7, 9-11, 13-15)
-  const WinMeta &m = d.wins[w];
-  const int P = m.P, ldh = m.ldh;
-  const int q4 = lane >> 4, l15 = lane & 15;
-  const int NTR = P / 16 + 1, ip = P / 16, rp = P % 16;   // the rhs row P sits in tile row ip, local row rp
-  extern __shared__ __attribute__((aligned(16))) double smt[];
-  double *Id = smt;                    // [TS] a 16 x 16 identity: the diagonal tile's inverse lanes start from it
-  double *Li = Id + TS;                // [NTR][TS] diagonal blocks on their way to the chain wave, then their inverses: Li[b][j * 17 + k] = Linv_b[j][k]
-  double *Pn = Li + NTR * TS;          // [NTR][TS] panel: Pn[i][m * 17 + c] = L_ik[m][c] of the current panel
-  double *tv = Pn + NTR * TS;          // [16 NTR] y, then the running right-hand side of the back-substitution
-  double *xs = tv + 16 * NTR;          // [16 NTR] solution
-  int &s_fail = *reinterpret_cast<int *>(xs + 16 * NTR);
-  long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of the chain wave / of update wave 0 at the phase boundaries
-#define CTV_BAR() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); } while (0)
-  if (chain) {
-    // ================================================================ the chain wave
-    int dbi = 0;
-#define CTV_STAMP() do { if (dbg && lane == 0 && dbi < 24) dbg[dbi++] = clock64(); } while (0)
-    if (lane == 0) s_fail = 0;
-    for (int i = lane; i < TS; i += 64) Id[i] = (i / 17 == i % 17) ? 1.0 : 0.0;
-    for (int i = lane; i < 16 * NTR; i += 64) tv[i] = 0.0;
-    if (dbg && lane == 0) dbg[30] = (long long)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);   // HW_REG_HW_ID[15:0]: wave, SIMD, pipe, CU
-    CTV_BAR();                                   // tile (0, 0) is in LDS
-    CTV_STAMP();
-    for (int k = 0; k < NTR; ++k) {
-      double *Dg = Li + k * TS;
-      double v[16];
-      int opaque0;   // a zero the compiler cannot see through (the 16 identity columns would be hoisted out of the panel loop otherwise)
-      asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));
-      // even rows of the wave: the tile's rows (whole rows: the factorisation never reads the upper half); odd rows: the identity, from LDS too
-      const double *src = ((lane & 16) ? Id : Dg) + (l15 + opaque0) * 17;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = src[c];
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();          // every lane has read its row before the block is overwritten with the inverse
-      const int nreal = P - 16 * k;             // pivots below this are real; the rhs row and the padding rows are not factored
-      int bad = 0;
-      chol16_dpp(v, nreal, bad);
-      if (lane >= 16 && lane < 32) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Dg[i * 17 + l15] = v[i];   // Linv[i][column l15]
-      }
-      if (k == ip && lane == rp) {              // the part of y inside the last diagonal tile: L[P][16 ip + c], c < rp
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c < rp) tv[16 * ip + c] = v[c];
-      }
-      if (lane == 0 && bad) s_fail = 1;
-      CTV_STAMP();
-      CTV_BAR();                                 // L_kk^-1 is in LDS; the update waves have applied panel k - 1
-      CTV_BAR();                                 // the L_ik of panel k are in LDS, and so is tile (k + 1, k + 1)
-      if (k < 4) CTV_STAMP();
-    }
-    // back-substitution: x of the last block, x_b[j] = sum_k Linv[k][j] t[k]: lane (q4, j = l15) sums k = 4 q4 .. 4 q4 + 3
-    {
-      const int bl = NTR - 1;
-      const double *Lb = Li + bl * TS;
-      double xa = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) xa += Lb[(4 * q4 + kk) * 17 + l15] * tv[16 * bl + 4 * q4 + kk];
-      xa += __shfl_xor(xa, 16);
-      xa += __shfl_xor(xa, 32);
-      if (q4 == 0) xs[16 * bl + l15] = xa;
-    }
-    CTV_STAMP();
-    CTV_BAR();
-    return;                                      // (the update waves finish the back-substitution among themselves)
-#undef CTV_STAMP
-  }
-  // ================================================================== update waves
-  const int utid = 64 * uw + lane;
-  const double *S = d.S + m.H0, *y = d.rhs + m.p0;
-  const double *Hc = d.HppS[lm.cur] + m.H0;
-  const bool from_h = d.schur_plain_in_H != 0;
-  const int K6 = 6 * m.K;
-  // (the same tile classification as k_schur_window_f64: W is non-zero in the knot columns, the line-delay column and the rhs row)
-  auto nz_row = [&](int b) { return (16 * b < K6) || (P >= 16 * b && P - 1 < 16 * b + 16); };
-  auto nz_col = [&](int b) { return (16 * b < K6) || (P - 1 >= 16 * b && P - 1 < 16 * b + 16); };
-  // activity of the unknowns as four 64-bit masks in SGPRs (each wave builds its own: four byte loads per lane, no LDS, no barrier)
-  unsigned long long amask[4] = {0ull, 0ull, 0ull, 0ull};
-  if (from_h) {
-    unsigned char ab[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ab[k] = d.active[m.u0 + min(lane + 64 * k, P - 1)];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) amask[k] = __ballot(lane + 64 * k < P && ab[k] != 0);
-  }
-  auto active_bit = [&](int i) {   // (i < 256; lane-variant)
-    const unsigned long long wlo = (i & 128) ? amask[2] : amask[0], whi = (i & 128) ? amask[3] : amask[1];
-    return (int)((((i & 64) ? whi : wlo) >> (i & 63)) & 1ull);
-  };
-  // ---- this wave's tiles (SGPRs) and their contents.  SPARSITY: tile (i, c) of the factor is empty for c < env_tile[i] (host_pack.hpp:
-  // plan_sparsity; fill stays inside the row envelope), so panel k neither solves nor updates with a tile whose row starts after it: ek = the
-  // first panel either row of the tile takes part in.  (The tiles are all resident -- the empty ones hold exact zeros.)
-  int ti[NS], tj[NS], ek[NS];
-  f64x4 acc[NS];
-#pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    const int a0 = CHOL_MAP.ti[NTR][uw][q], b0 = CHOL_MAP.tj[NTR][uw][q];
-    const int a = max(a0, 0), b = max(b0, 0);
-    ti[q] = __builtin_amdgcn_readfirstlane(a0);
-    tj[q] = __builtin_amdgcn_readfirstlane(a0 >= 0 ? b0 : 1 << 20);   // (never equal to a panel, never a trailing tile: ti < tj)
-    ek[q] = __builtin_amdgcn_readfirstlane(max(d.env_tile[m.tr0 + a], d.env_tile[m.tr0 + b]));
-    // unconditional loads on clamped addresses straight into the tile registers; fixed up below
-    const bool plain = from_h && !(nz_row(a) && nz_col(b));   // (wave-uniform)
-    const double *src = plain ? Hc : S;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rc = min(16 * a + q4 + 4 * r, P - 1);
-      acc[q][r] = src[(long long)rc * ldh + min(16 * b + l15, rc)];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    if (ti[q] < 0) continue;
-    const int col = 16 * tj[q] + l15;
-    if (from_h && !(nz_row(ti[q]) && nz_col(tj[q]))) {   // a tile without Schur products, straight from Hpp: damping and fixed unknowns here
-      const int a_j = active_bit(col);
-      double ddiag = 0.0;   // (a diagonal tile among them: a few bias-bias blocks per window; one L2 round trip for its wave)
-      if (ti[q] == tj[q]) ddiag = d.dd[m.u0 + min(col, P - 1)];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti[q] + q4 + 4 * r;
-        acc[q][r] = (active_bit(row) & a_j) ? acc[q][r] + (row == col ? ddiag : 0.0) : (row == col ? 1.0 : 0.0);
-      }
-    }
-    if (ti[q] == tj[q]) {             // diagonal tile: the upper half is not stored in S
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][r] = (col <= 16 * ti[q] + q4 + 4 * r) ? acc[q][r] : 0.0;
-    }
-    if (ti[q] == ip) {                // tile row of the rhs row P; identity beyond it
-      const double yv = y[min(col, P - 1)];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ip + q4 + 4 * r;
-        acc[q][r] = row < P ? acc[q][r] : (row == P ? (col < P ? yv : 0.0) : (row == col ? 1.0 : 0.0));
-      }
-    }
-    if (ti[q] == 0) {                 // tile (0, 0): to the chain wave
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Li[(q4 + 4 * r) * 17 + l15] = acc[q][r];
-    }
-  }
-  int dbi = 0;
-#define CTV_STAMP() do { if (dbg && utid == 0 && dbi < 40) dbg[64 + dbi++] = clock64(); } while (0)
-  CTV_STAMP();
-  CTV_BAR();
-  for (int k = 0; k < NTR; ++k) {
-    int opq;   // (a zero the compiler cannot see through: the per-slot LDS addresses are recomputed each panel -- one add each -- instead of
-    asm volatile("s_mov_b32 %0, 0" : "=s"(opq));   // being kept as loop-invariant registers beside the tiles)
-    double *Pnk = Pn + opq;
-    // ---- phase 1 (the chain wave factors tile (k, k) meanwhile): panel k - 1 applied to the trailing tiles (i, j), j >= k, A_ij -= L_i,k-1 L_j,k-1^T
-    //      -- all but (k, k), which got it in phase 2 of the previous panel
-    if (k > 0) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        if (ti[q] < 0 || tj[q] < k || tj[q] >= (1 << 20) || k - 1 < ek[q] || (ti[q] == k && tj[q] == k)) continue;   // (uniform)
-        const double *pa = Pnk + ti[q] * TS + l15 * 17 + q4, *pb = Pnk + tj[q] * TS + l15 * 17 + q4;
-        double a[4], b[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { a[s4] = -pa[4 * s4]; b[s4] = pb[4 * s4]; }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
-      }
-    }
-    if (k < 5) CTV_STAMP();
-    CTV_BAR();
-    if (k < 5) CTV_STAMP();
-    // ---- phase 2: L_ik = A_ik L_kk^-T for the tiles below the diagonal one (the accumulator -> operand transposition goes through the tile's
-    //      slice of the LDS panel); the owner of (k + 1, k) then brings (k + 1, k + 1) up to date and hands it to the chain wave
-    const double *Lk = Li + k * TS;
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      if (tj[q] != k || ti[q] <= k || k < ek[q]) continue;   // (uniform; an empty tile stays zero and publishes nothing)
-      double *blk = Pnk + ti[q] * TS;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = acc[q][r];
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      double a[4], b[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { a[s4] = blk[l15 * 17 + 4 * s4 + q4]; b[s4] = Lk[l15 * 17 + 4 * s4 + q4]; }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();          // operands are in registers before the slice is overwritten
-      f64x4 c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], c, 0, 0, 0);
-      acc[q] = c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = c[r];
-      if (ti[q] == ip && q4 == (rp & 3)) tv[16 * k + l15] = f64x4_get(c, rp >> 2);   // y: row P of L
-    }
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      if (ti[q] != k + 1 || tj[q] != k + 1) continue;        // (uniform) the next diagonal tile: its left neighbour was formed just above, by this wave
-      if (k >= ek[q]) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const double *pa = Pnk + (k + 1) * TS + l15 * 17 + q4;
-        double a[4], b[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { b[s4] = pa[4 * s4]; a[s4] = -b[s4]; }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
-      }
-      double *Dn = Li + (k + 1) * TS;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Dn[(q4 + 4 * r) * 17 + l15] = acc[q][r];
-    }
-    if (k < 5) CTV_STAMP();
-    CTV_BAR();
-    if (k < 5) CTV_STAMP();
-  }
-  CTV_STAMP();
-  CTV_BAR();                                      // x of the last block (chain wave)
-  // ---- back-substitution L^T x = y over the tiles in registers: ONE barrier per block.  After x_b is known, the only contribution t_{b-1}
-  // still lacks is that of tile (b, b - 1): its owner finishes t_{b-1} in registers and forms x_{b-1} = L_{b-1,b-1}^-T t_{b-1} at once (the sixteen
-  // t[k] read across the 16-lane rows by v_fmac_f64_dpp row_newbcast, the sum over the four row groups by v_permlane16/32_swap -- no LDS round
-  // trip on the chain); the owners of the other tiles (b, j) subtract their parts from t_j in LDS meanwhile.
-  for (int b = NTR - 1; b >= 1; --b) {
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      if (ti[q] != b || tj[q] >= b) continue;   // tiles (b, j), j < b: t_j -= L_bj^T x_b
-      double xb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xb[r] = xs[16 * b + q4 + 4 * r];
-      if (tj[q] == b - 1) {                     // (uniform) the chain
-        const double *Lb = Li + (b - 1) * TS;
-        double lk[16];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) lk[kk] = Lb[kk * 17 + l15];
-        const double tb = tv[16 * (b - 1) + l15];
-        double part = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += acc[q][r] * xb[r];
-        const double t = tb - rowgroup_sum(part);   // t_{b-1}[l15], in every row group
-        double xa = 0.0;
-        dpp_dot16<0>(xa, t, lk);
-        if (q4 == 0) xs[16 * (b - 1) + l15] = xa;
-      } else {
-        double part = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += acc[q][r] * xb[r];
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (q4 == 0) tv[16 * tj[q] + l15] -= part;
-      }
-    }
-    CTV_BAR();
-  }
-  CTV_STAMP();
-  double *x = d.delta + m.u0;
-  for (int i = utid; i < P; i += NTU) x[i] = xs[i];
-  if (utid == 0) lm.chol_fail = s_fail;
-#undef CTV_STAMP
-#undef CTV_BAR
 }
 
 // (Fusing this kernel into k_cholesky_tiles -- same workgroup, the pose step straight from LDS -- was built and measured: no gain for
