@@ -115,8 +115,11 @@ def algorithmic_bytes(w, phase, fp_bytes):
     K, F, L, M, V, P = w.K, w.F, w.L, w.M, w.V, w.P
     sp = sparsity(w)
     G, A = sp["groups"], sp["anchors"]
-    if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out
-        return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes)
+    if phase == "k_imu_linearize":   # per sample u + 6 measurements; per group 4 knots (fp64 state) + bias + 32x32 tile out; + the part of the
+        # normal equations this kernel CLEARS for the accumulating kernels behind it (imu_zero_share, zero_mode 1: the bias rows and the
+        # line-delay row of Hpp -- rows 6K .. P - 1, ldh doubles each -- and the gradient): stores that are this kernel's job, not waste
+        ldh = (P + 15) // 16 * 16
+        return M * 7 * fp_bytes + G * (4 * 7 * 8 + 6 * 8 + 1024 * fp_bytes) + ((P - 6 * K) * ldh + P) * 8
     # A block's record is 40 doubles (rotation columns of its own end 24, inverse depth 2, line delay 2, residual 2, A~ 6, cp1 4); an
     # anchor's record 50 (p_G 3, GR 36, cp0 4, y 3, h 3).
     if phase == "k_vis_eval":        # anchors: inputs (t, row, obs, indices: 36 B) in, record out and in again once (the blocks read it);
@@ -363,6 +366,8 @@ def compact_line(out, details_file):
     for k in ("device_resident_solves_per_s", "single_window_ms", "single_window_device_resident_ms"):
         if k in out:
             line[k] = out[k]
+    if isinstance(out.get("mixed_batch"), dict) and "mixed_over_periodic" in out["mixed_batch"]:
+        line["mixed_over_periodic_batch"] = out["mixed_batch"]["mixed_over_periodic"]
     for cfg in ("config3", "config5", "config5_spread", "tumrs"):
         if isinstance(out.get(cfg), dict) and "solves_per_s" in out[cfg]:
             line.setdefault("other_configs_solves_per_s", {})[cfg] = round(out[cfg]["solves_per_s"], 1)
@@ -402,6 +407,42 @@ def write_details(out, world):
         return rel
     except OSError:
         return None
+
+
+def mixed_batch(cv, torch, config, nwin, ndist, iters, device, steps=3):
+    """`nwin` windows per launch made of `ndist` DISTINCT windows (seeds 5000 ..: generated by tools/make_windows.py on a process pool in a
+    fresh interpreter) against the same launch made of the headline's 64 distinct ones: the 64-periodic batch terminates in lock-step, a mixed
+    one shows whatever tail effects there are.  Device-resident, one handle."""
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "w.npz")
+        t0 = time.perf_counter()
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_windows.py"), config, "5000", str(ndist), f], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            return {"error": p.stderr[-400:]}
+        z = np.load(f)
+        many = [cv.Window.from_dict(z, prefix=f"w{i}_") for i in range(ndist)]
+        tgen = time.perf_counter() - t0
+    few = [synth_window(cv, config, 1000 + i) for i in range(64)]
+    out = {"windows_per_launch": nwin, "generation_s": tgen}
+    for name, uniq in (("distinct_64", few), (f"distinct_{ndist}", many)):
+        with cv.Solver(device=device) as sv:
+            sv.set_windows([uniq[i % len(uniq)].copy() for i in range(nwin)])
+            sv.snapshot_state()
+            sms = sv.solve(iters, writeback=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sv.restore_state()
+                sv.solve_raw(iters)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            its = np.array([s["iterations"] for s in sms])
+            out[name] = {"solves_per_s": nwin / dt, "ms_per_launch": 1e3 * dt, "iterations_min_mean_max": [int(its.min()), float(its.mean()), int(its.max())],
+                         "terminations": sorted({s["termination"] for s in sms})}
+    out["mixed_over_periodic"] = out[f"distinct_{ndist}"]["solves_per_s"] / out["distinct_64"]["solves_per_s"]
+    return out
 
 
 def respawn_under_torchrun(args):
@@ -741,6 +782,7 @@ def main():
                                                 label="the same sizes with landmark l anchored in frame l mod 28: visual factors all along the window")
             out["tumrs"] = side_config(cv, lib, torch, "tumrs", 2048, 16, args.iters, 2, 8, local, ora, profile=True,
                                        label="the reference's native operating point: 200 Hz IMU (10 samples per group), <= 150 features per frame")
+            out["mixed_batch"] = mixed_batch(cv, torch, args.config, 2048, 256, args.iters, local)
             wt = cv.synth.make_window("tumrs", seed=1000)
             out["tumrs"]["imu_lane_utilisation"] = wt.M / (64.0 * imu_groups(wt))   # one 64-lane pass per (segment, bias) group
             # ---- rounds 1-4 let the replicas of a distinct window share its caller buffers (the packer read 11 MB out of L3): once, beside the headline
