@@ -52,7 +52,7 @@ struct DebugSwitches {
   int imu_general = 0;       // CTVIO_IMU_GENERAL=1      every IMU group through the general body (same as use_mfma = 2)
   int schur_tiles = 0;       // CTVIO_SCHUR_TILES=1      tile Schur kernels also for large batches of small windows
   int schur_copy_plain = 0;  // CTVIO_SCHUR_COPY_PLAIN=1 the per-window Schur kernel copies product-free tiles to S
-  int chol_tiles = -1;       // CTVIO_CHOL_TILES=0/1     P <= 223: panel kernel / register-resident tiles (default)
+  int chol_tiles = -1;       // CTVIO_CHOL_TILES=0/1/3   P <= 223: panel kernel / k_cholesky_tiles (round 5: barriers) / k_cholesky_flow (default)
   int dense = 0;             // CTVIO_DENSE=1            the sparsity plan degenerates to the dense one
   int schur_tile2 = -1;      // CTVIO_SCHUR_TILE2=0/1    one wave per tile / per 2 x 2 tiles
   int marg_debug = 0;        // CTVIO_MARG_DEBUG=1       sweep trace of the device eigen-solver on stderr
@@ -177,6 +177,7 @@ class SolverImpl : public SolverBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_solve<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_tiles<16, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_cholesky_flow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_assemble_vis_mfma<VCH, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -710,7 +711,9 @@ class SolverImpl : public SolverBase {
     if (chol_tiles()) {
       const int ntr = d.maxP / 16 + 1;
       const size_t lds = (size_t)(272 + 2 * ntr * 272 + 32 * ntr + 4 + 768) * sizeof(double);   // identity + panel + inverses + vectors + parked tiles
-      hipLaunchKernelGGL((k_cholesky_tiles<16, 7>), dim3(nw), dim3(1024), lds, stream_, d);
+      const size_t lds_flow = (size_t)(272 + 5 * ntr * 272 + 32 * ntr + 48) * sizeof(double);   // identity + inverses + sub-diagonal tiles + three panels + vectors + flags
+      if (chol_tiles() == 1) hipLaunchKernelGGL((k_cholesky_tiles<16, 7>), dim3(nw), dim3(1024), lds, stream_, d);   // (A/B: round 5's kernel)
+      else hipLaunchKernelGGL(k_cholesky_flow, dim3(nw), dim3(1024), lds_flow, stream_, d);
     }
     // (8 waves also when the panel's LDS footprint allows one workgroup per CU anyway -- P = 571: 157 KB -- where 4 waves left three quarters
     //  of the CU's wave slots empty)
@@ -758,11 +761,11 @@ class SolverImpl : public SolverBase {
   // Dev::schur_plain_in_H is part of the Dev struct the captured graph is keyed on: decided once per upload, never inside a launch
   // (launch_schur used to set it, so every upload -- which clears Dev -- invalidated the cached hipGraph of the headline configuration).
   int schur_plain_in_H_for_batch() const { return (schur_window_path() && chol_tiles() != 0 && !dbg_.schur_copy_plain) ? 1 : 0; }
-  // CTVIO_CHOL_TILES = 0 / 1 forces the choice (A/B measurements: panel kernel / register-resident tiles)
+  // CTVIO_CHOL_TILES = 0 / 1 / 3 forces the choice (A/B measurements: panel kernel / k_cholesky_tiles / k_cholesky_flow)
   int chol_tiles_for(int maxP) const {
     if (maxP > 223) return 0;
     if (dbg_.chol_tiles >= 0) return dbg_.chol_tiles;
-    return 1;   // (16 waves x 7 tiles: 10.7 ms per 2048-window solve against 11.2 ms for the panel kernel, and a fifth of its HBM traffic)
+    return 3;   // (register-resident tiles as a data-flow of waves: k_cholesky_flow; 1 = round 5's k_cholesky_tiles, the barrier-per-panel form)
   }
   int chol_tiles() const { return chol_tiles_; }   // the batch's choice, taken in pack_and_upload
   // CTVIO_DENSE=1: the sparsity plan degenerates to the dense one (every row range = all landmarks, envelope = the whole triangle) -- the
@@ -1298,7 +1301,7 @@ class SolverImpl : public SolverBase {
  private:
   ctvio_options opt_;
   const DebugSwitches dbg_;   // environment switches as they were when the handle was created
-  int chol_tiles_ = 1;        // the uploaded batch's factorisation kernel (0 panel kernel, 1 register tiles): pack_and_upload
+  int chol_tiles_ = 3;        // the uploaded batch's factorisation kernel (0 panel kernel, 1 / 3 register tiles): pack_and_upload
   int marg_ran_on_host_ = 0;  // the last ctvio_marginalize(_batch) call: 1 if the factorisation ran on the host
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

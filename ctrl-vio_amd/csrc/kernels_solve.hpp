@@ -1201,6 +1201,402 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 #undef CTV_STAMP
 }
 
+// ---- The same factorisation as a DATA-FLOW of waves (round 6): the critical path of a tile Cholesky is
+//      factor (k, k)  ->  L_(k+1,k) = A_(k+1,k) L_kk^-T  ->  A_(k+1,k+1) -= L_(k+1,k) L_(k+1,k)^T  ->  factor (k + 1, k + 1)  -> ...
+// and k_cholesky_tiles puts two workgroup barriers and every other tile's work into each of its fourteen links (clock stamps of one window,
+// CTVIO_DEBUG_STAMPS: 3.8 k + 1.7 k + 3.5 k .. 0.4 k cycles per panel, 63 % of the wave cycles parked).  Here ONE wave -- the CHAIN wave, wave 0 --
+// runs that path and nothing else (5.0 k cycles per link: 1.45 k for the two products, 3.5 k for the tile), with both tiles of a link handed to it
+// through LDS; the other fifteen waves (seven tile slots each, dealt in column-major order) are UPDATE waves that form the L_ik of the other rows
+// and apply the trailing updates, in panel order, BEHIND the chain.  There is no workgroup barrier inside the factorisation: every hand-over is a
+// flag in LDS that the consumer polls (s_sleep between polls, every loop bounded -- a bound trips the window's chol_fail instead of hanging):
+//   F_inv[k]   L_kk^-1 is in Li[k]                                   chain wave   -> update waves (their L_ik of panel k)
+//   F_row[i]   = c + 1: L_ic of panel c is in Pn[c % 3][i]            whoever formed it (chain wave for i = c + 1) -> every trailing update
+//   F_park[k]  = 2: tiles (k, k - 1) and (k, k), with every update up to panel k - 2 applied, are parked in Ls[k] / Li[k]
+//                                                                      their owners -> chain wave
+//   done_E[c]  = 15: every update wave is through with panel c       update waves -> whoever overwrites that panel's buffer (panel c + 3)
+// The three panel buffers bound the skew between waves to three panels.  Tile (k, k - 1) comes back from the chain wave as L_(k,k-1) in Ls[k], where
+// its owner picks it up for the back-substitution (unchanged, one barrier per block, the chain wave gone by then).  Every tile has one owner and
+// receives its updates in panel order: the arithmetic -- and so the bitwise reproducibility of the deterministic mode -- does not depend on timing.
+// Measured (tools/r6_chol.sh, profiles/r06_chol_flow.txt): 64 us per factorisation of one window against 70 (k_cholesky_tiles), one window's
+// solve 2.72 - 2.76 ms against 2.81; 2048 windows per launch 45.5 - 45.9 ms per solve against 45.8 - 46.0.  The chain wave still waits 1 - 6 k cycles
+// per panel for its tiles: in-order update waves with blocking waits form convoys.  Tried on the way: the chain wave alone on its SIMD (waves 4 /
+// 8 / 12 exit, twelve update waves x nine tiles): the updates on three SIMDs cannot keep up (70 -> 78 us); barriers instead of flags with the
+// chain overlapped (profiles/r06_chol_chain_experiment.txt): 69 - 71 us.
+constexpr int CHOL_NU = 15, CHOL_NS = 7;   // update waves, tile slots per wave (105 tiles at P = 211)
+struct CholMap { signed char ti[15][CHOL_NU][CHOL_NS], tj[15][CHOL_NU][CHOL_NS]; };   // [tile rows NTR][update wave][slot]: tile (ti, tj), -1 = empty slot
+constexpr CholMap make_chol_map() {
+  CholMap mp{};
+  for (int n = 0; n < 15; ++n) {
+    for (int o = 0; o < CHOL_NU; ++o)
+      for (int q = 0; q < CHOL_NS; ++q) { mp.ti[n][o][q] = -1; mp.tj[n][o][q] = -1; }
+    int t = 0;
+    for (int j = 0; j < n; ++j)          // column-major: a wave meets its tiles in the order the panels need them
+      for (int i = j; i < n; ++i, ++t) { mp.ti[n][t % CHOL_NU][t / CHOL_NU] = (signed char)i; mp.tj[n][t % CHOL_NU][t / CHOL_NU] = (signed char)j; }
+  }
+  return mp;
+}
+constexpr bool chol_map_complete(const CholMap &mp) {   // every tile of every size exactly once
+  for (int n = 0; n < 15; ++n) {
+    int seen = 0;
+    for (int o = 0; o < CHOL_NU; ++o)
+      for (int q = 0; q < CHOL_NS; ++q) {
+        const int i = mp.ti[n][o][q], j = mp.tj[n][o][q];
+        if (i < 0) continue;
+        if (j < 0 || j > i || i >= n) return false;
+        seen += 1;
+      }
+    if (seen != n * (n + 1) / 2) return false;
+  }
+  return true;
+}
+static_assert(chol_map_complete(make_chol_map()), "CHOL_MAP must hold every tile once, within seven slots per update wave");
+__constant__ const CholMap CHOL_MAP = make_chol_map();
+
+// poll an LDS flag until it reaches `target` (wave-uniform); a bound instead of a hang
+__device__ __forceinline__ void chol_wait(volatile int *f, int target, int &fail) {
+  int n = 0;
+  while (__builtin_amdgcn_readfirstlane(*f) < target) {
+    if (++n > (1 << 20)) { fail = 1; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+// everything this wave wrote to LDS is there; then the flag
+__device__ __forceinline__ void chol_post(volatile int *f, int value, int lane) {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) *f = value;
+}
+__device__ __forceinline__ void chol_count(int *f, int lane) {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) atomicAdd(f, 1);
+}
+
+__global__ __launch_bounds__(1024) void k_cholesky_flow(Dev d) {
+  constexpr int NU = CHOL_NU, NS = CHOL_NS, NTU = 64 * NU, TS = 16 * 17, NPB = 3;    // update waves, tile slots per wave; a 16 x 16 block in LDS: row stride 17
+  const int w = blockIdx.x;
+  Lm &lm = d.lm[w];
+  if (lm.status || lm.ls_active) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool chain = wave == 0;
+  const int uw = wave - 1;                      // update wave index 0 .. 14
+  const WinMeta &m = d.wins[w];
+  const int P = m.P, ldh = m.ldh;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const int NTR = P / 16 + 1, ip = P / 16, rp = P % 16;   // the rhs row P sits in tile row ip, local row rp
+  extern __shared__ __attribute__((aligned(16))) double smt[];
+  double *Id = smt;                    // [TS] a 16 x 16 identity: the diagonal tile's inverse lanes start from it
+  double *Li = Id + TS;                // [NTR][TS] diagonal blocks on their way to the chain wave, then their inverses: Li[b][j * 17 + k] = Linv_b[j][k]
+  double *Ls = Li + NTR * TS;          // [NTR][TS] tile (b, b - 1) on its way to the chain wave, then L_(b,b-1) (row major) for the back-substitution
+  double *Pn = Ls + NTR * TS;          // [NPB][NTR][TS] panels: Pn[c % NPB][i][m * 17 + cc] = L_ic[m][cc]
+  double *tv = Pn + NPB * NTR * TS;      // [16 NTR] y, then the running right-hand side of the back-substitution
+  double *xs = tv + 16 * NTR;          // [16 NTR] solution
+  int *fl = reinterpret_cast<int *>(xs + 16 * NTR);
+  int &s_fail = fl[0];
+  volatile int *F_inv = fl + 16, *F_row = fl + 32;
+  int *F_park = fl + 48, *done_E = fl + 64;
+  long long *dbg = (d.dbg && w == 0) ? d.dbg : nullptr;   // CTVIO_DEBUG_STAMPS: clock64 of the chain wave at its steps
+#define CTV_BAR() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); } while (0)
+  if (chain) {
+    // ================================================================ the chain wave
+    int dbi = 0, fail = 0;
+#define CTV_STAMP() do { if (dbg && lane == 0 && dbi < 30) dbg[dbi++] = clock64(); } while (0)
+    for (int i = lane; i < 80; i += 64) fl[i] = 0;
+    for (int i = lane; i < TS; i += 64) Id[i] = (i / 17 == i % 17) ? 1.0 : 0.0;
+    for (int i = lane; i < 16 * NTR; i += 64) tv[i] = 0.0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    CTV_BAR();                                   // tile (0, 0) is in LDS, the flags are clear
+    CTV_STAMP();
+    for (int k = 0; k < NTR; ++k) {
+      double *Dg = Li + k * TS;
+      if (k > 0) {
+        chol_wait(reinterpret_cast<volatile int *>(F_park + k), 2, fail);
+        if (k < 4) CTV_STAMP();
+        // ---- L_(k,k-1) = A_(k,k-1) L_(k-1,k-1)^-T: both operands are in LDS in row-major form (no accumulator -> operand round trip)
+        double *blk = Ls + k * TS;
+        const double *Lk = Li + (k - 1) * TS;
+        double a[4], b[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { a[s4] = blk[l15 * 17 + 4 * s4 + q4]; b[s4] = Lk[l15 * 17 + 4 * s4 + q4]; }
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Dg[(q4 + 4 * r) * 17 + l15];     // tile (k, k), requested with the operands
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        f64x4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], c, 0, 0, 0);
+        if (k > NPB) chol_wait(reinterpret_cast<volatile int *>(done_E + (k - 1 - NPB)), NU, fail);   // the buffer of panel k - 1 - NPB is free
+        double *pub = Pn + ((k - 1) % NPB) * NTR * TS + k * TS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { blk[(q4 + 4 * r) * 17 + l15] = c[r]; pub[(q4 + 4 * r) * 17 + l15] = c[r]; }
+        if (k == ip && q4 == (rp & 3)) tv[16 * (k - 1) + l15] = f64x4_get(c, rp >> 2);   // y: row P of L
+        chol_post(F_row + k, k, lane);           // L_(k,k-1) is published: panel k - 1 can be applied to the tiles of row / column k
+        // ---- A_kk -= L_(k,k-1) L_(k,k-1)^T
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { b[s4] = blk[l15 * 17 + 4 * s4 + q4]; a[s4] = -b[s4]; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dg[(q4 + 4 * r) * 17 + l15] = acc[r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (k < 4) CTV_STAMP();
+      }
+      double v[16];
+      int opaque0;   // a zero the compiler cannot see through (the 16 identity columns would be hoisted out of the panel loop otherwise)
+      asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));
+      // even rows of the wave: the tile's rows (whole rows: the factorisation never reads the upper half); odd rows: the identity, from LDS too
+      const double *src = ((lane & 16) ? Id : Dg) + (l15 + opaque0) * 17;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) v[cc] = src[cc];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();          // every lane has read its row before the block is overwritten with the inverse
+      const int nreal = P - 16 * k;             // pivots below this are real; the rhs row and the padding rows are not factored
+      int bad = 0;
+      chol16_dpp(v, nreal, bad);
+      if (lane >= 16 && lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Dg[i * 17 + l15] = v[i];   // Linv[i][column l15]
+      }
+      if (k == ip && lane == rp) {              // the part of y inside the last diagonal tile: L[P][16 ip + c], c < rp
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) if (cc < rp) tv[16 * ip + cc] = v[cc];
+      }
+      if (bad) fail = 1;
+      chol_post(F_inv + k, 1, lane);
+      CTV_STAMP();
+    }
+    if (lane == 0 && fail) s_fail = 1;
+    // back-substitution: x of the last block, x_b[j] = sum_k Linv[k][j] t[k]: lane (q4, j = l15) sums k = 4 q4 .. 4 q4 + 3
+    {
+      const int bl = NTR - 1;
+      const double *Lb = Li + bl * TS;
+      double xa = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) xa += Lb[(4 * q4 + kk) * 17 + l15] * tv[16 * bl + 4 * q4 + kk];
+      xa += __shfl_xor(xa, 16);
+      xa += __shfl_xor(xa, 32);
+      if (q4 == 0) xs[16 * bl + l15] = xa;
+    }
+    CTV_STAMP();
+    CTV_BAR();                                   // the factorisation is complete (the update waves arrive here when they are through)
+    return;                                      // (the update waves finish the back-substitution among themselves)
+#undef CTV_STAMP
+  }
+  // ================================================================== update waves
+  const int utid = 64 * uw + lane;
+  int fail = 0;
+  const double *S = d.S + m.H0, *y = d.rhs + m.p0;
+  const double *Hc = d.HppS[lm.cur] + m.H0;
+  const bool from_h = d.schur_plain_in_H != 0;
+  const int K6 = 6 * m.K;
+  // (the same tile classification as k_schur_window_f64: W is non-zero in the knot columns, the line-delay column and the rhs row)
+  auto nz_row = [&](int b) { return (16 * b < K6) || (P >= 16 * b && P - 1 < 16 * b + 16); };
+  auto nz_col = [&](int b) { return (16 * b < K6) || (P - 1 >= 16 * b && P - 1 < 16 * b + 16); };
+  // activity of the unknowns as four 64-bit masks in SGPRs (each wave builds its own: four byte loads per lane, no LDS, no barrier)
+  unsigned long long amask[4] = {0ull, 0ull, 0ull, 0ull};
+  if (from_h) {
+    unsigned char ab[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ab[k] = d.active[m.u0 + min(lane + 64 * k, P - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) amask[k] = __ballot(lane + 64 * k < P && ab[k] != 0);
+  }
+  auto active_bit = [&](int i) {   // (i < 256; lane-variant)
+    const unsigned long long wlo = (i & 128) ? amask[2] : amask[0], whi = (i & 128) ? amask[3] : amask[1];
+    return (int)((((i & 64) ? whi : wlo) >> (i & 63)) & 1ull);
+  };
+  // ---- this wave's tiles (SGPRs) and their contents.  SPARSITY: tile (i, c) of the factor is empty for c < env_tile[i] (host_pack.hpp:
+  // plan_sparsity; fill stays inside the row envelope), so panel k neither solves nor updates with a tile whose row starts after it: ek = the
+  // first panel either row of the tile takes part in.  (The tiles are all resident -- the empty ones hold exact zeros.)
+  int ti[NS], tj[NS], ek[NS];
+  f64x4 acc[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int a0 = CHOL_MAP.ti[NTR][uw][q], b0 = CHOL_MAP.tj[NTR][uw][q];
+    const int a = max(a0, 0), b = max(b0, 0);
+    ti[q] = __builtin_amdgcn_readfirstlane(a0);
+    tj[q] = __builtin_amdgcn_readfirstlane(a0 >= 0 ? b0 : 1 << 20);   // (never equal to a panel, never a trailing tile: ti < tj)
+    ek[q] = __builtin_amdgcn_readfirstlane(max(d.env_tile[m.tr0 + a], d.env_tile[m.tr0 + b]));
+    // unconditional loads on clamped addresses straight into the tile registers; fixed up below
+    const bool plain = from_h && !(nz_row(a) && nz_col(b));   // (wave-uniform)
+    const double *src = plain ? Hc : S;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rc = min(16 * a + q4 + 4 * r, P - 1);
+      acc[q][r] = src[(long long)rc * ldh + min(16 * b + l15, rc)];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    if (ti[q] < 0) continue;
+    const int col = 16 * tj[q] + l15;
+    if (from_h && !(nz_row(ti[q]) && nz_col(tj[q]))) {   // a tile without Schur products, straight from Hpp: damping and fixed unknowns here
+      const int a_j = active_bit(col);
+      double ddiag = 0.0;   // (a diagonal tile among them: a few bias-bias blocks per window; one L2 round trip for its wave)
+      if (ti[q] == tj[q]) ddiag = d.dd[m.u0 + min(col, P - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti[q] + q4 + 4 * r;
+        acc[q][r] = (active_bit(row) & a_j) ? acc[q][r] + (row == col ? ddiag : 0.0) : (row == col ? 1.0 : 0.0);
+      }
+    }
+    if (ti[q] == tj[q]) {             // diagonal tile: the upper half is not stored in S
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = (col <= 16 * ti[q] + q4 + 4 * r) ? acc[q][r] : 0.0;
+    }
+    if (ti[q] == ip) {                // tile row of the rhs row P; identity beyond it
+      const double yv = y[min(col, P - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ip + q4 + 4 * r;
+        acc[q][r] = row < P ? acc[q][r] : (row == P ? (col < P ? yv : 0.0) : (row == col ? 1.0 : 0.0));
+      }
+    }
+    if (ti[q] == 0) {                 // tile (0, 0): to the chain wave as it is (row 1 follows in iteration 0 of the loop below)
+      double *dst = Li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+    }
+  }
+  CTV_BAR();
+  // Iteration c of an update wave: panel c - 1 applied to its NEAR trailing tiles (columns c and c + 1: the tiles whose L_ic the next panel needs, and
+  // the two tiles of row c + 1 that go to the chain wave), then -- as soon as the chain wave has L_cc^-1 -- the L_ic of its tiles of column c, and
+  // panel c - 1 applied to the rest, which fills the wait for L_cc^-1 when that is not there yet.
+  for (int c = 0; c < NTR; ++c) {
+    int opq;   // (a zero the compiler cannot see through: the per-slot LDS addresses are recomputed each panel -- one add each -- instead of
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opq));   // being kept as loop-invariant registers beside the tiles)
+    double *Pnc = Pn + (c % NPB) * NTR * TS + opq;                      // panel c: written here
+    const double *Pnp = Pn + ((c + NPB - 1) % NPB) * NTR * TS + opq;    // panel c - 1: applied here
+    unsigned seen = 0;     // rows whose L_(i,c-1) this wave has already found published
+    // A_ij -= L_(i,c-1) L_(j,c-1)^T for this wave's tiles (i, j), j >= c, i >= c + 1: part 0 = the near columns (c, c + 1), parts 1 / 2 = the far
+    // columns in the first / second half of the wave's slots
+    auto apply_prev = [&](int part) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        if (ti[q] < c + 1 || tj[q] < c || tj[q] >= (1 << 20)) continue;   // (uniform)
+        if ((tj[q] <= c + 1 ? 0 : (q < (NS + 1) / 2 ? 1 : 2)) != part) continue;
+        if (c - 1 >= ek[q]) {
+          if (!((seen >> ti[q]) & 1u)) { chol_wait(F_row + ti[q], c, fail); seen |= 1u << ti[q]; }
+          if (!((seen >> tj[q]) & 1u)) { chol_wait(F_row + tj[q], c, fail); seen |= 1u << tj[q]; }
+          const double *pa = Pnp + ti[q] * TS + l15 * 17 + q4, *pb = Pnp + tj[q] * TS + l15 * 17 + q4;
+          double a[4], b[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) { a[s4] = -pa[4 * s4]; b[s4] = pb[4 * s4]; }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc[q], 0, 0, 0);
+        }
+        if (ti[q] == c + 1) {   // (uniform) tiles (c + 1, c) and (c + 1, c + 1): every update up to panel c - 1 is in; to the chain wave
+          double *dst = (tj[q] == c + 1 ? Li : Ls) + (c + 1) * TS;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+          chol_count(F_park + c + 1, lane);
+        }
+      }
+    };
+    auto form_column = [&]() {   // L_ic = A_ic L_cc^-T for this wave's tiles of column c, rows >= c + 2 (row c + 1 is the chain wave's), through the
+      const double *Lc = Li + c * TS;   // tile's slice of the panel buffer (accumulator -> operand transposition), published there
+      bool first = true;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        if (tj[q] != c || ti[q] < c + 2 || c < ek[q]) continue;   // (uniform; an empty tile stays zero and publishes nothing)
+        if (first) {
+          chol_wait(F_inv + c, 1, fail);
+          if (c >= NPB) chol_wait(reinterpret_cast<volatile int *>(done_E + (c - NPB)), NU, fail);   // nobody reads panel c - NPB any more
+          first = false;
+        }
+        double *blk = Pnc + ti[q] * TS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = acc[q][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        double a[4], b[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { a[s4] = blk[l15 * 17 + 4 * s4 + q4]; b[s4] = Lc[l15 * 17 + 4 * s4 + q4]; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();          // operands are in registers before the slice is overwritten
+        f64x4 cc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) cc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], cc, 0, 0, 0);
+        acc[q] = cc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[(q4 + 4 * r) * 17 + l15] = cc[r];
+        if (ti[q] == ip && q4 == (rp & 3)) tv[16 * c + l15] = f64x4_get(cc, rp >> 2);   // y: row P of L
+        chol_post(F_row + ti[q], c + 1, lane);
+      }
+    };
+    apply_prev(0);        // (c = 0: nothing to apply -- tiles (1, 0) and (1, 1) go to the chain wave as they are)
+    bool formed = false;  // the column is formed as soon as L_cc^-1 is seen -- checked before each part of the far work, which fills the wait
+    auto try_form = [&](bool must) {
+      if (formed) return;
+      if (!must && __builtin_amdgcn_readfirstlane(F_inv[c]) == 0) return;
+      asm volatile("" ::: "memory");
+      form_column();
+      formed = true;
+    };
+    try_form(false);
+    if (c > 0) apply_prev(1);
+    try_form(false);
+    if (c > 0) apply_prev(2);
+    try_form(true);
+    if (c > 0) chol_count(done_E + (c - 1), lane);   // this wave is through with panel c - 1
+  }
+  if (lane == 0 && fail) s_fail = 1;
+  CTV_BAR();                                      // the factorisation is complete; x of the last block (chain wave)
+  // the tiles (b, b - 1) come back from the chain wave as L_(b,b-1)
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    if (ti[q] < 1 || tj[q] != ti[q] - 1) continue;
+    const double *src = Ls + ti[q] * TS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = src[(q4 + 4 * r) * 17 + l15];
+  }
+  // ---- back-substitution L^T x = y over the tiles in registers: ONE barrier per block.  After x_b is known, the only contribution t_{b-1}
+  // still lacks is that of tile (b, b - 1): its owner finishes t_{b-1} in registers and forms x_{b-1} = L_{b-1,b-1}^-T t_{b-1} at once (the sixteen
+  // t[k] read across the 16-lane rows by v_fmac_f64_dpp row_newbcast, the sum over the four row groups by v_permlane16/32_swap -- no LDS round
+  // trip on the chain); the owners of the other tiles (b, j) subtract their parts from t_j in LDS meanwhile.
+  for (int b = NTR - 1; b >= 1; --b) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (ti[q] != b || tj[q] >= b) continue;   // tiles (b, j), j < b: t_j -= L_bj^T x_b
+      double xb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[r] = xs[16 * b + q4 + 4 * r];
+      if (tj[q] == b - 1) {                     // (uniform) the chain
+        const double *Lb = Li + (b - 1) * TS;
+        double lk[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) lk[kk] = Lb[kk * 17 + l15];
+        const double tb = tv[16 * (b - 1) + l15];
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += acc[q][r] * xb[r];
+        const double t = tb - rowgroup_sum(part);   // t_{b-1}[l15], in every row group
+        double xa = 0.0;
+        dpp_dot16<0>(xa, t, lk);
+        if (q4 == 0) xs[16 * (b - 1) + l15] = xa;
+      } else {
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += acc[q][r] * xb[r];
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (q4 == 0) tv[16 * tj[q] + l15] -= part;
+      }
+    }
+    CTV_BAR();
+  }
+  double *x = d.delta + m.u0;
+  for (int i = utid; i < P; i += NTU) x[i] = xs[i];
+  if (utid == 0) lm.chol_fail = s_fail;
+#undef CTV_BAR
+}
+
 // (Fusing this kernel into k_cholesky_tiles -- same workgroup, the pose step straight from LDS -- was built and measured: no gain for
 //  one window (3.09 vs 3.05 ms per solve) and slower for 2048 (15.4 vs 13.6 ms for the two phases): the fused kernel spills, and
 //  the landmark back-substitution wants more workgroups per CU than the tile kernel's registers allow.  Kept apart.)

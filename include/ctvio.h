@@ -275,7 +275,7 @@ int32_t ctvio_graph_captures(const ctvio_solver *s);
 /* ---- Diagnostic switches.  libctvio.so reads a fixed set of environment variables ONCE per handle, inside ctvio_create (csrc/ctvio.hip:
  * DebugSwitches, the only getenv of the library), and never again: kernel selection cannot change between ctvio_upload and ctvio_solve.
  * They exist for A/B measurements and for the tests' cross-checks; production callers set none of them.
- *   CTVIO_DENSE=1 (dense sparsity plan)   CTVIO_CHOL_TILES=0|1   CTVIO_SCHUR_TILE2=0|1   CTVIO_SCHUR_TILES=1   CTVIO_SCHUR_COPY_PLAIN=1
+ *   CTVIO_DENSE=1 (dense sparsity plan)   CTVIO_CHOL_TILES=0|1|3   CTVIO_SCHUR_TILE2=0|1   CTVIO_SCHUR_TILES=1   CTVIO_SCHUR_COPY_PLAIN=1
  *   CTVIO_STORE_PATH=0|1   CTVIO_SPLIT_LINEARIZE=1   CTVIO_MERGE_LINEARIZE=0|1   CTVIO_ZERO_KERNEL=1   CTVIO_NO_IMU_BAND=1   CTVIO_IMU_WAVES=n
  *   CTVIO_IMU_GENERAL=1   CTVIO_MARG_HOST=1   CTVIO_MARG_DEBUG=1   CTVIO_DEBUG_STAMPS=1
  *   CTVIO_SHARD_OVERSUBSCRIBE=1 (test only; read by ctvio_shards_used / ctvio_solve_sharded at call time) */

@@ -167,6 +167,44 @@ def test_headline_launch_vs_oracle(cv, oracle_solved):
     assert worst < 1e-6, worst
 
 
+@pytest.mark.parametrize("n", [1, 7, 200])
+def test_flow_cholesky_equals_the_barrier_cholesky(cv, oracle_solved, monkeypatch, n):
+    """k_cholesky_flow (the default for P <= 223: one chain wave factoring the diagonal tiles, fifteen update waves behind it, LDS flags instead of
+    workgroup barriers) against k_cholesky_tiles (round 5: two barriers per panel; CTVIO_CHOL_TILES=1) and the oracle -- windows of different sizes
+    in one batch (tiny: 4 tile rows; config 1 with fixed unknowns and a fixed line delay; config 2 / config 3 / tumrs: 14 tile rows, the last one
+    holding the rhs row at different offsets), as a single window, a small batch and a large one (per-window Schur kernel, tiles read from Hpp).
+    Every tile has one owner and receives its updates in panel order in both kernels: the solves must agree to rounding of the LAST bit pattern
+    at most -- asserted at 1e-12 on the state, identical decisions."""
+    base = [cv.synth.make_window("tiny", seed=41), cv.synth.make_window("config1", seed=1301), cv.synth.make_window("config2", seed=1002),
+            cv.synth.make_window("config3", seed=1003), cv.synth.make_window("tumrs", seed=1004), cv.synth.make_window("tiny", seed=42, with_prior=False),
+            cv.synth.make_window("config1", seed=1302)]
+    base[1].fixed_upto = 2
+    base[6].fix_ld = True
+    base[6].lock_bg = True
+    res = {}
+    for mode in ("3", "1"):
+        monkeypatch.setenv("CTVIO_CHOL_TILES", mode)
+        with cv.Solver() as s:
+            batch = [base[i % len(base)].copy() for i in range(n)]
+            s.set_windows(batch)
+            res[mode] = (batch, s.solve(15))
+    monkeypatch.delenv("CTVIO_CHOL_TILES")
+    for i in range(n):
+        a, b = res["3"][1][i], res["1"][1][i]
+        assert (a["iterations"], a["num_successful"], a["num_unsuccessful"], a["termination"]) == (b["iterations"], b["num_successful"], b["num_unsuccessful"], b["termination"]), i
+        # (n <= 64: the deterministic mode -- everything upstream of the factorisation is bitwise equal; n = 200: atomic assembly, run-to-run noise,
+        #  which the prior-free tiny window -- no gauge constraint -- amplifies)
+        if n > 64 and i % len(base) == 5:
+            continue
+        assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-12 if n <= 64 else 1e-8), i
+        assert cv.rel_state_error(res["3"][0][i], res["1"][0][i])["state"] < (1e-12 if n <= 64 else 1e-7), i
+    for cfg, seed, idx in (("config2", 1002, 2), ("config3", 1003, 3), ("tumrs", 1004, 4)):
+        if idx < n:
+            ref, so = oracle_solved(cfg, seed)
+            assert res["3"][1][idx]["iterations"] == so.iterations
+            assert cv.rel_state_error(res["3"][0][idx], ref)["state"] < 1e-6
+
+
 def test_equal_batches_capture_the_pass_once(cv):
     """A stream of equally shaped large batches (the headline configuration: >= 192 windows, P <= 223) captures its LM pass into a hipGraph
     ONCE: ctvio_set_batch clears the device descriptor, and a field that a launch used to set afterwards made every solve re-capture."""
