@@ -1222,6 +1222,8 @@ template <int NW, int NS> __global__ __launch_bounds__(64 * NW) void k_cholesky_
 // per panel for its tiles: in-order update waves with blocking waits form convoys.  Tried on the way: the chain wave alone on its SIMD (waves 4 /
 // 8 / 12 exit, twelve update waves x nine tiles): the updates on three SIMDs cannot keep up (70 -> 78 us); barriers instead of flags with the
 // chain overlapped (profiles/r06_chol_chain_experiment.txt): 69 - 71 us.
+// Also tried: the three tiles (r, r - 2), (r, r - 1), (r, r) of a row with ONE owner who applies panel r - 2 to the last two AHEAD of its other work
+// and parks them at once (the chain never waited in panels 1 - 3, and 5 - 6 k cycles in every later one: 84 us per factorisation).
 constexpr int CHOL_NU = 15, CHOL_NS = 7;   // update waves, tile slots per wave (105 tiles at P = 211)
 struct CholMap { signed char ti[15][CHOL_NU][CHOL_NS], tj[15][CHOL_NU][CHOL_NS]; };   // [tile rows NTR][update wave][slot]: tile (ti, tj), -1 = empty slot
 constexpr CholMap make_chol_map() {
