@@ -635,15 +635,19 @@ class SolverImpl : public SolverBase {
   void launch_linearize(int mode) {
     const Dev &d = dev_;
     const int nw = d.nwin;
+    const bool merged = merge_linearize();
     ph_begin(PH_ASM_REST);
     if (!store_path()) { if (!imu_zero_mode()) hipLaunchKernelGGL(k_zero_normal, dim3(64, nw), dim3(256), 0, stream_, d, vis_parts() == 1 ? 1 : 0, mode); }
-    else hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1, 0);   // prior gradient + cost share
+    else if (!merged) hipLaunchKernelGGL(k_misc, dim3(nw), dim3(256), std::max(d.maxPn, 1) * sizeof(double), stream_, d, mode, 1, 0);   // prior gradient + cost share
     ph_end();
-    if (merge_linearize()) {
-      // one launch for both evaluations (independent work: their latencies overlap on batches smaller than the chip); a profiled
-      // solve (and CTVIO_SPLIT_LINEARIZE=1, for rocprofv3 runs) keeps them apart so that each gets its own timing
-      if (d.Atot) hipLaunchKernelGGL(k_vis_anchor, dim3(nblk(d.Atot, 64)), dim3(64), 0, stream_, d, mode);
-      launch_linearize_merged(mode);
+    if (merged) {
+      // Small batches: TWO launches for the whole linearisation.  k_pre_linearize: the anchors' records, the IMU groups the specialised body
+      // leaves out and (store-semantics path) the prior gradient + cost share -- three launches of 5 - 7 us each until round 5; then
+      // k_linearize_f64: both evaluations (independent work: their latencies overlap on batches smaller than the chip).  A profiled
+      // solve (and CTVIO_SPLIT_LINEARIZE=1, for rocprofv3 runs) keeps everything apart so that each kernel gets its own timing.
+      const int nab = nblk(d.Atot, 64), with_misc = store_path() ? 1 : 0;
+      hipLaunchKernelGGL(k_pre_linearize, dim3(nab + nw + (with_misc ? nw : 0)), dim3(64), 0, stream_, d, mode, imu_general_only(), imu_zero_mode(), nab, with_misc);
+      hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode, imu_general_only(), imu_zero_mode());
       return;
     }
     ph_begin(PH_IMU_LIN);
@@ -740,7 +744,6 @@ class SolverImpl : public SolverBase {
   }
   int imu_walk_waves() const { return dbg_.imu_waves; }
   int imu_general_only() const { return (dbg_.imu_general || opt_.use_mfma == 2) ? 1 : 0; }
-  void launch_linearize_merged(int mode);
   void launch_assemble_vis_lds(int parts, int mode);
   void launch_assemble_vis_glb(int parts, int mode);
   void launch_assemble_vis_store(int parts, int mode) {
@@ -1352,11 +1355,6 @@ void SolverImpl::launch_imu_linearize(int mode) {
   const Dev &d = dev_;
   // (at most 2048 waves -- two rounds of one wave per SIMD -- each walking its share of the groups with the next group's data in flight)
   hipLaunchKernelGGL(k_imu_linearize_f64, dim3(std::min(d.Gtot, imu_walk_waves())), dim3(64), (size_t)(72 * 33 + 64) * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
-  hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
-}
-void SolverImpl::launch_linearize_merged(int mode) {
-  const Dev &d = dev_;
-  hipLaunchKernelGGL(k_linearize_f64, dim3(d.Gtot + nblk(d.Vtot, 64)), dim3(64), 0, stream_, d, mode, imu_general_only(), imu_zero_mode());
   hipLaunchKernelGGL(k_imu_linearize_rest, dim3(d.nwin), dim3(64), (size_t)64 * 33 * sizeof(double), stream_, d, mode, imu_general_only(), imu_zero_mode());
 }
 void SolverImpl::launch_assemble_vis_lds(int parts, int mode) {

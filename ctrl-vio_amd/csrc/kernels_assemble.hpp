@@ -547,9 +547,8 @@ __device__ __forceinline__ const double *prior_block_ptr(const WinMeta &m, int k
 // store != 0 (store-semantics assembly tail): nothing is added here -- the prior's gradient J0^T r0 + (J0^T J0) dx goes to Dev::pgrad,
 // and the assembly looks the prior and the chain up when it writes each entry.
 // with_imu != 0: the window's IMU group tiles are scattered first (assemble_imu_window: the accumulate path's k_assemble_imu, fused).
-__global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int with_imu) {
-  const int w = blockIdx.x;
-  extern __shared__ __attribute__((aligned(16))) double smd[];
+// NT threads per workgroup: 256 (k_misc), or 64 when the store-semantics part (prior gradient + cost share, with_imu = 0) rides in k_pre_linearize
+template <int NT> __device__ __forceinline__ void misc_body(const Dev &d, int mode, int store, int with_imu, int w, double *smd /* LDS [pn (+ band)] */, double *red /* LDS [NT] */) {
   // with_imu == 2: the launch carries 144 maxK doubles of LDS behind the prior's dx for the band of the IMU knot blocks (windows with K > 24)
   if (with_imu) { assemble_imu_window(d, mode, w, with_imu == 2 ? smd + ((max(d.maxPn, 1) + 1) & ~1) : nullptr); __syncthreads(); }
   const Lm &lm = d.lm[w];
@@ -561,10 +560,9 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
   const int tg = lin_target(lm, mode);
   double *Hpp = d.HppS[tg] + m.H0, *g = d.gS[tg] + m.u0;
   double *dx = smd;                 // [pn]
-  __shared__ double red[256];
   const int tid = threadIdx.x;
   double cost = 0.0;
-  for (int e = tid; e < m.NB * 6; e += 256) {
+  for (int e = tid; e < m.NB * 6; e += NT) {
     const int b = e / 6, k = e % 6;
     const int bi = d.bc_i[m.bc0 + b], bj = d.bc_j[m.bc0 + b];
     const double wv = d.bc_w[(size_t)(m.bc0 + b) * 6 + k];
@@ -582,9 +580,9 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
   }
   const int n = m.pn;
   if (n > 0) {
-    for (int i = tid; i < n; i += 256) dx[i] = 0.0;
+    for (int i = tid; i < n; i += NT) dx[i] = 0.0;
     __syncthreads();
-    for (int b = tid; b < m.pnb; b += 256) {
+    for (int b = tid; b < m.pnb; b += NT) {
       const int kind = d.p_kind[m.pblk0 + b], idx = d.p_index[m.pblk0 + b], off = d.p_off[m.pblk0 + b];
       const double *x = prior_block_ptr(m, kind, idx, quat, pos, bias, ldp, w);
       const double *x0 = d.p_x0 + 4 * (size_t)(m.pblk0 + b);
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
     __syncthreads();
     const double *pH = d.pH + m.pH0, *b0 = d.pb0 + m.pv0;
     const int *pcol = d.pcol + m.pv0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
       double hd = 0.0;
       for (int j = 0; j < n; ++j) hd += pH[(size_t)j * n + i] * dx[j];   // (J0^T J0 is symmetric: column i, coalesced over the threads)
       cost += dx[i] * (b0[i] + 0.5 * hd);
@@ -609,7 +607,7 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
     }
     if (tid == 0) cost += 0.5 * d.pc0[w];
     if (LIN) {
-      for (int e = tid; e < n * n; e += 256) {
+      for (int e = tid; e < n * n; e += NT) {
         const int i = e / n, j = e % n;
         const int ci = pcol[i], cj = pcol[j];
         if (ci >= 0 && cj >= 0 && ci >= cj) atomicAdd(&Hpp[(long long)ci * m.ldh + cj], pH[e]);
@@ -618,13 +616,32 @@ __global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int wi
   }
   red[tid] = cost;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+  for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
   if (tid == 0) {
     d.misc_cost[w] = red[0];
     if (store && !lin_cost_only(lm, mode, d.prm)) {   // (the generic path resets these in k_zero_normal)
       if (mode == LIN_SPEC) d.lm[w].cand_gmax_bits = 0ull; else d.lm[w].gmax_bits = 0ull;
     }
   }
+}
+__global__ __launch_bounds__(256) void k_misc(Dev d, int mode, int store, int with_imu) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  __shared__ double red[256];
+  misc_body<256>(d, mode, store, with_imu, blockIdx.x, smd, red);
+}
+// Small batches (the merged linearisation, <= 128 windows): everything that must precede k_linearize_f64 or is independent of it in ONE launch of
+// 64-thread workgroups -- [0, nA) the anchors' records (k_vis_anchor), [nA, nA + nwin) the IMU groups the specialised body leaves out
+// (k_imu_linearize_rest; nothing to do as a rule), and, on the store-semantics path, [nA + nwin, nA + 2 nwin) the prior gradient + cost share
+// (k_misc with store = 1).  For one window these were three launches of 5 - 7 us each in a pass of 180 us (the reference's operating mode:
+// one UpdateTrajectory per image, odometry_manager.cpp:268-277); their latencies now overlap.  The general IMU body sets the register
+// allocation (one wave per SIMD), which a batch smaller than the chip does not feel.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_pre_linearize(Dev d, int mode, int general_only, int zero_mode, int n_anchor_blocks, int with_misc) {
+  __shared__ __attribute__((aligned(32))) double srec[64 * AREC_LD];
+  static_assert(64 * AREC_LD >= 64 * 33, "the general IMU body's row buffer uses the anchor records' staging area");
+  const int b = blockIdx.x;
+  if (b < n_anchor_blocks) { vis_anchor_body(d, mode, srec, b); return; }
+  if (b < n_anchor_blocks + d.nwin) { imu_rest_body(d, mode, general_only, zero_mode, reinterpret_cast<unsigned char *>(srec), b - n_anchor_blocks); return; }
+  if (with_misc) misc_body<64>(d, mode, 1, 0, b - n_anchor_blocks - d.nwin, srec, srec + 64 * AREC_LD - 64);   // (dx: pn <= ~600 doubles, far below the reduction cells)
 }
 
 // Jacobi scaling (computed once, at iteration 0: Ceres jacobi_scaling), gradient max-norm of

@@ -505,9 +505,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
   if (!general_only) imu_linearize_f64_fast(d, mode, reinterpret_cast<double *>(smraw), blockIdx.x, gridDim.x, zero_mode);   // (skips the groups that are not its own)
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev d, int mode, int general_only, int zero_mode) {
-  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
-  const WinMeta &m = d.wins[blockIdx.x];
+__device__ __forceinline__ void imu_rest_body(const Dev &d, int mode, int general_only, int zero_mode, unsigned char *smraw /* LDS [64][33] doubles */, int w) {
+  const WinMeta &m = d.wins[w];
   for (int g0 = 0; g0 < m.ngrp; g0 += 64) {
     const int gl = g0 + (int)threadIdx.x;
     const bool need = gl < m.ngrp && (general_only || !imu_group_fast(d, m.grp0 + gl));
@@ -520,6 +519,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       __builtin_amdgcn_wave_barrier();
     }
   }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_imu_linearize_rest(Dev d, int mode, int general_only, int zero_mode) {
+  extern __shared__ __attribute__((aligned(32))) unsigned char smraw[];
+  imu_rest_body(d, mode, general_only, zero_mode, smraw, blockIdx.x);
 }
 
 // Scatter the group tiles into Hpp (lower triangle, fp64) and g.

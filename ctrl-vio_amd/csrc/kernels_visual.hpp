@@ -34,11 +34,10 @@ __device__ __forceinline__ void vis_times(const WinMeta &m, long long t_rel, int
 // every knot-pair log of its anchors below 0.5 rad (a ballot) -- takes the series-only evaluation (no branch, no closed-form code on the
 // path), the others the general one; both in the global frame.
 constexpr int AREC_LD = AREC + 1;   // odd LDS stride of the staged records
-__global__ __launch_bounds__(64) void k_vis_anchor(Dev d, int mode) {
+__device__ __forceinline__ void vis_anchor_body(const Dev &d, int mode, double *srec /* LDS [64][AREC_LD] */, int block) {
   // the records of the wave's 64 anchors are staged in LDS and written as ONE contiguous region with 16-byte stores (a lane writing
   // its own 400-byte record entry by entry costs 50 scattered partial-line stores: 229 MB of write traffic for 164 MB of records)
-  __shared__ __attribute__((aligned(16))) double srec[64 * AREC_LD];
-  const int a = blockIdx.x * 64 + threadIdx.x;
+  const int a = block * 64 + threadIdx.x;
   bool run = false;
   if (a < d.Atot) run = lin_run(d.lm[d.a_win[a]], mode);
   const unsigned long long run_mask = __ballot(run);
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(64) void k_vis_anchor(Dev d, int mode) {
   __builtin_amdgcn_wave_barrier();
   {
     const int lane = threadIdx.x;
-    double *dst = d.arec + (size_t)(blockIdx.x * 64) * AREC;
+    double *dst = d.arec + (size_t)(block * 64) * AREC;
     constexpr int HP = AREC / 2;                 // pairs per record
 #pragma unroll 5
     for (int k = 0; k < HP; ++k) {               // 64 * HP pairs, 64 per store (cost-only records carry p_G alone: the rest is never read)
@@ -91,6 +90,10 @@ __global__ __launch_bounds__(64) void k_vis_anchor(Dev d, int mode) {
       if ((run_mask >> bl) & 1ull) *reinterpret_cast<VecN<double, 2> *>(dst + (size_t)bl * AREC + r) = pr;
     }
   }
+}
+__global__ __launch_bounds__(64) void k_vis_anchor(Dev d, int mode) {
+  __shared__ __attribute__((aligned(16))) double srec[64 * AREC_LD];
+  vis_anchor_body(d, mode, srec, blockIdx.x);
 }
 
 // k_vis_eval<LIN> stages the records of its 64 blocks in LDS, block-major like the copy in HBM ([64][VT_LD]: this lane's block starts
