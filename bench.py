@@ -50,12 +50,12 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "fp64": 78.6}   # v_mfma_f32_32x32x2_f32 (gui
 
 def kernel_of_phase(precision):
     return {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_anchor + k_vis_eval",
-            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_tiles"}
+            "k_assemble_vis": "k_assemble_vis_mfma", "k_schur_mfma": "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_flow"}
 
 
 # rocprofv3 names of the kernels behind a launch group (counter tables: profiles/pmc_traffic.json, profiles/pmc_issue.json)
 PMC_KERNELS = {"k_imu_linearize": ["k_imu_linearize_f64"], "k_vis_eval": ["k_vis_anchor", "k_vis_eval"], "k_assemble_vis": ["k_assemble_vis_mfma"],
-               "k_schur_mfma": ["k_schur_window_f64"], "k_cholesky_solve": ["k_cholesky_tiles"]}
+               "k_schur_mfma": ["k_schur_window_f64"], "k_cholesky_solve": ["k_cholesky_flow"]}
 # fp64 instruction counts of the visual evaluation bodies, read off the ISA (tools/vis_isa_count.sh): per block 714 fp64 VALU instructions
 # = 972 flop (+ 24 + 6 + 72 of the landmark-row contributions), per anchor 813 = 1190 flop
 VIS_BLOCK_FLOP, VIS_ANCHOR_FLOP = 972 + 2 * (24 + 6) + 2 * 72 // 4, 1190
@@ -132,7 +132,7 @@ def algorithmic_bytes(w, phase, fp_bytes):
         K6 = 6 * K   # + the knot x knot part (24 x 24) of every IMU group tile, added into the same LDS Hessian
         return V * (38 * fp_bytes + 16) + A * 40 * 8 + (K6 * (K6 + 1) // 2 + K6 + 1) * 8 + G * 576 * fp_bytes
     if phase == "k_cholesky_solve":
-        # P <= 223 (k_cholesky_tiles): the triangle is READ once into registers and never written back; beyond (k_cholesky_solve): the entries
+        # P <= 223 (k_cholesky_flow): the triangle is READ once into registers and never written back; beyond (k_cholesky_solve): the entries
         # inside the envelope read and written once (the factor is needed by the back-substitution); rhs in, solution out
         return sp["env"] * 8 * (1 if P <= 223 else 2) + 2 * P * 8
     if phase == "k_schur_mfma":
@@ -214,7 +214,7 @@ def side_config(cv, lib, torch, config, nwin, nuniq, iters, steps, nseed, device
             out["phase_ms_profiled_solve"] = {names[i]: float(ms[i]) for i in range(7)}
             big = wl[0].P > 223
             kn = {"k_imu_linearize": "k_imu_linearize_f64", "k_vis_eval": "k_vis_anchor + k_vis_eval", "k_assemble_vis": "k_assemble_vis_mfma",
-                  "k_schur_mfma": "k_schur_tile2_f64" if big else "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve<8> (envelope panels)" if big else "k_cholesky_tiles"}
+                  "k_schur_mfma": "k_schur_tile2_f64" if big else "k_schur_window_f64", "k_cholesky_solve": "k_cholesky_solve<8> (envelope panels)" if big else "k_cholesky_flow"}
             lines = []
             for i in range(6):
                 if n[i] <= 0 or names[i] not in kn:

@@ -221,7 +221,7 @@ def test_large_batch_kernels_match_small_batch_kernels(cv, prec):
 
 
 def test_large_batch_fixed_unknowns_and_tiles_taken_from_hpp(cv, oracle, monkeypatch):
-    """Large batches: k_schur_window_f64 leaves the 16 x 16 tiles W never reaches unwritten and k_cholesky_tiles forms them from Hpp + D itself,
+    """Large batches: k_schur_window_f64 leaves the 16 x 16 tiles W never reaches unwritten and the tile Cholesky (k_cholesky_flow / k_cholesky_tiles) forms them from Hpp + D itself,
     fixed unknowns included (activity as ballot masks).  208 windows (4 distinct: constant knots in and out of the prefix, a fixed line
     delay, locked gyro biases) against the same 4 in a small batch (tile Schur kernel: S written whole) and the oracle -- and against the same batch with
     the tiles copied by the Schur kernel as before (CTVIO_SCHUR_COPY_PLAIN: identical arithmetic, S in HBM instead of straight from Hpp)."""
