@@ -782,7 +782,10 @@ def main():
                                                 label="the same sizes with landmark l anchored in frame l mod 28: visual factors all along the window")
             out["tumrs"] = side_config(cv, lib, torch, "tumrs", 2048, 16, args.iters, 2, 8, local, ora, profile=True,
                                        label="the reference's native operating point: 200 Hz IMU (10 samples per group), <= 150 features per frame")
-            out["mixed_batch"] = mixed_batch(cv, torch, args.config, 2048, 256, args.iters, local)
+            try:   # (a side measurement: it must not cost the run its record)
+                out["mixed_batch"] = mixed_batch(cv, torch, args.config, 2048, 256, args.iters, local)
+            except Exception as e:
+                out["mixed_batch"] = {"error": repr(e)[:300]}
             wt = cv.synth.make_window("tumrs", seed=1000)
             out["tumrs"]["imu_lane_utilisation"] = wt.M / (64.0 * imu_groups(wt))   # one 64-lane pass per (segment, bias) group
             # ---- rounds 1-4 let the replicas of a distinct window share its caller buffers (the packer read 11 MB out of L3): once, beside the headline
