@@ -205,6 +205,35 @@ def test_flow_cholesky_equals_the_barrier_cholesky(cv, oracle_solved, monkeypatc
             assert cv.rel_state_error(res["3"][0][idx], ref)["state"] < 1e-6
 
 
+# (frames, knot spacing in ms) -> P = 6K + 6F + 1: every number of tile rows from 3 to 14 and rhs-row offsets P mod 16 from 1 to 15
+_SIZES = [(2, 75), (2, 50), (2, 40), (3, 60), (3, 50), (3, 40), (4, 60), (4, 50), (6, 100), (4, 40), (5, 50), (6, 60), (5, 40), (6, 50), (7, 60),
+          (6, 40), (8, 60), (11, 100), (7, 40), (11, 75), (9, 50), (8, 40), (10, 50), (9, 40), (11, 50), (10, 40)]
+
+
+def test_flow_cholesky_every_tile_count_and_rhs_offset(cv, oracle):
+    """k_cholesky_flow on 26 windows of 26 different sizes in ONE launch -- P from 43 to 223: 3 to 14 tile rows (the ownership table CHOL_MAP of every
+    size), the rhs row P at offsets 1, 3, 5, ... 15 inside its tile, K from 5 to 27 (above K = 25 the assembly adds with global atomics) -- one LM step
+    of every window against the oracle's DENSE Cholesky of the un-eliminated system, and the same batch through k_cholesky_tiles."""
+    ws = [cv.synth.make_window("config1", seed=1700 + i, F=F, dt_ns=dt * 1_000_000, L=30, M=40 * F) for i, (F, dt) in enumerate(_SIZES)]
+    seen = {(w.P // 16 + 1, w.P % 16) for w in ws}
+    assert len(seen) == len(_SIZES) and {a for a, _ in seen} == set(range(3, 15)) and max(w.P for w in ws) == 223
+    steps = {}
+    for mode in ("3", "1"):
+        os.environ["CTVIO_CHOL_TILES"] = mode
+        try:
+            with cv.Solver() as s:
+                s.set_windows([w.copy() for w in ws])
+                steps[mode] = [s.lm_step(i, 1e4) for i in range(len(ws))]
+        finally:
+            del os.environ["CTVIO_CHOL_TILES"]
+    for i, w in enumerate(ws):
+        d_o, mc_o = oracle.OracleWindow(w.copy()).lm_step(1e4, use_schur=False)
+        d_g, mc_g = steps["3"][i]
+        assert np.abs(d_g - d_o).max() <= 1e-8 * np.abs(d_o).max(), (i, w.P)
+        assert mc_g == pytest.approx(mc_o, rel=1e-9), (i, w.P)
+        assert np.abs(d_g - steps["1"][i][0]).max() <= 1e-12 * np.abs(d_o).max(), (i, w.P)
+
+
 def test_equal_batches_capture_the_pass_once(cv):
     """A stream of equally shaped large batches (the headline configuration: >= 192 windows, P <= 223) captures its LM pass into a hipGraph
     ONCE: ctvio_set_batch clears the device descriptor, and a field that a launch used to set afterwards made every solve re-capture."""
