@@ -196,7 +196,7 @@ def test_flow_cholesky_equals_the_barrier_cholesky(cv, oracle_solved, monkeypatc
         #  which the prior-free tiny window -- no gauge constraint -- amplifies)
         if n > 64 and i % len(base) == 5:
             continue
-        assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-12 if n <= 64 else 1e-8), i
+        assert a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-12 if n <= 64 else 1e-7), i
         assert cv.rel_state_error(res["3"][0][i], res["1"][0][i])["state"] < (1e-12 if n <= 64 else 1e-7), i
     for cfg, seed, idx in (("config2", 1002, 2), ("config3", 1003, 3), ("tumrs", 1004, 4)):
         if idx < n:
