@@ -231,7 +231,8 @@ def test_flow_cholesky_every_tile_count_and_rhs_offset(cv, oracle):
         d_g, mc_g = steps["3"][i]
         assert np.abs(d_g - d_o).max() <= 1e-8 * np.abs(d_o).max(), (i, w.P)
         assert mc_g == pytest.approx(mc_o, rel=1e-9), (i, w.P)
-        assert np.abs(d_g - steps["1"][i][0]).max() <= 1e-12 * np.abs(d_o).max(), (i, w.P)
+        # (one window with K > 25 makes the batch accumulate with atomics: run-to-run differences ~1e-13 in H, more in the step)
+        assert np.abs(d_g - steps["1"][i][0]).max() <= 1e-9 * np.abs(d_o).max(), (i, w.P)
 
 
 def test_equal_batches_capture_the_pass_once(cv):
