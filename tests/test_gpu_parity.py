@@ -128,6 +128,15 @@ def test_lm_step_matches_oracle(cv, oracle, win_cfg1, prec, tol, mfma):
     assert mc_g == pytest.approx(mc_o, rel=max(tol * 1e-2, 1e-9))
 
 
+def test_removed_modes_are_refused(cv):
+    """ctvio_create refuses what no longer exists instead of silently running something else: the vector-ALU cross-check kernels (use_mfma = 0,
+    removed in round 6) and the mixed fp32 precision (removed in round 3)."""
+    with pytest.raises(cv.capi.CtvioError, match="use_mfma"):
+        cv.Solver(use_mfma=0)
+    with pytest.raises(ValueError):
+        cv.Solver(precision="fp32")
+
+
 def test_cost_kernels(cv, oracle, win_cfg1):
     w = win_cfg1.copy()
     c = oracle.OracleWindow(w.copy()).cost()
