@@ -235,7 +235,7 @@ class SolverImpl : public SolverBase {
     for (int wi = 0; wi < nw; ++wi) if (wins[wi]) maxP_pre = std::max(maxP_pre, 6 * wins[wi]->K + 6 * wins[wi]->F + 1);
     chol_tiles_ = chol_tiles_for(maxP_pre);   // (decided here, once per batch: launch_step and the Schur launch use the member)
     const bool dense_env = chol_tiles_ != 0 || sparsity_off();
-    parallel_for(nw, nth, [&](int wi) {
+    pool_.run(nw, nth, [&](int wi) {
       if (validate && !validate_window(wins[wi], tmp[wi].err)) {
         int cur = first_bad.load();
         while (wi < cur && !first_bad.compare_exchange_weak(cur, wi)) {}
@@ -357,7 +357,7 @@ class SolverImpl : public SolverBase {
     int32_t *h_tl_beg = CTV_H(int32_t, o_tl_beg), *h_tl_end = CTV_H(int32_t, o_tl_end), *h_env_first = CTV_H(int32_t, o_env_first), *h_env_tile = CTV_H(int32_t, o_env_tile);
     h_lm_pos_ = h_lm_pos; h_ld_ = h_ld;
     // ---- second pass: every window fills its own slices
-    parallel_for(nw, nth, [&](int wi) {
+    pool_.run(nw, nth, [&](int wi) {
       const ctvio_window &w = *wins[wi];
       const WinMeta &m = meta_[wi];
       const PackTmp &t = tmp[wi];
@@ -1321,6 +1321,7 @@ class SolverImpl : public SolverBase {
   int Mtot_ = 0, Vtot_ = 0;
   size_t chol_lds_ = 0, vis_lds_ = 0, vis_glb_ = 0, in_bytes_ = 0, state_doubles_ = 0;
   Arena in_, work_;          // uploaded inputs (pinned mirror) / device-only work buffers
+  WorkerPool pool_;          // the handle's packing threads (created on first use, kept)
   // scratch of the small per-call entries (spline query, gauge restore): grow-only device buffer + pinned host mirror
   DBuf<char> call_dev_;
   char *call_host_ = nullptr; size_t call_host_cap_ = 0;

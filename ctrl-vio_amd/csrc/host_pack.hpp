@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -27,18 +30,58 @@ inline int host_threads(int requested) {
   return (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
 }
 
-// f(i) for i in [0, n), dynamic distribution over `nthreads` threads (the calling thread included)
-template <class F> void parallel_for(int n, int nthreads, F &&f) {
-  if (nthreads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-  std::atomic<int> next{0};
-  auto worker = [&]() { for (;;) { const int i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; f(i); } };
-  std::vector<std::thread> th;
-  const int extra = std::min(nthreads, n) - 1;
-  th.reserve(extra);
-  for (int t = 0; t < extra; ++t) th.emplace_back(worker);
-  worker();
-  for (auto &t : th) t.join();
-}
+// f(i) for i in [0, n), dynamic distribution over `nthreads` threads (the calling thread included).  The threads belong to the solver handle and
+// live as long as it does: a batch is packed in two passes, and a pass that creates and joins its threads pays for them every time -- for a batch of 8
+// windows (BASELINE configs[3] as written: 8 windows per GPU) that was more than the packing itself.
+class WorkerPool {
+ public:
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  template <class F> void run(int n, int nthreads, F &&f) {
+    if (nthreads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    const int extra = std::min(nthreads, n) - 1;
+    while ((int)th_.size() < extra) th_.emplace_back([this] { loop(); });
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = [&f](int i) { f(i); };
+      n_ = n; next_.store(0, std::memory_order_relaxed); wanted_ = extra; started_ = 0; running_ = 0; ++epoch_;
+    }
+    cv_.notify_all();
+    work();                                  // the calling thread takes items too
+    std::unique_lock<std::mutex> lk(mu_);    // every helper that picked the job up has finished its last item (helpers that never woke take none)
+    wanted_ = 0;
+    done_.wait(lk, [&] { return running_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void work() { for (;;) { const int i = next_.fetch_add(1, std::memory_order_relaxed); if (i >= n_) break; job_(i); } }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return quit_ || (epoch_ != seen && started_ < wanted_); });
+        if (quit_) return;
+        seen = epoch_; ++started_; ++running_;
+      }
+      work();
+      { std::lock_guard<std::mutex> lk(mu_); --running_; }
+      done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)> job_;
+  std::atomic<int> next_{0};
+  int n_ = 0, wanted_ = 0, started_ = 0, running_ = 0;
+  unsigned long long epoch_ = 0;
+  bool quit_ = false;
+};
 
 // Grow-only device buffer, optionally mirrored by pinned host memory of the same size.
 struct Arena {
