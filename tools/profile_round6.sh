@@ -27,6 +27,7 @@ trace tumrs_x2048 --config tumrs --windows 2048 --unique 16 --steps 1 --warmup 1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --quick --steps 3 --warmup 1 > $O/kt_bench.json 2> $O/kt.err
 cd $R; python tools/prof_summary.py stats $(find $O/kt -name "*.db") > $O/kernel_stats_default_4x2048.txt
+cp $O/pmc_traffic.json $O/pmc_issue.json $O/pmc_lds.json $R/profiles/   # (the bench record below prints roofline.traffic from THIS run's counters)
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 300 $O/bench_n1.err; cp gpurun_out/bench_details_n1.json $O/bench_details_n1.json
 python tools/imu_isa_count.py > $O/imu_isa_count.txt 2>&1
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +4M -delete
